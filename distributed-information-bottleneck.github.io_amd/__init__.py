@@ -1,0 +1,13 @@
+"""MI355X-native Distributed Information Bottleneck training path.
+
+Drop-in for the reference's Python surface on this path (reference models.py / train.py):
+    DistributedIBNet, compile, fit, InfoBottleneckAnnealingCallback, SaveCompressionMatricesCallback
+backed by hand-written HIP kernels for gfx950 (csrc/) behind the C ABI in include/dib_hip.h.
+"""
+from . import data, losses, models, optimizers, utils, visualization  # noqa: F401
+from .models import (Callback, DistributedIBNet, History, InfoBottleneckAnnealingCallback, PositionalEncoding,  # noqa: F401
+                     SaveCompressionMatricesCallback)
+
+__all__ = ["DistributedIBNet", "InfoBottleneckAnnealingCallback", "SaveCompressionMatricesCallback",
+           "PositionalEncoding", "Callback", "History", "models", "losses", "optimizers", "data", "utils",
+           "visualization"]

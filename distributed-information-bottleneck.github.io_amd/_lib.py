@@ -1,0 +1,131 @@
+"""ctypes binding of libdib_hip.so (C ABI declared in include/dib_hip.h) + in-tree build helper.
+
+The library is built IN-TREE with hipcc for gfx950 (`build_library`) so the .so travels with the
+repo snapshot to the GPU box.  There is no CPU fallback: if the library cannot be loaded the
+product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h"]
+
+# error codes (include/dib_hip.h)
+DIB_OK = 0
+ACTIVATIONS = {None: 0, "linear": 0, "None": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "elu": 5,
+               "softplus": 6}
+LOSS_KINDS = {"bce_logits": 0, "bce": 1, "sparse_cce_logits": 2, "mse": 3}
+WS_U, WS_PRED, WS_ENC_OUT, WS_G_U, WS_STEP_OUT, WS_G_PRED = range(6)
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libdib_hip.so")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for s in SOURCES + [INCLUDE]:
+        p = s if os.path.isabs(s) else os.path.join(CSRC, s)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           os.path.join(CSRC, "dib_api.hip"), "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol declared in include/dib_hip.h
+SIGNATURES = {
+    "dib_version": (c_char_p, []),
+    "dib_error_string": (c_char_p, [c_int]),
+    "dib_layout_create": (c_int, [c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, POINTER(c_int), c_int,
+                                  c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "dib_layout_destroy": (None, [c_void_p]),
+    "dib_layout_param_count": (c_int64, [c_void_p]),
+    "dib_layout_param_block": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int64), POINTER(c_int),
+                                       POINTER(c_int)]),
+    "dib_layout_table_bytes": (c_int64, [c_void_p]),
+    "dib_layout_upload_tables": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "dib_workspace_bytes": (c_int64, [c_void_p, c_int]),
+    "dib_workspace_offset": (c_int64, [c_void_p, c_int, c_int]),
+    "dib_layout_wgrad_splits": (c_int, [c_void_p, c_int]),
+    "dib_encoder_bank_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_uint64,
+                                     c_uint32, c_int, c_void_p, c_void_p]),
+    "dib_integration_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dib_loss_fwd_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p,
+                                 c_void_p]),
+    "dib_integration_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                                     c_uint64, c_uint32, c_void_p, c_void_p]),
+    "dib_grads_finalize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dib_metrics_accumulate": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "dib_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_float,
+                              c_float, c_float, c_void_p]),
+    "dib_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
+    "dib_encode_deterministic": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_bhattacharyya": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dib_philox_normal_fill": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_uint64, c_uint32,
+                                       c_void_p]),
+    "dib_philox_normal_ref": (c_float, [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32]),
+    "dib_gemm": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                         c_void_p, c_int, c_int, c_void_p, c_void_p]),
+}
+
+
+def load_library(build_if_missing: bool = True):
+    """dlopen libdib_hip.so and attach signatures.  Raises (no fallback) if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and _stale():
+        try:
+            build_library()
+        except Exception:
+            if not os.path.exists(LIB_PATH):
+                raise
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class DibError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str = "") -> None:
+    if code != DIB_OK:
+        msg = load_library().dib_error_string(int(code)).decode()
+        raise DibError(f"libdib_hip {what} failed: {msg} (code {code})")

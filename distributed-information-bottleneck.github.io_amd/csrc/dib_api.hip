@@ -1,0 +1,582 @@
+// dib_api.hip - C ABI (include/dib_hip.h) of the MI355X Distributed-IB hot path: layout, workspace
+// carving and the launch sequences of the forward / backward / optimizer steps.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/dib_hip.h"
+#include "dib_elementwise.h"
+#include "dib_gemm.h"
+
+namespace {
+
+constexpr int64_t kAlign = 64;  // floats (256 B)
+inline int64_t align_up(int64_t v, int64_t a = kAlign) { return (v + a - 1) / a * a; }
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+struct GemmCall {  // one grouped launch: slice [first, first+count) of the descriptor table
+  int first = 0, count = 0;
+  int max_m = 0, max_n = 0;  // max logical dims over the groups (-1 => batch)
+};
+
+}  // namespace
+
+struct dib_layout {
+  int F = 0, n_enc = 0, E = 0, n_int = 0, out_dim = 0, use_pe = 0, n_freq = 0, act = 0, out_act = 0;
+  std::vector<int> dims, enc_units, int_units;
+  int sum_d = 0, pw = 0, n_blocks = 1;    // pw = total encoder-input width, n_blocks = 1 + #sinusoids
+  std::vector<int> in_dim, in_off, x_off; // per feature: encoder input width / its first column in P / in x
+  std::vector<int> enc_width;             // [n_enc+1] per-feature output width of each encoder layer
+  std::vector<int> int_width;             // [n_int+1]
+  int64_t n_params = 0;
+  std::vector<std::vector<int64_t>> enc_w_off, enc_b_off;  // [layer][feature]
+  std::vector<int64_t> int_w_off, int_b_off;
+  // descriptor table
+  std::vector<DibGemmGroup> table;
+  std::vector<int4> colmap;
+  std::vector<GemmCall> enc_fwd, enc_dgrad, enc_wgrad, int_fwd, int_dgrad, int_wgrad;
+  const DibGemmGroup* dev_groups = nullptr;
+  const int4* dev_colmap = nullptr;
+
+  // ---- workspace map (float offsets), all per-row widths scale with the batch ----
+  struct WsMap {
+    int64_t P, enc_out, U, pred, g_pred, g_u, dout;
+    std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, total;
+    int kl_blocks, loss_blocks, nsplit, rows_per_split;
+  };
+  WsMap map(int B) const {
+    WsMap m;
+    int64_t o = 0;
+    auto take = [&](int64_t nfloats) { int64_t r = o; o = align_up(o + nfloats); return r; };
+    m.P = take((int64_t)B * pw);
+    for (int l = 0; l < n_enc; ++l) m.enc_h.push_back(take((int64_t)B * F * enc_units[l]));
+    m.enc_out = take((int64_t)B * F * 2 * E);
+    m.U = take((int64_t)B * F * E);
+    for (int l = 0; l < n_int; ++l) m.int_h.push_back(take((int64_t)B * int_units[l]));
+    m.pred = take((int64_t)B * out_dim);
+    m.g_pred = take((int64_t)B * out_dim);
+    for (int l = 0; l < n_int; ++l) m.g_int_h.push_back(take((int64_t)B * int_units[l]));
+    m.g_u = take((int64_t)B * F * E);
+    m.dout = take((int64_t)B * F * 2 * E);
+    for (int l = 0; l < n_enc; ++l) m.g_enc_h.push_back(take((int64_t)B * F * enc_units[l]));
+    m.step_out = take(F + 3);
+    const int E4 = (E + 3) / 4;
+    const int rpb = std::max(1, 256 / E4);
+    m.kl_blocks = cdiv(B, rpb);
+    m.kl_partial = take((int64_t)m.kl_blocks * F);
+    m.loss_blocks = cdiv(B, 256);
+    m.loss_partial = take((int64_t)m.loss_blocks * 2);
+    // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= 1024 rows per split
+    int ns = std::min(32, std::max(1, B / 2048));
+    int rps = cdiv(cdiv(B, ns), 32) * 32;
+    ns = cdiv(B, rps);
+    m.nsplit = ns;
+    m.rows_per_split = rps;
+    m.wgrad_partial = take(ns > 1 ? (int64_t)ns * align_up(n_params, 4) : 0);
+    m.total = o;
+    return m;
+  }
+};
+
+namespace {
+
+const char* kVersion = "dib_hip 0.1 (gfx950, fp32 MFMA grouped GEMM path)";
+
+int act_ok(int a) { return a >= 0 && a <= 6; }
+
+DibGemmGroup make_group(int64_t a_off, int lda, int64_t b_off, int ldb, int64_t c_off, int ldc, int64_t bias_off,
+                        int64_t aux_off, int ldaux, int M, int N, int K) {
+  DibGemmGroup g;
+  std::memset(&g, 0, sizeof(g));
+  g.a_off = a_off; g.b_off = b_off; g.c_off = c_off; g.bias_off = bias_off; g.aux_off = aux_off;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+  g.flags = ((a_off % 4 == 0 && lda % 4 == 0) ? 1 : 0) | ((b_off % 4 == 0 && ldb % 4 == 0) ? 2 : 0);
+  return g;
+}
+
+template <int MODE>
+int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const float* B, float* C, const float* bias,
+                const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
+                long long split_stride, hipStream_t st) {
+  if (c.count == 0) return DIB_OK;
+  const int M = c.max_m < 0 ? batch : c.max_m;
+  const int N = c.max_n < 0 ? batch : c.max_n;
+  const int tm = cdiv(M, DIB_BM), tn = cdiv(N, DIB_BN);
+  dim3 grid;
+  if (MODE == 2) grid = dim3(nsplit, tm * tn, c.count);
+  else grid = dim3(tm, tn, c.count);
+  hipLaunchKernelGGL((dib_gemm_kernel<MODE>), grid, dim3(256), 0, st, l->dev_groups + c.first, A, B, C, bias, aux,
+                     bias_out, batch, act, tn, rows_per_split, split_stride);
+  return (int)hipGetLastError();
+}
+
+inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>((n + per_block - 1) / per_block, cap));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dib_version(void) { return kVersion; }
+
+const char* dib_error_string(int code) {
+  switch (code) {
+    case DIB_OK: return "ok";
+    case DIB_E_ARG: return "invalid argument";
+    case DIB_E_SHAPE: return "shape mismatch";
+    case DIB_E_WORKSPACE: return "workspace / descriptor tables missing";
+    case DIB_E_UNSUPPORTED: return "unsupported configuration";
+    case DIB_E_NODEVICE: return "no HIP device";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown dib error";
+  }
+}
+
+int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_units, int E, int n_int,
+                      const int* int_units, int out_dim, int use_pe, int n_freq, int act, int out_act,
+                      dib_layout** out) {
+  if (!out || F <= 0 || !feature_dims || n_enc < 0 || n_int < 0 || E <= 0 || out_dim <= 0) return DIB_E_ARG;
+  if ((n_enc > 0 && !enc_units) || (n_int > 0 && !int_units)) return DIB_E_ARG;
+  if (!act_ok(act) || !act_ok(out_act)) return DIB_E_UNSUPPORTED;
+  if ((E + 3) / 4 > 256) return DIB_E_UNSUPPORTED;
+  dib_layout* l = new (std::nothrow) dib_layout();
+  if (!l) return DIB_E_ARG;
+  l->F = F; l->n_enc = n_enc; l->E = E; l->n_int = n_int; l->out_dim = out_dim;
+  l->use_pe = use_pe ? 1 : 0; l->n_freq = n_freq; l->act = act; l->out_act = out_act;
+  l->dims.assign(feature_dims, feature_dims + F);
+  l->enc_units.assign(enc_units, enc_units + n_enc);
+  l->int_units.assign(int_units, int_units + n_int);
+  // reference models.py:70: frequencies = 2**arange(1, n_freq) -> n_freq-1 sinusoids
+  l->n_blocks = (l->use_pe && n_freq > 1) ? n_freq : 1;
+  for (int f = 0; f < F; ++f) {
+    if (l->dims[f] <= 0) { delete l; return DIB_E_ARG; }
+    l->x_off.push_back(l->sum_d);
+    l->in_off.push_back(l->pw);
+    l->in_dim.push_back(l->dims[f] * l->n_blocks);
+    l->sum_d += l->dims[f];
+    l->pw += l->dims[f] * l->n_blocks;
+    for (int c = 0; c < l->dims[f]; ++c) l->colmap.push_back(make_int4(f, c, l->dims[f], l->in_off[f]));
+  }
+  for (int i = 0; i < n_enc; ++i) { if (enc_units[i] <= 0) { delete l; return DIB_E_ARG; } l->enc_width.push_back(enc_units[i]); }
+  l->enc_width.push_back(2 * E);
+  for (int i = 0; i < n_int; ++i) { if (int_units[i] <= 0) { delete l; return DIB_E_ARG; } l->int_width.push_back(int_units[i]); }
+  l->int_width.push_back(out_dim);
+
+  // ---- flat parameter layout: per encoder layer {all kernels (feature-major), all biases}, then integration ----
+  int64_t o = 0;
+  const int LE = n_enc + 1, LI = n_int + 1;
+  l->enc_w_off.assign(LE, std::vector<int64_t>(F));
+  l->enc_b_off.assign(LE, std::vector<int64_t>(F));
+  for (int ly = 0; ly < LE; ++ly) {
+    const int wout = l->enc_width[ly];
+    for (int f = 0; f < F; ++f) {
+      const int win = ly == 0 ? l->in_dim[f] : l->enc_width[ly - 1];
+      o = align_up(o, 4);
+      l->enc_w_off[ly][f] = o;
+      o += (int64_t)win * wout;
+    }
+    o = align_up(o, 4);
+    for (int f = 0; f < F; ++f) { l->enc_b_off[ly][f] = o; o += wout; }
+  }
+  for (int ly = 0; ly < LI; ++ly) {
+    const int win = ly == 0 ? F * E : l->int_width[ly - 1];
+    const int wout = l->int_width[ly];
+    o = align_up(o, 4);
+    l->int_w_off.push_back(o);
+    o += (int64_t)win * wout;
+    o = align_up(o, 4);
+    l->int_b_off.push_back(o);
+    o += wout;
+  }
+  l->n_params = o;
+
+  // ---- GEMM group descriptors.  Activation matrices are [B, F*width] with feature f at column f*width ----
+  auto& T = l->table;
+  for (int ly = 0; ly < LE; ++ly) {
+    const int wout = l->enc_width[ly];
+    const int ldc = F * wout;
+    GemmCall fw, dg, wg;
+    fw.first = (int)T.size();
+    for (int f = 0; f < F; ++f) {
+      const int win = ly == 0 ? l->in_dim[f] : l->enc_width[ly - 1];
+      const int lda = ly == 0 ? l->pw : F * l->enc_width[ly - 1];
+      const int64_t a_off = ly == 0 ? l->in_off[f] : (int64_t)f * l->enc_width[ly - 1];
+      T.push_back(make_group(a_off, lda, l->enc_w_off[ly][f], wout, (int64_t)f * wout, ldc, l->enc_b_off[ly][f], 0, 0,
+                             -1, wout, win));
+    }
+    fw.count = F; fw.max_m = -1; fw.max_n = wout;
+    l->enc_fwd.push_back(fw);
+    // dgrad (ly >= 1): g_in[B, win] = (g_out[B, wout] @ W[win, wout]^T) * act'(h_in)
+    dg.first = (int)T.size();
+    if (ly >= 1) {
+      const int win = l->enc_width[ly - 1];
+      for (int f = 0; f < F; ++f)
+        T.push_back(make_group((int64_t)f * wout, ldc, l->enc_w_off[ly][f], wout, (int64_t)f * win, F * win, -1,
+                               (int64_t)f * win, F * win, -1, win, wout));
+      dg.count = F; dg.max_m = -1; dg.max_n = win;
+    }
+    l->enc_dgrad.push_back(dg);
+    // wgrad: dW[win, wout] = h_in[B, win]^T @ g_out[B, wout] ; db = colsum(g_out)
+    wg.first = (int)T.size();
+    int max_in = 0;
+    for (int f = 0; f < F; ++f) {
+      const int win = ly == 0 ? l->in_dim[f] : l->enc_width[ly - 1];
+      const int lda = ly == 0 ? l->pw : F * l->enc_width[ly - 1];
+      const int64_t a_off = ly == 0 ? l->in_off[f] : (int64_t)f * l->enc_width[ly - 1];
+      T.push_back(make_group(a_off, lda, (int64_t)f * wout, ldc, l->enc_w_off[ly][f], wout, l->enc_b_off[ly][f], 0, 0,
+                             win, wout, -1));
+      max_in = std::max(max_in, win);
+    }
+    wg.count = F; wg.max_m = max_in; wg.max_n = wout;
+    l->enc_wgrad.push_back(wg);
+  }
+  for (int ly = 0; ly < LI; ++ly) {
+    const int win = ly == 0 ? F * E : l->int_width[ly - 1];
+    const int wout = l->int_width[ly];
+    GemmCall fw, dg, wg;
+    fw.first = (int)T.size();
+    T.push_back(make_group(0, win, l->int_w_off[ly], wout, 0, wout, l->int_b_off[ly], 0, 0, -1, wout, win));
+    fw.count = 1; fw.max_m = -1; fw.max_n = wout;
+    l->int_fwd.push_back(fw);
+    dg.first = (int)T.size();
+    T.push_back(make_group(0, wout, l->int_w_off[ly], wout, 0, win, -1, 0, win, -1, win, wout));
+    dg.count = 1; dg.max_m = -1; dg.max_n = win;
+    l->int_dgrad.push_back(dg);
+    wg.first = (int)T.size();
+    T.push_back(make_group(0, win, 0, wout, l->int_w_off[ly], wout, l->int_b_off[ly], 0, 0, win, wout, -1));
+    wg.count = 1; wg.max_m = win; wg.max_n = wout;
+    l->int_wgrad.push_back(wg);
+  }
+  *out = l;
+  return DIB_OK;
+}
+
+void dib_layout_destroy(dib_layout* l) { delete l; }
+
+int64_t dib_layout_param_count(const dib_layout* l) { return l ? l->n_params : DIB_E_ARG; }
+
+int dib_layout_param_block(const dib_layout* l, int net, int layer, int feature, int what, int64_t* offset,
+                           int* rows, int* cols) {
+  if (!l || !offset || !rows || !cols) return DIB_E_ARG;
+  if (net == 0) {
+    if (layer < 0 || layer > l->n_enc || feature < 0 || feature >= l->F) return DIB_E_ARG;
+    const int win = layer == 0 ? l->in_dim[feature] : l->enc_width[layer - 1];
+    const int wout = l->enc_width[layer];
+    if (what == 0) { *offset = l->enc_w_off[layer][feature]; *rows = win; *cols = wout; }
+    else { *offset = l->enc_b_off[layer][feature]; *rows = 1; *cols = wout; }
+    return DIB_OK;
+  }
+  if (net == 1) {
+    if (layer < 0 || layer > l->n_int) return DIB_E_ARG;
+    const int win = layer == 0 ? l->F * l->E : l->int_width[layer - 1];
+    const int wout = l->int_width[layer];
+    if (what == 0) { *offset = l->int_w_off[layer]; *rows = win; *cols = wout; }
+    else { *offset = l->int_b_off[layer]; *rows = 1; *cols = wout; }
+    return DIB_OK;
+  }
+  return DIB_E_ARG;
+}
+
+int64_t dib_layout_table_bytes(const dib_layout* l) {
+  if (!l) return DIB_E_ARG;
+  return align_up((int64_t)l->table.size() * sizeof(DibGemmGroup), 256) + align_up((int64_t)l->colmap.size() * sizeof(int4), 256);
+}
+
+int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t stream) {
+  if (!l || !dev_tables) return DIB_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t gbytes = (int64_t)l->table.size() * sizeof(DibGemmGroup);
+  char* base = (char*)dev_tables;
+  hipError_t e = hipMemcpyAsync(base, l->table.data(), gbytes, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  char* cm = base + align_up(gbytes, 256);
+  e = hipMemcpyAsync(cm, l->colmap.data(), l->colmap.size() * sizeof(int4), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  l->dev_groups = (const DibGemmGroup*)base;
+  l->dev_colmap = (const int4*)cm;
+  return DIB_OK;
+}
+
+int64_t dib_workspace_bytes(const dib_layout* l, int batch) {
+  if (!l || batch <= 0) return DIB_E_ARG;
+  return l->map(batch).total * (int64_t)sizeof(float);
+}
+
+int64_t dib_workspace_offset(const dib_layout* l, int batch, int which) {
+  if (!l || batch <= 0) return DIB_E_ARG;
+  const auto m = l->map(batch);
+  int64_t o = -1;
+  switch (which) {
+    case DIB_WS_U: o = m.U; break;
+    case DIB_WS_PRED: o = m.pred; break;
+    case DIB_WS_ENC_OUT: o = m.enc_out; break;
+    case DIB_WS_G_U: o = m.g_u; break;
+    case DIB_WS_STEP_OUT: o = m.step_out; break;
+    case DIB_WS_G_PRED: o = m.g_pred; break;
+    default: return DIB_E_ARG;
+  }
+  return o * (int64_t)sizeof(float);
+}
+
+int dib_layout_wgrad_splits(const dib_layout* l, int batch) {
+  if (!l || batch <= 0) return DIB_E_ARG;
+  return l->map(batch).nsplit;
+}
+
+// ---- forward ---------------------------------------------------------------------------------
+static int encoder_chain_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params,
+                             int first_group_offset, int group_count, hipStream_t st) {
+  const int LE = l->n_enc + 1;
+  for (int ly = 0; ly < LE; ++ly) {
+    GemmCall c = l->enc_fwd[ly];
+    c.first += first_group_offset;
+    c.count = group_count;
+    const float* A = ly == 0 ? w + m.P : w + m.enc_h[ly - 1];
+    float* C = ly == LE - 1 ? w + m.enc_out : w + m.enc_h[ly];
+    const int act = ly == LE - 1 ? DIB_ACT_LINEAR : l->act;  // reference models.py:78: last Dense(2E) is linear
+    int rc = launch_gemm<0>(l, c, A, params, C, params, nullptr, nullptr, batch, act, 1, 0, 0, st);
+    if (rc) return rc;
+  }
+  return DIB_OK;
+}
+
+int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32_t* row_idx, int64_t row0, int batch,
+                         const float* params, uint64_t seed, uint32_t step, int deterministic, void* ws,
+                         dib_stream_t stream) {
+  if (!l || !x || !params || !ws || batch <= 0) return DIB_E_ARG;
+  if (!l->dev_groups) return DIB_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)batch * l->sum_d)), dim3(256), 0, st, x, (long long)ldx,
+                     (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P,
+                     (long long)l->pw);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
+                     w + m.kl_partial, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
+                     (unsigned long long)seed, (unsigned)step, deterministic);
+  rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, m.kl_blocks, l->F,
+                     w + m.step_out);
+  return (int)hipGetLastError();
+}
+
+int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream) {
+  if (!l || !params || !ws || batch <= 0) return DIB_E_ARG;
+  if (!l->dev_groups) return DIB_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  const int LI = l->n_int + 1;
+  for (int ly = 0; ly < LI; ++ly) {
+    const float* A = ly == 0 ? w + m.U : w + m.int_h[ly - 1];
+    float* C = ly == LI - 1 ? w + m.pred : w + m.int_h[ly];
+    const int act = ly == LI - 1 ? l->out_act : l->act;  // reference models.py:82-83
+    int rc = launch_gemm<0>(l, l->int_fwd[ly], A, params, C, params, nullptr, nullptr, batch, act, 1, 0, 0, st);
+    if (rc) return rc;
+  }
+  return DIB_OK;
+}
+
+// ---- loss + backward ----------------------------------------------------------------------------
+int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
+                     int batch, float inv_global_batch, void* ws, dib_stream_t stream) {
+  if (!l || !y || !ws || batch <= 0) return DIB_E_ARG;
+  if (loss_kind < 0 || loss_kind > 3) return DIB_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  hipLaunchKernelGGL(dib_loss_kernel, dim3(m.loss_blocks), dim3(256), 0, st, loss_kind, w + m.pred, l->out_dim, y,
+                     (long long)ldy, (const int*)row_idx, (long long)row0, batch, inv_global_batch, l->out_act,
+                     w + m.g_pred, w + m.loss_partial);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2), dim3(256), 0, st, w + m.loss_partial, m.loss_blocks, 2,
+                     w + m.step_out + l->F);
+  rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_set_scalar_kernel, dim3(1), dim3(1), 0, st, w + m.step_out + l->F + 2, (float)batch);
+  return (int)hipGetLastError();
+}
+
+static inline float* wgrad_target(const dib_layout::WsMap& m, float* w, float* grads) {
+  return m.nsplit > 1 ? w + m.wgrad_partial : grads;
+}
+
+int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* grads, void* ws, dib_stream_t stream) {
+  if (!l || !params || !grads || !ws || batch <= 0) return DIB_E_ARG;
+  if (!l->dev_groups) return DIB_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  float* gt = wgrad_target(m, w, grads);
+  const long long sstride = align_up(l->n_params, 4);
+  const int LI = l->n_int + 1;
+  for (int ly = LI - 1; ly >= 0; --ly) {
+    const float* gout = ly == LI - 1 ? w + m.g_pred : w + m.g_int_h[ly];
+    const float* hin = ly == 0 ? w + m.U : w + m.int_h[ly - 1];
+    int rc = launch_gemm<2>(l, l->int_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
+                            m.rows_per_split, sstride, st);
+    if (rc) return rc;
+    float* gin = ly == 0 ? w + m.g_u : w + m.g_int_h[ly - 1];
+    // u is not an activation output (no mask for ly == 0)
+    rc = launch_gemm<1>(l, l->int_dgrad[ly], gout, params, gin, nullptr, ly == 0 ? nullptr : hin, nullptr, batch,
+                        ly == 0 ? 0 : l->act, 1, 0, 0, st);
+    if (rc) return rc;
+  }
+  return DIB_OK;
+}
+
+int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                         float inv_global_batch, const int32_t* row_idx, int64_t row0, uint64_t seed, uint32_t step,
+                         void* ws, dib_stream_t stream) {
+  if (!l || !params || !grads || !beta_dev || !ws || batch <= 0) return DIB_E_ARG;
+  if (!l->dev_groups) return DIB_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  float* gt = wgrad_target(m, w, grads);
+  const long long sstride = align_up(l->n_params, 4);
+  hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
+                     w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
+                     (unsigned long long)seed, (unsigned)step);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  const int LE = l->n_enc + 1;
+  for (int ly = LE - 1; ly >= 0; --ly) {
+    const float* gout = ly == LE - 1 ? w + m.dout : w + m.g_enc_h[ly];
+    const float* hin = ly == 0 ? w + m.P : w + m.enc_h[ly - 1];
+    rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
+                        m.rows_per_split, sstride, st);
+    if (rc) return rc;
+    if (ly >= 1) {
+      rc = launch_gemm<1>(l, l->enc_dgrad[ly], gout, params, w + m.g_enc_h[ly - 1], nullptr, hin, nullptr, batch,
+                          l->act, 1, 0, 0, st);
+      if (rc) return rc;
+    }
+  }
+  return DIB_OK;
+}
+
+int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_stream_t stream) {
+  if (!l || !grads || !ws || batch <= 0) return DIB_E_ARG;
+  const auto m = l->map(batch);
+  if (m.nsplit <= 1) return DIB_OK;
+  hipStream_t st = (hipStream_t)stream;
+  float* w = (float*)ws;
+  // partial slabs are spaced align_up(n_params,4) apart; the reduce treats them as n = that stride
+  const long long n = align_up(l->n_params, 4);
+  hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, w + m.wgrad_partial, n,
+                     m.nsplit, grads);
+  return (int)hipGetLastError();
+}
+
+int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, float inv_global_batch,
+                           float* metrics_acc, void* ws, dib_stream_t stream) {
+  if (!l || !beta_dev || !metrics_acc || !ws || batch <= 0) return DIB_E_ARG;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  hipLaunchKernelGGL(dib_metrics_accumulate_kernel, dim3(cdiv(l->F + 3, 64)), dim3(64), 0, (hipStream_t)stream,
+                     w + m.step_out, l->F, beta_dev, inv_global_batch, metrics_acc);
+  return (int)hipGetLastError();
+}
+
+// ---- optimizers ------------------------------------------------------------------------------------
+int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64_t n, const float* lr_dev,
+                  int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale, dib_stream_t stream) {
+  if (!params || !grads || !mm || !vv || !lr_dev || !t_dev || n <= 0) return DIB_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
+                     lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev);
+  return (int)hipGetLastError();
+}
+
+int dib_sgd_step(float* params, const float* grads, int64_t n, const float* lr_dev, float grad_scale,
+                 dib_stream_t stream) {
+  if (!params || !grads || !lr_dev || n <= 0) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, (long long)n,
+                     lr_dev, grad_scale);
+  return (int)hipGetLastError();
+}
+
+// ---- evaluation helpers ------------------------------------------------------------------------------
+int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n, const float* params, float* out,
+                             void* ws, dib_stream_t stream) {
+  if (!l || !x_f || !params || !out || !ws || n <= 0) return DIB_E_ARG;
+  if (feature < 0 || feature >= l->F) return DIB_E_ARG;
+  if (!l->dev_groups) return DIB_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(n);
+  float* w = (float*)ws;
+  const int d = l->dims[feature];
+  hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, st, x_f, (long long)d,
+                     (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P,
+                     (long long)l->pw);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  rc = encoder_chain_fwd(l, m, w, n, params, feature, 1, st);
+  if (rc) return rc;
+  const int w2 = 2 * l->E;
+  return (int)hipMemcpy2DAsync(out, (size_t)w2 * sizeof(float), w + m.enc_out + (int64_t)feature * w2,
+                               (size_t)l->F * w2 * sizeof(float), (size_t)w2 * sizeof(float), (size_t)n,
+                               hipMemcpyDeviceToDevice, st);
+}
+
+int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu2, const float* lv2, int m, int dim,
+                      float* out, dib_stream_t stream) {
+  if (!mu1 || !lv1 || !mu2 || !lv2 || !out || n <= 0 || m <= 0 || dim <= 0) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_bhattacharyya_kernel, dim3(grid_for((int64_t)n * m)), dim3(256), 0, (hipStream_t)stream, mu1,
+                     lv1, n, mu2, lv2, m, dim, out);
+  return (int)hipGetLastError();
+}
+
+int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int batch, int F, int E, uint64_t seed,
+                           uint32_t step, dib_stream_t stream) {
+  if (!eps || batch <= 0 || F <= 0 || E <= 0) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_eps_fill_kernel, dim3(grid_for((int64_t)batch * F * ((E + 3) / 4))), dim3(256), 0,
+                     (hipStream_t)stream, eps, (const int*)row_idx, (long long)row0, batch, F, E,
+                     (unsigned long long)seed, (unsigned)step);
+  return (int)hipGetLastError();
+}
+
+float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t feature, uint32_t e) {
+  float out[4];
+  dib_eps4(seed, step, row, feature, e >> 2, out);
+  return out[e & 3];
+}
+
+int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+             const float* bias, const float* aux, int ldaux, int act, void* dev_desc, dib_stream_t stream) {
+  if (!A || !B || !C || !dev_desc || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return DIB_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DibGemmGroup g = make_group(0, lda, 0, ldb, 0, ldc, bias ? 0 : -1, 0, ldaux, M, N, K);
+  if (((uintptr_t)A & 15) != 0) g.flags &= ~1;
+  if (((uintptr_t)B & 15) != 0) g.flags &= ~2;
+  hipError_t e = hipMemcpyAsync(dev_desc, &g, sizeof(g), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  const int tm = cdiv(M, DIB_BM), tn = cdiv(N, DIB_BN);
+  const DibGemmGroup* dg = (const DibGemmGroup*)dev_desc;
+  if (mode == 0)
+    hipLaunchKernelGGL((dib_gemm_kernel<0>), dim3(tm, tn, 1), dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr,
+                       0, act, tn, 0, 0ll);
+  else if (mode == 1)
+    hipLaunchKernelGGL((dib_gemm_kernel<1>), dim3(tm, tn, 1), dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr,
+                       0, act, tn, 0, 0ll);
+  else  // single split over the whole contraction; bias (if given) receives the column sums of B
+    hipLaunchKernelGGL((dib_gemm_kernel<2>), dim3(1, tm * tn, 1), dim3(256), 0, st, dg, A, B, C, (const float*)nullptr,
+                       aux, (float*)bias, 0, act, tn, K, 0ll);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// dib_common.h - shared host/device helpers for the gfx950 Distributed-IB kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DIB_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator + Box-Muller.  The reference samples eps with the stateful
+// tf.random.normal (reference models.py:108); here eps is a pure function of
+// (seed, step, global row, feature, dim) so forward, backward (which regenerates it instead of
+// stashing 8 KB/sample), the CPU oracle (oracle/dib_oracle.py:philox_normal) and every
+// data-parallel sharding agree.
+// ---------------------------------------------------------------------------------------------
+struct dib_u4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline uint32_t dib_mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+__host__ __device__ inline dib_u4 dib_philox4x32_10(dib_u4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = dib_mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = dib_mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    dib_u4 n;
+    n.x = hi1 ^ c.y ^ k0;
+    n.y = lo1;
+    n.z = hi0 ^ c.w ^ k1;
+    n.w = lo0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// 4 standard normals for dims e = 4*blk .. 4*blk+3 of (row, feature) at `step`.
+__host__ __device__ inline void dib_eps4(uint64_t seed, uint32_t step, uint32_t row, uint32_t feature,
+                                         uint32_t blk, float out[4]) {
+  dib_u4 c = {row, feature, blk, step};
+  dib_u4 r = dib_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float s = 1.0f / 16777216.0f;
+  const float u0 = ((float)(r.x >> 8) + 0.5f) * s;
+  const float u1 = ((float)(r.y >> 8) + 0.5f) * s;
+  const float u2 = ((float)(r.z >> 8) + 0.5f) * s;
+  const float u3 = ((float)(r.w >> 8) + 0.5f) * s;
+  const float r0 = sqrtf(-2.0f * logf(u0));
+  const float r1 = sqrtf(-2.0f * logf(u2));
+  float s0, c0, s1, c1;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincospif(2.0f * u1, &s0, &c0);  // exact range reduction: angle = 2*pi*u
+  sincospif(2.0f * u3, &s1, &c1);
+#else
+  s0 = sinf(6.283185307179586f * u1); c0 = cosf(6.283185307179586f * u1);
+  s1 = sinf(6.283185307179586f * u3); c1 = cosf(6.283185307179586f * u3);
+#endif
+  out[0] = r0 * c0;
+  out[1] = r0 * s0;
+  out[2] = r1 * c1;
+  out[3] = r1 * s1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Activations.  ids match include/dib_hip.h.  Derivatives are expressed through the activation
+// OUTPUT so that only post-activation tensors are stashed.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dib_act(int act, float z) {
+  switch (act) {
+    case 1: return fmaxf(z, 0.0f);
+    case 2: return z > 0.0f ? z : 0.2f * z;
+    case 3: return tanhf(z);
+    case 4: return 1.0f / (1.0f + expf(-z));
+    case 5: return z > 0.0f ? z : expm1f(z);
+    case 6: return fmaxf(z, 0.0f) + log1pf(expf(-fabsf(z)));
+    default: return z;
+  }
+}
+
+__device__ __forceinline__ float dib_act_grad(int act, float y) {
+  switch (act) {
+    case 1: return y > 0.0f ? 1.0f : 0.0f;
+    case 2: return y > 0.0f ? 1.0f : 0.2f;
+    case 3: return 1.0f - y * y;
+    case 4: return y * (1.0f - y);
+    case 5: return y > 0.0f ? 1.0f : y + 1.0f;
+    case 6: return 1.0f - expf(-y);
+    default: return 1.0f;
+  }
+}
+
+// 64-lane wavefront sum (all lanes get the result)
+__device__ __forceinline__ float dib_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in thread 0. `red` = 4 floats of LDS.
+__device__ __forceinline__ float dib_block_sum_256(float v, float* red) {
+  v = dib_wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}

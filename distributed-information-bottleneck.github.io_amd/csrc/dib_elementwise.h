@@ -1,0 +1,338 @@
+// dib_elementwise.h - the HBM-bound kernels of the Distributed-IB path (gfx950).
+//   positional encoding (+ batch gather), fused Gaussian reparameterisation + KL-to-unit-prior,
+//   its backward, task losses, metric accumulation, split-batch gradient reduce, Keras-Adam.
+#pragma once
+#include "dib_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Positional encoding, reference models.py:22-23:  concat([x] + [sin(f*x) for f in freqs], -1)
+// (blockwise layout) fused with tf.split (models.py:101) and the shuffled-batch gather.
+// colmap[c] = {feature, local column, d_f, first encoder-input column of the feature}.
+// P[b, poff + j*d_f + c_local] = (j==0 ? x : sin(2^j * x)),  x = X[row(b), xcol0 + c]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restrict__ row_idx, long long row0,
+                  int batch, const int4* __restrict__ colmap, int ncols, int n_blocks /*1 + n sinusoids*/,
+                  float* __restrict__ P, long long ldp) {
+  const long long total = (long long)batch * ncols;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / ncols), c = (int)(i - (long long)b * ncols);
+    const long long row = row_idx ? (long long)row_idx[b] : row0 + b;
+    const float x = X[row * ldx + c];
+    const int4 cm = colmap[c];
+    float* dst = P + (long long)b * ldp + cm.w + cm.y;
+    dst[0] = x;
+    float fr = 2.0f;
+    for (int j = 1; j < n_blocks; ++j) {
+      dst[(long long)j * cm.z] = sinf(fr * x);  // accurate sinf (range-reduced), |fr*x| can reach ~100
+      fr *= 2.0f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused reparameterisation + KL, reference models.py:106-112:
+//   mu, logvar = split(enc_out_f, 2) ; u = mu + exp(logvar/2)*eps ; KL_f = mean_b sum_e 0.5(mu^2+e^lv-lv-1)
+// One block = (row tile, feature); thread = (row, 4 consecutive dims) -> one Philox call.
+// KL partial sums are written per block (second stage sums them in a fixed order: deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_reparam_kl_fwd_kernel(const float* __restrict__ enc_out, float* __restrict__ U, float* __restrict__ kl_partial,
+                          const int* __restrict__ row_idx, long long row0, int batch, int F, int E,
+                          unsigned long long seed, unsigned step, int deterministic) {
+  __shared__ float red[4];
+  const int E4 = (E + 3) >> 2;
+  const int rows_per_block = 256 / E4;
+  const int f = blockIdx.y;
+  const int r = threadIdx.x / E4, q = threadIdx.x - r * E4;
+  const int b = blockIdx.x * rows_per_block + r;
+  float klp = 0.f;
+  if (r < rows_per_block && b < batch) {
+    const long long grow = row_idx ? (long long)row_idx[b] : row0 + b;
+    const float* mu_p = enc_out + (long long)b * (2ll * F * E) + 2ll * f * E + 4 * q;
+    const float* lv_p = mu_p + E;
+    float* u_p = U + (long long)b * ((long long)F * E) + (long long)f * E + 4 * q;
+    float eps[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!deterministic) dib_eps4(seed, step, (uint32_t)grow, (uint32_t)f, (uint32_t)q, eps);
+    if ((E & 3) == 0) {
+      const float4 mu = *reinterpret_cast<const float4*>(mu_p);
+      const float4 lv = *reinterpret_cast<const float4*>(lv_p);
+      float4 u;
+      u.x = mu.x + expf(0.5f * lv.x) * eps[0];
+      u.y = mu.y + expf(0.5f * lv.y) * eps[1];
+      u.z = mu.z + expf(0.5f * lv.z) * eps[2];
+      u.w = mu.w + expf(0.5f * lv.w) * eps[3];
+      *reinterpret_cast<float4*>(u_p) = u;
+      klp = 0.5f * ((mu.x * mu.x + expf(lv.x) - lv.x - 1.f) + (mu.y * mu.y + expf(lv.y) - lv.y - 1.f) +
+                    (mu.z * mu.z + expf(lv.z) - lv.z - 1.f) + (mu.w * mu.w + expf(lv.w) - lv.w - 1.f));
+    } else {
+      for (int j = 0; j < 4; ++j) {
+        if (4 * q + j < E) {
+          const float mu = mu_p[j], lv = lv_p[j];
+          u_p[j] = mu + expf(0.5f * lv) * eps[j];
+          klp += 0.5f * (mu * mu + expf(lv) - lv - 1.f);
+        }
+      }
+    }
+  }
+  const float tot = dib_block_sum_256(klp, red);
+  if (threadIdx.x == 0) kl_partial[(long long)blockIdx.x * F + f] = tot;
+}
+
+// second stage: out[f] = sum_blocks partial[blk][f]   (one block per feature, fixed order)
+__global__ void __launch_bounds__(256)
+dib_colsum_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int f = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[(long long)i * stride + f];
+  const float tot = dib_block_sum_256(s, red);
+  if (threadIdx.x == 0) out[f] = tot;
+}
+
+// Backward of reparam + KL (what tape.gradient derives from models.py:108,111-112,118):
+//   dmu = g_u + beta*mu/Bg ;  dlogvar = g_u*eps*0.5*exp(lv/2) + beta*0.5*(exp(lv)-1)/Bg
+// eps is regenerated from the counter (never stored).
+__global__ void __launch_bounds__(256)
+dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __restrict__ GU,
+                          float* __restrict__ dout, const float* __restrict__ beta_dev, float inv_bg,
+                          const int* __restrict__ row_idx, long long row0, int batch, int F, int E,
+                          unsigned long long seed, unsigned step) {
+  const int E4 = (E + 3) >> 2;
+  const int rows_per_block = 256 / E4;
+  const int f = blockIdx.y;
+  const int r = threadIdx.x / E4, q = threadIdx.x - r * E4;
+  const int b = blockIdx.x * rows_per_block + r;
+  if (r >= rows_per_block || b >= batch) return;
+  const float kb = beta_dev[0] * inv_bg;
+  const long long grow = row_idx ? (long long)row_idx[b] : row0 + b;
+  const long long o = (long long)b * (2ll * F * E) + 2ll * f * E + 4 * q;
+  const float* gu_p = GU + (long long)b * ((long long)F * E) + (long long)f * E + 4 * q;
+  float eps[4];
+  dib_eps4(seed, step, (uint32_t)grow, (uint32_t)f, (uint32_t)q, eps);
+  if ((E & 3) == 0) {
+    const float4 mu = *reinterpret_cast<const float4*>(enc_out + o);
+    const float4 lv = *reinterpret_cast<const float4*>(enc_out + o + E);
+    const float4 gu = *reinterpret_cast<const float4*>(gu_p);
+    float4 dm, dl;
+    dm.x = gu.x + kb * mu.x; dm.y = gu.y + kb * mu.y; dm.z = gu.z + kb * mu.z; dm.w = gu.w + kb * mu.w;
+    dl.x = gu.x * eps[0] * 0.5f * expf(0.5f * lv.x) + kb * 0.5f * (expf(lv.x) - 1.f);
+    dl.y = gu.y * eps[1] * 0.5f * expf(0.5f * lv.y) + kb * 0.5f * (expf(lv.y) - 1.f);
+    dl.z = gu.z * eps[2] * 0.5f * expf(0.5f * lv.z) + kb * 0.5f * (expf(lv.z) - 1.f);
+    dl.w = gu.w * eps[3] * 0.5f * expf(0.5f * lv.w) + kb * 0.5f * (expf(lv.w) - 1.f);
+    *reinterpret_cast<float4*>(dout + o) = dm;
+    *reinterpret_cast<float4*>(dout + o + E) = dl;
+  } else {
+    for (int j = 0; j < 4; ++j) {
+      if (4 * q + j < E) {
+        const float mu = enc_out[o + j], lv = enc_out[o + E + j], gu = gu_p[j];
+        dout[o + j] = gu + kb * mu;
+        dout[o + E + j] = gu * eps[j] * 0.5f * expf(0.5f * lv) + kb * 0.5f * (expf(lv) - 1.f);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+dib_eps_fill_kernel(float* __restrict__ eps_out, const int* __restrict__ row_idx, long long row0, int batch, int F,
+                    int E, unsigned long long seed, unsigned step) {
+  const int E4 = (E + 3) >> 2;
+  const long long total = (long long)batch * F * E4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % E4);
+    const int f = (int)((i / E4) % F);
+    const int b = (int)(i / ((long long)E4 * F));
+    const long long grow = row_idx ? (long long)row_idx[b] : row0 + b;
+    float e[4];
+    dib_eps4(seed, step, (uint32_t)grow, (uint32_t)f, (uint32_t)q, e);
+    for (int j = 0; j < 4; ++j)
+      if (4 * q + j < E) eps_out[((long long)b * F + f) * E + 4 * q + j] = e[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Task loss + its gradient wrt the model output (Keras semantics).
+//   kind 0: BinaryCrossentropy(from_logits=True) (reference data.py:65): max(z,0) - z*y + log1p(exp(-|z|))
+//   kind 1: BinaryCrossentropy on probabilities (clip 1e-7)
+//   kind 2: SparseCategoricalCrossentropy(from_logits=True) (reference data.py:343)
+//   kind 3: 'mse'
+// One thread per batch row.  Writes g_pred (already multiplied by act'(pred) of the output
+// activation), per-block partial {loss sum, #correct}.  inv_bg = 1/B_global.
+// 'accuracy' follows Keras: 1-unit output -> binary accuracy thresholding the raw output at 0.5,
+// sparse labels -> argmax match.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_loss_kernel(int kind, const float* __restrict__ pred, int out_dim, const float* __restrict__ Y, long long ldy,
+                const int* __restrict__ row_idx, long long row0, int batch, float inv_bg, int out_act,
+                float* __restrict__ g_pred, float* __restrict__ partial /*[gridDim.x][2]*/) {
+  __shared__ float red[4];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  float lsum = 0.f, correct = 0.f;
+  if (b < batch) {
+    const long long row = row_idx ? (long long)row_idx[b] : row0 + b;
+    const float* p = pred + (long long)b * out_dim;
+    float* g = g_pred + (long long)b * out_dim;
+    const float* y = Y + row * ldy;
+    if (kind == 0 || kind == 1 || kind == 3) {
+      const float sc = inv_bg / (float)out_dim;
+      float nright = 0.f;
+      for (int o = 0; o < out_dim; ++o) {
+        const float z = p[o], yy = y[o];
+        float l, gg;
+        if (kind == 0) {
+          l = fmaxf(z, 0.f) - z * yy + log1pf(expf(-fabsf(z)));
+          gg = 1.0f / (1.0f + expf(-z)) - yy;
+        } else if (kind == 1) {
+          const float pc = fminf(fmaxf(z, 1e-7f), 1.0f - 1e-7f);
+          l = -(yy * logf(pc) + (1.f - yy) * logf(1.f - pc));
+          gg = (z < 1e-7f || z > 1.0f - 1e-7f) ? 0.f : (-(yy / pc) + (1.f - yy) / (1.f - pc));
+        } else {
+          const float d = z - yy;
+          l = d * d;
+          gg = 2.f * d;
+        }
+        lsum += l;
+        g[o] = gg * sc * dib_act_grad(out_act, z);
+        nright += ((z > 0.5f ? 1.f : 0.f) == yy) ? 1.f : 0.f;
+      }
+      lsum /= (float)out_dim;
+      correct = nright / (float)out_dim;
+    } else {  // sparse categorical cross-entropy from logits
+      const int lab = (int)y[0];
+      float m = -INFINITY;
+      int am = 0;
+      for (int o = 0; o < out_dim; ++o)
+        if (p[o] > m) { m = p[o]; am = o; }
+      float se = 0.f;
+      for (int o = 0; o < out_dim; ++o) se += expf(p[o] - m);
+      const float lse = m + logf(se);
+      lsum = lse - p[lab];
+      for (int o = 0; o < out_dim; ++o) g[o] = (expf(p[o] - lse) - (o == lab ? 1.f : 0.f)) * inv_bg;
+      correct = (am == lab) ? 1.f : 0.f;
+    }
+  }
+  const float tl = dib_block_sum_256(lsum, red);
+  const float tc = dib_block_sum_256(correct, red);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = tl;
+    partial[2 * blockIdx.x + 1] = tc;
+  }
+}
+
+// step_out layout: [0..F) KL local sums, [F] task-loss local sum, [F+1] #correct, [F+2] rows
+// metrics_acc[f]   += KL_f_sum * inv_bg                       (History 'KL{f}', reference models.py:115)
+// metrics_acc[F]   += task_sum + beta * sum_f KL_f_sum        ('loss' incl. beta*KL, models.py:118)
+// metrics_acc[F+1] += #correct ; metrics_acc[F+2] += rows
+__global__ void dib_metrics_accumulate_kernel(const float* __restrict__ step_out, int F, const float* beta_dev,
+                                              float inv_bg, float* __restrict__ acc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < F) acc[i] += step_out[i] * inv_bg;
+  if (i == F) {
+    float s = 0.f;
+    for (int f = 0; f < F; ++f) s += step_out[f];
+    acc[F] += step_out[F] + beta_dev[0] * s;
+  }
+  if (i == F + 1) acc[F + 1] += step_out[F + 1];
+  if (i == F + 2) acc[F + 2] += step_out[F + 2];
+}
+
+__global__ void dib_set_scalar_kernel(float* p, float v) { p[0] = v; }
+
+// grads[i] = sum_s partial[s][i]   (fixed order)
+__global__ void __launch_bounds__(256)
+dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsplit, float* __restrict__ out) {
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(partial)[i];
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(partial + (long long)k * n)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * n + i];
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Keras Adam (reference train.py:128-129 tf.keras.optimizers.get('adam')):
+//   m += (1-b1)(g-m); v += (1-b2)(g^2-v); theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)
+// t = *t_dev + 1 (device counter, bumped by dib_bump_counter_kernel afterwards).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                long long n, const float* __restrict__ lr_dev, const long long* __restrict__ t_dev, float b1,
+                float b2, float eps, float gscale) {
+  const float t = (float)(t_dev[0] + 1);
+  const float lr_t = lr_dev[0] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    gg.x *= gscale; gg.y *= gscale; gg.z *= gscale; gg.w *= gscale;
+    mm.x += (1.f - b1) * (gg.x - mm.x); vv.x += (1.f - b2) * (gg.x * gg.x - vv.x);
+    mm.y += (1.f - b1) * (gg.y - mm.y); vv.y += (1.f - b2) * (gg.y * gg.y - vv.y);
+    mm.z += (1.f - b1) * (gg.z - mm.z); vv.z += (1.f - b2) * (gg.z * gg.z - vv.z);
+    mm.w += (1.f - b1) * (gg.w - mm.w); vv.w += (1.f - b2) * (gg.w * gg.w - vv.w);
+    pp.x -= lr_t * mm.x / (sqrtf(vv.x) + eps);
+    pp.y -= lr_t * mm.y / (sqrtf(vv.y) + eps);
+    pp.z -= lr_t * mm.z / (sqrtf(vv.z) + eps);
+    pp.w -= lr_t * mm.w / (sqrtf(vv.w) + eps);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    const float gg = g[i] * gscale;
+    const float mm = m[i] + (1.f - b1) * (gg - m[i]);
+    const float vv = v[i] + (1.f - b2) * (gg * gg - v[i]);
+    m[i] = mm;
+    v[i] = vv;
+    p[i] -= lr_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+__global__ void dib_bump_counter_kernel(long long* t) { t[0] += 1; }
+
+__global__ void __launch_bounds__(256)
+dib_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, long long n, const float* __restrict__ lr_dev,
+               float gscale) {
+  const float lr = lr_dev[0] * gscale;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] -= lr * g[i];
+}
+
+// Bhattacharyya distance between diagonal Gaussians (reference utils.py:177-212; closed form instead of the
+// reference's dense [N,M,d,d] diagonal matrices): D = 1/8 sum dmu^2/sbar + 1/2 sum ln(sbar) - 1/4 (sum lv1 + sum lv2)
+__global__ void __launch_bounds__(256)
+dib_bhattacharyya_kernel(const float* __restrict__ mu1, const float* __restrict__ lv1, int n,
+                         const float* __restrict__ mu2, const float* __restrict__ lv2, int m, int dim,
+                         float* __restrict__ out) {
+  const long long total = (long long)n * m;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / m), j = (int)(idx - (long long)i * m);
+    float t1 = 0.f, t2 = 0.f;
+    for (int e = 0; e < dim; ++e) {
+      const float a = mu1[(long long)i * dim + e], b = mu2[(long long)j * dim + e];
+      const float la = lv1[(long long)i * dim + e], lb = lv2[(long long)j * dim + e];
+      const float sb = 0.5f * (expf(la) + expf(lb));
+      const float d = a - b;
+      t1 += d * d / sb;
+      t2 += logf(sb) - 0.5f * (la + lb);
+    }
+    out[idx] = 0.125f * t1 + 0.5f * t2;
+  }
+}

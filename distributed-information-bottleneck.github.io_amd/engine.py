@@ -1,0 +1,268 @@
+"""HipEngine: device state + launch sequencing of the Distributed-IB step on one MI355X.
+
+PyTorch is used only as plumbing (device memory, streams, torch.distributed); every FLOP of the
+path runs in libdib_hip.so (hand-written HIP for gfx950) through the C ABI in include/dib_hip.h.
+There is no CPU / eager fallback: constructing a HipEngine without a GPU or without the library
+raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from ctypes import byref, c_int, c_int64, c_void_p
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACTIVATIONS, LOSS_KINDS, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+class HipEngine:
+    """Owns the flat parameter / gradient / Adam buffers and the activation workspace.
+
+    The architecture arguments mirror DistributedIBNet.__init__ (reference models.py:56-66).
+    """
+
+    def __init__(self, feature_dimensionalities: Sequence[int], feature_encoder_architecture: Sequence[int],
+                 integration_network_architecture: Sequence[int], output_dimensionality: int,
+                 use_positional_encoding: bool = True, number_positional_encoding_frequencies: int = 5,
+                 activation_fn: Optional[str] = "relu", feature_embedding_dimension: int = 32,
+                 output_activation_fn: Optional[str] = None, device: Optional[str] = None, init_seed: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs an AMD GPU (torch.cuda.is_available() is False); "
+                               "the Distributed-IB path has no CPU fallback")
+        self.lib = _lib.load_library()
+        if activation_fn not in ACTIVATIONS or output_activation_fn not in ACTIVATIONS:
+            raise ValueError(f"unsupported activation {activation_fn!r}/{output_activation_fn!r}; "
+                             f"supported: {sorted(k for k in ACTIVATIONS if isinstance(k, str))}")
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.F = len(feature_dimensionalities)
+        self.E = int(feature_embedding_dimension)
+        self.dims = [int(d) for d in feature_dimensionalities]
+        self.sum_d = sum(self.dims)
+        self.out_dim = int(output_dimensionality)
+        self.enc_units = [int(u) for u in feature_encoder_architecture]
+        self.int_units = [int(u) for u in integration_network_architecture]
+        ci = lambda xs: (c_int * max(1, len(xs)))(*xs)
+        handle = c_void_p()
+        check(self.lib.dib_layout_create(self.F, ci(self.dims), len(self.enc_units), ci(self.enc_units), self.E,
+                                         len(self.int_units), ci(self.int_units), self.out_dim,
+                                         1 if use_positional_encoding else 0,
+                                         int(number_positional_encoding_frequencies), ACTIVATIONS[activation_fn],
+                                         ACTIVATIONS[output_activation_fn], byref(handle)), "dib_layout_create")
+        self.layout = handle
+        self.n_params = int(self.lib.dib_layout_param_count(self.layout))
+        n_alloc = (self.n_params + 3) // 4 * 4
+        with torch.cuda.device(self.device):
+            z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
+            self.params, self.grads, self.adam_m, self.adam_v = z(n_alloc), z(n_alloc), z(n_alloc), z(n_alloc)
+            self.beta_dev = torch.ones(1, dtype=torch.float32, device=self.device)  # reference models.py:86
+            self.lr_dev = torch.full((1,), 1e-3, dtype=torch.float32, device=self.device)
+            self.t_dev = z(1, torch.int64)
+            self.metrics_acc = z(self.F + 3)
+            tb = int(self.lib.dib_layout_table_bytes(self.layout))
+            self._tables = torch.zeros(tb, dtype=torch.uint8, device=self.device)
+            check(self.lib.dib_layout_upload_tables(self.layout, _ptr(self._tables), self._stream()),
+                  "dib_layout_upload_tables")
+            torch.cuda.synchronize(self.device)
+        self._ws: Dict[int, torch.Tensor] = {}
+        self.blocks = self._query_blocks()
+        self.set_flat_params(self.glorot_uniform(init_seed))
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    def _stream(self):
+        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __del__(self):
+        try:
+            if getattr(self, "layout", None):
+                self.lib.dib_layout_destroy(self.layout)
+                self.layout = None
+        except Exception:
+            pass
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        ws = self._ws.get(batch)
+        if ws is None:
+            nbytes = int(self.lib.dib_workspace_bytes(self.layout, batch))
+            if nbytes <= 0:
+                raise _lib.DibError(f"dib_workspace_bytes({batch}) -> {nbytes}")
+            # zero-filled: alignment gaps of the split-batch gradient slabs are summed by dib_grads_finalize
+            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
+            if len(self._ws) >= 4:  # keep the most recent few batch sizes (train, tail, validation, ...)
+                self._ws.pop(next(iter(self._ws)))
+            self._ws[batch] = ws
+        return ws
+
+    def ws_view(self, batch: int, which: int, numel: int) -> torch.Tensor:
+        off = int(self.lib.dib_workspace_offset(self.layout, batch, which))
+        if off < 0:
+            raise _lib.DibError(f"dib_workspace_offset -> {off}")
+        return self.workspace(batch)[off // 4: off // 4 + numel]
+
+    def _query_blocks(self) -> List[dict]:
+        out = []
+        off, rows, cols = c_int64(), c_int(), c_int()
+        for net, nl in ((0, len(self.enc_units) + 1), (1, len(self.int_units) + 1)):
+            for layer in range(nl):
+                for f in (range(self.F) if net == 0 else [0]):
+                    for what in (0, 1):
+                        check(self.lib.dib_layout_param_block(self.layout, net, layer, f, what, byref(off), byref(rows),
+                                                              byref(cols)), "dib_layout_param_block")
+                        out.append(dict(net=net, layer=layer, feature=f, what=what, offset=off.value, rows=rows.value,
+                                        cols=cols.value))
+        return out
+
+    def glorot_uniform(self, seed: int) -> np.ndarray:
+        """Keras Dense defaults: kernel U(+-sqrt(6/(in+out))), bias zeros."""
+        rng = np.random.default_rng(seed)
+        flat = np.zeros(self.params.numel(), dtype=np.float32)
+        for b in self.blocks:
+            if b["what"] == 0:
+                lim = math.sqrt(6.0 / (b["rows"] + b["cols"]))
+                n = b["rows"] * b["cols"]
+                flat[b["offset"]: b["offset"] + n] = rng.uniform(-lim, lim, size=n).astype(np.float32)
+        return flat
+
+    def set_flat_params(self, flat: np.ndarray) -> None:
+        flat = np.asarray(flat, dtype=np.float32).reshape(-1)
+        buf = np.zeros(self.params.numel(), dtype=np.float32)
+        buf[: min(len(flat), len(buf))] = flat[: len(buf)]
+        self.params.copy_(torch.from_numpy(buf))
+
+    def get_flat_params(self) -> np.ndarray:
+        return self.params.detach().cpu().numpy().copy()
+
+    def get_flat_grads(self) -> np.ndarray:
+        return self.grads.detach().cpu().numpy().copy()
+
+    def reset_optimizer(self) -> None:
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.t_dev.zero_()
+
+    def set_beta(self, v: float) -> None:
+        self.beta_dev.fill_(float(v))
+
+    def get_beta(self) -> float:
+        return float(self.beta_dev.item())
+
+    def set_lr(self, v: float) -> None:
+        self.lr_dev.fill_(float(v))
+
+    def to_device(self, a, dtype=torch.float32) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a))).to(device=self.device, dtype=dtype).contiguous()
+
+    # ---- the step -------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, row_idx: Optional[torch.Tensor], row0: int, batch: int, seed: int, step: int,
+                deterministic: bool = False) -> None:
+        """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT]."""
+        ws = self.workspace(batch)
+        st = self._stream()
+        check(self.lib.dib_encoder_bank_fwd(self.layout, _ptr(x), x.stride(0), _ptr(row_idx), int(row0), batch,
+                                            _ptr(self.params), int(seed), int(step) & 0xFFFFFFFF,
+                                            1 if deterministic else 0, _ptr(ws), st), "dib_encoder_bank_fwd")
+        check(self.lib.dib_integration_fwd(self.layout, batch, _ptr(self.params), _ptr(ws), st), "dib_integration_fwd")
+
+    def loss(self, loss_kind: str, y: torch.Tensor, row_idx, row0: int, batch: int, inv_global_batch: float) -> None:
+        ws = self.workspace(batch)
+        check(self.lib.dib_loss_fwd_bwd(self.layout, LOSS_KINDS[loss_kind], _ptr(y), y.stride(0), _ptr(row_idx),
+                                        int(row0), batch, float(inv_global_batch), _ptr(ws), self._stream()),
+              "dib_loss_fwd_bwd")
+
+    def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float) -> None:
+        ws = self.workspace(batch)
+        st = self._stream()
+        check(self.lib.dib_integration_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st),
+              "dib_integration_bwd")
+        check(self.lib.dib_encoder_bank_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads),
+                                            _ptr(self.beta_dev), float(inv_global_batch), _ptr(row_idx), int(row0),
+                                            int(seed), int(step) & 0xFFFFFFFF, _ptr(ws), st), "dib_encoder_bank_bwd")
+        check(self.lib.dib_grads_finalize(self.layout, batch, _ptr(self.grads), _ptr(ws), st), "dib_grads_finalize")
+
+    def accumulate_metrics(self, batch: int, inv_global_batch: float) -> None:
+        check(self.lib.dib_metrics_accumulate(self.layout, batch, _ptr(self.beta_dev), float(inv_global_batch),
+                                              _ptr(self.metrics_acc), _ptr(self.workspace(batch)), self._stream()),
+              "dib_metrics_accumulate")
+
+    def train_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
+                   inv_global_batch: Optional[float] = None, accumulate: bool = True) -> None:
+        """fwd + loss + bwd for the local rows; grads (partial sums over local rows / B_global) land in
+        self.grads, ready for the data-parallel all-reduce(sum) and the optimizer step."""
+        inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
+        self.forward(x, row_idx, row0, batch, seed, step)
+        self.loss(loss_kind, y, row_idx, row0, batch, inv)
+        self.backward(row_idx, row0, batch, seed, step, inv)
+        if accumulate:
+            self.accumulate_metrics(batch, inv)
+
+    def eval_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
+                  inv_global_batch: Optional[float] = None) -> None:
+        """validation: noise stays ON and the KL term is included (reference train.py:263-265)."""
+        inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
+        self.forward(x, row_idx, row0, batch, seed, step)
+        self.loss(loss_kind, y, row_idx, row0, batch, inv)
+        self.accumulate_metrics(batch, inv)
+
+    def adam_step(self, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0) -> None:
+        check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                     self.n_params, _ptr(self.lr_dev), _ptr(self.t_dev), beta1, beta2, eps,
+                                     float(grad_scale), self._stream()), "dib_adam_step")
+
+    def sgd_step(self, grad_scale=1.0) -> None:
+        check(self.lib.dib_sgd_step(_ptr(self.params), _ptr(self.grads), self.n_params, _ptr(self.lr_dev),
+                                    float(grad_scale), self._stream()), "dib_sgd_step")
+
+    def read_metrics(self, reset: bool = True) -> np.ndarray:
+        m = self.metrics_acc.detach().cpu().numpy().astype(np.float64)
+        if reset:
+            self.metrics_acc.zero_()
+        return m
+
+    # ---- views / helpers ---------------------------------------------------------------------
+    def pred(self, batch: int) -> torch.Tensor:
+        return self.ws_view(batch, _lib.WS_PRED, batch * self.out_dim).view(batch, self.out_dim)
+
+    def u(self, batch: int) -> torch.Tensor:
+        return self.ws_view(batch, _lib.WS_U, batch * self.F * self.E).view(batch, self.F * self.E)
+
+    def enc_out(self, batch: int) -> torch.Tensor:
+        return self.ws_view(batch, _lib.WS_ENC_OUT, batch * self.F * 2 * self.E).view(batch, self.F, 2 * self.E)
+
+    def g_u(self, batch: int) -> torch.Tensor:
+        return self.ws_view(batch, _lib.WS_G_U, batch * self.F * self.E).view(batch, self.F * self.E)
+
+    def step_out(self, batch: int) -> torch.Tensor:
+        return self.ws_view(batch, _lib.WS_STEP_OUT, self.F + 3)
+
+    def encode_feature(self, f: int, x_f) -> torch.Tensor:
+        """model.feature_encoders[f](x_f): deterministic [N, 2E] (reference models.py:183, visualization.py:31)."""
+        xf = self.to_device(x_f).reshape(-1, self.dims[f])
+        n = xf.shape[0]
+        out = torch.empty((n, 2 * self.E), dtype=torch.float32, device=self.device)
+        check(self.lib.dib_encode_deterministic(self.layout, int(f), _ptr(xf), n, _ptr(self.params), _ptr(out),
+                                                _ptr(self.workspace(n)), self._stream()), "dib_encode_deterministic")
+        return out
+
+    def bhattacharyya(self, mu1, lv1, mu2, lv2) -> torch.Tensor:
+        mu1, lv1, mu2, lv2 = [self.to_device(t) for t in (mu1, lv1, mu2, lv2)]
+        n, d = mu1.shape
+        m = mu2.shape[0]
+        out = torch.empty((n, m), dtype=torch.float32, device=self.device)
+        check(self.lib.dib_bhattacharyya(_ptr(mu1), _ptr(lv1), n, _ptr(mu2), _ptr(lv2), m, d, _ptr(out),
+                                         self._stream()), "dib_bhattacharyya")
+        return out
+
+    def eps(self, row_idx, row0: int, batch: int, seed: int, step: int) -> torch.Tensor:
+        out = torch.empty((batch, self.F, self.E), dtype=torch.float32, device=self.device)
+        check(self.lib.dib_philox_normal_fill(_ptr(out), _ptr(row_idx), int(row0), batch, self.F, self.E, int(seed),
+                                              int(step) & 0xFFFFFFFF, self._stream()), "dib_philox_normal_fill")
+        return out

@@ -1,0 +1,150 @@
+/*
+ * dib_hip.h - C ABI of libdib_hip.so: the MI355X (gfx950) Distributed-IB training hot path.
+ *
+ * The reference (distributed-information-bottleneck.github.io @ 2024_10_08) has NO FFI on this
+ * path: its boundary is the Python/Keras object surface.  This header is the
+ * C boundary beneath the Python mirror of that surface; each entry point cites the reference
+ * code (file:line under /root/reference) whose device math it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C"; every entry returns int: 0 = DIB_OK, negative = DIB_E_*, positive = hipError_t.
+ *   - Never throws, never allocates or frees device memory: the caller owns every buffer,
+ *     including the workspace (size from dib_workspace_bytes) and the descriptor tables
+ *     (size from dib_layout_table_bytes).
+ *   - Work is enqueued on the caller's hipStream_t; entry points return without synchronising
+ *     and use no hipMalloc/hipFree/hipDeviceSynchronize (hipGraph-capturable).
+ *   - All tensors are float32, row-major, contiguous unless a leading dimension is given.
+ *   - Parameters live in ONE flat float32 buffer described by the dib_layout (Keras [in,out]
+ *     kernel orientation, y = x @ W + b); gradients / Adam moments use the same layout, which
+ *     is also the RCCL all-reduce bucket.
+ *   - beta, learning-rate and the Adam step counter are DEVICE scalars (mirrors tf.Variable,
+ *     models.py:86) so a captured step can be replayed while the host anneals beta.
+ */
+#ifndef DIB_HIP_H
+#define DIB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dib_layout dib_layout; /* opaque, host-side */
+typedef void* dib_stream_t;           /* hipStream_t */
+
+#define DIB_OK 0
+#define DIB_E_ARG (-1)
+#define DIB_E_SHAPE (-2)
+#define DIB_E_WORKSPACE (-3)
+#define DIB_E_UNSUPPORTED (-4)
+#define DIB_E_NODEVICE (-5)
+
+/* activation ids (Keras names: None/'linear', 'relu', 'leaky_relu', 'tanh', 'sigmoid', 'elu', 'softplus') */
+enum { DIB_ACT_LINEAR = 0, DIB_ACT_RELU = 1, DIB_ACT_LEAKY_RELU = 2, DIB_ACT_TANH = 3,
+       DIB_ACT_SIGMOID = 4, DIB_ACT_ELU = 5, DIB_ACT_SOFTPLUS = 6 };
+
+/* loss kinds (data.py:65 BinaryCrossentropy(from_logits=True); data.py:343 SparseCategoricalCrossentropy;
+ * 'mse') */
+enum { DIB_LOSS_BCE_LOGITS = 0, DIB_LOSS_BCE = 1, DIB_LOSS_SPARSE_CCE_LOGITS = 2, DIB_LOSS_MSE = 3 };
+
+/* workspace sub-buffers addressable by the host (dib_workspace_offset) */
+enum { DIB_WS_U = 0,        /* [B, F*E]  sampled embeddings, models.py:108,122 */
+       DIB_WS_PRED = 1,     /* [B, out]  model output, models.py:122 */
+       DIB_WS_ENC_OUT = 2,  /* [B, F*2E] (mu|logvar) per feature, models.py:106 */
+       DIB_WS_G_U = 3,      /* [B, F*E]  dL/du */
+       DIB_WS_STEP_OUT = 4, /* [F+3]     per-step scalars: KL_f local sums, task-loss sum, #correct, rows */
+       DIB_WS_G_PRED = 5    /* [B, out]  dL/dpred */ };
+
+const char* dib_version(void);
+const char* dib_error_string(int code);
+
+/* ---- layout ------------------------------------------------------------------------------
+ * Mirrors DistributedIBNet.__init__ (models.py:56-86): F feature encoders
+ * [PositionalEncoding] -> Dense(units,act)* -> Dense(2E), an integration MLP Dense(units,act)* ->
+ * Dense(out,out_act).  n_freq is `number_positional_encoding_frequencies` (models.py:62,70:
+ * frequencies 2**arange(1,n_freq)). */
+int dib_layout_create(int num_features, const int* feature_dims, int n_enc_layers, const int* enc_units,
+                      int embedding_dim, int n_int_layers, const int* int_units, int output_dim,
+                      int use_positional_encoding, int n_freq, int activation, int output_activation,
+                      dib_layout** out);
+void dib_layout_destroy(dib_layout* l);
+int64_t dib_layout_param_count(const dib_layout* l);
+/* net: 0 = feature encoder bank, 1 = integration network. what: 0 = kernel [rows=in, cols=out], 1 = bias [cols]. */
+int dib_layout_param_block(const dib_layout* l, int net, int layer, int feature, int what, int64_t* offset,
+                           int* rows, int* cols);
+/* device-resident GEMM group descriptor tables (batch-size independent) */
+int64_t dib_layout_table_bytes(const dib_layout* l);
+int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t stream);
+/* workspace (activations, activation gradients, split-batch wgrad partials) for local batch B */
+int64_t dib_workspace_bytes(const dib_layout* l, int batch);
+int64_t dib_workspace_offset(const dib_layout* l, int batch, int which); /* byte offset, <0 on error */
+int dib_layout_wgrad_splits(const dib_layout* l, int batch);
+
+/* ---- forward -----------------------------------------------------------------------------
+ * dib_encoder_bank_fwd replaces models.py:101-115: tf.split, PositionalEncoding.call (models.py:22-23),
+ * the per-feature Dense chains (models.py:73-78,106), tf.split(.,2,-1), the reparameterised sample
+ * (models.py:108) and the per-feature KL (models.py:111-112).
+ *   x       : dataset matrix [*, ldx]; the batch is rows row_idx[0..B) (or row0..row0+B if row_idx NULL)
+ *   eps     : keyed by (seed, step, GLOBAL row id, feature, dim) - Philox4x32-10 + Box-Muller, see
+ *             dib_philox_normal_ref; global row id = row_idx[b] (or row0 + b).
+ *   deterministic != 0 : u = mu (no noise) - used by dib_encode_deterministic-style evaluation.
+ * Writes ws[ENC_OUT], ws[U] and the F local KL sums (sum over local rows, not yet divided) into
+ * ws[STEP_OUT][0..F). */
+int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32_t* row_idx, int64_t row0,
+                         int batch, const float* params, uint64_t seed, uint32_t step, int deterministic,
+                         void* ws, dib_stream_t stream);
+/* models.py:122 integration_network(concat(u)) -> ws[PRED] */
+int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream);
+
+/* ---- loss + backward ---------------------------------------------------------------------
+ * Keras train_step (explicit form train.py:203-219): L = mean_b loss(y, pred) + beta * sum_f KL_f
+ * (models.py:118).  inv_global_batch = 1/B_global so that data-parallel ranks produce partial
+ * sums that all-reduce(sum) to the global-mean gradient.
+ * dib_loss_fwd_bwd: ws[PRED] -> ws[G_PRED]; task-loss sum and #correct into ws[STEP_OUT][F], [F+1]. */
+int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx,
+                     int64_t row0, int batch, float inv_global_batch, void* ws, dib_stream_t stream);
+int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* grads, void* ws,
+                        dib_stream_t stream);
+int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                         float inv_global_batch, const int32_t* row_idx, int64_t row0, uint64_t seed,
+                         uint32_t step, void* ws, dib_stream_t stream);
+/* reduce the split-batch wgrad partials into `grads` (fixed order => deterministic) */
+int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_stream_t stream);
+/* metrics_acc[F+3] += {KL_f_local_sum * inv_global_batch (F), task_sum + beta*sum_f KL_f_local_sum,
+ * #correct, rows}: the History accounting of models.py:115,121 / train.py:169-172 without a host sync */
+int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, float inv_global_batch,
+                           float* metrics_acc, void* ws, dib_stream_t stream);
+
+/* ---- optimizer ---------------------------------------------------------------------------
+ * Keras Adam (train.py:128-129): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps), eps=1e-7.
+ * t_dev is a device int64 counter holding the number of steps already applied; the call increments it. */
+int dib_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, const float* lr_dev,
+                  int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale, dib_stream_t stream);
+int dib_sgd_step(float* params, const float* grads, int64_t n, const float* lr_dev, float grad_scale,
+                 dib_stream_t stream);
+
+/* ---- evaluation helpers ------------------------------------------------------------------
+ * model.feature_encoders[f](x_f) (models.py:183, visualization.py:31): deterministic [N, 2E]. x_f is [N, d_f]. */
+int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n, const float* params,
+                             float* out, void* ws, dib_stream_t stream);
+/* Bhattacharyya distance matrix between diagonal Gaussians (utils.py:177-212), closed form. */
+int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu2, const float* lv2, int m,
+                      int dim, float* out, dib_stream_t stream);
+/* fill eps[B, F, E] exactly as the fused kernels generate it (test / oracle cross-check) */
+int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int batch, int num_features,
+                           int embedding_dim, uint64_t seed, uint32_t step, dib_stream_t stream);
+/* host-side reference of the same generator (float32 evaluation) - no GPU needed */
+float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t feature, uint32_t e);
+
+/* ---- raw grouped GEMM (exposed for tests/benchmarks of the dominant kernel) ----------------
+ * mode 0: C[M,N] = act(A[M,K] @ B[K,N] + bias)    mode 1: C[M,N] = (A[M,K] @ B[N,K]^T) * act'(aux)
+ * mode 2: C[K... see DESIGN.md; single group, fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+             int ldc, const float* bias, const float* aux, int ldaux, int act, void* dev_desc /* >=128 B */,
+             dib_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIB_HIP_H */

@@ -1,0 +1,74 @@
+"""Test helpers: oracle <-> flat-buffer mapping, spec zoo."""
+import numpy as np
+
+import dib_oracle as orc
+
+
+def spec_kwargs(spec: orc.DIBSpec):
+    return dict(feature_dimensionalities=list(spec.feature_dimensionalities),
+                feature_encoder_architecture=list(spec.feature_encoder_architecture),
+                integration_network_architecture=list(spec.integration_network_architecture),
+                output_dimensionality=spec.output_dimensionality,
+                use_positional_encoding=spec.use_positional_encoding,
+                number_positional_encoding_frequencies=spec.number_positional_encoding_frequencies,
+                activation_fn=spec.activation_fn, feature_embedding_dimension=spec.feature_embedding_dimension,
+                output_activation_fn=spec.output_activation_fn)
+
+
+def flat_to_params(blocks, flat, spec: orc.DIBSpec, dtype=np.float64) -> orc.DIBParams:
+    F = spec.number_features
+    nle = len(spec.feature_encoder_architecture) + 1
+    nli = len(spec.integration_network_architecture) + 1
+    enc_W = [[None] * nle for _ in range(F)]
+    enc_b = [[None] * nle for _ in range(F)]
+    int_W, int_b = [None] * nli, [None] * nli
+    for b in blocks:
+        n = b["rows"] * b["cols"]
+        v = np.asarray(flat[b["offset"]: b["offset"] + n], dtype=dtype)
+        if b["net"] == 0:
+            if b["what"] == 0:
+                enc_W[b["feature"]][b["layer"]] = v.reshape(b["rows"], b["cols"]).copy()
+            else:
+                enc_b[b["feature"]][b["layer"]] = v.copy()
+        else:
+            if b["what"] == 0:
+                int_W[b["layer"]] = v.reshape(b["rows"], b["cols"]).copy()
+            else:
+                int_b[b["layer"]] = v.copy()
+    return orc.DIBParams(enc_W, enc_b, int_W, int_b)
+
+
+def params_to_flat(blocks, params: orc.DIBParams, n_alloc: int) -> np.ndarray:
+    flat = np.zeros(n_alloc, dtype=np.float32)
+    for b in blocks:
+        if b["net"] == 0:
+            t = params.enc_W[b["feature"]][b["layer"]] if b["what"] == 0 else params.enc_b[b["feature"]][b["layer"]]
+        else:
+            t = params.int_W[b["layer"]] if b["what"] == 0 else params.int_b[b["layer"]]
+        flat[b["offset"]: b["offset"] + t.size] = np.asarray(t, dtype=np.float32).reshape(-1)
+    return flat
+
+
+def random_params(spec: orc.DIBSpec, seed=0, bias_scale=0.1) -> orc.DIBParams:
+    p = orc.glorot_uniform_init(spec, seed)
+    rng = np.random.default_rng(seed + 1000)
+    for t in p.tensors():
+        if t.ndim == 1:
+            t[:] = bias_scale * rng.standard_normal(t.shape)
+    return p
+
+
+# a zoo of architectures: BASELINE configs at reduced size + ragged / odd shapes
+SPECS = {
+    "boolean4_32x32": orc.DIBSpec([1, 1, 1, 1], [32, 32], [64, 64], 1, feature_embedding_dimension=32),
+    "pendulum_ragged": orc.DIBSpec([2, 1, 2, 1], [128, 128], [256, 256], 6, feature_embedding_dimension=32),
+    "odd_shapes_tanh": orc.DIBSpec([3, 5, 1], [17, 9], [13], 3, activation_fn="tanh", feature_embedding_dimension=6,
+                                   number_positional_encoding_frequencies=3),
+    "no_posenc_leaky": orc.DIBSpec([4, 2], [24], [20, 12], 2, use_positional_encoding=False,
+                                   activation_fn="leaky_relu", feature_embedding_dimension=8),
+    "ib_single_feature": orc.DIBSpec([10], [64, 64], [32], 1, feature_embedding_dimension=16),
+    "no_hidden": orc.DIBSpec([1, 1], [], [], 1, feature_embedding_dimension=4),
+    "tabular8_default": orc.DIBSpec([1] * 8, [128, 128], [256, 256], 1, feature_embedding_dimension=32),
+    "sigmoid_out_elu": orc.DIBSpec([2, 2], [16], [16], 1, activation_fn="elu", output_activation_fn="sigmoid",
+                                   feature_embedding_dimension=4),
+}

@@ -1,0 +1,110 @@
+"""TEST-ONLY engine: implements the engine interface of dib_amd.models on top of the CPU oracle, so
+that the host logic (fit loop, callbacks, History accounting, data-parallel sharding + all-reduce)
+can be exercised without a GPU.  Lives in tests/ - the product package never imports it."""
+import numpy as np
+import torch
+
+import dib_oracle as orc
+from _helpers import flat_to_params, params_to_flat
+
+
+class OracleEngine:
+    def __init__(self, init_seed=0, **spec_kw):
+        self.spec = orc.DIBSpec(**spec_kw)
+        self.F, self.E = self.spec.number_features, self.spec.feature_embedding_dimension
+        self.dims = list(self.spec.feature_dimensionalities)
+        self.out_dim = self.spec.output_dimensionality
+        self.device = torch.device("cpu")
+        # flat layout: same block order idea as the HIP layout (exact offsets are engine-private)
+        self.blocks, off = [], 0
+        nle = len(self.spec.feature_encoder_architecture) + 1
+        for l in range(nle):
+            for f in range(self.F):
+                i, o = self.spec.encoder_layer_dims(f)[l]
+                self.blocks.append(dict(net=0, layer=l, feature=f, what=0, offset=off, rows=i, cols=o)); off += i * o
+            for f in range(self.F):
+                o = self.spec.encoder_layer_dims(f)[l][1]
+                self.blocks.append(dict(net=0, layer=l, feature=f, what=1, offset=off, rows=1, cols=o)); off += o
+        for l, (i, o) in enumerate(self.spec.integration_layer_dims()):
+            self.blocks.append(dict(net=1, layer=l, feature=0, what=0, offset=off, rows=i, cols=o)); off += i * o
+            self.blocks.append(dict(net=1, layer=l, feature=0, what=1, offset=off, rows=1, cols=o)); off += o
+        self.n_params = off
+        self.p = orc.glorot_uniform_init(self.spec, init_seed)
+        self.params = torch.from_numpy(params_to_flat(self.blocks, self.p, off).astype(np.float64))
+        self.grads = torch.zeros(off, dtype=torch.float64)
+        self.metrics_acc = torch.zeros(self.F + 3, dtype=torch.float64)
+        self.state = orc.adam_init(self.p)
+        self.beta, self.lr = 1.0, 1e-3
+        self._pred = None
+
+    # plumbing
+    def to_device(self, a, dtype=torch.float32):
+        return a.to(dtype) if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+    def set_beta(self, v): self.beta = float(v)
+    def get_beta(self): return self.beta
+    def set_lr(self, v): self.lr = float(v)
+    def get_flat_params(self): return params_to_flat(self.blocks, self.p, self.n_params).astype(np.float64)
+
+    def set_flat_params(self, flat):
+        self.p = flat_to_params(self.blocks, np.asarray(flat, dtype=np.float64), self.spec)
+
+    def _rows(self, row_idx, row0, batch):
+        return row_idx.numpy().astype(np.int64) if row_idx is not None else np.arange(row0, row0 + batch)
+
+    def _fwd(self, x, row_idx, row0, batch, seed, step):
+        rows = self._rows(row_idx, row0, batch)
+        xb = x.numpy().astype(np.float64)[rows]
+        eps = orc.philox_normal_all(seed, step, rows.astype(np.uint32), self.F, self.E)
+        return rows, xb, orc.forward(self.spec, self.p, xb, eps)
+
+    def forward(self, x, row_idx, row0, batch, seed, step, deterministic=False):
+        _, _, c = self._fwd(x, row_idx, row0, batch, seed, step)
+        self._pred, self._kl = c.pred, c.kl
+
+    def pred(self, batch): return torch.from_numpy(self._pred)
+    def step_out(self, batch): return torch.from_numpy(np.concatenate([self._kl * batch, [0, 0, batch]]))
+
+    def _account(self, c, task, yb, kind, batch, inv):
+        acc = self.metrics_acc.numpy()
+        acc[: self.F] += c.kl * batch * inv
+        acc[self.F] += task * batch + self.beta * c.kl.sum() * batch
+        if kind != "mse":
+            acc[self.F + 1] += orc.accuracy(kind, yb, c.pred) * batch
+        acc[self.F + 2] += batch
+
+    def train_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None, accumulate=True):
+        inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
+        rows, xb, c = self._fwd(x, row_idx, row0, batch, seed, step)
+        yb = y.numpy()[rows]
+        task, g, _ = orc.backward(self.spec, self.p, xb, yb, c, self.beta, loss_kind,
+                                  loss_scale_rows=int(round(1.0 / inv)))
+        self.grads.copy_(torch.from_numpy(params_to_flat(self.blocks, g, self.n_params).astype(np.float64)))
+        self._gstruct = g
+        if accumulate:
+            self._account(c, task, yb, loss_kind, batch, inv)
+
+    def eval_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None):
+        inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
+        rows, xb, c = self._fwd(x, row_idx, row0, batch, seed, step)
+        yb = y.numpy()[rows]
+        task, _ = orc.loss_and_grad(loss_kind, yb, c.pred)
+        self._account(c, task, yb, loss_kind, batch, inv)
+
+    def adam_step(self, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        g = flat_to_params(self.blocks, self.grads.numpy() * grad_scale, self.spec)
+        orc.adam_keras_step(self.p, g, self.state, lr=self.lr, b1=beta1, b2=beta2, eps=eps)
+
+    def sgd_step(self, grad_scale=1.0):
+        g = flat_to_params(self.blocks, self.grads.numpy() * grad_scale, self.spec)
+        for p, gg in zip(self.p.tensors(), g.tensors()):
+            p -= self.lr * gg
+
+    def read_metrics(self, reset=True):
+        m = self.metrics_acc.numpy().copy()
+        if reset:
+            self.metrics_acc.zero_()
+        return m
+
+    def encode_feature(self, f, x_f):
+        return torch.from_numpy(orc.encode_feature(self.spec, self.p, f, np.asarray(x_f, dtype=np.float64)))

@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (float32 device arithmetic vs float64 oracle): activations/predictions 2e-4 abs+rel,
+per-feature KL 1e-3 nats absolute (BASELINE.json north_star), gradients 2e-4 relative to the
+gradient's max-abs.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import dib_oracle as orc
+from _helpers import SPECS, flat_to_params, params_to_flat, random_params, spec_kwargs
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(spec, seed=0):
+    from dib_amd.engine import HipEngine
+    eng = HipEngine(**spec_kwargs(spec), init_seed=seed)
+    p = random_params(spec, seed)
+    eng.set_flat_params(params_to_flat(eng.blocks, p, eng.params.numel()))
+    # oracle sees exactly the float32-rounded parameters
+    return eng, flat_to_params(eng.blocks, eng.get_flat_params(), spec)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 70, 45), (1, 1, 1), (37, 129, 5), (300, 257, 130),
+                                   (64, 5, 2048), (1000, 64, 128)])
+def test_gemm_vs_numpy(mode, M, N, K):
+    from dib_amd import _lib
+    lib = _lib.load_library()
+    rng = np.random.default_rng(M * 1000 + N * 10 + K + mode)
+    dev = torch.device("cuda:0")
+    if mode == 0:
+        A, B = rng.standard_normal((M, K)), rng.standard_normal((K, N))
+        bias = rng.standard_normal(N)
+        ref = np.maximum(A @ B + bias, 0)
+    elif mode == 1:
+        A, B = rng.standard_normal((M, K)), rng.standard_normal((N, K))
+        aux = rng.standard_normal((M, N))
+        ref = (A @ B.T) * (aux > 0)
+    else:
+        A, B = rng.standard_normal((K, M)), rng.standard_normal((K, N))
+        ref = A.T @ B
+        ref_bias = B.sum(0)
+    At = torch.tensor(A, dtype=torch.float32, device=dev)
+    Bt = torch.tensor(B, dtype=torch.float32, device=dev)
+    Ct = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    desc = torch.zeros(256, dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if mode == 0:
+        bt = torch.tensor(bias, dtype=torch.float32, device=dev)
+        rc = lib.dib_gemm(0, M, N, K, _ptr(At), K, _ptr(Bt), N, _ptr(Ct), N, _ptr(bt), None, 0, 1, _ptr(desc), st)
+    elif mode == 1:
+        xt = torch.tensor(aux, dtype=torch.float32, device=dev)
+        rc = lib.dib_gemm(1, M, N, K, _ptr(At), K, _ptr(Bt), K, _ptr(Ct), N, None, _ptr(xt), N, 1, _ptr(desc), st)
+    else:
+        bt = torch.full((N,), float("nan"), dtype=torch.float32, device=dev)
+        rc = lib.dib_gemm(2, M, N, K, _ptr(At), M, _ptr(Bt), N, _ptr(Ct), N, _ptr(bt), None, 0, 0, _ptr(desc), st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = Ct.cpu().numpy()
+    scale = np.abs(ref).max() + 1e-6
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / scale < 2e-5
+    if mode == 2:
+        gb = bt.cpu().numpy()
+        assert np.abs(gb - ref_bias).max() / (np.abs(ref_bias).max() + 1e-6) < 2e-5
+
+
+def test_gemm_is_transpose_detecting():
+    """A = I with ASYMMETRIC B (cdna guide: symmetric inputs hide a row/col swap in the C write)."""
+    from dib_amd import _lib
+    lib = _lib.load_library()
+    dev = torch.device("cuda:0")
+    n = 96
+    A = torch.eye(n, dtype=torch.float32, device=dev)
+    B = (torch.arange(n * n, dtype=torch.float32, device=dev).view(n, n) * 0.001).contiguous()
+    C = torch.zeros((n, n), dtype=torch.float32, device=dev)
+    desc = torch.zeros(256, dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.dib_gemm(0, n, n, n, _ptr(A), n, _ptr(B), n, _ptr(C), n, None, None, 0, 0, _ptr(desc), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(C, B)  # exact: fp32 MFMA is an fmaf chain, products with 0/1 are exact
+
+
+def test_eps_matches_oracle_and_host_ref():
+    spec = SPECS["odd_shapes_tanh"]
+    eng, _ = _engine(spec)
+    rows = np.array([0, 5, 17, 123456, 2 ** 31 + 5, 99], dtype=np.int64)
+    idx = torch.tensor(rows.astype(np.uint32).view(np.int32), dtype=torch.int32, device=eng.device)
+    got = eng.eps(idx, 0, len(rows), seed=0x1234567890ABCDEF, step=77).cpu().numpy()
+    ref = orc.philox_normal_all(0x1234567890ABCDEF, 77, rows.astype(np.uint32), spec.number_features,
+                                spec.feature_embedding_dimension)
+    assert np.abs(got - ref).max() < 1e-5
+    host = eng.lib.dib_philox_normal_ref(0x1234567890ABCDEF, 77, 17, 1, 4)
+    assert abs(host - ref[2, 1, 4]) < 1e-5
+    # contiguous-row form
+    got2 = eng.eps(None, 1000, 4, seed=3, step=1).cpu().numpy()
+    ref2 = orc.philox_normal_all(3, 1, np.arange(1000, 1004), spec.number_features, spec.feature_embedding_dimension)
+    assert np.abs(got2 - ref2).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+@pytest.mark.parametrize("B", [1, 37, 300])
+def test_forward_backward_parity(name, B):
+    spec = SPECS[name]
+    eng, p = _engine(spec, seed=hash(name) % 1000)
+    F, E = spec.number_features, spec.feature_embedding_dimension
+    rng = np.random.default_rng(B)
+    n = B + 11
+    x = rng.standard_normal((n, sum(spec.feature_dimensionalities))).astype(np.float32)
+    if spec.output_dimensionality == 1:
+        kind = "bce" if spec.output_activation_fn == "sigmoid" else "bce_logits"
+        y = rng.integers(0, 2, (n, 1)).astype(np.float32)
+    elif name == "pendulum_ragged":
+        kind = "mse"
+        y = rng.standard_normal((n, spec.output_dimensionality)).astype(np.float32)
+    else:
+        kind = "sparse_cce_logits"
+        y = rng.integers(0, spec.output_dimensionality, (n, 1)).astype(np.float32)
+    rows = rng.permutation(n)[:B].astype(np.int32)
+    xd, yd = eng.to_device(x), eng.to_device(y)
+    idx = eng.to_device(rows, dtype=torch.int32)
+    beta, seed, step = 0.37, 11, 5
+    eng.set_beta(beta)
+    eng.train_step(xd, yd, idx, 0, B, seed, step, kind)
+    torch.cuda.synchronize()
+
+    eps = orc.philox_normal_all(seed, step, rows, F, E)
+    c = orc.forward(spec, p, x[rows].astype(np.float64), eps)
+    task, grads, g_u = orc.backward(spec, p, x[rows].astype(np.float64), y[rows], c, beta, kind)
+
+    def close(got, ref, tol=2e-4):
+        got = np.asarray(got, dtype=np.float64)
+        return np.abs(got - ref).max() <= tol * (1.0 + np.abs(ref).max())
+
+    enc_out = eng.enc_out(B).cpu().numpy()
+    assert close(enc_out[:, :, :E], c.mu), "mu"
+    assert close(enc_out[:, :, E:], c.logvar), "logvar"
+    assert close(eng.u(B).cpu().numpy(), c.u), "u"
+    assert close(eng.pred(B).cpu().numpy(), c.pred), "pred"
+    so = eng.step_out(B).cpu().numpy()
+    assert np.abs(so[:F] / B - c.kl).max() < 1e-3, "KL per feature (nats)"
+    assert abs(so[F] / B - task) < 2e-4 * (1 + abs(task)), "task loss"
+    assert so[F + 2] == B
+    if kind != "mse":
+        assert abs(so[F + 1] / B - orc.accuracy(kind, y[rows], c.pred)) < 1e-6
+    assert close(eng.g_u(B).cpu().numpy(), g_u, 3e-4), "g_u"
+    gflat = eng.get_flat_grads()
+    gref = params_to_flat(eng.blocks, grads, eng.params.numel()).astype(np.float64)
+    for b in eng.blocks:
+        sl = slice(b["offset"], b["offset"] + b["rows"] * b["cols"])
+        ref = gref[sl]
+        err = np.abs(gflat[sl] - ref).max()
+        assert err <= 3e-4 * (np.abs(ref).max() + 1e-3), (b, err, np.abs(ref).max())
+
+
+def test_split_batch_wgrad_and_dp_equivalence():
+    """B large enough to use split-batch wgrad partials; and two half-batches with
+    inv_global_batch = 1/B reproduce the full-batch gradient (the data-parallel contract)."""
+    spec = SPECS["tabular8_default"]
+    eng, p = _engine(spec, 3)
+    B = 8192
+    assert eng.lib.dib_layout_wgrad_splits(eng.layout, B) > 1
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B, 8)).astype(np.float32)
+    y = (x[:, 0] > 0).astype(np.float32)[:, None]
+    xd, yd = eng.to_device(x), eng.to_device(y)
+    eng.set_beta(0.05)
+    eng.train_step(xd, yd, None, 0, B, 1, 2, "bce_logits")
+    g_full = eng.get_flat_grads().astype(np.float64)
+    kl_full = eng.step_out(B).cpu().numpy()[:8].copy()
+    eps = orc.philox_normal_all(1, 2, np.arange(B), 8, 32)
+    c = orc.forward(spec, p, x.astype(np.float64), eps)
+    _, grads, _ = orc.backward(spec, p, x.astype(np.float64), y, c, 0.05, "bce_logits")
+    gref = params_to_flat(eng.blocks, grads, eng.params.numel()).astype(np.float64)
+    assert np.abs(g_full - gref).max() <= 3e-4 * np.abs(gref).max()
+    assert np.abs(kl_full / B - c.kl).max() < 1e-3
+    h = B // 2
+    eng.train_step(xd, yd, None, 0, h, 1, 2, "bce_logits", inv_global_batch=1.0 / B)
+    g0 = eng.get_flat_grads().astype(np.float64)
+    eng.train_step(xd, yd, None, h, h, 1, 2, "bce_logits", inv_global_batch=1.0 / B)
+    g1 = eng.get_flat_grads().astype(np.float64)
+    assert np.abs((g0 + g1) - g_full).max() <= 1e-5 * np.abs(g_full).max() + 1e-9
+
+
+def test_adam_matches_keras_form():
+    spec = SPECS["odd_shapes_tanh"]
+    eng, p = _engine(spec, 5)
+    rng = np.random.default_rng(1)
+    st = orc.adam_init(p)
+    eng.set_lr(3e-4)
+    for it in range(5):
+        g = rng.standard_normal(eng.params.numel()).astype(np.float32) * (10.0 ** rng.integers(-4, 1))
+        eng.grads.copy_(torch.from_numpy(g))
+        eng.adam_step()
+        orc.adam_keras_step(p, flat_to_params(eng.blocks, g, spec), st, lr=3e-4)
+    got = flat_to_params(eng.blocks, eng.get_flat_params(), spec)
+    for a, b in zip(got.tensors(), p.tensors()):
+        assert np.abs(a - b).max() < 2e-6
+    assert int(eng.t_dev.item()) == 5
+
+
+def test_encode_deterministic_and_bhattacharyya():
+    spec = SPECS["pendulum_ragged"]
+    eng, p = _engine(spec, 9)
+    rng = np.random.default_rng(2)
+    E = spec.feature_embedding_dimension
+    for f, d in enumerate(spec.feature_dimensionalities):
+        xf = rng.standard_normal((50, d)).astype(np.float32)
+        got = eng.encode_feature(f, xf).cpu().numpy()
+        ref = orc.encode_feature(spec, p, f, xf.astype(np.float64))
+        assert np.abs(got - ref).max() < 2e-4 * (1 + np.abs(ref).max())
+        bh = eng.bhattacharyya(got[:, :E], got[:, E:], got[:20, :E], got[:20, E:]).cpu().numpy()
+        bref = orc.bhattacharyya_dist_mat(got[:, :E], got[:, E:], got[:20, :E], got[:20, E:])
+        assert np.abs(bh - bref).max() < 1e-3 * (1 + np.abs(bref).max())
+
+
+def test_fit_trajectory_matches_oracle_fit():
+    """BASELINE metric 2: per-epoch KL{f} within 1e-3 nats of the oracle over a full fit()
+    (same init, same batch order, same counter-based eps), incl. validation and accuracy."""
+    import dib_amd
+    spec = orc.DIBSpec([1, 1, 1, 1], [32, 32], [64, 64], 1, feature_embedding_dimension=8)
+    x, y = orc.boolean_circuit_truth_table([0, 1, 2, 3, [0, 2, 0], [2, 4, 3], [0, 5, 1]], 4)  # SI circuit (c)
+    x = np.tile(x, (8, 1)).astype(np.float32)
+    y = np.tile(y, 8).astype(np.float32)
+    model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=4, shuffle_seed=6, init_seed=2)
+    opt = dib_amd.optimizers.get("adam")
+    opt.learning_rate = 3e-3
+    model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+    cb = dib_amd.InfoBottleneckAnnealingCallback(1e-3, 1.0, 2, 6)
+    p = flat_to_params(model.param_blocks(), model.get_flat_weights(), spec)
+    epochs, bs = 8, 48  # 128 rows -> 2 full batches + a partial one
+    hist = model.fit(x, y, epochs=epochs, shuffle=True, batch_size=bs, callbacks=[cb], verbose=False,
+                     validation_data=(x[:40], y[:40]))
+    ref = orc.fit(spec, p, x, y, epochs=epochs, batch_size=bs, loss_kind="bce_logits",
+                  beta_fn=lambda e: orc.beta_schedule(e, 1e-3, 1.0, 2, 6), lr=3e-3, shuffle=True,
+                  validation_data=(x[:40], y[:40]), noise_seed=4, shuffle_seed=6, metrics=["accuracy"])
+    assert set(ref) == set(hist.history)
+    for k in ref:
+        got, want = np.array(hist.history[k]), np.array(ref[k])
+        tol = 1e-3 if "KL" in k else 2e-3
+        assert np.abs(got - want).max() < tol * (1 + np.abs(want).max()), (k, got, want)
+
+
+def test_north_star_shape_properties():
+    """BASELINE config 3 at full size (F=64, B=65536): size-independent properties -
+    KL >= 0 and finite, deterministic replay bit-exact, u - mu = exp(lv/2)*eps, grads finite."""
+    spec = orc.DIBSpec([1] * 64, [128, 128], [256, 256], 1)
+    from dib_amd.engine import HipEngine
+    eng = HipEngine(**spec_kwargs(spec), init_seed=1)
+    B = 65536
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn((B, 64), generator=g)
+    y = (x[:, 0] + 0.5 * x[:, 1] * x[:, 2] > 0).float()[:, None]
+    xd, yd = eng.to_device(x), eng.to_device(y)
+    eng.set_beta(1e-2)
+    eng.train_step(xd, yd, None, 0, B, 0, 0, "bce_logits")
+    g1 = eng.grads.clone()
+    so1 = eng.step_out(B).clone()
+    u = eng.u(B).view(B, 64, 32)[:256].clone()
+    eo = eng.enc_out(B)[:256].clone()
+    eng.train_step(xd, yd, None, 0, B, 0, 0, "bce_logits")
+    assert torch.equal(g1, eng.grads), "replay must be bit-exact (fixed-order reductions)"
+    assert torch.equal(so1, eng.step_out(B))
+    assert torch.isfinite(g1).all() and torch.isfinite(so1).all()
+    assert (so1[:64] >= 0).all()
+    eps = eng.eps(None, 0, 256, 0, 0)
+    resid = u - (eo[:, :, :32] + torch.exp(0.5 * eo[:, :, 32:]) * eps)
+    assert resid.abs().max() < 1e-5
+    # oracle spot check on the first 64 rows' predictions
+    p = flat_to_params(eng.blocks, eng.get_flat_params(), spec)
+    c = orc.forward(spec, p, x[:64].numpy().astype(np.float64), orc.philox_normal_all(0, 0, np.arange(64), 64, 32))
+    assert np.abs(eng.pred(B)[:64].cpu().numpy() - c.pred).max() < 2e-4 * (1 + np.abs(c.pred).max())

@@ -1,0 +1,136 @@
+"""CPU: pin the oracle against every golden vector the reference offers for this path
+(tests/golden/*.npz were produced by EXECUTING reference code, see tests/golden/make_golden.py) and
+against the numbers printed in the reference's notebooks."""
+import os
+
+import numpy as np
+import pytest
+
+import dib_oracle as orc
+from _helpers import SPECS, random_params
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_boolean_circuit_truth_table_matches_reference_data_py():
+    g = np.load(os.path.join(GOLD, "boolean_circuit.npz"))
+    x, y = orc.boolean_circuit_truth_table()
+    assert np.array_equal(x, g["x_train"]) and np.array_equal(y, g["y_train"])
+    p1 = y.mean()
+    hy = orc.entropy_bits([p1, 1 - p1])
+    assert abs(hy - float(g["entropy_y_bits"])) < 1e-12
+    assert abs(hy - 0.758) < 5e-4  # Boolean_circuits.ipynb:238
+    assert bool(g["loss_from_logits"]) and bool(g["loss_is_info_based"])
+    import dib_amd
+    d = dib_amd.data.fetch_boolean_circuit()
+    assert np.array_equal(d["x_train"], g["x_train"]) and np.array_equal(d["y_train"], g["y_train"])
+    assert d["loss"].kind == "bce_logits" and d["feature_dimensionalities"] == [1] * 10
+
+
+def test_distance_matrices_match_reference_utils_py():
+    g = np.load(os.path.join(GOLD, "utils_distance_mats.npz"))
+    import dib_amd
+    for mod in (orc, dib_amd.utils):
+        assert np.allclose(mod.bhattacharyya_dist_mat(g["mus1"], g["lvs1"], g["mus2"], g["lvs2"]), g["bhattacharyya"],
+                           rtol=1e-10, atol=1e-12)
+        assert np.allclose(mod.bhattacharyya_dist_mat(g["mus1"], g["lvs1"], g["mus1"], g["lvs1"]),
+                           g["bhattacharyya_self"], rtol=1e-10, atol=1e-12)
+        assert np.allclose(mod.kl_divergence_mat(g["mus1"], g["lvs1"], g["mus2"], g["lvs2"]), g["kl"], rtol=1e-10)
+    assert abs(dib_amd.utils.compute_entropy_bits(g["probs"]) - float(g["entropy_bits"])) < 1e-12
+    assert abs(orc.entropy_bits(g["probs"]) - float(g["entropy_bits"])) < 1e-12
+
+
+@pytest.mark.parametrize("circuit,hy", [
+    ([0, 1, 2, 3, [0, 2, 0], [2, 4, 3], [0, 5, 1]], 0.811),   # SI circuit (c), Boolean_circuits.ipynb:987-992
+    ([0, 1, 2, 3, [1, 1, 3], [0, 4, 0], [2, 2, 5]], 1.000),   # SI circuit (d), :1058-1063
+])
+def test_si_circuit_entropies_from_notebook(circuit, hy):
+    x, y = orc.boolean_circuit_truth_table(circuit, 4)
+    p1 = y.mean()
+    assert abs(orc.entropy_bits([p1, 1 - p1]) - hy) < 1e-3
+    full = orc.subset_mutual_information_bits(x, y, [0, 1, 2, 3])
+    assert abs(full - orc.entropy_bits([p1, 1 - p1])) < 1e-12  # deterministic circuit: I(X;Y) = H(Y)
+    for s in ([0], [1], [0, 1], [2, 3]):
+        assert -1e-12 <= orc.subset_mutual_information_bits(x, y, s) <= full + 1e-12
+
+
+def test_positional_encoding_layout_is_blockwise():
+    x = np.array([[0.1, 0.2]])
+    out = orc.positional_encoding(x, [2, 4])
+    assert np.allclose(out, [[0.1, 0.2, np.sin(0.2), np.sin(0.4), np.sin(0.4), np.sin(0.8)]])
+    spec = orc.DIBSpec([1], [4], [4], 1)
+    assert list(spec.frequencies) == [2, 4, 8, 16] and spec.encoder_input_dim(0) == 5  # models.py:70
+
+
+def test_kl_known_answers():
+    spec = orc.DIBSpec([1, 1], [], [], 1, use_positional_encoding=False, feature_embedding_dimension=4)
+    p = orc.glorot_uniform_init(spec)
+    for f in range(2):
+        p.enc_W[f][0][:] = 0
+    c = 0.7
+    p.enc_b[0][0][:4] = c  # mu = c, logvar = 0  => KL = E*c^2/2
+    x = np.zeros((5, 2))
+    out = orc.forward(spec, p, x, np.zeros((5, 2, 4)))
+    assert np.allclose(out.kl, [4 * c * c / 2, 0.0])
+
+
+def test_beta_schedule_endpoints_and_geometric_ramp():
+    assert orc.beta_schedule(0, 1e-4, 3.0, 10, 100) == np.float32(1e-4) or abs(orc.beta_schedule(0, 1e-4, 3.0, 10, 100) - 1e-4) < 1e-10
+    assert abs(orc.beta_schedule(10, 1e-4, 3.0, 10, 100) - 1e-4) < 1e-10
+    assert abs(orc.beta_schedule(110, 1e-4, 3.0, 10, 100) - 3.0) < 1e-5
+    r1 = orc.beta_schedule(61, 1e-4, 3.0, 10, 100) / orc.beta_schedule(60, 1e-4, 3.0, 10, 100)
+    r2 = orc.beta_schedule(31, 1e-4, 3.0, 10, 100) / orc.beta_schedule(30, 1e-4, 3.0, 10, 100)
+    assert abs(r1 - r2) < 1e-4
+    import dib_amd
+    cb = dib_amd.InfoBottleneckAnnealingCallback(1e-4, 3.0, 10, 100)
+    for e in (0, 5, 10, 11, 60, 110):
+        assert cb.beta_at(e) == orc.beta_schedule(e, 1e-4, 3.0, 10, 100)
+
+
+@pytest.mark.parametrize("name", ["odd_shapes_tanh", "no_posenc_leaky", "sigmoid_out_elu", "boolean4_32x32"])
+def test_oracle_backward_gradcheck(name):
+    spec = SPECS[name]
+    p = random_params(spec, 1)
+    rng = np.random.default_rng(0)
+    B = 6
+    x = rng.standard_normal((B, sum(spec.feature_dimensionalities)))
+    if spec.output_dimensionality == 1:
+        kind = "bce" if spec.output_activation_fn == "sigmoid" else "bce_logits"
+        y = rng.integers(0, 2, (B, 1))
+    else:
+        kind = "sparse_cce_logits"
+        y = rng.integers(0, spec.output_dimensionality, (B, 1))
+    eps = orc.philox_normal_all(5, 3, np.arange(B), spec.number_features, spec.feature_embedding_dimension)
+    beta = 0.3
+
+    def L():
+        c = orc.forward(spec, p, x, eps)
+        return orc.loss_and_grad(kind, y, c.pred)[0] + beta * c.kl.sum()
+
+    c = orc.forward(spec, p, x, eps)
+    _, g, _ = orc.backward(spec, p, x, y, c, beta, kind)
+    for t, gt in zip(p.tensors(), g.tensors()):
+        for _ in range(4):
+            idx = tuple(rng.integers(0, s) for s in t.shape)
+            old, h = t[idx], 1e-6
+            t[idx] = old + h; lp = L()
+            t[idx] = old - h; lm = L()
+            t[idx] = old
+            assert abs((lp - lm) / (2 * h) - gt[idx]) < 1e-6
+
+
+def test_param_count_and_flops_match_survey():
+    s3 = orc.DIBSpec([1] * 64, [128, 128], [256, 256], 1)
+    assert s3.num_params() == 2224897 and s3.gemm_flops_per_sample() == 13141504
+    s1 = orc.DIBSpec([1] * 4, [32, 32], [256, 256], 1)
+    assert s1.num_params() == 112513 and s1.gemm_flops_per_sample() == 667648
+
+
+def test_philox_known_answer_and_moments():
+    # Random123 known-answer test vector for philox4x32-10: counter=key=0
+    out = orc.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(v) for v in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    out = orc.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(v) for v in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    e = orc.philox_normal_all(1, 0, np.arange(20000), 2, 32)
+    assert abs(e.mean()) < 5e-3 and abs(e.std() - 1) < 5e-3 and abs((e ** 4).mean() - 3) < 0.05
