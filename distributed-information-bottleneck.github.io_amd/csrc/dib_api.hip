@@ -84,6 +84,30 @@ struct dib_layout {
 
 namespace {
 
+// ---- optional live kernel timing (bench.py roofline): HIP events around every launch, on the launch stream ----
+constexpr int kProfCats = 4;  // 0 fwd GEMM, 1 dgrad GEMM, 2 wgrad GEMM, 3 everything else (HBM-bound kernels)
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool;                     // recycled events
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[kProfCats];
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+} g_prof;
+
+struct ProfScope {
+  int cat; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(int c, hipStream_t s) : cat(c), st(s) {
+    if (g_prof.on) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
+  }
+  ~ProfScope() {
+    if (a) { (void)hipEventRecord(b, st); g_prof.spans[cat].push_back({a, b}); }
+  }
+};
+
 const char* kVersion = "dib_hip 0.1 (gfx950, fp32 MFMA grouped GEMM path)";
 
 int act_ok(int a) { return a >= 0 && a <= 6; }
@@ -103,6 +127,7 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
                 const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
                 long long split_stride, hipStream_t st) {
   if (c.count == 0) return DIB_OK;
+  ProfScope ps(MODE, st);
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
   const int tm = cdiv(M, DIB_BM), tn = cdiv(N, DIB_BN);
@@ -352,6 +377,7 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)batch * l->sum_d)), dim3(256), 0, st, x, (long long)ldx,
                      (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P,
                      (long long)l->pw);
@@ -359,11 +385,13 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   if (rc) return rc;
   rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
   if (rc) return rc;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
                      w + m.kl_partial, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
                      (unsigned long long)seed, (unsigned)step, deterministic);
   rc = (int)hipGetLastError();
   if (rc) return rc;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, m.kl_blocks, l->F,
                      w + m.step_out);
   return (int)hipGetLastError();
@@ -394,15 +422,18 @@ int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, 
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_loss_kernel, dim3(m.loss_blocks), dim3(256), 0, st, loss_kind, w + m.pred, l->out_dim, y,
                      (long long)ldy, (const int*)row_idx, (long long)row0, batch, inv_global_batch, l->out_act,
                      w + m.g_pred, w + m.loss_partial);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2), dim3(256), 0, st, w + m.loss_partial, m.loss_blocks, 2,
                      w + m.step_out + l->F);
   rc = (int)hipGetLastError();
   if (rc) return rc;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_set_scalar_kernel, dim3(1), dim3(1), 0, st, w + m.step_out + l->F + 2, (float)batch);
   return (int)hipGetLastError();
 }
@@ -445,6 +476,7 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   float* w = (float*)ws;
   float* gt = wgrad_target(m, w, grads);
   const long long sstride = align_up(l->n_params, 4);
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
                      w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
                      (unsigned long long)seed, (unsigned)step);
@@ -474,6 +506,7 @@ int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_str
   float* w = (float*)ws;
   // partial slabs are spaced align_up(n_params,4) apart; the reduce treats them as n = that stride
   const long long n = align_up(l->n_params, 4);
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, w + m.wgrad_partial, n,
                      m.nsplit, grads);
   return (int)hipGetLastError();
@@ -484,6 +517,7 @@ int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, floa
   if (!l || !beta_dev || !metrics_acc || !ws || batch <= 0) return DIB_E_ARG;
   const auto m = l->map(batch);
   float* w = (float*)ws;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_metrics_accumulate_kernel, dim3(cdiv(l->F + 3, 64)), dim3(64), 0, (hipStream_t)stream,
                      w + m.step_out, l->F, beta_dev, inv_global_batch, metrics_acc);
   return (int)hipGetLastError();
@@ -494,10 +528,12 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
                   int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale, dib_stream_t stream) {
   if (!params || !grads || !mm || !vv || !lr_dev || !t_dev || n <= 0) return DIB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
                      lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev);
   return (int)hipGetLastError();
 }
@@ -505,6 +541,7 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
 int dib_sgd_step(float* params, const float* grads, int64_t n, const float* lr_dev, float grad_scale,
                  dib_stream_t stream) {
   if (!params || !grads || !lr_dev || n <= 0) return DIB_E_ARG;
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, (long long)n,
                      lr_dev, grad_scale);
   return (int)hipGetLastError();
@@ -520,6 +557,7 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
   const auto m = l->map(n);
   float* w = (float*)ws;
   const int d = l->dims[feature];
+  { ProfScope ps(3, (hipStream_t)stream); }
   hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, st, x_f, (long long)d,
                      (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P,
                      (long long)l->pw);
@@ -548,6 +586,33 @@ int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int
                      (hipStream_t)stream, eps, (const int*)row_idx, (long long)row0, batch, F, E,
                      (unsigned long long)seed, (unsigned)step);
   return (int)hipGetLastError();
+}
+
+int dib_profile_enable(int on) {
+  for (int c = 0; c < kProfCats; ++c) {
+    for (auto& sp : g_prof.spans[c]) { g_prof.pool.push_back(sp.first); g_prof.pool.push_back(sp.second); }
+    g_prof.spans[c].clear();
+  }
+  g_prof.on = on != 0;
+  return DIB_OK;
+}
+
+int dib_profile_summary(double* ms_by_category, int* launches_by_category) {
+  if (!ms_by_category || !launches_by_category) return DIB_E_ARG;
+  for (int c = 0; c < kProfCats; ++c) {
+    double tot = 0.0;
+    for (auto& sp : g_prof.spans[c]) {
+      hipError_t e = hipEventSynchronize(sp.second);
+      if (e != hipSuccess) return (int)e;
+      float ms = 0.f;
+      e = hipEventElapsedTime(&ms, sp.first, sp.second);
+      if (e != hipSuccess) return (int)e;
+      tot += ms;
+    }
+    ms_by_category[c] = tot;
+    launches_by_category[c] = (int)g_prof.spans[c].size();
+  }
+  return DIB_OK;
 }
 
 float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t feature, uint32_t e) {

@@ -227,6 +227,16 @@ class HipEngine:
             self.metrics_acc.zero_()
         return m
 
+    def profile_enable(self, on: bool) -> None:
+        check(self.lib.dib_profile_enable(1 if on else 0), "dib_profile_enable")
+
+    def profile_summary(self) -> dict:
+        """{'fwd'|'dgrad'|'wgrad'|'other': (total ms, launches)} since profile_enable(True); synchronises."""
+        ms = (ctypes.c_double * 4)()
+        cnt = (c_int * 4)()
+        check(self.lib.dib_profile_summary(ms, cnt), "dib_profile_summary")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(("fwd", "dgrad", "wgrad", "other"))}
+
     # ---- views / helpers ---------------------------------------------------------------------
     def pred(self, batch: int) -> torch.Tensor:
         return self.ws_view(batch, _lib.WS_PRED, batch * self.out_dim).view(batch, self.out_dim)
