@@ -112,14 +112,33 @@ const char* kVersion = "dib_hip 0.1 (gfx950, fp32 MFMA grouped GEMM path)";
 
 int act_ok(int a) { return a >= 0 && a <= 6; }
 
-DibGemmGroup make_group(int64_t a_off, int lda, int64_t b_off, int ldb, int64_t c_off, int ldc, int64_t bias_off,
-                        int64_t aux_off, int ldaux, int M, int N, int K) {
+// Off = {fixed element offset, offset per batch row} : activations are feature-major [F][B][width]
+struct Off { int64_t fixed = 0, per_batch = 0; };
+inline Off fixed_off(int64_t o) { Off r; r.fixed = o; return r; }
+inline Off batch_off(int64_t o) { Off r; r.per_batch = o; return r; }
+
+DibGemmGroup make_group(Off a, int lda, Off b, int ldb, Off c, int ldc, int64_t bias_off, Off aux, int ldaux, int M,
+                        int N, int K) {
   DibGemmGroup g;
   std::memset(&g, 0, sizeof(g));
-  g.a_off = a_off; g.b_off = b_off; g.c_off = c_off; g.bias_off = bias_off; g.aux_off = aux_off;
+  g.a_off = a.fixed; g.a_boff = a.per_batch; g.b_off = b.fixed; g.b_boff = b.per_batch;
+  g.c_off = c.fixed; g.c_boff = c.per_batch; g.aux_off = aux.fixed; g.aux_boff = aux.per_batch;
+  g.bias_off = bias_off;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
-  g.flags = ((a_off % 4 == 0 && lda % 4 == 0) ? 1 : 0) | ((b_off % 4 == 0 && ldb % 4 == 0) ? 2 : 0);
   return g;
+}
+
+template <int MODE, int NI, int NJ>
+int launch_gemm_t(const dib_layout* l, const GemmCall& c, int M, int N, const float* A, const float* B, float* C,
+                  const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit,
+                  int rows_per_split, long long split_stride, hipStream_t st) {
+  const int tm = cdiv(M, 64 * NI), tn = cdiv(N, 64 * NJ);
+  dim3 grid;
+  if (MODE == 2) grid = dim3(nsplit, tm * tn, c.count);
+  else grid = dim3(8 * cdiv(tm, 8) * tn, 1, c.count);  // XCD-aware 1-D tile order, see dib_gemm.h
+  hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ>), grid, dim3(256), 0, st, l->dev_groups + c.first, A, B, C, bias,
+                     aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride);
+  return (int)hipGetLastError();
 }
 
 template <int MODE>
@@ -130,13 +149,12 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
   ProfScope ps(MODE, st);
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
-  const int tm = cdiv(M, DIB_BM), tn = cdiv(N, DIB_BN);
-  dim3 grid;
-  if (MODE == 2) grid = dim3(nsplit, tm * tn, c.count);
-  else grid = dim3(tm, tn, c.count);
-  hipLaunchKernelGGL((dib_gemm_kernel<MODE>), grid, dim3(256), 0, st, l->dev_groups + c.first, A, B, C, bias, aux,
-                     bias_out, batch, act, tn, rows_per_split, split_stride);
-  return (int)hipGetLastError();
+  const bool ni1 = (MODE == 2) && M <= 64, nj1 = N <= 64;   // narrow tiles for narrow outputs
+#define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(l, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
+                                                   rows_per_split, split_stride, st)
+  if (ni1) return nj1 ? DIB_GO(1, 1) : DIB_GO(1, 2);
+  return nj1 ? DIB_GO(2, 1) : DIB_GO(2, 2);
+#undef DIB_GO
 }
 
 inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
@@ -219,19 +237,19 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
   }
   l->n_params = o;
 
-  // ---- GEMM group descriptors.  Activation matrices are [B, F*width] with feature f at column f*width ----
+  // ---- GEMM group descriptors.  Encoder-bank activations are FEATURE-MAJOR: [F][B][width], i.e. feature f's
+  // operand is the dense matrix at element offset (f*width)*B (ragged first layer: in_off[f]*B).  U / g_u (the
+  // integration network's operand, reference models.py:122 tf.concat) stay sample-major [B, F*E]. ----
   auto& T = l->table;
   for (int ly = 0; ly < LE; ++ly) {
     const int wout = l->enc_width[ly];
-    const int ldc = F * wout;
     GemmCall fw, dg, wg;
     fw.first = (int)T.size();
     for (int f = 0; f < F; ++f) {
       const int win = ly == 0 ? l->in_dim[f] : l->enc_width[ly - 1];
-      const int lda = ly == 0 ? l->pw : F * l->enc_width[ly - 1];
-      const int64_t a_off = ly == 0 ? l->in_off[f] : (int64_t)f * l->enc_width[ly - 1];
-      T.push_back(make_group(a_off, lda, l->enc_w_off[ly][f], wout, (int64_t)f * wout, ldc, l->enc_b_off[ly][f], 0, 0,
-                             -1, wout, win));
+      const Off a = batch_off(ly == 0 ? (int64_t)l->in_off[f] : (int64_t)f * win);
+      T.push_back(make_group(a, win, fixed_off(l->enc_w_off[ly][f]), wout, batch_off((int64_t)f * wout), wout,
+                             l->enc_b_off[ly][f], Off(), 0, -1, wout, win));
     }
     fw.count = F; fw.max_m = -1; fw.max_n = wout;
     l->enc_fwd.push_back(fw);
@@ -240,8 +258,8 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
     if (ly >= 1) {
       const int win = l->enc_width[ly - 1];
       for (int f = 0; f < F; ++f)
-        T.push_back(make_group((int64_t)f * wout, ldc, l->enc_w_off[ly][f], wout, (int64_t)f * win, F * win, -1,
-                               (int64_t)f * win, F * win, -1, win, wout));
+        T.push_back(make_group(batch_off((int64_t)f * wout), wout, fixed_off(l->enc_w_off[ly][f]), wout,
+                               batch_off((int64_t)f * win), win, -1, batch_off((int64_t)f * win), win, -1, win, wout));
       dg.count = F; dg.max_m = -1; dg.max_n = win;
     }
     l->enc_dgrad.push_back(dg);
@@ -250,10 +268,9 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
     int max_in = 0;
     for (int f = 0; f < F; ++f) {
       const int win = ly == 0 ? l->in_dim[f] : l->enc_width[ly - 1];
-      const int lda = ly == 0 ? l->pw : F * l->enc_width[ly - 1];
-      const int64_t a_off = ly == 0 ? l->in_off[f] : (int64_t)f * l->enc_width[ly - 1];
-      T.push_back(make_group(a_off, lda, (int64_t)f * wout, ldc, l->enc_w_off[ly][f], wout, l->enc_b_off[ly][f], 0, 0,
-                             win, wout, -1));
+      const Off a = batch_off(ly == 0 ? (int64_t)l->in_off[f] : (int64_t)f * win);
+      T.push_back(make_group(a, win, batch_off((int64_t)f * wout), wout, fixed_off(l->enc_w_off[ly][f]), wout,
+                             l->enc_b_off[ly][f], Off(), 0, win, wout, -1));
       max_in = std::max(max_in, win);
     }
     wg.count = F; wg.max_m = max_in; wg.max_n = wout;
@@ -264,15 +281,17 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
     const int wout = l->int_width[ly];
     GemmCall fw, dg, wg;
     fw.first = (int)T.size();
-    T.push_back(make_group(0, win, l->int_w_off[ly], wout, 0, wout, l->int_b_off[ly], 0, 0, -1, wout, win));
+    T.push_back(make_group(Off(), win, fixed_off(l->int_w_off[ly]), wout, Off(), wout, l->int_b_off[ly], Off(), 0, -1,
+                           wout, win));
     fw.count = 1; fw.max_m = -1; fw.max_n = wout;
     l->int_fwd.push_back(fw);
     dg.first = (int)T.size();
-    T.push_back(make_group(0, wout, l->int_w_off[ly], wout, 0, win, -1, 0, win, -1, win, wout));
+    T.push_back(make_group(Off(), wout, fixed_off(l->int_w_off[ly]), wout, Off(), win, -1, Off(), win, -1, win, wout));
     dg.count = 1; dg.max_m = -1; dg.max_n = win;
     l->int_dgrad.push_back(dg);
     wg.first = (int)T.size();
-    T.push_back(make_group(0, win, 0, wout, l->int_w_off[ly], wout, l->int_b_off[ly], 0, 0, win, wout, -1));
+    T.push_back(make_group(Off(), win, Off(), wout, fixed_off(l->int_w_off[ly]), wout, l->int_b_off[ly], Off(), 0, win,
+                           wout, -1));
     wg.count = 1; wg.max_m = win; wg.max_n = wout;
     l->int_wgrad.push_back(wg);
   }
@@ -377,23 +396,22 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)batch * l->sum_d)), dim3(256), 0, st, x, (long long)ldx,
-                     (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P,
-                     (long long)l->pw);
+                     (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
                      w + m.kl_partial, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
-                     (unsigned long long)seed, (unsigned)step, deterministic);
+                     (unsigned long long)seed, (unsigned)step, deterministic); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, m.kl_blocks, l->F,
-                     w + m.step_out);
+                     w + m.step_out); }
   return (int)hipGetLastError();
 }
 
@@ -422,19 +440,19 @@ int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, 
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_loss_kernel, dim3(m.loss_blocks), dim3(256), 0, st, loss_kind, w + m.pred, l->out_dim, y,
                      (long long)ldy, (const int*)row_idx, (long long)row0, batch, inv_global_batch, l->out_act,
-                     w + m.g_pred, w + m.loss_partial);
+                     w + m.g_pred, w + m.loss_partial); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2), dim3(256), 0, st, w + m.loss_partial, m.loss_blocks, 2,
-                     w + m.step_out + l->F);
+                     w + m.step_out + l->F); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream); }
-  hipLaunchKernelGGL(dib_set_scalar_kernel, dim3(1), dim3(1), 0, st, w + m.step_out + l->F + 2, (float)batch);
+  { ProfScope ps(3, (hipStream_t)stream);
+  hipLaunchKernelGGL(dib_set_scalar_kernel, dim3(1), dim3(1), 0, st, w + m.step_out + l->F + 2, (float)batch); }
   return (int)hipGetLastError();
 }
 
@@ -476,10 +494,10 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   float* w = (float*)ws;
   float* gt = wgrad_target(m, w, grads);
   const long long sstride = align_up(l->n_params, 4);
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
                      w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
-                     (unsigned long long)seed, (unsigned)step);
+                     (unsigned long long)seed, (unsigned)step); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   const int LE = l->n_enc + 1;
@@ -506,9 +524,9 @@ int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_str
   float* w = (float*)ws;
   // partial slabs are spaced align_up(n_params,4) apart; the reduce treats them as n = that stride
   const long long n = align_up(l->n_params, 4);
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, w + m.wgrad_partial, n,
-                     m.nsplit, grads);
+                     m.nsplit, grads); }
   return (int)hipGetLastError();
 }
 
@@ -517,9 +535,9 @@ int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, floa
   if (!l || !beta_dev || !metrics_acc || !ws || batch <= 0) return DIB_E_ARG;
   const auto m = l->map(batch);
   float* w = (float*)ws;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_metrics_accumulate_kernel, dim3(cdiv(l->F + 3, 64)), dim3(64), 0, (hipStream_t)stream,
-                     w + m.step_out, l->F, beta_dev, inv_global_batch, metrics_acc);
+                     w + m.step_out, l->F, beta_dev, inv_global_batch, metrics_acc); }
   return (int)hipGetLastError();
 }
 
@@ -528,22 +546,22 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
                   int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale, dib_stream_t stream) {
   if (!params || !grads || !mm || !vv || !lr_dev || !t_dev || n <= 0) return DIB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
-                     lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale);
+                     lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream); }
-  hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev);
+  { ProfScope ps(3, (hipStream_t)stream);
+  hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev); }
   return (int)hipGetLastError();
 }
 
 int dib_sgd_step(float* params, const float* grads, int64_t n, const float* lr_dev, float grad_scale,
                  dib_stream_t stream) {
   if (!params || !grads || !lr_dev || n <= 0) return DIB_E_ARG;
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, (long long)n,
-                     lr_dev, grad_scale);
+                     lr_dev, grad_scale); }
   return (int)hipGetLastError();
 }
 
@@ -557,18 +575,16 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
   const auto m = l->map(n);
   float* w = (float*)ws;
   const int d = l->dims[feature];
-  { ProfScope ps(3, (hipStream_t)stream); }
+  { ProfScope ps(3, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, st, x_f, (long long)d,
-                     (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P,
-                     (long long)l->pw);
+                     (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   rc = encoder_chain_fwd(l, m, w, n, params, feature, 1, st);
   if (rc) return rc;
   const int w2 = 2 * l->E;
-  return (int)hipMemcpy2DAsync(out, (size_t)w2 * sizeof(float), w + m.enc_out + (int64_t)feature * w2,
-                               (size_t)l->F * w2 * sizeof(float), (size_t)w2 * sizeof(float), (size_t)n,
-                               hipMemcpyDeviceToDevice, st);
+  return (int)hipMemcpyAsync(out, w + m.enc_out + (int64_t)feature * n * w2, (size_t)n * w2 * sizeof(float),
+                             hipMemcpyDeviceToDevice, st);
 }
 
 int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu2, const float* lv2, int m, int dim,
@@ -625,22 +641,22 @@ int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float
              const float* bias, const float* aux, int ldaux, int act, void* dev_desc, dib_stream_t stream) {
   if (!A || !B || !C || !dev_desc || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 2) return DIB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  DibGemmGroup g = make_group(0, lda, 0, ldb, 0, ldc, bias ? 0 : -1, 0, ldaux, M, N, K);
-  if (((uintptr_t)A & 15) != 0) g.flags &= ~1;
-  if (((uintptr_t)B & 15) != 0) g.flags &= ~2;
+  DibGemmGroup g = make_group(Off(), lda, Off(), ldb, Off(), ldc, bias ? 0 : -1, Off(), ldaux, M, N, K);
+  if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return DIB_E_ARG;  // operands must be 16-byte aligned
   hipError_t e = hipMemcpyAsync(dev_desc, &g, sizeof(g), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
-  const int tm = cdiv(M, DIB_BM), tn = cdiv(N, DIB_BN);
+  const int tm = cdiv(M, 128), tn = cdiv(N, 128);
   const DibGemmGroup* dg = (const DibGemmGroup*)dev_desc;
+  const dim3 g1(8 * cdiv(tm, 8) * tn, 1, 1);
   if (mode == 0)
-    hipLaunchKernelGGL((dib_gemm_kernel<0>), dim3(tm, tn, 1), dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr,
-                       0, act, tn, 0, 0ll);
+    hipLaunchKernelGGL((dib_gemm_kernel<0, 2, 2>), g1, dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr, 0,
+                       act, tm, tn, 0, 0ll);
   else if (mode == 1)
-    hipLaunchKernelGGL((dib_gemm_kernel<1>), dim3(tm, tn, 1), dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr,
-                       0, act, tn, 0, 0ll);
+    hipLaunchKernelGGL((dib_gemm_kernel<1, 2, 2>), g1, dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr, 0,
+                       act, tm, tn, 0, 0ll);
   else  // single split over the whole contraction; bias (if given) receives the column sums of B
-    hipLaunchKernelGGL((dib_gemm_kernel<2>), dim3(1, tm * tn, 1), dim3(256), 0, st, dg, A, B, C, (const float*)nullptr,
-                       aux, (float*)bias, 0, act, tn, K, 0ll);
+    hipLaunchKernelGGL((dib_gemm_kernel<2, 2, 2>), dim3(1, tm * tn, 1), dim3(256), 0, st, dg, A, B, C,
+                       (const float*)nullptr, aux, (float*)bias, 0, act, tm, tn, K, 0ll);
   return (int)hipGetLastError();
 }
 

@@ -7,13 +7,14 @@
 // ---------------------------------------------------------------------------------------------
 // Positional encoding, reference models.py:22-23:  concat([x] + [sin(f*x) for f in freqs], -1)
 // (blockwise layout) fused with tf.split (models.py:101) and the shuffled-batch gather.
-// colmap[c] = {feature, local column, d_f, first encoder-input column of the feature}.
-// P[b, poff + j*d_f + c_local] = (j==0 ? x : sin(2^j * x)),  x = X[row(b), xcol0 + c]
+// colmap[c] = {feature, local column, d_f, sum of encoder-input widths of the features before it}.
+// P is feature-major and ragged: P_f = P + poff*batch is a dense [batch, n_blocks*d_f] matrix and
+// P_f[b, j*d_f + c_local] = (j==0 ? x : sin(2^j * x)),  x = X[row(b), c]
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restrict__ row_idx, long long row0,
                   int batch, const int4* __restrict__ colmap, int ncols, int n_blocks /*1 + n sinusoids*/,
-                  float* __restrict__ P, long long ldp) {
+                  float* __restrict__ P) {
   const long long total = (long long)batch * ncols;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
@@ -21,7 +22,7 @@ dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restr
     const long long row = row_idx ? (long long)row_idx[b] : row0 + b;
     const float x = X[row * ldx + c];
     const int4 cm = colmap[c];
-    float* dst = P + (long long)b * ldp + cm.w + cm.y;
+    float* dst = P + (long long)cm.w * batch + (long long)b * (n_blocks * cm.z) + cm.y;
     dst[0] = x;
     float fr = 2.0f;
     for (int j = 1; j < n_blocks; ++j) {
@@ -50,7 +51,7 @@ dib_reparam_kl_fwd_kernel(const float* __restrict__ enc_out, float* __restrict__
   float klp = 0.f;
   if (r < rows_per_block && b < batch) {
     const long long grow = row_idx ? (long long)row_idx[b] : row0 + b;
-    const float* mu_p = enc_out + (long long)b * (2ll * F * E) + 2ll * f * E + 4 * q;
+    const float* mu_p = enc_out + ((long long)f * batch + b) * (2ll * E) + 4 * q;  // enc_out is [F][B][2E]
     const float* lv_p = mu_p + E;
     float* u_p = U + (long long)b * ((long long)F * E) + (long long)f * E + 4 * q;
     float eps[4] = {0.f, 0.f, 0.f, 0.f};
@@ -107,7 +108,7 @@ dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __rest
   if (r >= rows_per_block || b >= batch) return;
   const float kb = beta_dev[0] * inv_bg;
   const long long grow = row_idx ? (long long)row_idx[b] : row0 + b;
-  const long long o = (long long)b * (2ll * F * E) + 2ll * f * E + 4 * q;
+  const long long o = ((long long)f * batch + b) * (2ll * E) + 4 * q;  // enc_out / dout are [F][B][2E]
   const float* gu_p = GU + (long long)b * ((long long)F * E) + (long long)f * E + 4 * q;
   float eps[4];
   dib_eps4(seed, step, (uint32_t)grow, (uint32_t)f, (uint32_t)q, eps);

@@ -245,7 +245,9 @@ class HipEngine:
         return self.ws_view(batch, _lib.WS_U, batch * self.F * self.E).view(batch, self.F * self.E)
 
     def enc_out(self, batch: int) -> torch.Tensor:
-        return self.ws_view(batch, _lib.WS_ENC_OUT, batch * self.F * 2 * self.E).view(batch, self.F, 2 * self.E)
+        # stored feature-major [F][B][2E] on the device; presented as [B, F, 2E]
+        return self.ws_view(batch, _lib.WS_ENC_OUT, batch * self.F * 2 * self.E).view(self.F, batch, 2 * self.E) \
+            .permute(1, 0, 2)
 
     def g_u(self, batch: int) -> torch.Tensor:
         return self.ws_view(batch, _lib.WS_G_U, batch * self.F * self.E).view(batch, self.F * self.E)

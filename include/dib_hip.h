@@ -51,7 +51,7 @@ enum { DIB_LOSS_BCE_LOGITS = 0, DIB_LOSS_BCE = 1, DIB_LOSS_SPARSE_CCE_LOGITS = 2
 /* workspace sub-buffers addressable by the host (dib_workspace_offset) */
 enum { DIB_WS_U = 0,        /* [B, F*E]  sampled embeddings, models.py:108,122 */
        DIB_WS_PRED = 1,     /* [B, out]  model output, models.py:122 */
-       DIB_WS_ENC_OUT = 2,  /* [B, F*2E] (mu|logvar) per feature, models.py:106 */
+       DIB_WS_ENC_OUT = 2,  /* [F][B][2E] feature-major (mu|logvar) per feature, models.py:106 */
        DIB_WS_G_U = 3,      /* [B, F*E]  dL/du */
        DIB_WS_STEP_OUT = 4, /* [F+3]     per-step scalars: KL_f local sums, task-loss sum, #correct, rows */
        DIB_WS_G_PRED = 5    /* [B, out]  dL/dpred */ };
