@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -10,6 +11,7 @@
 #include "../../include/dib_hip.h"
 #include "dib_elementwise.h"
 #include "dib_gemm.h"
+#include "dib_fused.h"
 
 namespace {
 
@@ -40,6 +42,12 @@ struct dib_layout {
   std::vector<GemmCall> enc_fwd, enc_dgrad, enc_wgrad, int_fwd, int_dgrad, int_wgrad;
   const DibGemmGroup* dev_groups = nullptr;
   const int4* dev_colmap = nullptr;
+  // fused encoder-bank kernels (dib_fused.h): -1 = not applicable, else index into the instantiation table
+  int fused_id = -1;
+  std::vector<long long> fused_offs;   // [3][F] kernel offsets then [3][F] bias offsets
+  std::vector<int4> featmap;           // [F] {d_f, in_dim_f, x column, 0}
+  const long long* dev_fused_offs = nullptr;
+  const int4* dev_featmap = nullptr;
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
@@ -67,7 +75,7 @@ struct dib_layout {
     const int E4 = (E + 3) / 4;
     const int rpb = std::max(1, 256 / E4);
     m.kl_blocks = cdiv(B, rpb);
-    m.kl_partial = take((int64_t)m.kl_blocks * F);
+    m.kl_partial = take((int64_t)std::max(m.kl_blocks, 8 * 256) * F);  // fused fwd: <= 256 workgroups x 8 waves
     m.loss_blocks = cdiv(B, 256);
     m.loss_partial = take((int64_t)m.loss_blocks * 2);
     // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= 1024 rows per split
@@ -162,6 +170,43 @@ inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
 }
 
 }  // namespace
+
+template <int H1, int H2, int E>
+static int launch_fused_fwd(const DibFusedFwdArgs& a, int gx, int F, hipStream_t st) {
+  using C = DibFusedCfg<H1, H2, E>;
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_fwd_kernel<H1, H2, E>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dib_fused_encoder_fwd_kernel<H1, H2, E>), dim3(gx, F), dim3(512), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w, const float* x, int64_t ldx,
+                             const int32_t* row_idx, int64_t row0, int batch, const float* params, uint64_t seed,
+                             uint32_t step, int deterministic, hipStream_t st, int* gx_out) {
+  DibFusedFwdArgs a;
+  a.P = w + m.P; a.row_idx = (const int*)row_idx; a.row0 = row0; a.batch = batch; a.params = params;
+  a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap;
+  a.n_blocks = l->n_blocks; a.act = l->act;
+  a.h1 = w + m.enc_h[0]; a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.U = w + m.U;
+  a.kl_partial = w + m.kl_partial; a.F = l->F; a.seed = seed; a.step = step; a.deterministic = deterministic;
+  const int n_tiles = cdiv(batch, 256);
+  const int gx = std::max(1, std::min(n_tiles, cdiv(256, l->F)));
+  *gx_out = gx;
+  ProfScope ps(0, st);  // counted with the forward GEMM category (it replaces the three encoder fwd GEMMs)
+  switch (l->fused_id) {
+    case 0: return launch_fused_fwd<128, 128, 32>(a, gx, l->F, st);
+    case 1: return launch_fused_fwd<32, 32, 32>(a, gx, l->F, st);
+    case 2: return launch_fused_fwd<32, 32, 8>(a, gx, l->F, st);
+    case 3: return launch_fused_fwd<64, 64, 16>(a, gx, l->F, st);
+    default: return DIB_E_UNSUPPORTED;
+  }
+}
 
 extern "C" {
 
@@ -295,6 +340,25 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
     wg.count = 1; wg.max_m = win; wg.max_n = wout;
     l->int_wgrad.push_back(wg);
   }
+  // fused encoder-bank path: two hidden layers, instantiated (H1,H2,E), encoder inputs <= 16 wide
+  {
+    static const int kFused[][3] = {{128, 128, 32}, {32, 32, 32}, {32, 32, 8}, {64, 64, 16}};
+    const char* dis = std::getenv("DIB_DISABLE_FUSED");
+    bool in_ok = true;
+    for (int f = 0; f < F; ++f) in_ok = in_ok && l->in_dim[f] <= 16;
+    if (!(dis && dis[0] == '1') && n_enc == 2 && in_ok && act >= 0 && act <= 2)
+      for (int i = 0; i < 4; ++i)
+        if (kFused[i][0] == enc_units[0] && kFused[i][1] == enc_units[1] && kFused[i][2] == E) l->fused_id = i;
+    for (int ly = 0; ly < LE && ly < 3; ++ly)
+      for (int f = 0; f < F; ++f) l->fused_offs.push_back(l->enc_w_off[ly][f]);
+    for (int ly = LE; ly < 3; ++ly)
+      for (int f = 0; f < F; ++f) l->fused_offs.push_back(0);
+    for (int ly = 0; ly < LE && ly < 3; ++ly)
+      for (int f = 0; f < F; ++f) l->fused_offs.push_back(l->enc_b_off[ly][f]);
+    for (int ly = LE; ly < 3; ++ly)
+      for (int f = 0; f < F; ++f) l->fused_offs.push_back(0);
+    for (int f = 0; f < F; ++f) l->featmap.push_back(make_int4(l->dims[f], l->in_dim[f], l->x_off[f], l->in_off[f]));
+  }
   *out = l;
   return DIB_OK;
 }
@@ -327,7 +391,10 @@ int dib_layout_param_block(const dib_layout* l, int net, int layer, int feature,
 
 int64_t dib_layout_table_bytes(const dib_layout* l) {
   if (!l) return DIB_E_ARG;
-  return align_up((int64_t)l->table.size() * sizeof(DibGemmGroup), 256) + align_up((int64_t)l->colmap.size() * sizeof(int4), 256);
+  return align_up((int64_t)l->table.size() * sizeof(DibGemmGroup), 256) +
+         align_up((int64_t)l->colmap.size() * sizeof(int4), 256) +
+         align_up((int64_t)l->fused_offs.size() * sizeof(long long), 256) +
+         align_up((int64_t)l->featmap.size() * sizeof(int4), 256);
 }
 
 int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t stream) {
@@ -340,8 +407,16 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
   char* cm = base + align_up(gbytes, 256);
   e = hipMemcpyAsync(cm, l->colmap.data(), l->colmap.size() * sizeof(int4), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
+  char* fo = cm + align_up((int64_t)l->colmap.size() * sizeof(int4), 256);
+  e = hipMemcpyAsync(fo, l->fused_offs.data(), l->fused_offs.size() * sizeof(long long), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
+  char* fmp = fo + align_up((int64_t)l->fused_offs.size() * sizeof(long long), 256);
+  e = hipMemcpyAsync(fmp, l->featmap.data(), l->featmap.size() * sizeof(int4), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return (int)e;
   l->dev_groups = (const DibGemmGroup*)base;
   l->dev_colmap = (const int4*)cm;
+  l->dev_fused_offs = (const long long*)fo;
+  l->dev_featmap = (const int4*)fmp;
   return DIB_OK;
 }
 
@@ -401,6 +476,15 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
                      (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
+  if (l->fused_id >= 0) {  // one launch: positional encoding + 3 layers + reparameterisation + KL
+    int gx = 1;
+    rc = fused_encoder_fwd(l, m, w, x, ldx, row_idx, row0, batch, params, seed, step, deterministic, st, &gx);
+    if (rc) return rc;
+    { ProfScope ps(3, (hipStream_t)stream);
+    hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, gx * 8, l->F,
+                       w + m.step_out); }
+    return (int)hipGetLastError();
+  }
   rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
   if (rc) return rc;
   { ProfScope ps(3, (hipStream_t)stream);
