@@ -208,6 +208,42 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   }
 }
 
+template <int H1, int H2, int E>
+static int launch_fused_bwd(const DibFusedBwdArgs& a, int gx, int F, hipStream_t st) {
+  using C = DibFusedBwdCfg<H1, H2, E>;
+  const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_bwd_kernel<H1, H2, E>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dib_fused_encoder_bwd_kernel<H1, H2, E>), dim3(gx, F), dim3(512), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+// fused backward dgrad chain is instantiated for the configs whose E is a multiple of 32
+static bool fused_bwd_ok(const dib_layout* l) { return l->fused_id == 0 || l->fused_id == 1; }
+
+static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params,
+                             const float* beta_dev, float inv_bg, const int32_t* row_idx, int64_t row0, uint64_t seed,
+                             uint32_t step, hipStream_t st) {
+  DibFusedBwdArgs a;
+  a.P = w + m.P; a.row_idx = (const int*)row_idx; a.row0 = row0; a.batch = batch; a.params = params;
+  a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap; a.act = l->act;
+  a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.GU = w + m.g_u;
+  a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dh1 = w + m.g_enc_h[0];
+  a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F; a.seed = seed; a.step = step;
+  const int gx = std::max(1, std::min(cdiv(batch, 256), cdiv(256, l->F)));
+  ProfScope ps(1, st);  // counted with the dgrad GEMM category (it replaces both encoder dgrad GEMMs)
+  switch (l->fused_id) {
+    case 0: return launch_fused_bwd<128, 128, 32>(a, gx, l->F, st);
+    case 1: return launch_fused_bwd<32, 32, 32>(a, gx, l->F, st);
+    default: return DIB_E_UNSUPPORTED;
+  }
+}
+
 extern "C" {
 
 const char* dib_version(void) { return kVersion; }
@@ -578,11 +614,17 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   float* w = (float*)ws;
   float* gt = wgrad_target(m, w, grads);
   const long long sstride = align_up(l->n_params, 4);
-  { ProfScope ps(3, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
-                     w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
-                     (unsigned long long)seed, (unsigned)step); }
-  int rc = (int)hipGetLastError();
+  int rc = DIB_OK;
+  const bool fused = fused_bwd_ok(l);
+  if (fused) {  // reparam/KL backward + both dgrads in one launch (dib_fused.h); wgrads below read its outputs
+    rc = fused_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, row_idx, row0, seed, step, st);
+  } else {
+    { ProfScope ps(3, (hipStream_t)stream);
+    hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
+                       w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
+                       (unsigned long long)seed, (unsigned)step); }
+    rc = (int)hipGetLastError();
+  }
   if (rc) return rc;
   const int LE = l->n_enc + 1;
   for (int ly = LE - 1; ly >= 0; --ly) {
@@ -591,7 +633,7 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
     rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
                         m.rows_per_split, sstride, st);
     if (rc) return rc;
-    if (ly >= 1) {
+    if (ly >= 1 && !fused) {
       rc = launch_gemm<1>(l, l->enc_dgrad[ly], gout, params, w + m.g_enc_h[ly - 1], nullptr, hin, nullptr, batch,
                           l->act, 1, 0, 0, st);
       if (rc) return rc;

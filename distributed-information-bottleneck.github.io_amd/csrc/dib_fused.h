@@ -72,12 +72,12 @@ __device__ __forceinline__ void dib_store_tile(float* __restrict__ patch, const 
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<float4*>(patch + m * 36 + 8 * g + 4 * h) = make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS ops are in order; this also pins the compiler
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering them
   const int rr = lane >> 3, cc = (lane & 7) * 4;
   float4 v[4];
 #pragma unroll
   for (int pss = 0; pss < 4; ++pss) v[pss] = *reinterpret_cast<const float4*>(patch + (rr + 8 * pss) * 36 + cc);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // patch is reused by the next tile
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering them
   if (rows_valid >= 32) {  // wave-uniform fast path: four unconditional 16-byte stores
 #pragma unroll
     for (int pss = 0; pss < 4; ++pss) *reinterpret_cast<float4*>(dst + (long long)(rr + 8 * pss) * ld + cc) = v[pss];
@@ -293,4 +293,234 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     for (int r = 0; r < 8; ++r) p[r] = pn[r];
   }
   if (lane == 0) a.kl_partial[((long long)blockIdx.x * 8 + wave) * F + f] = kl_acc;
+}
+
+// =====================================================================================================
+// BACKWARD "dgrad chain" (what tape.gradient derives for reference models.py:106-118, explicit at
+// train.py:203-219), ONE launch replacing the reparam/KL backward and both encoder dgrad GEMMs:
+//   dmu = g_u + beta*mu/Bg ; dlogvar = g_u*eps*0.5*exp(lv/2) + beta*0.5*(exp(lv)-1)/Bg       -> dout  [F][B][2E]
+//   dh2 = (dout @ W3^T) * act'(h2)                                                         -> dh2   [F][B][H2]
+//   dh1 = (dh2  @ W2^T) * act'(h1)     (h1 is RECOMPUTED from the encoded input: 4..8 MFMAs) -> dh1   [F][B][H1]
+// Same structure as the forward: one workgroup per feature, W2 / W3 resident in LDS in their natural
+// [in][out] orientation (they are the A operand of the transposed product dH_in^T = W * dH_out^T, fetched with
+// conflict-free ds_read_b128), gradients chained in MFMA accumulator registers, eps regenerated from the
+// Philox counter.  Row-major tiles (h2, mu|logvar, g_u in; dout, dh2, dh1 out) cross between HBM and the
+// fragment layout through a wave-private LDS patch so every global access is a full 128-byte line.
+// The weight gradients (contractions over the batch) then run as the grouped wgrad GEMMs on these buffers.
+// =====================================================================================================
+struct DibFusedBwdArgs {
+  const float* P; const int* row_idx; long long row0; int batch;
+  const float* params; const long long* w_off; const long long* b_off; const int4* featmap;
+  int act;
+  const float* h2; const float* enc_out; const float* GU;   // stashes + dL/du [B][F*E]
+  float* dout; float* dh2; float* dh1;
+  const float* beta_dev; float inv_bg;
+  int F; unsigned long long seed; unsigned step;
+};
+
+template <int H1, int H2, int E>
+struct DibFusedBwdCfg {
+  static constexpr int E2 = 2 * E;
+  static constexpr int N3 = (E2 + 31) / 32 * 32;
+  static constexpr int K1P = 20;                        // layer-1 transposed image pitch (inputs <= 16 wide)
+  static constexpr int P2 = H2 + 4, P3 = N3 + 4;        // W2 image [H1][H2+4], W3 image [H2][N3+4]
+  static constexpr int W1_FLOATS = H1 * K1P, W2_FLOATS = H1 * P2, W3_FLOATS = H2 * P3;
+  static constexpr int PATCH = 32 * 36;
+  static constexpr int LDS_FLOATS = W1_FLOATS + W2_FLOATS + W3_FLOATS + H1 + 8 * PATCH;
+  static constexpr int T1 = H1 / 32, T2 = H2 / 32, T3 = N3 / 32;
+};
+
+// issue the 4 coalesced 16-byte loads of one 32x32 row-major tile (rows clamped to the valid range)
+struct DibTile4 { float4 a, b, c, d; };
+__device__ __forceinline__ DibTile4 dib_tile_gload(const float* __restrict__ src, long long ld, int rows_valid, int lane) {
+  const int rr = lane >> 3, cc = (lane & 7) * 4;
+  DibTile4 t;
+  t.a = *reinterpret_cast<const float4*>(src + (long long)min(rr, rows_valid - 1) * ld + cc);
+  t.b = *reinterpret_cast<const float4*>(src + (long long)min(rr + 8, rows_valid - 1) * ld + cc);
+  t.c = *reinterpret_cast<const float4*>(src + (long long)min(rr + 16, rows_valid - 1) * ld + cc);
+  t.d = *reinterpret_cast<const float4*>(src + (long long)min(rr + 24, rows_valid - 1) * ld + cc);
+  return t;
+}
+// row-major tile (already in registers) -> transposed-product C fragment, through the wave-private LDS patch
+__device__ __forceinline__ dib_f32x16 dib_tile_to_frag(float* __restrict__ patch, const DibTile4 t, int lane) {
+  const int rr = lane >> 3, cc = (lane & 7) * 4, m = lane & 31, h = lane >> 5;
+  *reinterpret_cast<float4*>(patch + rr * 36 + cc) = t.a;
+  *reinterpret_cast<float4*>(patch + (rr + 8) * 36 + cc) = t.b;
+  *reinterpret_cast<float4*>(patch + (rr + 16) * 36 + cc) = t.c;
+  *reinterpret_cast<float4*>(patch + (rr + 24) * 36 + cc) = t.d;
+  __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering them
+  const float4 q0 = *reinterpret_cast<const float4*>(patch + m * 36 + 4 * h);
+  const float4 q1 = *reinterpret_cast<const float4*>(patch + m * 36 + 8 + 4 * h);
+  const float4 q2 = *reinterpret_cast<const float4*>(patch + m * 36 + 16 + 4 * h);
+  const float4 q3 = *reinterpret_cast<const float4*>(patch + m * 36 + 24 + 4 * h);
+  __builtin_amdgcn_wave_barrier();
+  dib_f32x16 c;
+  c[0] = q0.x; c[1] = q0.y; c[2] = q0.z; c[3] = q0.w; c[4] = q1.x; c[5] = q1.y; c[6] = q1.z; c[7] = q1.w;
+  c[8] = q2.x; c[9] = q2.y; c[10] = q2.z; c[11] = q2.w; c[12] = q3.x; c[13] = q3.y; c[14] = q3.z; c[15] = q3.w;
+  return c;
+}
+
+template <int H1, int H2, int E>
+__global__ void __launch_bounds__(512)
+dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
+  static_assert(E % 32 == 0, "fused backward: embedding dimension must be a multiple of 32");
+  using C = DibFusedBwdCfg<H1, H2, E>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wt1 = lds;                      // [H1][K1P]  Wt1[n][k] = W1[k][n] (for the h1 recompute)
+  float* W2i = Wt1 + C::W1_FLOATS;       // [H1][H2+4] W2[k1][k2]
+  float* W3i = W2i + C::W2_FLOATS;       // [H2][N3+4] W3[k2][n], columns >= 2E zero
+  float* B1 = W3i + C::W3_FLOATS;        // b1
+  float* patch = B1 + H1 + (threadIdx.x >> 6) * C::PATCH;
+
+  const int f = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const int4 fm = a.featmap[f];
+  const int in_dim = fm.y;
+  const int F = a.F;
+  const float* Pf = a.P + (long long)fm.w * a.batch;
+  {
+    const float* W1 = a.params + a.w_off[0 * F + f];
+    const float* W2 = a.params + a.w_off[1 * F + f];
+    const float* W3 = a.params + a.w_off[2 * F + f];
+    for (int i = tid; i < H1 * 16; i += 512) {
+      const int k = i / H1, n = i - k * H1;
+      Wt1[n * C::K1P + k] = (k < in_dim) ? W1[(long long)k * H1 + n] : 0.f;
+    }
+    for (int i = tid; i < H1 * H2; i += 512) {
+      const int k1 = i / H2, k2 = i - k1 * H2;
+      W2i[k1 * C::P2 + k2] = W2[i];
+    }
+    for (int i = tid; i < H2 * C::N3; i += 512) {
+      const int k2 = i / C::N3, n = i - k2 * C::N3;
+      W3i[k2 * C::P3 + n] = (n < C::E2) ? W3[(long long)k2 * C::E2 + n] : 0.f;
+    }
+    const float* b1 = a.params + a.b_off[0 * F + f];
+    for (int i = tid; i < H1; i += 512) B1[i] = b1[i];
+  }
+  __syncthreads();
+
+  const int n_tiles = (a.batch + 255) / 256;
+  const int ksteps1 = 4 * ((in_dim + 7) / 8);
+  const float slope = dib_neg_slope(a.act);
+  const float kb = a.beta_dev[0] * a.inv_bg;
+
+  auto load_p = [&](int tile, float (&dstp)[8]) {
+    const int bb = min(tile * 256 + wave * 32 + m, a.batch - 1);
+    const float* src = Pf + (long long)bb * in_dim;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = dib_crow(r, h);
+      const float v = src[min(k, in_dim - 1)];
+      dstp[r] = (k < in_dim) ? v : 0.f;
+    }
+  };
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int wrow0 = tile * 256 + wave * 32;
+    if (wrow0 >= a.batch) continue;  // wave-uniform; no barriers inside the loop
+    const int rows_valid = min(32, a.batch - wrow0);
+    const int b = min(wrow0 + m, a.batch - 1);
+    const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
+    float p[8];
+    load_p(tile, p);
+
+    // ---- dout = d(loss + beta*KL)/d(mu|logvar), lane-local in fragment layout ----
+    dib_f32x16 dout[C::T3];
+    {
+      const float* eo = a.enc_out + ((long long)f * a.batch + wrow0) * C::E2;
+      const float* gu = a.GU + (long long)wrow0 * ((long long)F * E) + (long long)f * E;
+#pragma unroll
+      for (int t = 0; t < E / 32; ++t) {
+        const DibTile4 vm = dib_tile_gload(eo + 32 * t, C::E2, rows_valid, lane);
+        const DibTile4 vl = dib_tile_gload(eo + E + 32 * t, C::E2, rows_valid, lane);
+        const DibTile4 vg = dib_tile_gload(gu + 32 * t, (long long)F * E, rows_valid, lane);
+        const dib_f32x16 mu = dib_tile_to_frag(patch, vm, lane);
+        const dib_f32x16 lv = dib_tile_to_frag(patch, vl, lane);
+        const dib_f32x16 g = dib_tile_to_frag(patch, vg, lane);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int e0 = 32 * t + 8 * gq + 4 * h;
+          float eps[4];
+          dib_eps4(a.seed, a.step, (uint32_t)grow, (uint32_t)f, (uint32_t)(e0 >> 2), eps);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * gq + j;
+            const float s = expf(0.5f * lv[r]);
+            dout[t][r] = g[r] + kb * mu[r];
+            dout[t + E / 32][r] = g[r] * eps[j] * 0.5f * s + kb * 0.5f * (s * s - 1.f);
+          }
+        }
+      }
+      float* dd = a.dout + ((long long)f * a.batch + wrow0) * C::E2;
+#pragma unroll
+      for (int t = 0; t < C::T3; ++t) dib_store_tile(patch, dout[t], dd + 32 * t, C::E2, rows_valid, lane);
+    }
+
+    // ---- dh2^T = W3 dout^T, masked by act'(h2) ----
+    dib_f32x16 dh2[C::T2];
+    {
+      const float* h2g = a.h2 + ((long long)f * a.batch + wrow0) * H2;
+      float* dg = a.dh2 + ((long long)f * a.batch + wrow0) * H2;
+#pragma unroll
+      for (int jo = 0; jo < C::T2; ++jo) {
+        const DibTile4 vh = dib_tile_gload(h2g + 32 * jo, H2, rows_valid, lane);  // in flight during the MFMAs below
+        dib_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < C::T3; ++jt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 w = *reinterpret_cast<const float4*>(W3i + (32 * jo + m) * C::P3 + 32 * jt + 8 * g + 4 * h);
+            acc = DIB_MFMA(w.x, dout[jt][4 * g + 0], acc);
+            acc = DIB_MFMA(w.y, dout[jt][4 * g + 1], acc);
+            acc = DIB_MFMA(w.z, dout[jt][4 * g + 2], acc);
+            acc = DIB_MFMA(w.w, dout[jt][4 * g + 3], acc);
+          }
+        const dib_f32x16 hv = dib_tile_to_frag(patch, vh, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= (hv[r] > 0.f ? 1.f : slope);
+        dh2[jo] = acc;
+        dib_store_tile(patch, acc, dg + 32 * jo, H2, rows_valid, lane);
+      }
+    }
+
+    // ---- dh1^T = W2 dh2^T, masked by act'(h1); h1 tile recomputed from the encoded input ----
+    {
+      float* dg = a.dh1 + ((long long)f * a.batch + wrow0) * H1;
+#pragma unroll
+      for (int jo = 0; jo < C::T1; ++jo) {
+        dib_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < C::T2; ++jt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 w = *reinterpret_cast<const float4*>(W2i + (32 * jo + m) * C::P2 + 32 * jt + 8 * g + 4 * h);
+            acc = DIB_MFMA(w.x, dh2[jt][4 * g + 0], acc);
+            acc = DIB_MFMA(w.y, dh2[jt][4 * g + 1], acc);
+            acc = DIB_MFMA(w.z, dh2[jt][4 * g + 2], acc);
+            acc = DIB_MFMA(w.w, dh2[jt][4 * g + 3], acc);
+          }
+        dib_f32x16 h1v;  // pre-activation of h1 tile jo: W1^T p + b1 (sign decides act')
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1v[r] = B1[32 * jo + dib_crow(r, h)];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          if (4 * g < ksteps1) {
+            const float4 w = *reinterpret_cast<const float4*>(Wt1 + (32 * jo + m) * C::K1P + 8 * g + 4 * h);
+            h1v = DIB_MFMA(w.x, p[4 * g + 0], h1v);
+            h1v = DIB_MFMA(w.y, p[4 * g + 1], h1v);
+            h1v = DIB_MFMA(w.z, p[4 * g + 2], h1v);
+            h1v = DIB_MFMA(w.w, p[4 * g + 3], h1v);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= (h1v[r] > 0.f ? 1.f : slope);
+        dib_store_tile(patch, acc, dg + 32 * jo, H1, rows_valid, lane);
+      }
+    }
+  }
 }
