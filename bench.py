@@ -29,6 +29,17 @@ sys.path.insert(0, ROOT)
 
 FLOPS_PER_SAMPLE = 13141504      # GEMM FLOPs fwd+dgrad+wgrad, config 3
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+# HBM bytes per launch of each kernel from rocprofv3 PMC passes (profiles/, see DESIGN.md "Measurement"); filled in
+# from the committed counter collection, None where not collected.
+def _load_hbm_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic_per_kernel.json")) as fh:
+            return {k: v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"] for k, v in json.load(fh).items()}
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+HBM_TRAFFIC = _load_hbm_traffic()
 F, E, BATCH = 64, 32, 65536
 ENC, INTEG = [128, 128], [256, 256]
 
@@ -41,15 +52,24 @@ def synthetic(n_rows, seed=20241008):
     return x, y
 
 
-def gemm_flops_by_mode():
-    """algorithmic GEMM FLOPs per sample of each kernel instantiation (sum = FLOPS_PER_SAMPLE)."""
+def flops_by_kernel():
+    """algorithmic GEMM FLOPs per sample executed by each kernel symbol for BASELINE config 3
+    (sum = FLOPS_PER_SAMPLE; recompute inside the fused backward is NOT counted)."""
     enc = [(5, 128), (128, 128), (128, 2 * E)]
     integ = [(F * E, 256), (256, 256), (256, 1)]
-    fwd = sum(2 * i * o for i, o in enc) * F + sum(2 * i * o for i, o in integ)
-    dgrad = sum(2 * i * o for i, o in enc[1:]) * F + sum(2 * i * o for i, o in integ)
-    wgrad = fwd
-    assert fwd + dgrad + wgrad == FLOPS_PER_SAMPLE
-    return {"fwd": fwd, "dgrad": dgrad, "wgrad": wgrad}
+    fl = lambda i, o: 2 * i * o
+    out = {
+        "dib_fused_encoder_fwd_kernel": sum(fl(i, o) for i, o in enc) * F,            # 3 encoder layers fwd
+        "dib_fused_encoder_bwd_kernel": sum(fl(i, o) for i, o in enc[1:]) * F,        # dgrad of layers 3, 2
+        "dib_gemm_kernel<0, 2, 2>": fl(*integ[0]) + fl(*integ[1]),                    # integration fwd, N >= 128
+        "dib_gemm_kernel<0, 2, 1>": fl(*integ[2]),                                    # integration fwd, N = 1
+        "dib_gemm_kernel<1, 2, 2>": sum(fl(i, o) for i, o in integ),                  # integration dgrads
+        "dib_gemm_kernel<2, 2, 1>": fl(*integ[2]) + fl(*enc[2]) * F,                  # wgrads with N <= 64
+        "dib_gemm_kernel<2, 2, 2>": fl(*integ[0]) + fl(*integ[1]) + fl(*enc[1]) * F,  # wgrads with M, N >= 128
+        "dib_gemm_kernel<2, 1, 2>": fl(*enc[0]) * F,                                  # encoder layer-1 wgrad (M = 5)
+    }
+    assert sum(out.values()) == FLOPS_PER_SAMPLE
+    return out
 
 
 def _cpu_baseline_worker(threads, budget_s):
@@ -186,23 +206,22 @@ def main():
                                  "frac": round(sps * FLOPS_PER_SAMPLE / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
                                  "note": "whole-step algorithmic GEMM FLOPs / wall time, per GPU"}}
         if prof:
-            fl = gemm_flops_by_mode()
+            fl = flops_by_kernel()
             per = {}
-            for name in ("fwd", "dgrad", "wgrad"):
-                ms, cnt = prof[name]
-                if cnt:
+            for name, (ms, cnt) in prof.items():
+                if name in fl and cnt:
                     tf = fl[name] * B * args.steps / (ms * 1e-3) / 1e12
-                    per[name] = {"kernel": f"dib_gemm_kernel<{['fwd', 'dgrad', 'wgrad'].index(name)}>",
-                                 "launches": cnt, "avg_launch_ms": round(ms / cnt, 5), "achieved": round(tf, 2),
+                    per[name] = {"launches": cnt, "avg_launch_ms": round(ms / cnt, 5), "ms_per_step": round(ms / args.steps, 4),
+                                 "flops_per_launch": fl[name] * B * args.steps // cnt, "achieved": round(tf, 2),
                                  "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
             if per:
-                dom = max(per, key=lambda k: per[k]["avg_launch_ms"] * per[k]["launches"])
+                dom = max(per, key=lambda k: per[k]["ms_per_step"])
                 out["roofline"] = {"bound": "mfma", "achieved": per[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": None,
-                                   "kernel": per[dom]["kernel"], "avg_launch_ms": per[dom]["avg_launch_ms"],
-                                   "launches": per[dom]["launches"]}
+                                   "unit": "TFLOP/s", "frac": per[dom]["frac"], "traffic": HBM_TRAFFIC.get(dom),
+                                   "kernel": dom, "avg_launch_ms": per[dom]["avg_launch_ms"],
+                                   "launches": per[dom]["launches"], "flops_per_launch": per[dom]["flops_per_launch"]}
                 out["roofline_by_kernel"] = per
-                out["gemm_ms_per_step"] = round(sum(prof[k][0] for k in ("fwd", "dgrad", "wgrad")) / args.steps, 4)
+                out["hbm_bound_kernels_ms_per_step"] = round(prof.get("other", (0.0, 0))[0] / args.steps, 4)
         if "roofline" not in out:
             out["roofline"] = dict(out["step_roofline"], traffic=None)
         if world == 1 and not args.no_cpu_baseline:

@@ -93,7 +93,10 @@ struct dib_layout {
 namespace {
 
 // ---- optional live kernel timing (bench.py roofline): HIP events around every launch, on the launch stream ----
-constexpr int kProfCats = 4;  // 0 fwd GEMM, 1 dgrad GEMM, 2 wgrad GEMM, 3 everything else (HBM-bound kernels)
+// categories = kernel symbols: 0..11 dib_gemm_kernel<MODE,NI,NJ> at MODE*4 + (NI-1)*2 + (NJ-1); 12 fused encoder fwd;
+// 13 fused encoder bwd; 14 every other (HBM-bound) kernel
+constexpr int kProfCats = 15;
+constexpr int kProfFusedFwd = 12, kProfFusedBwd = 13, kProfOther = 14;
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;                     // recycled events
@@ -154,10 +157,10 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
                 const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
                 long long split_stride, hipStream_t st) {
   if (c.count == 0) return DIB_OK;
-  ProfScope ps(MODE, st);
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
   const bool ni1 = (MODE == 2) && M <= 64, nj1 = N <= 64;   // narrow tiles for narrow outputs
+  ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(l, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
                                                    rows_per_split, split_stride, st)
   if (ni1) return nj1 ? DIB_GO(1, 1) : DIB_GO(1, 2);
@@ -198,7 +201,7 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   const int n_tiles = cdiv(batch, 256);
   const int gx = std::max(1, std::min(n_tiles, cdiv(256, l->F)));
   *gx_out = gx;
-  ProfScope ps(0, st);  // counted with the forward GEMM category (it replaces the three encoder fwd GEMMs)
+  ProfScope ps(kProfFusedFwd, st);
   switch (l->fused_id) {
     case 0: return launch_fused_fwd<128, 128, 32>(a, gx, l->F, st);
     case 1: return launch_fused_fwd<32, 32, 32>(a, gx, l->F, st);
@@ -236,7 +239,7 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dh1 = w + m.g_enc_h[0];
   a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F; a.seed = seed; a.step = step;
   const int gx = std::max(1, std::min(cdiv(batch, 256), cdiv(256, l->F)));
-  ProfScope ps(1, st);  // counted with the dgrad GEMM category (it replaces both encoder dgrad GEMMs)
+  ProfScope ps(kProfFusedBwd, st);
   switch (l->fused_id) {
     case 0: return launch_fused_bwd<128, 128, 32>(a, gx, l->F, st);
     case 1: return launch_fused_bwd<32, 32, 32>(a, gx, l->F, st);
@@ -507,7 +510,7 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)batch * l->sum_d)), dim3(256), 0, st, x, (long long)ldx,
                      (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
@@ -516,20 +519,20 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
     int gx = 1;
     rc = fused_encoder_fwd(l, m, w, x, ldx, row_idx, row0, batch, params, seed, step, deterministic, st, &gx);
     if (rc) return rc;
-    { ProfScope ps(3, (hipStream_t)stream);
+    { ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, gx * 8, l->F,
                        w + m.step_out); }
     return (int)hipGetLastError();
   }
   rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
                      w + m.kl_partial, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
                      (unsigned long long)seed, (unsigned)step, deterministic); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, m.kl_blocks, l->F,
                      w + m.step_out); }
   return (int)hipGetLastError();
@@ -560,18 +563,18 @@ int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, 
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_loss_kernel, dim3(m.loss_blocks), dim3(256), 0, st, loss_kind, w + m.pred, l->out_dim, y,
                      (long long)ldy, (const int*)row_idx, (long long)row0, batch, inv_global_batch, l->out_act,
                      w + m.g_pred, w + m.loss_partial); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2), dim3(256), 0, st, w + m.loss_partial, m.loss_blocks, 2,
                      w + m.step_out + l->F); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_set_scalar_kernel, dim3(1), dim3(1), 0, st, w + m.step_out + l->F + 2, (float)batch); }
   return (int)hipGetLastError();
 }
@@ -619,7 +622,7 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   if (fused) {  // reparam/KL backward + both dgrads in one launch (dib_fused.h); wgrads below read its outputs
     rc = fused_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, row_idx, row0, seed, step, st);
   } else {
-    { ProfScope ps(3, (hipStream_t)stream);
+    { ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
                        w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
                        (unsigned long long)seed, (unsigned)step); }
@@ -650,7 +653,7 @@ int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_str
   float* w = (float*)ws;
   // partial slabs are spaced align_up(n_params,4) apart; the reduce treats them as n = that stride
   const long long n = align_up(l->n_params, 4);
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, w + m.wgrad_partial, n,
                      m.nsplit, grads); }
   return (int)hipGetLastError();
@@ -661,7 +664,7 @@ int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, floa
   if (!l || !beta_dev || !metrics_acc || !ws || batch <= 0) return DIB_E_ARG;
   const auto m = l->map(batch);
   float* w = (float*)ws;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_metrics_accumulate_kernel, dim3(cdiv(l->F + 3, 64)), dim3(64), 0, (hipStream_t)stream,
                      w + m.step_out, l->F, beta_dev, inv_global_batch, metrics_acc); }
   return (int)hipGetLastError();
@@ -672,12 +675,12 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
                   int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale, dib_stream_t stream) {
   if (!params || !grads || !mm || !vv || !lr_dev || !t_dev || n <= 0) return DIB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
                      lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev); }
   return (int)hipGetLastError();
 }
@@ -685,7 +688,7 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
 int dib_sgd_step(float* params, const float* grads, int64_t n, const float* lr_dev, float grad_scale,
                  dib_stream_t stream) {
   if (!params || !grads || !lr_dev || n <= 0) return DIB_E_ARG;
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, (long long)n,
                      lr_dev, grad_scale); }
   return (int)hipGetLastError();
@@ -701,7 +704,7 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
   const auto m = l->map(n);
   float* w = (float*)ws;
   const int d = l->dims[feature];
-  { ProfScope ps(3, (hipStream_t)stream);
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, st, x_f, (long long)d,
                      (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();

@@ -231,11 +231,13 @@ class HipEngine:
         check(self.lib.dib_profile_enable(1 if on else 0), "dib_profile_enable")
 
     def profile_summary(self) -> dict:
-        """{'fwd'|'dgrad'|'wgrad'|'other': (total ms, launches)} since profile_enable(True); synchronises."""
-        ms = (ctypes.c_double * 4)()
-        cnt = (c_int * 4)()
+        """{kernel symbol: (total ms, launches)} since profile_enable(True); synchronises."""
+        ms = (ctypes.c_double * 15)()
+        cnt = (c_int * 15)()
         check(self.lib.dib_profile_summary(ms, cnt), "dib_profile_summary")
-        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(("fwd", "dgrad", "wgrad", "other"))}
+        names = [f"dib_gemm_kernel<{mode}, {ni}, {nj}>" for mode in (0, 1, 2) for ni in (1, 2) for nj in (1, 2)]
+        names += ["dib_fused_encoder_fwd_kernel", "dib_fused_encoder_bwd_kernel", "other"]
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names) if cnt[i]}
 
     # ---- views / helpers ---------------------------------------------------------------------
     def pred(self, batch: int) -> torch.Tensor:

@@ -138,9 +138,10 @@ int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int
 float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t feature, uint32_t e);
 
 /* ---- live kernel timing for bench.py's roofline: HIP events around every launch on the launch stream.
- * categories: 0 = fwd GEMM, 1 = dgrad GEMM, 2 = wgrad GEMM, 3 = all HBM-bound kernels. summary() synchronises. */
+ * 15 categories = kernel symbols: 0..11 dib_gemm_kernel<MODE,NI,NJ> at MODE*4 + (NI-1)*2 + (NJ-1); 12 = fused
+ * encoder forward; 13 = fused encoder backward; 14 = all other (HBM-bound) kernels.  summary() synchronises. */
 int dib_profile_enable(int on);
-int dib_profile_summary(double* ms_by_category /*[4]*/, int* launches_by_category /*[4]*/);
+int dib_profile_summary(double* ms_by_category /*[15]*/, int* launches_by_category /*[15]*/);
 
 /* ---- raw grouped GEMM (exposed for tests/benchmarks of the dominant kernel) ----------------
  * mode 0: C[M,N] = act(A[M,K] @ B[K,N] + bias)    mode 1: C[M,N] = (A[M,K] @ B[N,K]^T) * act'(aux)

@@ -95,4 +95,4 @@ class TorchCpuDIB:
                 m.add_((1 - b1) * (g - m))
                 v.add_((1 - b2) * (g * g - v))
                 p.sub_(lr_t * m / (torch.sqrt(v) + e))
-        return float(task), kl.detach(), grads
+        return float(task.detach()), kl.detach(), grads

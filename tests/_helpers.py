@@ -38,14 +38,14 @@ def flat_to_params(blocks, flat, spec: orc.DIBSpec, dtype=np.float64) -> orc.DIB
     return orc.DIBParams(enc_W, enc_b, int_W, int_b)
 
 
-def params_to_flat(blocks, params: orc.DIBParams, n_alloc: int) -> np.ndarray:
-    flat = np.zeros(n_alloc, dtype=np.float32)
+def params_to_flat(blocks, params: orc.DIBParams, n_alloc: int, dtype=np.float32) -> np.ndarray:
+    flat = np.zeros(n_alloc, dtype=dtype)
     for b in blocks:
         if b["net"] == 0:
             t = params.enc_W[b["feature"]][b["layer"]] if b["what"] == 0 else params.enc_b[b["feature"]][b["layer"]]
         else:
             t = params.int_W[b["layer"]] if b["what"] == 0 else params.int_b[b["layer"]]
-        flat[b["offset"]: b["offset"] + t.size] = np.asarray(t, dtype=np.float32).reshape(-1)
+        flat[b["offset"]: b["offset"] + t.size] = np.asarray(t, dtype=dtype).reshape(-1)
     return flat
 
 

@@ -30,7 +30,7 @@ class OracleEngine:
             self.blocks.append(dict(net=1, layer=l, feature=0, what=1, offset=off, rows=1, cols=o)); off += o
         self.n_params = off
         self.p = orc.glorot_uniform_init(self.spec, init_seed)
-        self.params = torch.from_numpy(params_to_flat(self.blocks, self.p, off).astype(np.float64))
+        self.params = torch.from_numpy(params_to_flat(self.blocks, self.p, off, np.float64))
         self.grads = torch.zeros(off, dtype=torch.float64)
         self.metrics_acc = torch.zeros(self.F + 3, dtype=torch.float64)
         self.state = orc.adam_init(self.p)
@@ -44,7 +44,7 @@ class OracleEngine:
     def set_beta(self, v): self.beta = float(v)
     def get_beta(self): return self.beta
     def set_lr(self, v): self.lr = float(v)
-    def get_flat_params(self): return params_to_flat(self.blocks, self.p, self.n_params).astype(np.float64)
+    def get_flat_params(self): return params_to_flat(self.blocks, self.p, self.n_params, np.float64)
 
     def set_flat_params(self, flat):
         self.p = flat_to_params(self.blocks, np.asarray(flat, dtype=np.float64), self.spec)
@@ -79,7 +79,7 @@ class OracleEngine:
         yb = y.numpy()[rows]
         task, g, _ = orc.backward(self.spec, self.p, xb, yb, c, self.beta, loss_kind,
                                   loss_scale_rows=int(round(1.0 / inv)))
-        self.grads.copy_(torch.from_numpy(params_to_flat(self.blocks, g, self.n_params).astype(np.float64)))
+        self.grads.copy_(torch.from_numpy(params_to_flat(self.blocks, g, self.n_params, np.float64)))
         self._gstruct = g
         if accumulate:
             self._account(c, task, yb, loss_kind, batch, inv)

@@ -1,0 +1,69 @@
+"""CPU, world_size 2 over gloo: the data-parallel path of fit() - row-wise sharding of every global batch,
+all-reduce(sum) of the flat gradient buffer, metric all-reduce - must reproduce the single-process run.
+Uses the TEST-ONLY oracle engine (the HIP engine needs a GPU); the host code under test is the product's."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(rank, world, port, out_dir):
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dib_amd
+    import dib_oracle as orc
+    from _helpers import spec_kwargs
+    from _oracle_engine import OracleEngine
+    spec = orc.DIBSpec([1, 1, 1, 1], [8], [8], 1, feature_embedding_dimension=4)
+    x, y = orc.boolean_circuit_truth_table([0, 1, 2, 3, [0, 2, 0], [2, 4, 3], [0, 5, 1]], 4)
+    x = np.tile(x, (5, 1)).astype(np.float32)
+    y = np.tile(y, 5).astype(np.float32)
+    model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=1, shuffle_seed=2, init_seed=3)
+    model._engine_factory = OracleEngine
+    opt = dib_amd.optimizers.get("adam")
+    opt.learning_rate = 5e-3
+    model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+    cb = dib_amd.InfoBottleneckAnnealingCallback(1e-3, 0.5, 1, 2)
+    hist = model.fit(x, y, epochs=3, batch_size=32, callbacks=[cb], verbose=False, validation_data=(x[:30], y[:30]))
+    np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), params=model._engine.get_flat_params(),
+             **{k: np.array(v) for k, v in hist.history.items()})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_fit_equals_single_process(tmp_path):
+    out = str(tmp_path)
+    _run(0, 1, _free_port(), out)
+    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    ref = np.load(os.path.join(out, "w1_r0.npz"))
+    r0 = np.load(os.path.join(out, "w2_r0.npz"))
+    r1 = np.load(os.path.join(out, "w2_r1.npz"))
+    assert np.allclose(r0["params"], r1["params"], rtol=0, atol=0), "ranks diverged"
+    assert np.allclose(r0["params"], ref["params"], rtol=1e-9, atol=1e-12)
+    for k in ref.files:
+        if k == "params":
+            continue
+        assert np.allclose(r0[k], ref[k], rtol=1e-9, atol=1e-12), k
+        assert np.allclose(r1[k], ref[k], rtol=1e-9, atol=1e-12), k

@@ -1,0 +1,145 @@
+"""CPU: host logic of the drop-in surface (fit loop, callbacks, History accounting, compression-matrix
+callback, Keras-shaped objects) exercised with the TEST-ONLY oracle engine (tests/_oracle_engine.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import dib_oracle as orc
+from _helpers import spec_kwargs
+from _oracle_engine import OracleEngine
+
+
+def _model(spec, **kw):
+    import dib_amd
+    m = dib_amd.DistributedIBNet(**spec_kwargs(spec), **kw)
+    m._engine_factory = OracleEngine
+    return m
+
+
+def _si_circuit(copies=4):
+    x, y = orc.boolean_circuit_truth_table([0, 1, 2, 3, [0, 2, 0], [2, 4, 3], [0, 5, 1]], 4)
+    return np.tile(x, (copies, 1)).astype(np.float32), np.tile(y, copies).astype(np.float32)
+
+
+def test_fit_history_contract_matches_oracle_fit():
+    """History keys/units of reference train.py:169-172 and bit-level agreement of the host loop
+    (shuffle order, partial last batch, beta schedule, validation pass) with oracle.fit."""
+    import dib_amd
+    spec = orc.DIBSpec([1, 1, 1, 1], [8], [8], 1, feature_embedding_dimension=4)
+    x, y = _si_circuit()
+    model = _model(spec, noise_seed=3, shuffle_seed=5, init_seed=1)
+    opt = dib_amd.optimizers.get("adam")
+    opt.learning_rate = 1e-2
+    model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+    cb = dib_amd.InfoBottleneckAnnealingCallback(1e-3, 1.0, 1, 3)
+    hist = model.fit(x, y, epochs=4, shuffle=True, batch_size=24, callbacks=[cb], verbose=False,
+                     validation_data=(x[:20], y[:20]))
+    p = orc.glorot_uniform_init(spec, 1)
+    ref = orc.fit(spec, p, x, y, epochs=4, batch_size=24, loss_kind="bce_logits",
+                  beta_fn=lambda e: orc.beta_schedule(e, 1e-3, 1.0, 1, 3), lr=1e-2, validation_data=(x[:20], y[:20]),
+                  noise_seed=3, shuffle_seed=5, metrics=["accuracy"])
+    assert set(hist.history) == set(ref) == {"loss", "val_loss", "beta", "val_beta", "accuracy", "val_accuracy",
+                                             *[f"KL{f}" for f in range(4)], *[f"val_KL{f}" for f in range(4)]}
+    for k in ref:
+        assert np.allclose(hist.history[k], ref[k], rtol=1e-9, atol=1e-12), k
+    assert hist.epoch == [0, 1, 2, 3]
+    # train.py:169-178 post-processing
+    beta_series, kl_bits, loss_bits = orc.postprocess_history(hist.history, 4, True)
+    assert kl_bits.shape == (4, 4) and np.all(kl_bits >= 0)
+    assert np.allclose(loss_bits * np.log(2), np.array(hist.history["loss"]) - beta_series * kl_bits.sum(-1) * np.log(2),
+                       atol=1e-6)
+
+
+def test_beta_variable_and_annealing_callback():
+    import dib_amd
+    spec = orc.DIBSpec([1, 1], [4], [4], 1, feature_embedding_dimension=4)
+    model = _model(spec)
+    assert float(model.beta.value()) == 1.0  # reference models.py:86
+    model.beta.assign(0.25)
+    assert model._ensure_engine().get_beta() == 0.25
+    cb = dib_amd.InfoBottleneckAnnealingCallback(1e-4, 3.0, 10, 100)
+    cb.set_model(model)
+    cb.on_epoch_begin(0)
+    assert float(model.beta.value()) == pytest.approx(1e-4, rel=1e-6)
+    cb.on_epoch_begin(110)
+    assert float(model.beta.value()) == pytest.approx(3.0, rel=1e-5)
+    assert model.feature_dimensionalities == [1, 1] and model.number_features == 2
+
+
+def test_compile_accepts_reference_style_arguments():
+    import dib_amd
+    spec = orc.DIBSpec([1, 1], [4], [4], 3, feature_embedding_dimension=4)
+    m = _model(spec)
+    m.compile(optimizer="adam", loss=dib_amd.losses.SparseCategoricalCrossentropy(from_logits=True), metrics=["accuracy"])
+    assert m.optimizer.learning_rate == 1e-3 and m.optimizer.epsilon == 1e-7 and m.loss.kind == "sparse_cce_logits"
+    m.compile(optimizer=dib_amd.optimizers.SGD(0.1), loss="mse")
+    assert m.loss.kind == "mse"
+    with pytest.raises(NotImplementedError):
+        m.compile(optimizer="adam", loss="infonce")
+    with pytest.raises(ValueError):
+        m.compile(optimizer="lion", loss="mse")
+    with pytest.raises(RuntimeError):
+        _model(spec).fit(np.zeros((2, 2)), np.zeros(2))
+
+
+def test_save_compression_matrices_callback(tmp_path):
+    import dib_amd
+    spec = orc.DIBSpec([1, 1, 1, 1], [8], [8], 1, feature_embedding_dimension=4)
+    x, y = _si_circuit()
+    model = _model(spec, init_seed=2)
+    model.compile(optimizer="adam", loss=dib_amd.losses.BinaryCrossentropy(from_logits=True))
+    cb = dib_amd.SaveCompressionMatricesCallback(2, x, x, str(tmp_path))
+    model.fit(x, y, epochs=3, batch_size=32, callbacks=[cb], verbose=False)
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 4 and all(f.startswith("feature_") and "log10beta_0.000" in f for f in files)  # epochs 0, 2 same beta
+    mat = cb.matrices[(2, 0)]
+    # Boolean inputs have 2 unique values -> 2x2 matrix, unit diagonal, symmetric (visualization.py:17-22)
+    assert mat.shape == (2, 2) and np.allclose(np.diag(mat), 1.0) and np.allclose(mat, mat.T)
+    p = model._engine.p
+    ref = orc.compression_matrix(spec, p, 0, np.array([[-1.0], [1.0]]))
+    assert np.allclose(mat, ref, atol=1e-9)
+
+
+def test_info_plane_plot_and_utils(tmp_path):
+    import dib_amd
+    kl = np.abs(np.random.default_rng(0).standard_normal((40, 3)))
+    out = dib_amd.visualization.save_distributed_info_plane(kl, np.linspace(1, 0, 40), str(tmp_path), entropy_y=0.8)
+    assert os.path.exists(out)
+    assert dib_amd.utils.compute_entropy([0, 0, 1, 1]) == pytest.approx(1.0)
+    pe = dib_amd.PositionalEncoding([2, 4])
+    assert np.allclose(pe(np.array([[0.5]])), [[0.5, np.sin(1.0), np.sin(2.0)]])
+
+
+def test_synthetic_tabular_dataset_definition():
+    import dib_amd
+    d = dib_amd.data.DATASETS["synthetic_tabular"](synthetic_rows=4096, synthetic_features=64)
+    assert d["x_train"].shape == (4096, 64) and d["x_train"].dtype == np.float32
+    assert set(np.unique(d["y_train"])) == {0.0, 1.0} and 0.3 < d["y_train"].mean() < 0.7
+    rng = np.random.default_rng(20241008)
+    x = rng.standard_normal((4096, 64), dtype=np.float32)
+    assert np.array_equal(x, d["x_train"])
+
+
+def test_torch_cpu_restatement_agrees_with_numpy_oracle():
+    """The cpu_baseline implementation (autograd backward) cross-checks the hand-derived oracle backward."""
+    import torch
+    from dib_torch_cpu import TorchCpuDIB
+    from _helpers import random_params
+    spec = orc.DIBSpec([2, 1, 1], [16, 8], [12], 1, feature_embedding_dimension=4)
+    p = random_params(spec, 2)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((9, 4))
+    y = rng.integers(0, 2, (9, 1)).astype(np.float64)
+    eps = orc.philox_normal_all(1, 2, np.arange(9), 3, 4)
+    c = orc.forward(spec, p, x, eps)
+    task, g, _ = orc.backward(spec, p, x, y, c, 0.4, "bce_logits")
+    m = TorchCpuDIB(spec, p, dtype=torch.float64)
+    t_task, t_kl, t_grads = m.train_step(torch.tensor(x), torch.tensor(y), torch.tensor(eps), 0.4, "bce_logits")
+    assert abs(t_task - task) < 1e-12 and np.allclose(t_kl.numpy(), c.kl, atol=1e-12)
+    for a, b in zip(t_grads, g.tensors()):
+        assert np.allclose(a.numpy(), b, atol=1e-12)
+    st = orc.adam_init(p)
+    orc.adam_keras_step(p, g, st)
+    for a, b in zip(m.tensors(), p.tensors()):
+        assert np.allclose(a.detach().numpy(), b, atol=1e-12)
