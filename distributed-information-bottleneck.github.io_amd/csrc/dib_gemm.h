@@ -40,26 +40,24 @@ struct DibGemmGroup {
   int flags;                                         // reserved
 };
 
-#define DIB_BK 32
-#define DIB_KC_PITCH 36
-
-template <bool KC, int EXT>
+template <bool KC, int EXT, int BK>
 struct DibStage {
-  static constexpr int NP = EXT / 32;              // float4 per thread per tile
+  static constexpr int NP = EXT * BK / 1024;       // float4 per thread per tile (256 threads)
+  static constexpr int KC_PITCH = BK + 4;
   static constexpr int MC_PITCH = EXT + 4;
-  static constexpr int FLOATS = KC ? EXT * DIB_KC_PITCH : DIB_BK * MC_PITCH;
-  // KC: element (mn,k) = base[(mn0+mn)*ld + k0+k]   thread: mn = (tid>>3)+32p, k = 4*(tid&7)
+  static constexpr int FLOATS = KC ? EXT * KC_PITCH : BK * MC_PITCH;
+  // KC: element (mn,k) = base[(mn0+mn)*ld + k0+k]   thread: mn = tid/(BK/4) + (1024/BK)p, k = 4*(tid%(BK/4))
   // MC: element (k,mn) = base[(k0+k)*ld + mn0+mn]   thread: k = tid/(EXT/4) + (1024/EXT)p, mn = 4*(tid%(EXT/4))
   static __device__ __forceinline__ int row(int tid, int p) {
-    return KC ? ((tid >> 3) + 32 * p) : (tid / (EXT / 4) + (1024 / EXT) * p);
+    return KC ? (tid / (BK / 4) + (1024 / BK) * p) : (tid / (EXT / 4) + (1024 / EXT) * p);
   }
-  static __device__ __forceinline__ int col(int tid) { return KC ? ((tid & 7) * 4) : ((tid % (EXT / 4)) * 4); }
+  static __device__ __forceinline__ int col(int tid) { return KC ? ((tid % (BK / 4)) * 4) : ((tid % (EXT / 4)) * 4); }
 
   static __device__ __forceinline__ void gload(float4 (&r)[NP], const float* __restrict__ base, long long ld,
                                                int mn0, int mn_max, int k0, int k_max, bool vec, int tid) {
     const int r0 = KC ? mn0 : k0, c0 = KC ? k0 : mn0;
     const int Rmax = KC ? mn_max : k_max, Cmax = KC ? k_max : mn_max;
-    const int rext = KC ? EXT : DIB_BK, cext = KC ? DIB_BK : EXT;
+    const int rext = KC ? EXT : BK, cext = KC ? BK : EXT;
     if (vec && r0 + rext <= Rmax && c0 + cext <= Cmax) {  // interior tile: unconditional 16 B loads
 #pragma unroll
       for (int p = 0; p < NP; ++p)
@@ -87,12 +85,12 @@ struct DibStage {
   static __device__ __forceinline__ void lstore(float* __restrict__ T, const float4 (&r)[NP], int tid) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-      *reinterpret_cast<float4*>(T + row(tid, p) * (KC ? DIB_KC_PITCH : MC_PITCH) + col(tid)) = r[p];
+      *reinterpret_cast<float4*>(T + row(tid, p) * (KC ? KC_PITCH : MC_PITCH) + col(tid)) = r[p];
   }
   // the 4 operand values (MFMA steps t=0..3 of k-block q) for the 32-wide sub-tile at mn_base
   static __device__ __forceinline__ float4 frag(const float* __restrict__ T, int mn_base, int q, int l31, int h) {
     if (KC) {
-      return *reinterpret_cast<const float4*>(T + (mn_base + l31) * DIB_KC_PITCH + q * 8 + h * 4);
+      return *reinterpret_cast<const float4*>(T + (mn_base + l31) * KC_PITCH + q * 8 + h * 4);
     } else {
       const float* p = T + (q * 8 + h * 4) * MC_PITCH + mn_base + l31;
       return make_float4(p[0], p[MC_PITCH], p[2 * MC_PITCH], p[3 * MC_PITCH]);
@@ -102,8 +100,8 @@ struct DibStage {
 
 #define DIB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-template <int MODE, int NI, int NJ>
-__global__ void __launch_bounds__(256)
+template <int MODE, int NI, int NJ, int BK>
+__global__ void __launch_bounds__(256, 2)  // >= 2 workgroups per CU: keep VGPR+AGPR <= 256
 dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict__ Abase,
                 const float* __restrict__ Bbase, float* __restrict__ Cbase, const float* __restrict__ bias,
                 const float* __restrict__ aux, float* __restrict__ bias_out, int batch, int act, int tiles_m,
@@ -111,8 +109,8 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
   constexpr bool A_KC = (MODE != 2);
   constexpr bool B_KC = (MODE == 1);
   constexpr int BM = 64 * NI, BN = 64 * NJ;
-  using SA = DibStage<A_KC, BM>;
-  using SB = DibStage<B_KC, BN>;
+  using SA = DibStage<A_KC, BM, BK>;
+  using SB = DibStage<B_KC, BN, BK>;
   __shared__ __attribute__((aligned(16))) float smem[SA::FLOATS + SB::FLOATS];
   float* As = smem;
   float* Bs = smem + SA::FLOATS;
@@ -166,23 +164,23 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     SA::gload(ra, Ag, g.lda, m0, M, kbeg, kend, vecA, tid);
     SB::gload(rb, Bg, g.ldb, n0, N, kbeg, kend, vecB, tid);
   }
-  for (int k0 = kbeg; k0 < kend; k0 += DIB_BK) {
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     SA::lstore(As, ra, tid);
     SB::lstore(Bs, rb, tid);
     __syncthreads();
-    if (k0 + DIB_BK < kend) {  // next tile's global loads fly during this tile's MFMAs
-      SA::gload(ra, Ag, g.lda, m0, M, k0 + DIB_BK, kend, vecA, tid);
-      SB::gload(rb, Bg, g.ldb, n0, N, k0 + DIB_BK, kend, vecB, tid);
+    if (k0 + BK < kend) {  // next tile's global loads fly during this tile's MFMAs
+      SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
+      SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
     }
     if (do_bias) {
-      constexpr int PARTS = 256 / BN, RPP = DIB_BK / PARTS;
+      constexpr int PARTS = 256 / BN, RPP = BK / PARTS;
       const int colb = tid % BN, part = tid / BN;
 #pragma unroll
       for (int r = 0; r < RPP; ++r) bsum += Bs[(part * RPP + r) * SB::MC_PITCH + colb];
     }
-    if (active) {  // rows/cols/k beyond the matrix edge are zero-filled in LDS, so all 16 k-steps always run
+    if (active) {  // rows/cols/k beyond the matrix edge are zero-filled in LDS, so all BK/2 k-steps always run
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < BK / 8; ++q) {
         float4 a[NI], b[NJ];
 #pragma unroll
         for (int i = 0; i < NI; ++i) a[i] = SA::frag(As, wm * 32 * NI + i * 32, q, l31, h);
