@@ -5,9 +5,9 @@ Drop-in for the reference's Python surface on this path (reference models.py / t
 backed by hand-written HIP kernels for gfx950 (csrc/) behind the C ABI in include/dib_hip.h.
 """
 from . import data, losses, models, optimizers, utils, visualization  # noqa: F401
-from .models import (Callback, DistributedIBNet, History, InfoBottleneckAnnealingCallback, PositionalEncoding,  # noqa: F401
-                     SaveCompressionMatricesCallback)
+from .models import (Callback, DistributedIBNet, History, InfoBottleneckAnnealingCallback, InfoPerFeatureCallback,  # noqa: F401
+                     PositionalEncoding, SaveCompressionMatricesCallback)
 
 __all__ = ["DistributedIBNet", "InfoBottleneckAnnealingCallback", "SaveCompressionMatricesCallback",
-           "PositionalEncoding", "Callback", "History", "models", "losses", "optimizers", "data", "utils",
+           "InfoPerFeatureCallback", "PositionalEncoding", "Callback", "History", "models", "losses", "optimizers", "data", "utils",
            "visualization"]

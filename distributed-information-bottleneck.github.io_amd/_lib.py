@@ -91,6 +91,9 @@ SIGNATURES = {
     "dib_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
     "dib_encode_deterministic": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_bhattacharyya": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dib_mi_workspace_bytes": (c_int64, [c_int, c_int]),
+    "dib_mi_sandwich_rows": (c_int, [c_void_p, c_int, c_int, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "dib_philox_normal_fill": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_uint64, c_uint32,
                                        c_void_p]),
     "dib_philox_normal_ref": (c_float, [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32]),

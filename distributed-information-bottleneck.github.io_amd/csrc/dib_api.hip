@@ -725,6 +725,27 @@ int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu
   return (int)hipGetLastError();
 }
 
+int64_t dib_mi_workspace_bytes(int n, int E) {
+  if (n <= 0 || E <= 0) return DIB_E_ARG;
+  return (int64_t)sizeof(double) * (2ll * n * E + n);
+}
+
+int dib_mi_sandwich_rows(const float* enc_out, int n, int E, uint64_t seed, uint32_t step, uint32_t feature,
+                         double* lower_rows, double* upper_rows, void* ws, dib_stream_t stream) {
+  if (!enc_out || !lower_rows || !upper_rows || !ws || n <= 1 || E <= 0) return DIB_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  double* inv_sigma = (double*)ws;
+  double* u = inv_sigma + (int64_t)n * E;
+  double* cj = u + (int64_t)n * E;
+  hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, enc_out, n, E, (unsigned long long)seed,
+                     (unsigned)step, (unsigned)feature, inv_sigma, u, cj);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_mi_rows_kernel, dim3(n), dim3(256), 0, st, enc_out, n, E, (const double*)inv_sigma,
+                     (const double*)u, (const double*)cj, lower_rows, upper_rows);
+  return (int)hipGetLastError();
+}
+
 int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int batch, int F, int E, uint64_t seed,
                            uint32_t step, dib_stream_t stream) {
   if (!eps || batch <= 0 || F <= 0 || E <= 0) return DIB_E_ARG;

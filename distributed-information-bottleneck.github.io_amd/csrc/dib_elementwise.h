@@ -337,3 +337,91 @@ dib_bhattacharyya_kernel(const float* __restrict__ mu1, const float* __restrict_
     out[idx] = 0.125f * t1 + 0.5f * t2;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Mutual-information sandwich bounds (reference utils.py:10-73, Poole et al. 2019): for a batch of N
+// encoded points with p(u|x_j) = N(mu_j, diag(exp(logvar_j))) and one sample u_i ~ p(u|x_i),
+//   log p_ij = -1/2 sum_e ((u_ie - mu_je)/sigma_je)^2 - 1/2 sum_e logvar_je - E/2 ln(2 pi)
+//   InfoNCE lower_i = log p_ii - log( 1/N sum_j    p_ij )
+//   leave-one-out upper_i = log p_ii - log( 1/N sum_{j!=i} p_ij )      (the reference divides by N, not N-1)
+// Everything in float64 like the reference (utils.py:39-40), but with a log-sum-exp so that well separated
+// Gaussians do not underflow to log(0) as the reference's exp-then-log does.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_mi_prep_kernel(const float* __restrict__ enc_out /*[N][2E]*/, int n, int E, unsigned long long seed, unsigned step,
+                   unsigned feature, double* __restrict__ inv_sigma /*[N][E]*/, double* __restrict__ u /*[N][E]*/,
+                   double* __restrict__ cj /*[N]*/) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float* mu = enc_out + (long long)j * 2 * E;
+  const float* lv = mu + E;
+  double slv = 0.0;
+  for (int q = 0; q < (E + 3) / 4; ++q) {
+    float eps[4];
+    dib_eps4(seed, step, (uint32_t)j, feature, (uint32_t)q, eps);
+    for (int t = 0; t < 4 && 4 * q + t < E; ++t) {
+      const int e = 4 * q + t;
+      const double l = (double)lv[e];
+      const double sd = exp(0.5 * l);
+      inv_sigma[(long long)j * E + e] = 1.0 / sd;
+      u[(long long)j * E + e] = (double)mu[e] + sd * (double)eps[t];
+      slv += l;
+    }
+  }
+  cj[j] = -0.5 * slv - 0.5 * (double)E * 1.8378770664093454835606594728112;  // ln(2 pi)
+}
+
+__device__ __forceinline__ void dib_lse_add(double& mx, double& sm, double v) {
+  if (v > mx) { sm = sm * exp(mx - v) + 1.0; mx = v; }
+  else sm += exp(v - mx);
+}
+
+__global__ void __launch_bounds__(256)
+dib_mi_rows_kernel(const float* __restrict__ enc_out, int n, int E, const double* __restrict__ inv_sigma,
+                   const double* __restrict__ u, const double* __restrict__ cj, double* __restrict__ lower_rows,
+                   double* __restrict__ upper_rows) {
+  __shared__ double smx[256], ssm[256];
+  const int i = blockIdx.x;
+  const double* ui = u + (long long)i * E;
+  double mx = -1.0e300, sm = 0.0;  // log-sum-exp over j != i
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if (j == i) continue;
+    const float* mu = enc_out + (long long)j * 2 * E;
+    const double* is = inv_sigma + (long long)j * E;
+    double q = 0.0;
+    for (int e = 0; e < E; ++e) {
+      const double d = (ui[e] - (double)mu[e]) * is[e];
+      q = fma(d, d, q);
+    }
+    dib_lse_add(mx, sm, cj[j] - 0.5 * q);
+  }
+  smx[threadIdx.x] = mx;
+  ssm[threadIdx.x] = sm;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double m1 = smx[threadIdx.x], m2 = smx[threadIdx.x + s];
+      const double s1 = ssm[threadIdx.x], s2 = ssm[threadIdx.x + s];
+      const double m = m1 > m2 ? m1 : m2;
+      smx[threadIdx.x] = m;
+      ssm[threadIdx.x] = s1 * exp(m1 - m) + s2 * exp(m2 - m);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float* mu = enc_out + (long long)i * 2 * E;
+    const double* is = inv_sigma + (long long)i * E;
+    double q = 0.0;
+    for (int e = 0; e < E; ++e) {
+      const double d = (ui[e] - (double)mu[e]) * is[e];
+      q = fma(d, d, q);
+    }
+    const double lii = cj[i] - 0.5 * q;
+    const double lse_off = (ssm[0] > 0.0) ? smx[0] + log(ssm[0]) : -INFINITY;
+    const double mall = lii > lse_off ? lii : lse_off;
+    const double lse_all = mall + log(exp(lii - mall) + exp(lse_off - mall));
+    const double logn = log((double)n);
+    lower_rows[i] = lii - (lse_all - logn);
+    upper_rows[i] = lii - (lse_off - logn);
+  }
+}

@@ -275,6 +275,18 @@ class HipEngine:
                                          self._stream()), "dib_bhattacharyya")
         return out
 
+    def mi_sandwich_bounds(self, enc_out: torch.Tensor, seed: int, step: int, feature: int):
+        """(InfoNCE lower, leave-one-out upper) in nats for one batch enc_out [N, 2E] (reference utils.py:36-62)."""
+        enc_out = self.to_device(enc_out)
+        n, e2 = enc_out.shape
+        ws = torch.empty(int(self.lib.dib_mi_workspace_bytes(n, e2 // 2)) // 8, dtype=torch.float64, device=self.device)
+        rows = torch.empty((2, n), dtype=torch.float64, device=self.device)
+        check(self.lib.dib_mi_sandwich_rows(_ptr(enc_out), n, e2 // 2, int(seed), int(step) & 0xFFFFFFFF, int(feature),
+                                            _ptr(rows[0]), _ptr(rows[1]), _ptr(ws), self._stream()),
+              "dib_mi_sandwich_rows")
+        m = rows.mean(dim=1).cpu().numpy()
+        return float(m[0]), float(m[1])
+
     def eps(self, row_idx, row0: int, batch: int, seed: int, step: int) -> torch.Tensor:
         out = torch.empty((batch, self.F, self.E), dtype=torch.float32, device=self.device)
         check(self.lib.dib_philox_normal_fill(_ptr(out), _ptr(row_idx), int(row0), batch, self.F, self.E, int(seed),

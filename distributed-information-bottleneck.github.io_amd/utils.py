@@ -48,3 +48,28 @@ def compute_entropy(seq):
 def entropy_rate_scaling_ansatz(N, h_inf, gamma, c):
     """reference utils.py:251-254 (Schurmann & Grassberger 1995)."""
     return h_inf + np.log2(N) / (N ** gamma) / np.abs(c)
+
+
+def estimate_mi_sandwich_bounds(encoder, dataset, evaluation_batch_size=1024, number_evaluation_batches=8, seed=0):
+    """Lower (InfoNCE) and upper (leave-one-out) bounds, in nats, on the information transmitted by one feature
+    encoder (reference utils.py:10-73; Poole et al. 2019).
+
+    `encoder` is `model.feature_encoders[f]`; `dataset` is that feature's data, array-like [N, d_f] (the reference
+    takes a tf.data.Dataset and draws `number_evaluation_batches` shuffled batches with wrap-around, utils.py:68-71;
+    here the batches are drawn with a seeded numpy generator).  The N x N x E pairwise Gaussian log-densities are
+    evaluated on the GPU in float64 with a log-sum-exp (dib_mi_sandwich_rows), so well separated encodings give
+    log N instead of the reference's underflow."""
+    x = np.asarray(dataset, dtype=np.float32)
+    if x.ndim == 1:
+        x = x[:, None]
+    n = x.shape[0]
+    bs = int(evaluation_batch_size)
+    rng = np.random.default_rng(seed)
+    model = encoder._model
+    eng = model._ensure_engine()
+    estimates = []
+    for b in range(int(number_evaluation_batches)):
+        rows = rng.permutation(n)[:bs] if n >= bs else rng.integers(0, n, bs)
+        enc_out = eng.encode_feature(encoder.index, x[rows])
+        estimates.append(eng.mi_sandwich_bounds(enc_out, seed, b, encoder.index))
+    return np.mean(np.stack(estimates, 0), 0)

@@ -131,6 +131,13 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
 /* Bhattacharyya distance matrix between diagonal Gaussians (utils.py:177-212), closed form. */
 int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu2, const float* lv2, int m,
                       int dim, float* out, dib_stream_t stream);
+/* Mutual-information sandwich bounds (utils.estimate_mi_sandwich_bounds, utils.py:10-73; used by
+ * InfoPerFeatureCallback models.py:188-223): per-row InfoNCE-lower / leave-one-out-upper terms (nats, float64,
+ * log-sum-exp) for one batch of n encoded points enc_out[n, 2E] = (mu|logvar); u_i = mu_i + sigma_i*eps with eps
+ * from the Philox generator keyed (seed, step, row i, feature).  The bounds are the means of the two row arrays. */
+int64_t dib_mi_workspace_bytes(int n, int embedding_dim);
+int dib_mi_sandwich_rows(const float* enc_out, int n, int embedding_dim, uint64_t seed, uint32_t step,
+                         uint32_t feature, double* lower_rows, double* upper_rows, void* ws, dib_stream_t stream);
 /* fill eps[B, F, E] exactly as the fused kernels generate it (test / oracle cross-check) */
 int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int batch, int num_features,
                            int embedding_dim, uint64_t seed, uint32_t step, dib_stream_t stream);

@@ -108,3 +108,9 @@ class OracleEngine:
 
     def encode_feature(self, f, x_f):
         return torch.from_numpy(orc.encode_feature(self.spec, self.p, f, np.asarray(x_f, dtype=np.float64)))
+
+    def mi_sandwich_bounds(self, enc_out, seed, step, feature):
+        e = enc_out.numpy() if hasattr(enc_out, "numpy") else np.asarray(enc_out)
+        E = e.shape[1] // 2
+        u = orc.mi_sandwich_sample_u(e[:, :E], e[:, E:], seed, step, feature)
+        return orc.mi_sandwich_bounds_batch(e[:, :E], e[:, E:], u)

@@ -280,3 +280,48 @@ def test_north_star_shape_properties():
     p = flat_to_params(eng.blocks, eng.get_flat_params(), spec)
     c = orc.forward(spec, p, x[:64].numpy().astype(np.float64), orc.philox_normal_all(0, 0, np.arange(64), 64, 32))
     assert np.abs(eng.pred(B)[:64].cpu().numpy() - c.pred).max() < 2e-4 * (1 + np.abs(c.pred).max())
+
+
+def test_mi_sandwich_bounds_match_oracle():
+    """dib_mi_sandwich_rows (float64 log-sum-exp on device) vs the literal restatement of utils.py:36-62."""
+    import dib_amd
+    spec = SPECS["pendulum_ragged"]
+    eng, p = _engine(spec, 4)
+    rng = np.random.default_rng(5)
+    E = spec.feature_embedding_dimension
+    for f, d in enumerate(spec.feature_dimensionalities):
+        xf = rng.standard_normal((300, d)).astype(np.float32)
+        enc = eng.encode_feature(f, xf)
+        lo, up = eng.mi_sandwich_bounds(enc, seed=9, step=2, feature=f)
+        e = enc.cpu().numpy().astype(np.float64)
+        u = orc.mi_sandwich_sample_u(e[:, :E], e[:, E:], 9, 2, f)
+        rlo, rup = orc.mi_sandwich_bounds_batch(e[:, :E], e[:, E:], u)
+        assert abs(lo - rlo) < 1e-4 * (1 + abs(rlo)) and abs(up - rup) < 1e-4 * (1 + abs(rup)), (lo, rlo, up, rup)
+        assert lo <= up + 1e-9
+    # well separated encodings: the reference underflows to inf, the LSE version saturates at log N
+    mu = (np.arange(64, dtype=np.float32)[:, None] * 100.0) * np.ones((1, E), dtype=np.float32)
+    enc = torch.tensor(np.concatenate([mu, np.zeros_like(mu)], 1), device=eng.device)
+    lo, up = eng.mi_sandwich_bounds(enc, 0, 0, 0)
+    assert abs(lo - np.log(64)) < 1e-9 and up > 1e3
+
+
+def test_info_per_feature_callback_and_train_script(tmp_path):
+    """The reference-style script path end to end on the GPU: dib_amd.train main() + InfoPerFeatureCallback."""
+    import dib_amd
+    from dib_amd import train
+    hist = train.main(["--dataset", "boolean_circuit", "--number_pretraining_epochs", "2", "--number_annealing_epochs", "3",
+                       "--batch_size", "128", "--artifact_outdir", str(tmp_path), "--save_compression_matrices_frequency", "4",
+                       "--feature_encoder_architecture", "32", "32", "--integration_network_architecture", "64",
+                       "--feature_embedding_dimension", "8"])
+    assert len(hist.history["loss"]) == 5 and np.isfinite(hist.history["loss"]).all()
+    import os
+    assert os.path.exists(os.path.join(str(tmp_path), "distributed_info_plane.png"))
+    assert any(f.startswith("feature_0_log10beta") for f in os.listdir(str(tmp_path)))
+    d = dib_amd.data.fetch_boolean_circuit()
+    model = dib_amd.DistributedIBNet(d["feature_dimensionalities"], [32, 32], [64], 1, feature_embedding_dimension=8)
+    model.compile(optimizer="adam", loss=d["loss"], metrics=d["metrics"])
+    cb = dib_amd.InfoPerFeatureCallback(1, d["x_valid"], info_bound_batch_size=256, info_bound_number_batches=2)
+    model.fit(d["x_train"], d["y_train"], epochs=2, batch_size=256, callbacks=[cb], verbose=False)
+    b = np.array(cb.bounds)
+    assert b.shape == (20, 2) and np.isfinite(b).all() and (b[:, 0] <= b[:, 1] + 1e-6).all()
+    assert (b[:, 1] <= np.log(2) + 0.2).all()  # a binary input carries at most 1 bit

@@ -134,3 +134,18 @@ def test_philox_known_answer_and_moments():
     assert [int(v) for v in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     e = orc.philox_normal_all(1, 0, np.arange(20000), 2, 32)
     assert abs(e.mean()) < 5e-3 and abs(e.std() - 1) < 5e-3 and abs((e ** 4).mean() - 3) < 0.05
+
+
+def test_mi_sandwich_bounds_analytic_limits():
+    """SURVEY section 4 pins for utils.estimate_mi_sandwich_bounds: X ~ U({+-1}^k) through a Gaussian channel:
+    zero separation -> 0 nats; large separation -> k bits (as long as log N allows); lower <= upper."""
+    rng = np.random.default_rng(0)
+    n, k = 512, 2
+    bits = rng.integers(0, 2, (n, k)) * 2.0 - 1.0
+    lv = np.zeros((n, k))
+    for sep, want in ((0.0, 0.0), (6.0, k * np.log(2))):
+        mus = sep * bits
+        u = orc.mi_sandwich_sample_u(mus, lv, 1, 0, 0)
+        lo, up = orc.mi_sandwich_bounds_batch(mus, lv, u)
+        assert lo <= up + 1e-9
+        assert abs(lo - want) < 0.08 and abs(up - want) < 0.08, (sep, lo, up, want)
