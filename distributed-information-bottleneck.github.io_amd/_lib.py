@@ -24,6 +24,7 @@ ACTIVATIONS = {None: 0, "linear": 0, "None": 0, "relu": 1, "leaky_relu": 2, "tan
                "softplus": 6}
 LOSS_KINDS = {"bce_logits": 0, "bce": 1, "sparse_cce_logits": 2, "mse": 3}
 WS_U, WS_PRED, WS_ENC_OUT, WS_G_U, WS_STEP_OUT, WS_G_PRED = range(6)
+SIMILARITIES = {"l2sq": 0, "l2": 1, "l1": 2, "linf": 3, "cosine": 4}
 
 
 def _hipcc() -> str:
@@ -91,6 +92,10 @@ SIGNATURES = {
     "dib_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
     "dib_encode_deterministic": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_bhattacharyya": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dib_infonce_workspace_bytes": (c_int64, [c_int]),
+    "dib_infonce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    "dib_positional_encoding": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_mi_workspace_bytes": (c_int64, [c_int, c_int]),
     "dib_mi_sandwich_rows": (c_int, [c_void_p, c_int, c_int, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),

@@ -725,6 +725,39 @@ int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu
   return (int)hipGetLastError();
 }
 
+int64_t dib_infonce_workspace_bytes(int batch) {
+  if (batch <= 0) return DIB_E_ARG;
+  return (int64_t)sizeof(float) * ((int64_t)batch * batch + 2ll * batch + 64);
+}
+
+int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int dim, int similarity, float temperature,
+                        float* g_x, float* g_y, float* loss_out, void* ws, dib_stream_t stream) {
+  if (!emb_x || !emb_y || !loss_out || !ws || batch <= 0 || dim <= 0 || temperature <= 0.f) return DIB_E_ARG;
+  if (similarity < 0 || similarity > 4 || dim > 256) return DIB_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  float* S = (float*)ws;
+  float* lse = S + (int64_t)batch * batch;
+  const float inv_t = 1.0f / temperature;
+  ProfScope ps(kProfOther, st);
+  hipLaunchKernelGGL(dib_infonce_sim_kernel, dim3(grid_for((int64_t)batch * batch)), dim3(256), 0, st, emb_x, emb_y, batch,
+                     dim, similarity, inv_t, S);
+  hipLaunchKernelGGL(dib_infonce_lse_kernel, dim3(batch, 2), dim3(256), 0, st, (const float*)S, batch, lse);
+  hipLaunchKernelGGL(dib_infonce_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)S, (const float*)lse, batch,
+                     loss_out);
+  if (g_x && g_y)
+    hipLaunchKernelGGL(dib_infonce_grad_kernel, dim3(batch, 2), dim3(256), 256 * sizeof(float), st, emb_x, emb_y,
+                       (const float*)S, (const float*)lse, batch, dim, similarity, inv_t, g_x, g_y);
+  return (int)hipGetLastError();
+}
+
+int dib_positional_encoding(const float* x, int64_t ldx, int n, int d, int n_freq, float* out, dib_stream_t stream) {
+  if (!x || !out || n <= 0 || d <= 0) return DIB_E_ARG;
+  const int n_blocks = n_freq > 1 ? n_freq : 1;
+  hipLaunchKernelGGL(dib_posenc_dense_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)ldx, n, d, n_blocks, out);
+  return (int)hipGetLastError();
+}
+
 int64_t dib_mi_workspace_bytes(int n, int E) {
   if (n <= 0 || E <= 0) return DIB_E_ARG;
   return (int64_t)sizeof(double) * (2ll * n * E + n);

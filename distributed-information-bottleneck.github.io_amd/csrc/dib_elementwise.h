@@ -425,3 +425,144 @@ dib_mi_rows_kernel(const float* __restrict__ enc_out, int n, int E, const double
     upper_rows[i] = lii - (lse_off - logn);
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// InfoNCE path (reference train.py:201-220 eval_batch_infonce; utils.py:75-175 get_scaled_similarity):
+//   S = similarity(emb_x, emb_y) / T  [B,B] ;  loss = mean_i CE(i, S[i,:]) + mean_j CE(j, S[:,j])  (NOT halved)
+// similarity ids: 0 l2sq, 1 l2, 2 l1, 3 linf, 4 cosine.  B is the batch (<= a few thousand), D the shared
+// embedding width: B^2*D work - tiny next to the encoder bank, so plain (deterministic) VALU kernels.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dib_similarity(int kind, const float* __restrict__ a, const float* __restrict__ b, int D,
+                                                float inv_t) {
+  float s = 0.f;
+  if (kind == 0 || kind == 1) {  // utils.py:85-90: max(|a|^2 + |b|^2 - 2 a.b, 0)
+    float na = 0.f, nb = 0.f, ab = 0.f;
+    for (int e = 0; e < D; ++e) { na += a[e] * a[e]; nb += b[e] * b[e]; ab += a[e] * b[e]; }
+    const float d2 = fmaxf(na + nb - 2.0f * ab, 0.f);
+    s = (kind == 0) ? -d2 : -sqrtf(d2 + 1e-9f);
+  } else if (kind == 2) {
+    for (int e = 0; e < D; ++e) s -= fabsf(a[e] - b[e]);
+  } else if (kind == 3) {
+    float mx = 0.f;
+    for (int e = 0; e < D; ++e) mx = fmaxf(mx, fabsf(a[e] - b[e]));
+    s = -mx;
+  } else {
+    float na = 0.f, nb = 0.f, ab = 0.f;
+    for (int e = 0; e < D; ++e) { na += a[e] * a[e]; nb += b[e] * b[e]; ab += a[e] * b[e]; }
+    s = ab / (sqrtf(na) * sqrtf(nb));
+  }
+  return s * inv_t;
+}
+
+__global__ void __launch_bounds__(256)
+dib_infonce_sim_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, int kind, float inv_t,
+                       float* __restrict__ S) {
+  const long long total = (long long)B * B;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx / B), j = (int)(idx - (long long)i * B);
+    S[idx] = dib_similarity(kind, X + (long long)i * D, Y + (long long)j * D, D, inv_t);
+  }
+}
+
+// lse[0][i] = LSE_j S[i][j] (rows), lse[1][j] = LSE_i S[i][j] (columns); one block per row / column
+__global__ void __launch_bounds__(256)
+dib_infonce_lse_kernel(const float* __restrict__ S, int B, float* __restrict__ lse) {
+  __shared__ float red[4];
+  const int which = blockIdx.y, idx = blockIdx.x;
+  const long long stride = which == 0 ? 1 : B, base = which == 0 ? (long long)idx * B : idx;
+  float mx = -INFINITY;
+  for (int t = threadIdx.x; t < B; t += 256) mx = fmaxf(mx, S[base + t * stride]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sm = 0.f;
+  for (int t = threadIdx.x; t < B; t += 256) sm += expf(S[base + t * stride] - mx);
+  const float tot = dib_block_sum_256(sm, red);
+  if (threadIdx.x == 0) lse[(long long)which * B + idx] = mx + logf(tot);
+}
+
+// loss = (1/B) sum_i (lse_r[i] - S_ii) + (1/B) sum_j (lse_c[j] - S_jj)
+__global__ void __launch_bounds__(256)
+dib_infonce_loss_kernel(const float* __restrict__ S, const float* __restrict__ lse, int B, float* __restrict__ loss_out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256) s += lse[i] + lse[B + i] - 2.0f * S[(long long)i * B + i];
+  const float tot = dib_block_sum_256(s, red);
+  if (threadIdx.x == 0) loss_out[0] = tot / (float)B;
+}
+
+// gradient wrt the embeddings.  dL/dS_ij = (softmax_row_i(S)_ij + softmax_col_j(S)_ij - 2 delta_ij) / B.
+// which = 0: block i accumulates g_x[i] = sum_j dL/dS_ij * dS_ij/dx_i ; which = 1: block j accumulates g_y[j].
+__global__ void __launch_bounds__(256)
+dib_infonce_grad_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ S,
+                        const float* __restrict__ lse, int B, int D, int kind, float inv_t, float* __restrict__ GX,
+                        float* __restrict__ GY) {
+  extern __shared__ float acc[];  // [256][D] partial gradients would be too big: use [4 waves][D] via atomics-free tree
+  const int which = blockIdx.y, me = blockIdx.x;
+  const float* self = (which == 0 ? X : Y) + (long long)me * D;
+  const float* others = which == 0 ? Y : X;
+  float* out = (which == 0 ? GX : GY) + (long long)me * D;
+  // each thread handles a strided subset of partners and a strided subset of dims is impossible at once, so:
+  // thread t owns dimension e = t % D for partner group t / D (requires 256 % D == 0 or D <= 256)
+  const int groups = max(1, 256 / D);
+  const int e = threadIdx.x % D, grp = threadIdx.x / D;
+  float g = 0.f;
+  if (grp < groups) {
+    const float invB = 1.0f / (float)B;
+    for (int o = grp; o < B; o += groups) {
+      const int i = which == 0 ? me : o, j = which == 0 ? o : me;
+      const float sij = S[(long long)i * B + j];
+      float w = (expf(sij - lse[i]) + expf(sij - lse[B + j]) - (i == j ? 2.0f : 0.f)) * invB * inv_t;
+      const float* a = self;                       // the embedding being differentiated
+      const float* b = others + (long long)o * D;  // its partner
+      float d = 0.f;                                // d(sim)/d(self_e) before the 1/T factor
+      if (kind == 0 || kind == 1) {
+        float na = 0.f, nb = 0.f, ab = 0.f;
+        for (int q = 0; q < D; ++q) { na += a[q] * a[q]; nb += b[q] * b[q]; ab += a[q] * b[q]; }
+        const float d2 = na + nb - 2.0f * ab;
+        if (d2 > 0.f) {
+          d = -2.0f * (a[e] - b[e]);
+          if (kind == 1) d *= 0.5f / sqrtf(d2 + 1e-9f);
+        }
+      } else if (kind == 2) {
+        const float df = a[e] - b[e];
+        d = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f);
+      } else if (kind == 3) {
+        float mx = -1.f; int am = 0;
+        for (int q = 0; q < D; ++q) { const float v = fabsf(a[q] - b[q]); if (v > mx) { mx = v; am = q; } }
+        if (am == e) { const float df = a[e] - b[e]; d = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f); }
+      } else {
+        float na = 0.f, nb = 0.f, ab = 0.f;
+        for (int q = 0; q < D; ++q) { na += a[q] * a[q]; nb += b[q] * b[q]; ab += a[q] * b[q]; }
+        const float ra = rsqrtf(na), rb = rsqrtf(nb);
+        d = (b[e] * rb - (ab * ra * rb) * a[e] * ra) * ra;
+      }
+      g += w * d;
+    }
+  }
+  acc[threadIdx.x] = (grp < groups) ? g : 0.f;
+  __syncthreads();
+  if (threadIdx.x < D) {  // fixed-order sum over the partner groups
+    float s = 0.f;
+    for (int q = 0; q < groups; ++q) s += acc[q * D + threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
+// dense positional encoding of a single [N, d] matrix (reference train.py:186-188: PositionalEncoding on the Y encoder)
+__global__ void __launch_bounds__(256)
+dib_posenc_dense_kernel(const float* __restrict__ X, long long ldx, int n, int d, int n_blocks, float* __restrict__ P) {
+  const long long total = (long long)n * d;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / d), c = (int)(i - (long long)r * d);
+    const float x = X[r * ldx + c];
+    float* dst = P + (long long)r * d * n_blocks + c;
+    dst[0] = x;
+    float fr = 2.0f;
+    for (int j = 1; j < n_blocks; ++j) { dst[(long long)j * d] = sinf(fr * x); fr *= 2.0f; }
+  }
+}

@@ -72,4 +72,40 @@ def fetch_synthetic_tabular(**kwargs):
                 loss=losses.BinaryCrossentropy(from_logits=True), loss_is_info_based=True, metrics=['accuracy'])
 
 
-DATASETS = {'boolean_circuit': fetch_boolean_circuit, 'synthetic_tabular': fetch_synthetic_tabular}
+def fetch_double_pendulum(**kwargs):
+    """reference data.py:83-147: predict the state `pendulum_time_delta` seconds ahead; 4 features
+    (theta1 as a unit vector [2], dtheta1 [1], theta2 as a unit vector [2], dtheta2 [1]); loss 'infonce'.
+    Generates the trajectories on first use (simulate_pendulum, `pendulum_number_trajectories` to keep it small).
+    Defect A11 of SURVEY App. A (the reference's np.split makes the FIRST 10 % the training set) is not replicated:
+    10 % of the trajectories are held out for validation."""
+    import os
+    data_path = kwargs.get('data_path', './data/')
+    fname = os.path.join(data_path, 'double_pendulum.npy')
+    if not os.path.exists(fname):
+        from . import simulate_pendulum
+        prm = {}
+        if kwargs.get('pendulum_number_trajectories'):
+            prm['number_trajectories'] = int(kwargs['pendulum_number_trajectories'])
+        simulate_pendulum.simulate_double_pendulum(data_path=data_path, simulation_params_dict=prm,
+                                                   rng=np.random.default_rng(kwargs.get('seed', 0)))
+    arr = np.load(fname)
+    time_delta = kwargs.get('pendulum_time_delta', 2.)
+
+    def preprocess(a):  # data.py:100-107: angles -> (sin, -cos), velocities as is
+        return np.stack([np.sin(a[:, :, 0]), -np.cos(a[:, :, 0]), a[:, :, 1], np.sin(a[:, :, 2]), -np.cos(a[:, :, 2]),
+                         a[:, :, 3]], -1)
+
+    n_valid = max(1, int(arr.shape[0] * 0.1))
+    train, valid = preprocess(arr[n_valid:]), preprocess(arr[:n_valid])
+    steps = int(time_delta / 0.02)  # dt_saving of the simulation (data.py:116-117)
+    pair = lambda a: (a[:, :-steps].reshape(-1, 6).astype(np.float32), a[:, steps:].reshape(-1, 6).astype(np.float32))
+    x_train, y_train = pair(train)
+    x_valid, y_valid = pair(valid)
+    dims = [2, 1, 2, 1]
+    return dict(x_train=x_train, y_train=y_train, x_valid=x_valid, y_valid=y_valid, feature_dimensionalities=dims,
+                number_features=len(dims), output_dimensionality=6, output_activation_fn=None, loss='infonce',
+                loss_is_info_based=True, feature_labels=['theta1', 'theta1_dot', 'theta2', 'theta2_dot'])
+
+
+DATASETS = {'boolean_circuit': fetch_boolean_circuit, 'synthetic_tabular': fetch_synthetic_tabular,
+            'double_pendulum': fetch_double_pendulum}

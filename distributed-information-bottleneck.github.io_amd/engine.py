@@ -275,6 +275,27 @@ class HipEngine:
                                          self._stream()), "dib_bhattacharyya")
         return out
 
+    def infonce(self, emb_x: torch.Tensor, emb_y: torch.Tensor, similarity: str = "l2", temperature: float = 1.0,
+                want_grads: bool = True):
+        """Symmetric InfoNCE (reference train.py:201-214, utils.py:131-175) -> (loss [1] device tensor, g_x, g_y)."""
+        emb_x, emb_y = emb_x.contiguous(), emb_y.contiguous()
+        b, d = emb_x.shape
+        ws = torch.empty(int(self.lib.dib_infonce_workspace_bytes(b)) // 4, dtype=torch.float32, device=self.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        gx = torch.empty_like(emb_x) if want_grads else None
+        gy = torch.empty_like(emb_y) if want_grads else None
+        check(self.lib.dib_infonce_fwd_bwd(_ptr(emb_x), _ptr(emb_y), b, d, _lib.SIMILARITIES[similarity], float(temperature),
+                                           _ptr(gx), _ptr(gy), _ptr(loss), _ptr(ws), self._stream()), "dib_infonce_fwd_bwd")
+        return loss, gx, gy
+
+    def backward_from_pred_grad(self, g_pred: torch.Tensor, row_idx, row0: int, batch: int, seed: int, step: int,
+                                inv_global_batch: Optional[float] = None) -> None:
+        """Backward of the model given dL/d(model output) from a custom loss (reference train.py:216-219): the
+        beta*KL term (models.py:118) is added inside the encoder-bank backward.  Gradients land in self.grads."""
+        inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
+        self.ws_view(batch, _lib.WS_G_PRED, batch * self.out_dim).view(batch, self.out_dim).copy_(g_pred)
+        self.backward(row_idx, row0, batch, seed, step, inv)
+
     def mi_sandwich_bounds(self, enc_out: torch.Tensor, seed: int, step: int, feature: int):
         """(InfoNCE lower, leave-one-out upper) in nats for one batch enc_out [N, 2E] (reference utils.py:36-62)."""
         enc_out = self.to_device(enc_out)

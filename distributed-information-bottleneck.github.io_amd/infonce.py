@@ -1,0 +1,102 @@
+"""The reference's custom InfoNCE training loop (train.py:180-289) on the MI355X-native engine.
+
+X is encoded by the DistributedIBNet (its output is the shared-space embedding), Y by a DenseStack MLP
+(train.py:184-192); the loss is the symmetric InfoNCE over the in-batch similarity matrix (train.py:203-215) plus
+beta * sum KL (models.py:118).  Epoch bookkeeping follows the reference: full batches from a repeating shuffled
+stream, epoch boundaries at round(steps_per_epoch * epoch) (train.py:222-236), beta updated with numpy maths at each
+boundary (train.py:248), validation with noise on over number_full_validation_batches + 1 batches (train.py:230-234,
+262-268).  Differences, by intent: the tf.data shuffle buffer is replaced by seeded whole-dataset permutations, and
+`infonce_space_dimensionality` (a typo'd attribute in the reference) is the
+`--infonce_shared_dimensionality` flag.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .dense import DenseStack
+
+
+class _BatchStream:
+    """repeat().shuffle().batch(batch_size): endless full batches of row indices."""
+
+    def __init__(self, n: int, batch_size: int, seed: int):
+        self.n, self.bs, self.rng = n, batch_size, np.random.default_rng(seed)
+        self.buf = np.empty(0, dtype=np.int64)
+
+    def next(self) -> np.ndarray:
+        while len(self.buf) < self.bs:
+            self.buf = np.concatenate([self.buf, self.rng.permutation(self.n)])
+        out, self.buf = self.buf[: self.bs], self.buf[self.bs:]
+        return out
+
+
+def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, number_pretraining_epochs: int,
+                number_annealing_epochs: int, beta_start: float, beta_end: float, learning_rate: float,
+                y_encoder_architecture=(128, 128), shared_dimensionality: int = 64, similarity: str = 'l2',
+                temperature: float = 1.0, use_positional_encoding: bool = True,
+                number_positional_encoding_frequencies: int = 5, activation_fn: Optional[str] = 'relu', seed: int = 0,
+                epoch_callback=None) -> Dict[str, np.ndarray]:
+    """Returns dict(beta, kl [epochs,F] nats, loss_infonce, kl_validation, loss_infonce_validation) - the series the
+    reference builds at train.py:237-279 (before its conversion to bits)."""
+    eng = model._ensure_engine()
+    assert model.output_dimensionality == shared_dimensionality, "model output must be the shared embedding space"
+    F = model.number_features
+    xd, yd = eng.to_device(np.asarray(x_train, dtype=np.float32)), eng.to_device(np.asarray(y_train, dtype=np.float32))
+    xvd, yvd = eng.to_device(np.asarray(x_valid, dtype=np.float32)), eng.to_device(np.asarray(y_valid, dtype=np.float32))
+    yenc = DenseStack(eng, yd.shape[1], list(y_encoder_architecture), shared_dimensionality, activation_fn,
+                      use_positional_encoding, number_positional_encoding_frequencies, seed=seed + 1)
+    model.output_encoder = yenc
+    number_epochs = number_pretraining_epochs + number_annealing_epochs
+    n, nv = xd.shape[0], xvd.shape[0]
+    steps_per_epoch = n / batch_size
+    epoch_steps = np.round(steps_per_epoch * np.arange(number_epochs)).astype(np.int32)  # train.py:236
+    n_val_batches = nv // batch_size + 1                                                 # train.py:231-234
+    stream, vstream = _BatchStream(n, batch_size, seed), _BatchStream(nv, batch_size, seed + 7)
+    B = batch_size
+
+    def eval_batch(xs, ys, rows_np, training, step):
+        idx = eng.to_device(rows_np.astype(np.int32), dtype=torch.int32)
+        eng.forward(xs, idx, 0, B, model.noise_seed, step)        # model(inps): noise always on (train.py:263-265)
+        emb_x = eng.pred(B)
+        emb_y = yenc.forward(ys.index_select(0, idx.long()))
+        loss, gx, gy = eng.infonce(emb_x, emb_y, similarity, temperature, want_grads=training)
+        kl = eng.step_out(B)[:F].clone() / B                       # kl_loss / beta (train.py:220)
+        if training:
+            eng.backward_from_pred_grad(gx, idx, 0, B, model.noise_seed, step)
+            yenc.backward(gy)
+            eng.set_lr(learning_rate)
+            eng.adam_step()                                        # one Keras Adam over all variables (train.py:196,219)
+            yenc.adam_step(learning_rate)
+        return loss, kl
+
+    series = dict(beta=[], kl=[], loss_infonce=[], kl_validation=[], loss_infonce_validation=[])
+    run_l, run_k = [], []
+    step_num, total_steps = 0, int(epoch_steps[-1])
+    eng.set_beta(float(model.beta.value()))
+    for step_num in range(total_steps):
+        l, k = eval_batch(xd, yd, stream.next(), True, step_num)
+        run_l.append(l)
+        run_k.append(k)
+        hits = np.where(epoch_steps == step_num)[0]
+        if len(hits):
+            epoch_num = int(hits[0])
+            next_beta = np.exp(np.log(beta_start) + float(max(epoch_num - number_pretraining_epochs, 0)) /
+                               number_annealing_epochs * (np.log(beta_end) - np.log(beta_start)))  # train.py:248
+            series['beta'].append(next_beta)
+            model.beta.assign(next_beta)
+            if epoch_callback is not None:
+                epoch_callback(epoch_num, model)
+            vl, vk = [], []
+            for vb in range(n_val_batches):
+                l2, k2 = eval_batch(xvd, yvd, vstream.next(), False, (1 << 31) + epoch_num * 1024 + vb)
+                vl.append(l2)
+                vk.append(k2)
+            series['loss_infonce'].append(float(torch.stack(run_l).mean()))
+            series['kl'].append(torch.stack(run_k).mean(0).cpu().numpy())
+            series['loss_infonce_validation'].append(float(torch.stack(vl).mean()))
+            series['kl_validation'].append(torch.stack(vk).mean(0).cpu().numpy())
+            run_l, run_k = [], []
+    return {k: np.asarray(v) for k, v in series.items()}

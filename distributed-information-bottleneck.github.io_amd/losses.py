@@ -54,8 +54,9 @@ def get(identifier) -> Loss:
         return identifier
     if isinstance(identifier, str):
         if identifier == "infonce":
-            raise NotImplementedError("the InfoNCE custom loop (reference train.py:180-289) is a 'next' row "
-                                      "(SURVEY 8f); use a Keras-path loss")
+            raise NotImplementedError("'infonce' is not a Keras-path loss: it trains through the custom loop "
+                                      "(reference train.py:180-289) -> dib_amd.infonce.fit_infonce / "
+                                      "`python -m dib_amd.train --infonce_loss True`")
         if identifier in _BY_NAME:
             return _BY_NAME[identifier]()
     kind = getattr(identifier, "kind", None)

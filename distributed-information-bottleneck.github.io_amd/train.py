@@ -25,7 +25,7 @@ def _bool(v):
 
 def get_args(argv=None):
     p = argparse.ArgumentParser(description="Distributed IB training (MI355X-native)")
-    p.add_argument('--dataset', default='boolean_circuit', choices=['boolean_circuit', 'synthetic_tabular'])
+    p.add_argument('--dataset', default='boolean_circuit', choices=['boolean_circuit', 'synthetic_tabular', 'double_pendulum'])
     p.add_argument('--data_path', type=str, default='./data/')
     p.add_argument('--artifact_outdir', type=str, default='./training_artifacts/')
     p.add_argument('--ib', type=_bool, default=False, help='vanilla IB: treat all features as one (train.py:111-113)')
@@ -44,6 +44,12 @@ def get_args(argv=None):
     p.add_argument('--number_positional_encoding_frequencies', type=int, default=5)
     p.add_argument('--integration_network_architecture', type=int, nargs='+', default=[256, 256])
     p.add_argument('--infonce_loss', type=_bool, default=False)
+    p.add_argument('--infonce_shared_dimensionality', type=int, default=64)
+    p.add_argument('--infonce_y_encoder_architecture', type=int, nargs='+', default=[128, 128])
+    p.add_argument('--infonce_similarity', type=str, default='l2')
+    p.add_argument('--infonce_temperature', type=float, default=1.)
+    p.add_argument('--pendulum_time_delta', type=float, default=2)
+    p.add_argument('--pendulum_number_trajectories', type=int, default=0, help='0 = simulator default (1000)')
     p.add_argument('--boolean_random_circuit', type=_bool, default=False)
     p.add_argument('--boolean_number_input_gates', type=int, default=10)
     p.add_argument('--synthetic_rows', type=int, default=1 << 20)
@@ -56,8 +62,6 @@ def get_args(argv=None):
 def main(argv=None):
     from . import data, models, optimizers, visualization
     args = get_args(argv)
-    if args.infonce_loss:
-        raise NotImplementedError("the InfoNCE custom loop (reference train.py:180-289) is not on this path yet")
     import torch
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
@@ -70,7 +74,10 @@ def main(argv=None):
     dataset_dict = data.DATASETS[args.dataset](
         data_path=args.data_path, boolean_random_circuit=args.boolean_random_circuit,
         boolean_number_input_gates=args.boolean_number_input_gates, synthetic_rows=args.synthetic_rows,
-        synthetic_features=args.synthetic_features)
+        synthetic_features=args.synthetic_features, pendulum_time_delta=args.pendulum_time_delta,
+        pendulum_number_trajectories=args.pendulum_number_trajectories, seed=args.seed)
+    if dataset_dict['loss'] == 'infonce' and not args.infonce_loss:
+        raise ValueError(f"dataset {args.dataset} trains with --infonce_loss True (reference data.py:131)")
     if rank == 0:
         print(f'Dataset {args.dataset} loaded.')
     if args.ib:  # train.py:111-113
@@ -79,12 +86,36 @@ def main(argv=None):
     activation = None if args.activation_fn in ('None', 'none', '') else args.activation_fn
     model = models.DistributedIBNet(
         dataset_dict['feature_dimensionalities'], args.feature_encoder_architecture,
-        args.integration_network_architecture, dataset_dict['output_dimensionality'],
+        args.integration_network_architecture,
+        dataset_dict['output_dimensionality'] if not args.infonce_loss else args.infonce_shared_dimensionality,  # train.py:116
         use_positional_encoding=args.use_positional_encoding,
         number_positional_encoding_frequencies=args.number_positional_encoding_frequencies, activation_fn=activation,
         feature_embedding_dimension=args.feature_embedding_dimension,
-        output_activation_fn=dataset_dict['output_activation_fn'], noise_seed=args.seed, init_seed=args.seed,
-        shuffle_seed=args.seed)
+        output_activation_fn=dataset_dict['output_activation_fn'] if not args.infonce_loss else None,
+        noise_seed=args.seed, init_seed=args.seed, shuffle_seed=args.seed)
+    if args.infonce_loss:  # ---- custom training loop, reference train.py:180-289 ----
+        from . import infonce
+        F = dataset_dict['number_features']
+        out = infonce.fit_infonce(
+            model, dataset_dict['x_train'], dataset_dict['y_train'], dataset_dict['x_valid'], dataset_dict['y_valid'],
+            batch_size=args.batch_size, number_pretraining_epochs=args.number_pretraining_epochs,
+            number_annealing_epochs=args.number_annealing_epochs, beta_start=args.beta_start, beta_end=args.beta_end,
+            learning_rate=args.learning_rate, y_encoder_architecture=args.infonce_y_encoder_architecture,
+            shared_dimensionality=args.infonce_shared_dimensionality, similarity=args.infonce_similarity,
+            temperature=args.infonce_temperature, use_positional_encoding=args.use_positional_encoding,
+            number_positional_encoding_frequencies=args.number_positional_encoding_frequencies, activation_fn=activation,
+            seed=args.seed)
+        # train.py:271-286: KL and (info based) losses to bits
+        kl_series, kl_series_validation = out['kl'] / np.log(2), out['kl_validation'] / np.log(2)
+        loss_series, loss_series_validation = out['loss_infonce'], out['loss_infonce_validation']
+        if dataset_dict['loss_is_info_based']:
+            loss_series, loss_series_validation = loss_series / np.log(2), loss_series_validation / np.log(2)
+        if rank == 0:
+            print('Finished training.')
+            np.savez(os.path.join(args.artifact_outdir, 'history.npz'), beta=np.float32(out['beta']), kl_bits=kl_series,
+                     loss=loss_series, kl_bits_validation=kl_series_validation, loss_validation=loss_series_validation)
+            visualization.save_distributed_info_plane(kl_series_validation, loss_series_validation, args.artifact_outdir)
+        return out
     optimizer = optimizers.get(args.optimizer)
     optimizer.learning_rate = args.learning_rate  # train.py:128-129
     model.compile(optimizer=optimizer, loss=dataset_dict['loss'], metrics=dataset_dict['metrics'])

@@ -131,6 +131,16 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
 /* Bhattacharyya distance matrix between diagonal Gaussians (utils.py:177-212), closed form. */
 int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu2, const float* lv2, int m,
                       int dim, float* out, dib_stream_t stream);
+/* InfoNCE custom-loop path (train.py:201-220 eval_batch_infonce; utils.get_scaled_similarity utils.py:131-175):
+ * S = sim(emb_x, emb_y)/T [B,B]; loss = mean_i CE(i, S[i,:]) + mean_j CE(j, S[:,j]) (not halved, train.py:209-214);
+ * writes the loss (device scalar) and, if g_x/g_y are non-NULL, dloss/d emb_x and dloss/d emb_y.
+ * similarity: 0 'l2sq', 1 'l2' (eps 1e-9 inside the sqrt), 2 'l1', 3 'linf', 4 'cosine'. */
+int64_t dib_infonce_workspace_bytes(int batch);
+int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int dim, int similarity, float temperature,
+                        float* g_x, float* g_y, float* loss_out, void* ws, dib_stream_t stream);
+/* PositionalEncoding.call (models.py:22-23) of one dense [n, d] matrix -> [n, d*n_freq] (train.py:186-188: Y encoder) */
+int dib_positional_encoding(const float* x, int64_t ldx, int n, int d, int n_freq, float* out, dib_stream_t stream);
+
 /* Mutual-information sandwich bounds (utils.estimate_mi_sandwich_bounds, utils.py:10-73; used by
  * InfoPerFeatureCallback models.py:188-223): per-row InfoNCE-lower / leave-one-out-upper terms (nats, float64,
  * log-sum-exp) for one batch of n encoded points enc_out[n, 2E] = (mu|logvar); u_i = mu_i + sigma_i*eps with eps

@@ -325,3 +325,67 @@ def test_info_per_feature_callback_and_train_script(tmp_path):
     b = np.array(cb.bounds)
     assert b.shape == (20, 2) and np.isfinite(b).all() and (b[:, 0] <= b[:, 1] + 1e-6).all()
     assert (b[:, 1] <= np.log(2) + 0.2).all()  # a binary input carries at most 1 bit
+
+
+@pytest.mark.parametrize("kind", ["l2sq", "l2", "l1", "linf", "cosine"])
+def test_infonce_loss_and_grads_match_oracle(kind):
+    """dib_infonce_fwd_bwd vs the numpy restatement of train.py:203-215 / utils.py:131-175 (grads by central differences)."""
+    eng, _ = _engine(SPECS["no_hidden"])
+    rng = np.random.default_rng(3)
+    B, D = 12, 8
+    a = rng.standard_normal((B, D)).astype(np.float32)
+    b = (a + 0.7 * rng.standard_normal((B, D))).astype(np.float32)
+    loss, gx, gy = eng.infonce(eng.to_device(a), eng.to_device(b), kind, 0.7)
+    ref = orc.infonce_loss(a, b, kind, 0.7)
+    assert abs(float(loss.item()) - ref) < 2e-5 * (1 + abs(ref))
+    g1, g2 = orc.infonce_grads_numeric(a, b, kind, 0.7)
+    assert np.abs(gx.cpu().numpy() - g1).max() < 2e-4 * (1 + np.abs(g1).max())
+    assert np.abs(gy.cpu().numpy() - g2).max() < 2e-4 * (1 + np.abs(g2).max())
+
+
+def test_dense_stack_matches_numpy():
+    """The Y-encoder MLP (DenseStack over dib_gemm): forward, backward and Keras-Adam vs numpy."""
+    from dib_amd.dense import DenseStack
+    eng, _ = _engine(SPECS["no_hidden"])
+    ds = DenseStack(eng, 6, [20, 12], 5, "relu", True, 3, seed=4)
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((37, 6)).astype(np.float32)
+    out = ds.forward(eng.to_device(y)).cpu().numpy()
+    Ws = [ds.kernel(l).cpu().numpy().astype(np.float64) for l in range(3)]
+    bs = [rng.standard_normal(ds.dims[l][1]) * 0.1 for l in range(3)]
+    for l in range(3):
+        ds.bias(l).copy_(torch.tensor(bs[l], dtype=torch.float32))
+    out = ds.forward(eng.to_device(y)).cpu().numpy()
+    h = orc.positional_encoding(y.astype(np.float64), [2, 4])
+    hs = [h]
+    for l in range(3):
+        z = hs[-1] @ Ws[l] + np.float32(bs[l]).astype(np.float64)
+        hs.append(np.maximum(z, 0) if l < 2 else z)
+    assert np.abs(out - hs[-1]).max() < 1e-4
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    ds.backward(eng.to_device(g))
+    gg = g.astype(np.float64)
+    for l in reversed(range(3)):
+        gw = hs[l].T @ gg
+        gb = gg.sum(0)
+        i, o = ds.dims[l]
+        got_w = ds.grads[ds.w_off[l]: ds.w_off[l] + i * o].view(i, o).cpu().numpy()
+        got_b = ds.grads[ds.b_off[l]: ds.b_off[l] + o].cpu().numpy()
+        assert np.abs(got_w - gw).max() < 2e-4 * (1 + np.abs(gw).max()) and np.abs(got_b - gb).max() < 2e-4 * (1 + np.abs(gb).max())
+        if l > 0:
+            gg = (gg @ Ws[l].T) * (hs[l] > 0)
+
+
+def test_infonce_training_loop_on_pendulum(tmp_path):
+    """BASELINE config 2 path: the custom InfoNCE loop (train.py:180-289) on simulated double-pendulum data -
+    runs end to end, the InfoNCE loss drops below its untrained value ~ 2 ln B, series have the reference shapes."""
+    from dib_amd import train
+    out = train.main(["--dataset", "double_pendulum", "--infonce_loss", "True", "--data_path", str(tmp_path),
+                      "--pendulum_number_trajectories", "6", "--number_pretraining_epochs", "2",
+                      "--number_annealing_epochs", "3", "--batch_size", "256", "--learning_rate", "1e-3",
+                      "--artifact_outdir", str(tmp_path), "--beta_start", "1e-4", "--beta_end", "1e-2"])
+    # the reference's loop takes epoch_steps[-1] steps, so it records number_epochs - 1 boundaries (train.py:236-240)
+    assert out["kl"].shape == (4, 4) and out["kl_validation"].shape == (4, 4) and out["beta"].shape == (4,)
+    assert np.isfinite(out["loss_infonce"]).all() and np.isfinite(out["kl"]).all()
+    assert out["loss_infonce"][-1] < out["loss_infonce"][0] < 2 * np.log(256) + 0.5
+    assert abs(out["beta"][0] - 1e-4) < 1e-10 and abs(out["beta"][-1] - 1e-4 * 100 ** (1 / 3)) < 1e-7

@@ -149,3 +149,19 @@ def test_mi_sandwich_bounds_analytic_limits():
         lo, up = orc.mi_sandwich_bounds_batch(mus, lv, u)
         assert lo <= up + 1e-9
         assert abs(lo - want) < 0.08 and abs(up - want) < 0.08, (sep, lo, up, want)
+
+
+@pytest.mark.parametrize("kind", ["l2sq", "l2", "l1", "linf", "cosine"])
+def test_infonce_oracle_similarity_properties(kind):
+    """utils.get_scaled_similarity semantics (utils.py:131-175): self-similarity is maximal, temperature divides,
+    and the symmetric InfoNCE of perfectly matched, well separated embeddings tends to 0."""
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((6, 5))
+    S = orc.scaled_similarity(a, a, kind, 2.0)
+    assert np.allclose(np.diag(S), S.max(axis=1), atol=1e-4)
+    assert np.allclose(orc.scaled_similarity(a, a, kind, 1.0), 2.0 * S)
+    if kind != "cosine":
+        assert orc.infonce_loss(20 * a, 20 * a, kind, 1.0) < 1e-3
+    b = rng.standard_normal((6, 5))
+    l0 = orc.infonce_loss(a, b, kind, 1.0)
+    assert l0 > 0 and abs(l0 - orc.infonce_loss(b, a, kind, 1.0)) < 1e-12  # symmetric in (X, Y)
