@@ -53,7 +53,7 @@ struct dib_layout {
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
-    int64_t step_out, kl_partial, loss_partial, wgrad_partial, total;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, total;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
   WsMap map(int B) const {
@@ -85,6 +85,8 @@ struct dib_layout {
     m.nsplit = ns;
     m.rows_per_split = rps;
     m.wgrad_partial = take(ns > 1 ? (int64_t)ns * align_up(n_params, 4) : 0);
+    // fused backward: per-wave partials of d(W1|b1), [<= ceil(256/F) workgroups x 8 waves][F][16][H1]
+    m.dw1_partial = take(fused_id >= 0 && n_enc == 2 ? (int64_t)cdiv(256, F) * 8 * F * 16 * enc_units[0] : 0);
     m.total = o;
     return m;
   }
@@ -228,7 +230,13 @@ static int launch_fused_bwd(const DibFusedBwdArgs& a, int gx, int F, hipStream_t
 }
 
 // fused backward dgrad chain is instantiated for the configs whose E is a multiple of 32
-static bool fused_bwd_ok(const dib_layout* l) { return l->fused_id == 0 || l->fused_id == 1; }
+static bool fused_bwd_ok(const dib_layout* l) {
+  if (!(l->fused_id == 0 || l->fused_id == 1)) return false;
+  for (int f = 0; f < l->F; ++f)
+    if (l->in_dim[f] > 15) return false;  // row in_dim of the 16-row d(W1|b1) tile carries the bias gradient
+  return true;
+}
+static int fused_gx(const dib_layout* l, int batch) { return std::max(1, std::min(cdiv(batch, 256), cdiv(256, l->F))); }
 
 static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params,
                              const float* beta_dev, float inv_bg, const int32_t* row_idx, int64_t row0, uint64_t seed,
@@ -237,9 +245,9 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.P = w + m.P; a.row_idx = (const int*)row_idx; a.row0 = row0; a.batch = batch; a.params = params;
   a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap; a.act = l->act;
   a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.GU = w + m.g_u;
-  a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dh1 = w + m.g_enc_h[0];
+  a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dw1_partial = w + m.dw1_partial;
   a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F; a.seed = seed; a.step = step;
-  const int gx = std::max(1, std::min(cdiv(batch, 256), cdiv(256, l->F)));
+  const int gx = fused_gx(l, batch);
   ProfScope ps(kProfFusedBwd, st);
   switch (l->fused_id) {
     case 0: return launch_fused_bwd<128, 128, 32>(a, gx, l->F, st);
@@ -632,6 +640,7 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   if (rc) return rc;
   const int LE = l->n_enc + 1;
   for (int ly = LE - 1; ly >= 0; --ly) {
+    if (fused && ly == 0) break;  // d(W1|b1) is produced inside the fused kernel and reduced in dib_grads_finalize
     const float* gout = ly == LE - 1 ? w + m.dout : w + m.g_enc_h[ly];
     const float* hin = ly == 0 ? w + m.P : w + m.enc_h[ly - 1];
     rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
@@ -649,14 +658,23 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
 int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_stream_t stream) {
   if (!l || !grads || !ws || batch <= 0) return DIB_E_ARG;
   const auto m = l->map(batch);
-  if (m.nsplit <= 1) return DIB_OK;
   hipStream_t st = (hipStream_t)stream;
   float* w = (float*)ws;
-  // partial slabs are spaced align_up(n_params,4) apart; the reduce treats them as n = that stride
-  const long long n = align_up(l->n_params, 4);
-  { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, w + m.wgrad_partial, n,
-                     m.nsplit, grads); }
+  if (m.nsplit > 1) {
+    // partial slabs are spaced align_up(n_params,4) apart; the reduce treats them as n = that stride
+    const long long n = align_up(l->n_params, 4);
+    { ProfScope ps(kProfOther, (hipStream_t)stream);
+    hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, w + m.wgrad_partial, n,
+                       m.nsplit, grads); }
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+  }
+  if (fused_bwd_ok(l)) {  // layer-1 weight/bias gradients: fixed-order sum of the fused kernel's per-wave partials
+    ProfScope ps(kProfOther, (hipStream_t)stream);
+    hipLaunchKernelGGL(dib_dw1_reduce_kernel, dim3(l->F), dim3(256), 0, st, (const float*)(w + m.dw1_partial),
+                       fused_gx(l, batch) * 8, l->F, l->enc_units[0], l->dev_fused_offs, l->dev_fused_offs + 3 * l->F,
+                       l->dev_featmap, grads);
+  }
   return (int)hipGetLastError();
 }
 

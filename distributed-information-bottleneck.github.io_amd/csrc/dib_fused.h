@@ -300,20 +300,27 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
 // train.py:203-219), ONE launch replacing the reparam/KL backward and both encoder dgrad GEMMs:
 //   dmu = g_u + beta*mu/Bg ; dlogvar = g_u*eps*0.5*exp(lv/2) + beta*0.5*(exp(lv)-1)/Bg       -> dout  [F][B][2E]
 //   dh2 = (dout @ W3^T) * act'(h2)                                                         -> dh2   [F][B][H2]
-//   dh1 = (dh2  @ W2^T) * act'(h1)     (h1 is RECOMPUTED from the encoded input: 4..8 MFMAs) -> dh1   [F][B][H1]
+//   dh1 = (dh2  @ W2^T) * act'(h1)     (h1 is RECOMPUTED from the encoded input: 4..8 MFMAs)   (never leaves the CU)
+//   d(W1|b1) += [P | 1]^T @ dh1         (v_mfma_f32_16x16x4_f32 on the dh1 tile while it sits in the LDS patch;
+//                                        per-wave partials, reduced in fixed order by dib_dw1_reduce_kernel)
 // Same structure as the forward: one workgroup per feature, W2 / W3 resident in LDS in their natural
 // [in][out] orientation (they are the A operand of the transposed product dH_in^T = W * dH_out^T, fetched with
 // conflict-free ds_read_b128), gradients chained in MFMA accumulator registers, eps regenerated from the
-// Philox counter.  Row-major tiles (h2, mu|logvar, g_u in; dout, dh2, dh1 out) cross between HBM and the
+// Philox counter.  Row-major tiles (h2, mu|logvar, g_u in; dout, dh2 out) cross between HBM and the
 // fragment layout through a wave-private LDS patch so every global access is a full 128-byte line.
-// The weight gradients (contractions over the batch) then run as the grouped wgrad GEMMs on these buffers.
+// The layer-2/3 weight gradients (contractions over the batch) then run as the grouped wgrad GEMMs on these buffers;
+// the layer-1 gradient (5 x H1 per feature: hopeless as a GEMM tile, and dh1 is 2.1 GB) is finished here.
 // =====================================================================================================
+typedef float dib_f32x4 __attribute__((ext_vector_type(4)));
+#define DIB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
 struct DibFusedBwdArgs {
   const float* P; const int* row_idx; long long row0; int batch;
   const float* params; const long long* w_off; const long long* b_off; const int4* featmap;
   int act;
   const float* h2; const float* enc_out; const float* GU;   // stashes + dL/du [B][F*E]
-  float* dout; float* dh2; float* dh1;
+  float* dout; float* dh2;
+  float* dw1_partial;       // [gridDim.x*8 waves][F][16][H1]: per-wave partial of d(W1|b1) (row in_dim = bias gradient)
   const float* beta_dev; float inv_bg;
   int F; unsigned long long seed; unsigned step;
 };
@@ -404,6 +411,11 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
   const int ksteps1 = 4 * ((in_dim + 7) / 8);
   const float slope = dib_neg_slope(a.act);
   const float kb = a.beta_dev[0] * a.inv_bg;
+  // d(W1|b1) accumulators: 16x16 tiles (rows = encoder-input index k, row in_dim = bias; cols = 16 hidden units)
+  dib_f32x4 dw1[2 * C::T1];
+#pragma unroll
+  for (int t = 0; t < 2 * C::T1; ++t) dw1[t] = dib_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, lg = lane >> 4;
 
   auto load_p = [&](int tile, float (&dstp)[8]) {
     const int bb = min(tile * 256 + wave * 32 + m, a.batch - 1);
@@ -422,9 +434,6 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
     const int rows_valid = min(32, a.batch - wrow0);
     const int b = min(wrow0 + m, a.batch - 1);
     const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
-    float p[8];
-    load_p(tile, p);
-
     // ---- dout = d(loss + beta*KL)/d(mu|logvar), lane-local in fragment layout ----
     dib_f32x16 dout[C::T3];
     {
@@ -455,6 +464,18 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
       float* dd = a.dout + ((long long)f * a.batch + wrow0) * C::E2;
 #pragma unroll
       for (int t = 0; t < C::T3; ++t) dib_store_tile(patch, dout[t], dd + 32 * t, C::E2, rows_valid, lane);
+    }
+
+    // encoded inputs for the h1 recompute (B operand) and for the layer-1 weight gradient (A operand: lane (i = lane&15,
+    // g = lane>>4) supplies [P | 1][row 4s+g][i]); issued here so they land during the dh2 MFMAs
+    float p[8];
+    load_p(tile, p);
+    float pa[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int rl = 4 * s8 + lg;                                   // row within the wave's 32 samples
+      const float v = Pf[(long long)min(wrow0 + rl, a.batch - 1) * in_dim + min(l15, in_dim - 1)];
+      pa[s8] = (rl < rows_valid) ? (l15 < in_dim ? v : (l15 == in_dim ? 1.f : 0.f)) : 0.f;
     }
 
     // ---- dh2^T = W3 dout^T, masked by act'(h2) ----
@@ -488,7 +509,6 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
 
     // ---- dh1^T = W2 dh2^T, masked by act'(h1); h1 tile recomputed from the encoded input ----
     {
-      float* dg = a.dh1 + ((long long)f * a.batch + wrow0) * H1;
 #pragma unroll
       for (int jo = 0; jo < C::T1; ++jo) {
         dib_f32x16 acc;
@@ -519,8 +539,45 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] *= (h1v[r] > 0.f ? 1.f : slope);
-        dib_store_tile(patch, acc, dg + 32 * jo, H1, rows_valid, lane);
+        // dh1 tile -> LDS patch as row-major [m][n] (it never goes to HBM), then d(W1|b1) += [P|1]^T dh1 on 16x16x4 MFMAs:
+        // step s contracts samples 4s..4s+3; B operand: lane (j, g) reads dh1[4s+g][16*half + j] from the patch.
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(patch + m * 36 + 8 * g + 4 * h) =
+              make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const float b0 = patch[(4 * s8 + lg) * 36 + l15];
+          const float b1v = patch[(4 * s8 + lg) * 36 + 16 + l15];
+          dw1[2 * jo] = DIB_MFMA16(pa[s8], b0, dw1[2 * jo]);
+          dw1[2 * jo + 1] = DIB_MFMA16(pa[s8], b1v, dw1[2 * jo + 1]);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     }
+  }
+  // per-wave partial of d(W1|b1): C/D map of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+  {
+    float* dst = a.dw1_partial + (((long long)blockIdx.x * 8 + wave) * F + f) * (16ll * H1);
+#pragma unroll
+    for (int t = 0; t < 2 * C::T1; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(long long)(lg * 4 + r) * H1 + 16 * t + l15] = dw1[t][r];
+  }
+}
+
+// grads[W1 block of feature f][k][n] = sum_p partial[p][f][k][n] (k < in_dim); grads[b1 block][n] = sum_p partial[p][f][in_dim][n]
+__global__ void __launch_bounds__(256)
+dib_dw1_reduce_kernel(const float* __restrict__ partial, int nparts, int F, int H1, const long long* __restrict__ w_off,
+                      const long long* __restrict__ b_off, const int4* __restrict__ featmap, float* __restrict__ grads) {
+  const int f = blockIdx.x;
+  const int in_dim = featmap[f].y;
+  for (int idx = threadIdx.x; idx < (in_dim + 1) * H1; idx += 256) {
+    const int k = idx / H1, n = idx - k * H1;
+    float s = 0.f;
+    for (int pz = 0; pz < nparts; ++pz) s += partial[(((long long)pz * F + f) * 16 + k) * H1 + n];
+    if (k < in_dim) grads[w_off[f] + (long long)k * H1 + n] = s;
+    else grads[b_off[f] + n] = s;
   }
 }
