@@ -86,6 +86,8 @@ SIGNATURES = {
     "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                      c_uint64, c_uint32, c_void_p, c_void_p]),
     "dib_grads_finalize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dib_grads_finalize_part": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dib_layout_part_range": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "dib_metrics_accumulate": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "dib_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_float,
                               c_float, c_float, c_void_p]),

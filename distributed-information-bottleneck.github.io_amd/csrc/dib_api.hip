@@ -114,7 +114,9 @@ struct Prof {
 struct ProfScope {
   int cat; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(int c, hipStream_t s) : cat(c), st(s) {
-    if (g_prof.on) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
+    // the small HBM-bound kernels are not bracketed (event pairs serialise kernel boundaries: ~10 us each); rocprofv3
+    // reports them (profiles/*_kernel_stats.csv)
+    if (g_prof.on && cat != 14) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
   }
   ~ProfScope() {
     if (a) { (void)hipEventRecord(b, st); g_prof.spans[cat].push_back({a, b}); }
@@ -655,27 +657,42 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   return DIB_OK;
 }
 
-int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_stream_t stream) {
-  if (!l || !grads || !ws || batch <= 0) return DIB_E_ARG;
+int dib_layout_part_range(const dib_layout* l, int part, int64_t* offset, int64_t* count) {
+  if (!l || !offset || !count || part < 0 || part > 1) return DIB_E_ARG;
+  const int64_t split = l->int_w_off[0];  // encoder-bank parameters come first, then the integration network
+  *offset = part == 0 ? 0 : split;
+  *count = part == 0 ? split : l->n_params - split;
+  return DIB_OK;
+}
+
+// part: 0 = encoder bank, 1 = integration network, -1 = everything
+int dib_grads_finalize_part(dib_layout* l, int batch, int part, float* grads, void* ws, dib_stream_t stream) {
+  if (!l || !grads || !ws || batch <= 0 || part < -1 || part > 1) return DIB_E_ARG;
   const auto m = l->map(batch);
   hipStream_t st = (hipStream_t)stream;
   float* w = (float*)ws;
   if (m.nsplit > 1) {
-    // partial slabs are spaced align_up(n_params,4) apart; the reduce treats them as n = that stride
-    const long long n = align_up(l->n_params, 4);
+    // partial slabs are spaced align_up(n_params,4) apart
+    const long long stride = align_up(l->n_params, 4);
+    const long long split = l->int_w_off[0];  // multiple of 4 by construction of the layout
+    const long long beg = part == 1 ? split : 0, end = part == 0 ? split : stride;
     { ProfScope ps(kProfOther, (hipStream_t)stream);
-    hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, w + m.wgrad_partial, n,
-                       m.nsplit, grads); }
+    hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for((end - beg) / 4)), dim3(256), 0, st,
+                       (const float*)(w + m.wgrad_partial + beg), end - beg, m.nsplit, stride, grads + beg); }
     int rc = (int)hipGetLastError();
     if (rc) return rc;
   }
-  if (fused_bwd_ok(l)) {  // layer-1 weight/bias gradients: fixed-order sum of the fused kernel's per-wave partials
+  if (part != 1 && fused_bwd_ok(l)) {  // layer-1 weight/bias gradients: fixed-order sum of the fused kernel's partials
     ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_dw1_reduce_kernel, dim3(l->F), dim3(256), 0, st, (const float*)(w + m.dw1_partial),
                        fused_gx(l, batch) * 8, l->F, l->enc_units[0], l->dev_fused_offs, l->dev_fused_offs + 3 * l->F,
                        l->dev_featmap, grads);
   }
   return (int)hipGetLastError();
+}
+
+int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_stream_t stream) {
+  return dib_grads_finalize_part(l, batch, -1, grads, ws, stream);
 }
 
 int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, float inv_global_batch,

@@ -241,15 +241,16 @@ __global__ void dib_metrics_accumulate_kernel(const float* __restrict__ step_out
 
 __global__ void dib_set_scalar_kernel(float* p, float v) { p[0] = v; }
 
-// grads[i] = sum_s partial[s][i]   (fixed order)
+// out[i] = sum_s partial[s*stride + i], i < n   (fixed order => deterministic)
 __global__ void __launch_bounds__(256)
-dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsplit, float* __restrict__ out) {
+dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsplit, long long stride,
+                         float* __restrict__ out) {
   const long long n4 = n >> 2;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(partial)[i];
     for (int k = 1; k < nsplit; ++k) {
-      const float4 v = reinterpret_cast<const float4*>(partial + (long long)k * n)[i];
+      const float4 v = reinterpret_cast<const float4*>(partial + (long long)k * stride)[i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     reinterpret_cast<float4*>(out)[i] = s;
@@ -257,7 +258,7 @@ dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsp
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * n + i];
+    for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * stride + i];
     out[i] = s;
   }
 }

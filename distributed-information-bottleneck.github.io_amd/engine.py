@@ -178,15 +178,31 @@ class HipEngine:
                                         int(row0), batch, float(inv_global_batch), _ptr(ws), self._stream()),
               "dib_loss_fwd_bwd")
 
-    def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float) -> None:
+    def part_range(self, part: int):
+        """(offset, count) of all-reduce bucket `part` (0 = encoder bank, 1 = integration network) in the flat buffers."""
+        off, cnt = c_int64(), c_int64()
+        check(self.lib.dib_layout_part_range(self.layout, part, byref(off), byref(cnt)), "dib_layout_part_range")
+        return off.value, cnt.value
+
+    def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float,
+                 on_integration_grads_ready=None) -> None:
+        """Backward pass.  The integration-network gradients (bucket 1) are final right after dib_integration_bwd;
+        `on_integration_grads_ready(grads_slice)` is called at that point so a data-parallel caller can start their
+        all-reduce while the encoder-bank backward (the bulk of the step) is still running."""
         ws = self.workspace(batch)
         st = self._stream()
         check(self.lib.dib_integration_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st),
               "dib_integration_bwd")
+        if on_integration_grads_ready is not None:
+            check(self.lib.dib_grads_finalize_part(self.layout, batch, 1, _ptr(self.grads), _ptr(ws), st),
+                  "dib_grads_finalize_part")
+            off, cnt = self.part_range(1)
+            on_integration_grads_ready(self.grads[off: off + cnt])
         check(self.lib.dib_encoder_bank_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads),
                                             _ptr(self.beta_dev), float(inv_global_batch), _ptr(row_idx), int(row0),
                                             int(seed), int(step) & 0xFFFFFFFF, _ptr(ws), st), "dib_encoder_bank_bwd")
-        check(self.lib.dib_grads_finalize(self.layout, batch, _ptr(self.grads), _ptr(ws), st), "dib_grads_finalize")
+        check(self.lib.dib_grads_finalize_part(self.layout, batch, 0 if on_integration_grads_ready is not None else -1,
+                                               _ptr(self.grads), _ptr(ws), st), "dib_grads_finalize_part")
 
     def accumulate_metrics(self, batch: int, inv_global_batch: float) -> None:
         check(self.lib.dib_metrics_accumulate(self.layout, batch, _ptr(self.beta_dev), float(inv_global_batch),
@@ -194,13 +210,14 @@ class HipEngine:
               "dib_metrics_accumulate")
 
     def train_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
-                   inv_global_batch: Optional[float] = None, accumulate: bool = True) -> None:
+                   inv_global_batch: Optional[float] = None, accumulate: bool = True,
+                   on_integration_grads_ready=None) -> None:
         """fwd + loss + bwd for the local rows; grads (partial sums over local rows / B_global) land in
         self.grads, ready for the data-parallel all-reduce(sum) and the optimizer step."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         self.forward(x, row_idx, row0, batch, seed, step)
         self.loss(loss_kind, y, row_idx, row0, batch, inv)
-        self.backward(row_idx, row0, batch, seed, step, inv)
+        self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready)
         if accumulate:
             self.accumulate_metrics(batch, inv)
 

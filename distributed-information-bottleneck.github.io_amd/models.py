@@ -354,13 +354,24 @@ class DistributedIBNet:
                 gb = min(bs, n - s0)  # last partial batch is kept (Keras)
                 lo = (gb * rank) // world
                 hi = (gb * (rank + 1)) // world
+                pending = []
                 if hi > lo:
+                    overlap = None
+                    if dist is not None and hasattr(eng, "part_range"):
+                        # bucket 1 (integration network) is all-reduced while the encoder-bank backward still runs
+                        overlap = lambda g: pending.append(dist.all_reduce(g, async_op=True))
                     eng.train_step(xd, yd, order_dev[s0 + lo: s0 + hi], 0, hi - lo, self.noise_seed, self._step, kind,
-                                   inv_global_batch=1.0 / gb)
+                                   inv_global_batch=1.0 / gb, on_integration_grads_ready=overlap)
                 else:
                     eng.grads.zero_()
                 if dist is not None:
-                    dist.all_reduce(eng.grads)
+                    if pending:  # bucket 0 (encoder bank) after the backward; then wait for both
+                        off, cnt = eng.part_range(0)
+                        pending.append(dist.all_reduce(eng.grads[off: off + cnt], async_op=True))
+                        for w in pending:
+                            w.wait()
+                    else:
+                        dist.all_reduce(eng.grads)
                 self._optimizer_step(eng)
                 self._step += 1
                 nsteps += 1

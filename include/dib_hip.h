@@ -109,8 +109,12 @@ int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* gr
 int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
                          float inv_global_batch, const int32_t* row_idx, int64_t row0, uint64_t seed,
                          uint32_t step, void* ws, dib_stream_t stream);
-/* reduce the split-batch wgrad partials into `grads` (fixed order => deterministic) */
+/* reduce the split-batch wgrad partials into `grads` (fixed order => deterministic).
+ * _part finalises one all-reduce bucket: 0 = encoder bank, 1 = integration network (its gradients are complete right
+ * after dib_integration_bwd, so its RCCL all-reduce can overlap the encoder-bank backward), -1 = everything. */
 int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_stream_t stream);
+int dib_grads_finalize_part(dib_layout* l, int batch, int part, float* grads, void* ws, dib_stream_t stream);
+int dib_layout_part_range(const dib_layout* l, int part, int64_t* offset, int64_t* count);
 /* metrics_acc[F+3] += {KL_f_local_sum * inv_global_batch (F), task_sum + beta*sum_f KL_f_local_sum,
  * #correct, rows}: the History accounting of models.py:115,121 / train.py:169-172 without a host sync */
 int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, float inv_global_batch,

@@ -73,7 +73,12 @@ class OracleEngine:
             acc[self.F + 1] += orc.accuracy(kind, yb, c.pred) * batch
         acc[self.F + 2] += batch
 
-    def train_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None, accumulate=True):
+    def part_range(self, part):
+        split = min(b["offset"] for b in self.blocks if b["net"] == 1)
+        return (0, split) if part == 0 else (split, self.n_params - split)
+
+    def train_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None, accumulate=True,
+                   on_integration_grads_ready=None):
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         rows, xb, c = self._fwd(x, row_idx, row0, batch, seed, step)
         yb = y.numpy()[rows]
@@ -81,6 +86,9 @@ class OracleEngine:
                                   loss_scale_rows=int(round(1.0 / inv)))
         self.grads.copy_(torch.from_numpy(params_to_flat(self.blocks, g, self.n_params, np.float64)))
         self._gstruct = g
+        if on_integration_grads_ready is not None:  # two-bucket data-parallel protocol of the product engine
+            off, cnt = self.part_range(1)
+            on_integration_grads_ready(self.grads[off: off + cnt])
         if accumulate:
             self._account(c, task, yb, loss_kind, batch, inv)
 
