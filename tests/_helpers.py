@@ -71,4 +71,14 @@ SPECS = {
     "tabular8_default": orc.DIBSpec([1] * 8, [128, 128], [256, 256], 1, feature_embedding_dimension=32),
     "sigmoid_out_elu": orc.DIBSpec([2, 2], [16], [16], 1, activation_fn="elu", output_activation_fn="sigmoid",
                                    feature_embedding_dimension=4),
+    # fused-kernel edge cases: leaky / linear activations, no positional encoding, encoder-input widths at the
+    # fused-backward limit (15: fused fwd+bwd) and just above it (16: fused fwd + general GEMM bwd), fwd-only configs
+    "fused_leaky": orc.DIBSpec([1, 2, 1], [32, 32], [24], 1, activation_fn="leaky_relu", feature_embedding_dimension=32),
+    "fused_linear_act": orc.DIBSpec([1, 1], [32, 32], [16], 1, activation_fn=None, feature_embedding_dimension=32),
+    "fused_no_posenc": orc.DIBSpec([3, 2, 5], [128, 128], [32], 1, use_positional_encoding=False,
+                                   feature_embedding_dimension=32),
+    "fused_in15": orc.DIBSpec([3, 1], [32, 32], [16], 1, feature_embedding_dimension=32),
+    "fused_fwd_in16_gemm_bwd": orc.DIBSpec([4, 2], [32, 32], [16], 1, number_positional_encoding_frequencies=4,
+                                           feature_embedding_dimension=32),
+    "fused_fwd_only_e16": orc.DIBSpec([1, 1, 2], [64, 64], [32], 1, feature_embedding_dimension=16),
 }
