@@ -240,6 +240,41 @@ class DistributedIBNet:
 
     call = __call__
 
+    # ---- autograd bridge for custom PyTorch training loops ------------------------------------------
+    def forward_autograd(self, inputs, row_ids=None):
+        """Differentiable forward for hand-written loops (the reference's custom-loop contract, train.py:196-220:
+        `model(x)`, `model.losses`, `model.trainable_variables` under a gradient tape).
+
+        Returns `(prediction [B, out], kl_loss)` where `kl_loss = beta * sum_f KL_f` (models.py:118) - both are
+        autograd-connected to `model.flat_parameters` (a leaf tensor aliasing the engine's flat parameter buffer):
+
+            pred, kl_loss = model.forward_autograd(x)
+            loss = my_loss(pred, y) + kl_loss
+            loss.backward()                       # runs the HIP backward kernels; fills model.flat_parameters.grad
+            torch_optimizer.step()                # any torch.optim optimizer over [model.flat_parameters]
+
+        `row_ids` (int tensor [B]) keys the noise per sample; default arange(B).  The batch-mean convention of the
+        KL term matches the reference: the caller's loss should be a mean over the batch."""
+        eng = self._ensure_engine()
+        x = eng.to_device(np.asarray(inputs, dtype=np.float32) if not isinstance(inputs, torch.Tensor) else inputs)
+        if x.dim() == 1:
+            x = x.view(1, -1)
+        idx = None if row_ids is None else eng.to_device(row_ids, dtype=torch.int32)
+        step = self._step
+        self._step += 1
+        pred, kl_loss = _DIBFunction.apply(self.flat_parameters, self, x, idx, step)
+        self.losses = [kl_loss]
+        return pred, kl_loss
+
+    @property
+    def flat_parameters(self) -> torch.Tensor:
+        """The engine's flat fp32 parameter buffer as an autograd leaf (shares memory: optimizer updates are seen by
+        the kernels directly)."""
+        eng = self._ensure_engine()
+        if getattr(self, "_flat_leaf", None) is None or self._flat_leaf.data_ptr() != eng.params.data_ptr():
+            self._flat_leaf = eng.params.detach().requires_grad_(True)
+        return self._flat_leaf
+
     def predict(self, x, batch_size=None, verbose=0):
         eng = self._ensure_engine()
         xd = eng.to_device(x)
@@ -419,6 +454,32 @@ class DistributedIBNet:
             eng.eval_step(xd, yd, None, s0, b, self.noise_seed, (1 << 31) - 1, self.loss.kind)
             steps += 1
         return self._epoch_logs(eng.read_metrics(), steps, "")
+
+
+class _DIBFunction(torch.autograd.Function):
+    """torch.autograd bridge: forward = dib_encoder_bank_fwd + dib_integration_fwd, backward = the HIP backward
+    kernels with the caller's dL/dpred injected (engine.backward_from_pred_grad)."""
+
+    @staticmethod
+    def forward(ctx, flat_params, model, x, idx, step):
+        eng = model._ensure_engine()
+        B = x.shape[0]
+        eng.forward(x, idx, 0, B, model.noise_seed, step)
+        ctx.model, ctx.idx, ctx.step, ctx.B = model, idx, step, B
+        ctx.beta = float(model.beta.value())
+        kl = eng.step_out(B)[: model.number_features].sum() / B
+        return eng.pred(B).clone(), (kl * ctx.beta).reshape(())
+
+    @staticmethod
+    def backward(ctx, g_pred, g_kl):
+        model = ctx.model
+        eng = model._ensure_engine()
+        # d/dparams of (beta * sum KL) scaled by the incoming gradient of the KL-loss output
+        eng.set_beta(ctx.beta * float(g_kl.item()) if g_kl is not None else 0.0)
+        eng.backward_from_pred_grad(g_pred.contiguous(), ctx.idx, 0, ctx.B, model.noise_seed, ctx.step,
+                                    inv_global_batch=1.0 / ctx.B)
+        eng.set_beta(float(model.beta.value()))
+        return eng.grads.clone(), None, None, None, None
 
 
 class InfoBottleneckAnnealingCallback(Callback):

@@ -389,3 +389,33 @@ def test_infonce_training_loop_on_pendulum(tmp_path):
     assert np.isfinite(out["loss_infonce"]).all() and np.isfinite(out["kl"]).all()
     assert out["loss_infonce"][-1] < out["loss_infonce"][0] < 2 * np.log(256) + 0.5
     assert abs(out["beta"][0] - 1e-4) < 1e-10 and abs(out["beta"][-1] - 1e-4 * 100 ** (1 / 3)) < 1e-7
+
+
+def test_autograd_bridge_matches_oracle_gradients():
+    """Custom-loop contract (reference train.py:196-220): `model.forward_autograd(x)` is differentiable under
+    torch.autograd; gradients of  mean-loss(pred) + kl_loss  equal the oracle's, and a torch optimizer over
+    `model.flat_parameters` updates the weights the kernels use."""
+    import dib_amd
+    spec = SPECS["boolean4_32x32"]
+    model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=5, init_seed=3)
+    model.beta.assign(0.2)
+    eng = model._ensure_engine()
+    p = flat_to_params(eng.blocks, eng.get_flat_params(), spec)
+    rng = np.random.default_rng(0)
+    B = 50
+    x = rng.standard_normal((B, 4)).astype(np.float32)
+    y = rng.integers(0, 2, (B, 1)).astype(np.float32)
+    pred, kl_loss = model.forward_autograd(x)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(pred, torch.tensor(y, device=pred.device)) + kl_loss
+    loss.backward()
+    got = model.flat_parameters.grad.cpu().numpy()
+    c = orc.forward(spec, p, x.astype(np.float64), orc.philox_normal_all(5, 0, np.arange(B), 4, 32))
+    task, grads, _ = orc.backward(spec, p, x.astype(np.float64), y, c, 0.2, "bce_logits")
+    ref = params_to_flat(eng.blocks, grads, eng.params.numel()).astype(np.float64)
+    assert abs(float(loss.item()) - (task + 0.2 * c.kl.sum())) < 2e-4
+    assert np.abs(got - ref).max() < 3e-4 * (np.abs(ref).max() + 1e-3)
+    before = eng.get_flat_params().copy()
+    opt = torch.optim.SGD([model.flat_parameters], lr=0.1)
+    opt.step()
+    after = eng.get_flat_params()
+    assert np.allclose(after, before - 0.1 * got, atol=1e-6) and not np.allclose(after, before)
