@@ -48,6 +48,7 @@ struct dib_layout {
   std::vector<int4> featmap;           // [F] {d_f, in_dim_f, x column, 0}
   const long long* dev_fused_offs = nullptr;
   const int4* dev_featmap = nullptr;
+  const unsigned* step_dev = nullptr;  // optional device-resident noise step (dib_layout_set_step_counter)
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
@@ -203,6 +204,7 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.n_blocks = l->n_blocks; a.act = l->act;
   a.h1 = w + m.enc_h[0]; a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.U = w + m.U;
   a.kl_partial = w + m.kl_partial; a.F = l->F; a.seed = seed; a.step = step; a.deterministic = deterministic;
+  a.step_dev = l->step_dev;
   const int n_tiles = cdiv(batch, 256);
   const int gx = std::max(1, std::min(n_tiles, cdiv(256, l->F)));
   *gx_out = gx;
@@ -248,7 +250,7 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap; a.act = l->act;
   a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.GU = w + m.g_u;
   a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dw1_partial = w + m.dw1_partial;
-  a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F; a.seed = seed; a.step = step;
+  a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F; a.seed = seed; a.step = step; a.step_dev = l->step_dev;
   const int gx = fused_gx(l, batch);
   ProfScope ps(kProfFusedBwd, st);
   switch (l->fused_id) {
@@ -470,6 +472,12 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
   return DIB_OK;
 }
 
+int dib_layout_set_step_counter(dib_layout* l, const uint32_t* step_dev) {
+  if (!l) return DIB_E_ARG;
+  l->step_dev = (const unsigned*)step_dev;
+  return DIB_OK;
+}
+
 int64_t dib_workspace_bytes(const dib_layout* l, int batch) {
   if (!l || batch <= 0) return DIB_E_ARG;
   return l->map(batch).total * (int64_t)sizeof(float);
@@ -540,7 +548,7 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
                      w + m.kl_partial, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
-                     (unsigned long long)seed, (unsigned)step, deterministic); }
+                     (unsigned long long)seed, (unsigned)step, deterministic, l->step_dev); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
@@ -636,7 +644,7 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
     { ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
                        w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
-                       (unsigned long long)seed, (unsigned)step); }
+                       (unsigned long long)seed, (unsigned)step, l->step_dev); }
     rc = (int)hipGetLastError();
   }
   if (rc) return rc;

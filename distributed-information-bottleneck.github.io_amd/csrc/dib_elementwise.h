@@ -41,8 +41,9 @@ dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restr
 __global__ void __launch_bounds__(256)
 dib_reparam_kl_fwd_kernel(const float* __restrict__ enc_out, float* __restrict__ U, float* __restrict__ kl_partial,
                           const int* __restrict__ row_idx, long long row0, int batch, int F, int E,
-                          unsigned long long seed, unsigned step, int deterministic) {
+                          unsigned long long seed, unsigned step, int deterministic, const unsigned* step_dev) {
   __shared__ float red[4];
+  if (step_dev) step = step_dev[0];
   const int E4 = (E + 3) >> 2;
   const int rows_per_block = 256 / E4;
   const int f = blockIdx.y;
@@ -99,7 +100,8 @@ __global__ void __launch_bounds__(256)
 dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __restrict__ GU,
                           float* __restrict__ dout, const float* __restrict__ beta_dev, float inv_bg,
                           const int* __restrict__ row_idx, long long row0, int batch, int F, int E,
-                          unsigned long long seed, unsigned step) {
+                          unsigned long long seed, unsigned step, const unsigned* step_dev) {
+  if (step_dev) step = step_dev[0];
   const int E4 = (E + 3) >> 2;
   const int rows_per_block = 256 / E4;
   const int f = blockIdx.y;

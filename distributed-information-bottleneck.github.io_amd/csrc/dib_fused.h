@@ -35,6 +35,7 @@ struct DibFusedFwdArgs {
   int act;
   float* h1; float* h2; float* enc_out; float* U; float* kl_partial;  // kl_partial[gridDim.x*8][F]
   int F; unsigned long long seed; unsigned step; int deterministic;
+  const unsigned* step_dev;  // if non-NULL the noise step is read from device memory (hipGraph replay)
 };
 
 template <int H1, int H2, int E>
@@ -134,6 +135,7 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
   __syncthreads();
 
   const int n_tiles = (a.batch + 255) / 256;
+  const unsigned nstep = a.step_dev ? a.step_dev[0] : a.step;
   const float slope = dib_neg_slope(a.act);
   const int ksteps1 = 4 * ((in_dim + 7) / 8);  // layer-1 MFMA steps per output tile (k-blocks of 8 that hold data)
   float kl_acc = 0.f;
@@ -258,7 +260,7 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       const int g_lv = (E >= 32) ? g_mu : (gi + E / 8);
       const int e0 = 32 * t_mu + 8 * g_mu + 4 * h;  // first of 4 consecutive embedding dims held by this lane
       float eps[4] = {0.f, 0.f, 0.f, 0.f};
-      if (!a.deterministic) dib_eps4(a.seed, a.step, (uint32_t)grow, (uint32_t)f, (uint32_t)(e0 >> 2), eps);
+      if (!a.deterministic) dib_eps4(a.seed, nstep, (uint32_t)grow, (uint32_t)f, (uint32_t)(e0 >> 2), eps);
       float4 mu = make_float4(o[t_mu][4 * g_mu], o[t_mu][4 * g_mu + 1], o[t_mu][4 * g_mu + 2], o[t_mu][4 * g_mu + 3]);
       float4 lv = make_float4(o[t_lv][4 * g_lv], o[t_lv][4 * g_lv + 1], o[t_lv][4 * g_lv + 2], o[t_lv][4 * g_lv + 3]);
       float4 u;
@@ -323,6 +325,7 @@ struct DibFusedBwdArgs {
   float* dw1_partial;       // [gridDim.x*8 waves][F][16][H1]: per-wave partial of d(W1|b1) (row in_dim = bias gradient)
   const float* beta_dev; float inv_bg;
   int F; unsigned long long seed; unsigned step;
+  const unsigned* step_dev;  // if non-NULL the noise step is read from device memory (hipGraph replay)
 };
 
 template <int H1, int H2, int E>
@@ -410,6 +413,7 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
   const int n_tiles = (a.batch + 255) / 256;
   const int ksteps1 = 4 * ((in_dim + 7) / 8);
   const float slope = dib_neg_slope(a.act);
+  const unsigned nstep = a.step_dev ? a.step_dev[0] : a.step;
   const float kb = a.beta_dev[0] * a.inv_bg;
   // d(W1|b1) accumulators: 16x16 tiles (rows = encoder-input index k, row in_dim = bias; cols = 16 hidden units)
   dib_f32x4 dw1[2 * C::T1];
@@ -451,7 +455,7 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
         for (int gq = 0; gq < 4; ++gq) {
           const int e0 = 32 * t + 8 * gq + 4 * h;
           float eps[4];
-          dib_eps4(a.seed, a.step, (uint32_t)grow, (uint32_t)f, (uint32_t)(e0 >> 2), eps);
+          dib_eps4(a.seed, nstep, (uint32_t)grow, (uint32_t)f, (uint32_t)(e0 >> 2), eps);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * gq + j;

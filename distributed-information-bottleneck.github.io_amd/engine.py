@@ -229,6 +229,50 @@ class HipEngine:
         self.loss(loss_kind, y, row_idx, row0, batch, inv)
         self.accumulate_metrics(batch, inv)
 
+    # ---- hipGraph capture of a whole step (launch-bound small-batch regime) -----------------------
+    def enable_step_counter(self, value: int = 0) -> None:
+        """Key the noise with a DEVICE-resident step counter (dib_layout_set_step_counter) so that a captured step
+        can be replayed; from now on the by-value `step` arguments are ignored by the kernels."""
+        if getattr(self, "step_dev", None) is None:
+            self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+            check(self.lib.dib_layout_set_step_counter(self.layout, _ptr(self.step_dev)), "dib_layout_set_step_counter")
+        self.set_step_counter(value)
+
+    def set_step_counter(self, value: int) -> None:
+        v = int(value) & 0xFFFFFFFF
+        self.step_dev.fill_(v - (1 << 32) if v >= (1 << 31) else v)  # uint32 bit pattern in an int32 tensor
+
+    def capture_step_graph(self, x, y, batch: int, loss_kind: str, inv_global_batch: float, seed: int, train: bool,
+                           optimizer: str = "adam", opt_args=(0.9, 0.999, 1e-7)):
+        """Capture fwd + loss [+ bwd + optimizer] + metric accumulation + step-counter bump for `batch` rows whose
+        dataset indices are read from a fixed staging buffer.  Returns (graph, idx_stage): copy the batch's int32 row
+        indices into idx_stage, then graph.replay().  Everything the step reads that changes between replays (beta,
+        lr, Adam t, noise step, row indices) lives in device memory."""
+        assert getattr(self, "step_dev", None) is not None, "call enable_step_counter() first"
+        idx_stage = torch.zeros(batch, dtype=torch.int32, device=self.device)
+        self.workspace(batch)
+        saved = (self.metrics_acc.clone(), self.grads.clone())
+        # eager warm-up: loads modules / sets kernel attributes outside the capture; state is restored afterwards
+        self.forward(x, idx_stage, 0, batch, seed, 0)
+        self.loss(loss_kind, y, idx_stage, 0, batch, inv_global_batch)
+        if train:
+            self.backward(idx_stage, 0, batch, seed, 0, inv_global_batch)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            if train:
+                self.train_step(x, y, idx_stage, 0, batch, seed, 0, loss_kind, inv_global_batch)
+                if optimizer == "adam":
+                    self.adam_step(*opt_args)
+                else:
+                    self.sgd_step()
+            else:
+                self.eval_step(x, y, idx_stage, 0, batch, seed, 0, loss_kind, inv_global_batch)
+            self.step_dev.add_(1)
+        self.metrics_acc.copy_(saved[0])
+        self.grads.copy_(saved[1])
+        return graph, idx_stage
+
     def adam_step(self, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0) -> None:
         check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
                                      self.n_params, _ptr(self.lr_dev), _ptr(self.t_dev), beta1, beta2, eps,

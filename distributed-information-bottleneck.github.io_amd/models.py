@@ -377,6 +377,26 @@ class DistributedIBNet:
             dist.all_reduce(t)
             return t.cpu().numpy()
 
+        # Optional hipGraph replay of the whole step (DIB_ENABLE_GRAPHS=1; needs the device-resident noise step counter;
+        # single-process only).  Bit-identical to the eager launch sequence (tests).  OFF by default: measured on MI355X
+        # for the reference's default Boolean-circuit run (B = 128, ~30 launches/step) the replay is ~8 % SLOWER than
+        # eager (4.09 vs 3.76 ms/epoch, tools/small_batch_bench.py) - the step is bound by the latency of its dependent
+        # kernels, not by launch overhead.
+        n_full = n // bs
+        use_graphs = (dist is None and hasattr(eng, "capture_step_graph") and bs <= 8192 and n_full * epochs >= 64
+                      and os.environ.get("DIB_ENABLE_GRAPHS", "0") == "1")
+        graphs = {}
+        if use_graphs:
+            eng.enable_step_counter(self._step)
+            eng.set_lr(self.optimizer.learning_rate)
+            opt_args = ((self.optimizer.beta_1, self.optimizer.beta_2, self.optimizer.epsilon)
+                        if self.optimizer.name == "adam" else ())
+            graphs["train"] = eng.capture_step_graph(xd, yd, bs, kind, 1.0 / bs, self.noise_seed, True,
+                                                     self.optimizer.name, opt_args)
+            eng.set_step_counter(self._step)
+        elif getattr(eng, "step_dev", None) is not None:
+            eng.set_step_counter(self._step)
+
         for epoch in range(initial_epoch, epochs):
             for cb in cbs:
                 cb.on_epoch_begin(epoch)
@@ -387,6 +407,14 @@ class DistributedIBNet:
             nsteps = 0
             for s0 in range(0, n, bs):
                 gb = min(bs, n - s0)  # last partial batch is kept (Keras)
+                if use_graphs and gb == bs:
+                    g, stage = graphs["train"]
+                    eng.set_lr(self.optimizer.learning_rate)
+                    stage.copy_(order_dev[s0: s0 + bs])
+                    g.replay()  # fwd + loss + bwd + optimizer + metrics + step-counter bump
+                    self._step += 1
+                    nsteps += 1
+                    continue
                 lo = (gb * rank) // world
                 hi = (gb * (rank + 1)) // world
                 pending = []
@@ -410,10 +438,14 @@ class DistributedIBNet:
                 self._optimizer_step(eng)
                 self._step += 1
                 nsteps += 1
+                if getattr(eng, "step_dev", None) is not None:
+                    eng.set_step_counter(self._step)  # eager step under the device counter: keep it in sync
             logs = self._epoch_logs(reduce_metrics(eng.read_metrics()), nsteps, "")
             if validation_data is not None:
                 nv = xvd.shape[0]
                 vsteps = 0
+                if getattr(eng, "step_dev", None) is not None:
+                    eng.set_step_counter((1 << 31) + epoch)  # validation noise stream, same key as the eager path
                 for s0 in range(0, nv, bs):
                     gb = min(bs, nv - s0)
                     lo = (gb * rank) // world
@@ -422,6 +454,8 @@ class DistributedIBNet:
                         eng.eval_step(xvd, yvd, None, s0 + lo, hi - lo, self.noise_seed, (1 << 31) + epoch, kind,
                                       inv_global_batch=1.0 / gb)
                     vsteps += 1
+                if getattr(eng, "step_dev", None) is not None:
+                    eng.set_step_counter(self._step)
                 logs.update(self._epoch_logs(reduce_metrics(eng.read_metrics()), vsteps, "val_"))
             for k, v in logs.items():
                 hist.history.setdefault(k, []).append(float(v))

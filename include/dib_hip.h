@@ -76,6 +76,9 @@ int dib_layout_param_block(const dib_layout* l, int net, int layer, int feature,
 /* device-resident GEMM group descriptor tables (batch-size independent) */
 int64_t dib_layout_table_bytes(const dib_layout* l);
 int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t stream);
+/* hipGraph replay: when step_dev is non-NULL every kernel keys its noise with *step_dev (device uint32, bumped by the
+ * caller between replays) instead of the by-value `step` arguments below; NULL restores the by-value behaviour. */
+int dib_layout_set_step_counter(dib_layout* l, const uint32_t* step_dev);
 /* workspace (activations, activation gradients, split-batch wgrad partials) for local batch B */
 int64_t dib_workspace_bytes(const dib_layout* l, int batch);
 int64_t dib_workspace_offset(const dib_layout* l, int batch, int which); /* byte offset, <0 on error */

@@ -419,3 +419,41 @@ def test_autograd_bridge_matches_oracle_gradients():
     opt.step()
     after = eng.get_flat_params()
     assert np.allclose(after, before - 0.1 * got, atol=1e-6) and not np.allclose(after, before)
+
+
+def test_hipgraph_fit_is_bit_identical_to_eager_and_matches_oracle(monkeypatch):
+    """fit() can replay the captured step (hipGraph, DIB_ENABLE_GRAPHS=1): History must be bit-identical to the eager
+    launch sequence (same kernels, device-resident noise step counter) and match the oracle like the eager path does."""
+    import dib_amd
+    spec = orc.DIBSpec([1, 1, 1, 1], [32, 32], [64, 64], 1, feature_embedding_dimension=8)
+    x, y = orc.boolean_circuit_truth_table([0, 1, 2, 3, [1, 1, 3], [0, 4, 0], [2, 2, 5]], 4)  # SI circuit (d)
+    x = np.tile(x, (33, 1)).astype(np.float32)[:520]   # 520 rows: 8 full batches of 64 + a partial one (eager)
+    y = np.tile(y, 33).astype(np.float32)[:520]
+
+    def run():
+        model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=4, shuffle_seed=6, init_seed=2)
+        opt = dib_amd.optimizers.get("adam")
+        opt.learning_rate = 2e-3
+        model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+        cb = dib_amd.InfoBottleneckAnnealingCallback(1e-3, 0.5, 2, 6)
+        p0 = flat_to_params(model.param_blocks(), model.get_flat_weights(), spec)
+        h = model.fit(x, y, epochs=9, shuffle=True, batch_size=64, callbacks=[cb], verbose=False,
+                      validation_data=(x[:100], y[:100]))
+        return h.history, model.get_flat_weights(), p0, model
+
+    monkeypatch.setenv("DIB_ENABLE_GRAPHS", "1")
+    hist_g, w_g, p0, model_g = run()
+    assert getattr(model_g._engine, "step_dev", None) is not None, "graph path was not taken"
+    monkeypatch.setenv("DIB_ENABLE_GRAPHS", "0")
+    hist_e, w_e, _, model_e = run()
+    assert getattr(model_e._engine, "step_dev", None) is None
+    for k in hist_e:
+        assert hist_g[k] == hist_e[k], k
+    assert np.array_equal(w_g, w_e)
+    ref = orc.fit(spec, p0, x, y, epochs=9, batch_size=64, loss_kind="bce_logits",
+                  beta_fn=lambda e: orc.beta_schedule(e, 1e-3, 0.5, 2, 6), lr=2e-3, shuffle=True,
+                  validation_data=(x[:100], y[:100]), noise_seed=4, shuffle_seed=6, metrics=["accuracy"])
+    for k in ref:
+        got, want = np.array(hist_g[k]), np.array(ref[k])
+        tol = 1e-3 if "KL" in k else 3e-3
+        assert np.abs(got - want).max() < tol * (1 + np.abs(want).max()), (k, got, want)

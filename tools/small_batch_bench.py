@@ -10,7 +10,7 @@ m.compile(optimizer=opt, loss=d['loss'], metrics=d['metrics'])
 cb=dib_amd.InfoBottleneckAnnealingCallback(1e-4,3.0,10,40)
 m.fit(d['x_train'],d['y_train'],epochs=3,batch_size=128,callbacks=[cb],verbose=False,validation_data=(d['x_valid'],d['y_valid']))
 torch.cuda.synchronize(); t=time.time()
-E=50
+E=int(os.environ.get("DIB_SMALL_EPOCHS", "300"))
 m.fit(d['x_train'],d['y_train'],epochs=E,batch_size=128,callbacks=[cb],verbose=False,validation_data=(d['x_valid'],d['y_valid']))
 torch.cuda.synchronize(); el=time.time()-t
 print(f"boolean circuit (F=10, B=128): {el/E*1e3:.2f} ms/epoch (8 train + 8 val steps) -> {el/E/8*1e6:.0f} us per train+val step pair; 11000 epochs = {el/E*11000:.0f} s")
