@@ -54,7 +54,7 @@ struct dib_layout {
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
-    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, total;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, total;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
   WsMap map(int B) const {
@@ -88,6 +88,7 @@ struct dib_layout {
     m.wgrad_partial = take(ns > 1 ? (int64_t)ns * align_up(n_params, 4) : 0);
     // fused backward: per-wave partials of d(W1|b1), [<= ceil(256/F) workgroups x 8 waves][F][16][H1]
     m.dw1_partial = take(fused_id >= 0 && n_enc == 2 ? (int64_t)cdiv(256, F) * 8 * F * 16 * enc_units[0] : 0);
+    m.h2mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);  // [F][B][2] x 64-bit act'(h2) masks (fused fwd -> fused bwd)
     m.total = o;
     return m;
   }
@@ -204,6 +205,7 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.n_blocks = l->n_blocks; a.act = l->act;
   a.h1 = w + m.enc_h[0]; a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.U = w + m.U;
   a.kl_partial = w + m.kl_partial; a.F = l->F; a.seed = seed; a.step = step; a.deterministic = deterministic;
+  a.h2mask = (unsigned long long*)(w + m.h2mask);
   a.step_dev = l->step_dev;
   const int n_tiles = cdiv(batch, 256);
   const int gx = std::max(1, std::min(n_tiles, cdiv(256, l->F)));
@@ -248,7 +250,7 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   DibFusedBwdArgs a;
   a.P = w + m.P; a.row_idx = (const int*)row_idx; a.row0 = row0; a.batch = batch; a.params = params;
   a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap; a.act = l->act;
-  a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.GU = w + m.g_u;
+  a.h2mask = (const unsigned long long*)(w + m.h2mask); a.enc_out = w + m.enc_out; a.GU = w + m.g_u;
   a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dw1_partial = w + m.dw1_partial;
   a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F; a.seed = seed; a.step = step; a.step_dev = l->step_dev;
   const int gx = fused_gx(l, batch);

@@ -34,6 +34,7 @@ struct DibFusedFwdArgs {
   int n_blocks;             // 1 + number of sinusoids
   int act;
   float* h1; float* h2; float* enc_out; float* U; float* kl_partial;  // kl_partial[gridDim.x*8][F]
+  unsigned long long* h2mask;  // [F][B][2] sign bits of h2 in fragment order (bit 16*tile + reg), for the fused backward
   int F; unsigned long long seed; unsigned step; int deterministic;
   const unsigned* step_dev;  // if non-NULL the noise step is read from device memory (hipGraph replay)
 };
@@ -222,6 +223,14 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
 #pragma unroll
       for (int jo = 0; jo < C::T2; ++jo) dib_store_tile(patch, h2[jo], dst + 32 * jo, H2, rows_valid, lane);
     }
+    if (a.h2mask != nullptr && valid) {  // act'(h2) as one bit per unit: the fused backward needs nothing else of h2
+      unsigned long long bits = 0ull;
+#pragma unroll
+      for (int jo = 0; jo < C::T2; ++jo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= (unsigned long long)(h2[jo][r] > 0.f ? 1 : 0) << (16 * jo + r);
+      a.h2mask[((long long)f * a.batch + b) * 2 + h] = bits;
+    }
 
     // ---- layer 3 (linear, reference models.py:78): out^T = W3^T h2^T + b3 ; rows [0,E) = mu, [E,2E) = logvar ----
     dib_f32x16 o[C::T3];
@@ -301,14 +310,14 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
 // BACKWARD "dgrad chain" (what tape.gradient derives for reference models.py:106-118, explicit at
 // train.py:203-219), ONE launch replacing the reparam/KL backward and both encoder dgrad GEMMs:
 //   dmu = g_u + beta*mu/Bg ; dlogvar = g_u*eps*0.5*exp(lv/2) + beta*0.5*(exp(lv)-1)/Bg       -> dout  [F][B][2E]
-//   dh2 = (dout @ W3^T) * act'(h2)                                                         -> dh2   [F][B][H2]
+//   dh2 = (dout @ W3^T) * act'(h2)   (act'(h2) from the 1-bit/unit mask the forward stashed)  -> dh2   [F][B][H2]
 //   dh1 = (dh2  @ W2^T) * act'(h1)     (h1 is RECOMPUTED from the encoded input: 4..8 MFMAs)   (never leaves the CU)
 //   d(W1|b1) += [P | 1]^T @ dh1         (v_mfma_f32_16x16x4_f32 on the dh1 tile while it sits in the LDS patch;
 //                                        per-wave partials, reduced in fixed order by dib_dw1_reduce_kernel)
 // Same structure as the forward: one workgroup per feature, W2 / W3 resident in LDS in their natural
 // [in][out] orientation (they are the A operand of the transposed product dH_in^T = W * dH_out^T, fetched with
 // conflict-free ds_read_b128), gradients chained in MFMA accumulator registers, eps regenerated from the
-// Philox counter.  Row-major tiles (h2, mu|logvar, g_u in; dout, dh2 out) cross between HBM and the
+// Philox counter.  Row-major tiles (mu|logvar, g_u in; dout, dh2 out) cross between HBM and the
 // fragment layout through a wave-private LDS patch so every global access is a full 128-byte line.
 // The layer-2/3 weight gradients (contractions over the batch) then run as the grouped wgrad GEMMs on these buffers;
 // the layer-1 gradient (5 x H1 per feature: hopeless as a GEMM tile, and dh1 is 2.1 GB) is finished here.
@@ -320,7 +329,7 @@ struct DibFusedBwdArgs {
   const float* P; const int* row_idx; long long row0; int batch;
   const float* params; const long long* w_off; const long long* b_off; const int4* featmap;
   int act;
-  const float* h2; const float* enc_out; const float* GU;   // stashes + dL/du [B][F*E]
+  const unsigned long long* h2mask; const float* enc_out; const float* GU;   // stashes + dL/du [B][F*E]
   float* dout; float* dh2;
   float* dw1_partial;       // [gridDim.x*8 waves][F][16][H1]: per-wave partial of d(W1|b1) (row in_dim = bias gradient)
   const float* beta_dev; float inv_bg;
@@ -438,6 +447,7 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
     const int rows_valid = min(32, a.batch - wrow0);
     const int b = min(wrow0 + m, a.batch - 1);
     const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
+    const unsigned long long hbits = a.h2mask[((long long)f * a.batch + b) * 2 + h];  // act'(h2) bits, fragment order
     // ---- dout = d(loss + beta*KL)/d(mu|logvar), lane-local in fragment layout ----
     dib_f32x16 dout[C::T3];
     {
@@ -485,11 +495,9 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
     // ---- dh2^T = W3 dout^T, masked by act'(h2) ----
     dib_f32x16 dh2[C::T2];
     {
-      const float* h2g = a.h2 + ((long long)f * a.batch + wrow0) * H2;
       float* dg = a.dh2 + ((long long)f * a.batch + wrow0) * H2;
 #pragma unroll
       for (int jo = 0; jo < C::T2; ++jo) {
-        const DibTile4 vh = dib_tile_gload(h2g + 32 * jo, H2, rows_valid, lane);  // in flight during the MFMAs below
         dib_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -503,9 +511,8 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
             acc = DIB_MFMA(w.z, dout[jt][4 * g + 2], acc);
             acc = DIB_MFMA(w.w, dout[jt][4 * g + 3], acc);
           }
-        const dib_f32x16 hv = dib_tile_to_frag(patch, vh, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= (hv[r] > 0.f ? 1.f : slope);
+        for (int r = 0; r < 16; ++r) acc[r] *= ((hbits >> (16 * jo + r)) & 1ull) ? 1.f : slope;
         dh2[jo] = acc;
         dib_store_tile(patch, acc, dg + 32 * jo, H2, rows_valid, lane);
       }
