@@ -5,6 +5,7 @@ per-feature KL 1e-3 nats absolute (BASELINE.json north_star), gradients 2e-4 rel
 gradient's max-abs.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -457,3 +458,20 @@ def test_hipgraph_fit_is_bit_identical_to_eager_and_matches_oracle(monkeypatch):
         got, want = np.array(hist_g[k]), np.array(ref[k])
         tol = 1e-3 if "KL" in k else 3e-3
         assert np.abs(got - want).max() < tol * (1 + np.abs(want).max()), (k, got, want)
+
+
+def test_science_level_si_circuit_information_allocation():
+    """SURVEY section 4 science-level KAT on SI circuit (c) of the reference notebook (Boolean_circuits.ipynb:987-992;
+    Y = AND(XOR(AND(x2,x0),x3),x1), H(Y) = 0.811 bits, Shapley values [0.096, 0.377, 0.096, 0.242]):
+    with beta small the DIB predicts perfectly; as beta is annealed the features are dropped in the order of their
+    importance (x0/x2 first, then x3, x1 last); at large beta all KL -> 0 and the loss -> H(Y)."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location(
+        "si_circuit_run", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "si_circuit_run.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    kl, loss_bits, acc, beta = mod.run()
+    assert acc[99] == 1.0 and loss_bits[99] < 0.05                       # end of pre-training (beta = 1e-3)
+    mid = kl[450]                                                        # beta ~ 0.27
+    assert mid[1] > 0.2 and mid[1] > mid[3] > max(mid[0], mid[2]), mid   # x1 kept longest, then x3, x0/x2 gone first
+    assert kl[-1].sum() < 0.02 and abs(loss_bits[-1] - 0.811) < 0.05 and abs(acc[-1] - 0.75) < 1e-6
