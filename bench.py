@@ -62,9 +62,9 @@ def flops_by_kernel():
         "dib_fused_encoder_fwd_kernel": sum(fl(i, o) for i, o in enc) * F,            # 3 encoder layers fwd
         "dib_fused_encoder_bwd_kernel": (sum(fl(i, o) for i, o in enc[1:]) + fl(*enc[0])) * F,  # dgrads L3, L2 + wgrad L1
         "dib_gemm_kernel<0, 2, 2, 64>": fl(*integ[0]) + fl(*integ[1]),                    # integration fwd, N >= 128
-        "dib_gemm_kernel<0, 2, 1, 32>": fl(*integ[2]),                                    # integration fwd, N = 1
-        "dib_gemm_kernel<1, 2, 2, 64>": sum(fl(i, o) for i, o in integ),                  # integration dgrads
-        "dib_gemm_kernel<2, 2, 1, 32>": fl(*integ[2]) + fl(*enc[2]) * F,                  # wgrads with N <= 64
+        "dib_gemm_kernel<1, 2, 2, 64>": fl(*integ[0]) + fl(*integ[1]),                    # integration dgrads, N >= 128
+        "dib_gemm_kernel<2, 2, 1, 32>": fl(*enc[2]) * F,                                  # encoder layer-3 wgrad (N = 64)
+        "dib_skinny_{fwd,dgrad,wgrad}_kernel": 3 * fl(*integ[2]),                         # 256 -> 1 output layer (HBM-bound)
         "dib_gemm_kernel<2, 2, 2, 64>": fl(*integ[0]) + fl(*integ[1]) + fl(*enc[1]) * F,  # wgrads with M, N >= 128
     }
     assert sum(out.values()) == FLOPS_PER_SAMPLE

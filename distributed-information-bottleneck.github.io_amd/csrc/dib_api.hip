@@ -54,7 +54,8 @@ struct dib_layout {
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
-    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, total;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, skinny_partial, total;
+    int skinny_chunks, skinny_rows;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
   WsMap map(int B) const {
@@ -88,7 +89,14 @@ struct dib_layout {
     m.wgrad_partial = take(ns > 1 ? (int64_t)ns * align_up(n_params, 4) : 0);
     // fused backward: per-wave partials of d(W1|b1), [<= ceil(256/F) workgroups x 8 waves][F][16][H1]
     m.dw1_partial = take(fused_id >= 0 && n_enc == 2 ? (int64_t)cdiv(256, F) * 8 * F * 16 * enc_units[0] : 0);
-    m.h2mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);  // [F][B][2] x 64-bit act'(h2) masks (fused fwd -> fused bwd)
+    m.h2mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
+    // skinny output layer wgrad: row chunks of >= 64 rows, <= 512 chunks
+    m.skinny_rows = std::max(64, cdiv(B, 512));
+    m.skinny_chunks = cdiv(B, m.skinny_rows);
+    {
+      const int win = n_int == 0 ? F * E : int_units[n_int - 1];
+      m.skinny_partial = take(out_dim <= 8 ? (int64_t)m.skinny_chunks * ((int64_t)win * out_dim + out_dim) : 0);
+    }  // [F][B][2] x 64-bit act'(h2) masks (fused fwd -> fused bwd)
     m.total = o;
     return m;
   }
@@ -570,7 +578,16 @@ int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws,
     const float* A = ly == 0 ? w + m.U : w + m.int_h[ly - 1];
     float* C = ly == LI - 1 ? w + m.pred : w + m.int_h[ly];
     const int act = ly == LI - 1 ? l->out_act : l->act;  // reference models.py:82-83
-    int rc = launch_gemm<0>(l, l->int_fwd[ly], A, params, C, params, nullptr, nullptr, batch, act, 1, 0, 0, st);
+    int rc;
+    if (ly == LI - 1 && l->out_dim <= DIB_SKINNY_MAX) {  // 1-unit logit & co: HBM-bound stream, not an MFMA tile
+      const int win = ly == 0 ? l->F * l->E : l->int_width[ly - 1];
+      ProfScope ps(kProfOther, st);
+      hipLaunchKernelGGL(dib_skinny_fwd_kernel, dim3(grid_for((int64_t)batch * 64, 256, 2048)), dim3(256), 0, st, A, batch,
+                         win, params + l->int_w_off[ly], params + l->int_b_off[ly], l->out_dim, act, C);
+      rc = (int)hipGetLastError();
+    } else {
+      rc = launch_gemm<0>(l, l->int_fwd[ly], A, params, C, params, nullptr, nullptr, batch, act, 1, 0, 0, st);
+    }
     if (rc) return rc;
   }
   return DIB_OK;
@@ -616,10 +633,27 @@ int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* gr
   for (int ly = LI - 1; ly >= 0; --ly) {
     const float* gout = ly == LI - 1 ? w + m.g_pred : w + m.g_int_h[ly];
     const float* hin = ly == 0 ? w + m.U : w + m.int_h[ly - 1];
-    int rc = launch_gemm<2>(l, l->int_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
-                            m.rows_per_split, sstride, st);
-    if (rc) return rc;
     float* gin = ly == 0 ? w + m.g_u : w + m.g_int_h[ly - 1];
+    int rc;
+    if (ly == LI - 1 && l->out_dim <= DIB_SKINNY_MAX) {
+      const int win = ly == 0 ? l->F * l->E : l->int_width[ly - 1];
+      ProfScope ps(kProfOther, st);
+      // stage 1 per row chunk, stage 2 into slab 0 (the other slabs of this block stay zero), both fixed-order
+      hipLaunchKernelGGL(dib_skinny_wgrad_kernel, dim3(m.skinny_chunks), dim3(256), 0, st, hin, gout, batch, win, l->out_dim,
+                         m.skinny_rows, w + m.skinny_partial);
+      hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(cdiv((int64_t)win * l->out_dim + l->out_dim, 256)), dim3(256),
+                         0, st, (const float*)(w + m.skinny_partial), m.skinny_chunks, win, l->out_dim,
+                         gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
+      hipLaunchKernelGGL(dib_skinny_dgrad_kernel, dim3(grid_for((int64_t)batch * win)), dim3(256), 0, st, gout, batch, win,
+                         params + l->int_w_off[ly], l->out_dim, ly == 0 ? (const float*)nullptr : hin, ly == 0 ? 0 : l->act,
+                         gin);
+      rc = (int)hipGetLastError();
+      if (rc) return rc;
+      continue;
+    }
+    rc = launch_gemm<2>(l, l->int_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
+                        m.rows_per_split, sstride, st);
+    if (rc) return rc;
     // u is not an activation output (no mask for ly == 0)
     rc = launch_gemm<1>(l, l->int_dgrad[ly], gout, params, gin, nullptr, ly == 0 ? nullptr : hin, nullptr, batch,
                         ly == 0 ? 0 : l->act, 1, 0, 0, st);

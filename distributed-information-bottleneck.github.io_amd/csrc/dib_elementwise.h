@@ -569,3 +569,84 @@ dib_posenc_dense_kernel(const float* __restrict__ X, long long ldx, int n, int d
     for (int j = 1; j < n_blocks; ++j) { dst[(long long)j * d] = sinf(fr * x); fr *= 2.0f; }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Skinny output layer (out_dim <= 8, e.g. the reference's 1-unit logit, models.py:83): a [B,K] x [K,out] product is
+// a GEMV-like HBM-bound stream, not an MFMA tile (N=1 padded to 64 columns wastes 98 % of the matrix core and ran
+// at 0.4 TB/s).  One wave per row for fwd, elementwise dgrad, block-per-slab column reduction for wgrad.
+// ---------------------------------------------------------------------------------------------
+#define DIB_SKINNY_MAX 8
+
+__global__ void __launch_bounds__(256)
+dib_skinny_fwd_kernel(const float* __restrict__ A, int batch, int K, const float* __restrict__ W /*[K][out]*/,
+                      const float* __restrict__ bias, int out, int act, float* __restrict__ C /*[B][out]*/) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+  for (int b = wave; b < batch; b += nwaves) {
+    const float* a = A + (long long)b * K;
+    float acc[DIB_SKINNY_MAX];
+#pragma unroll
+    for (int o = 0; o < DIB_SKINNY_MAX; ++o) acc[o] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float av = a[k];
+#pragma unroll
+      for (int o = 0; o < DIB_SKINNY_MAX; ++o)
+        if (o < out) acc[o] += av * W[(long long)k * out + o];
+    }
+#pragma unroll
+    for (int o = 0; o < DIB_SKINNY_MAX; ++o) {
+      if (o < out) {
+        const float s = dib_wave_sum(acc[o]);
+        if (lane == 0) C[(long long)b * out + o] = dib_act(act, s + (bias ? bias[o] : 0.f));
+      }
+    }
+  }
+}
+
+// g_in[b][k] = (sum_o g[b][o] W[k][o]) * act'(a_in[b][k])
+__global__ void __launch_bounds__(256)
+dib_skinny_dgrad_kernel(const float* __restrict__ G /*[B][out]*/, int batch, int K, const float* __restrict__ W, int out,
+                        const float* __restrict__ Ain /*[B][K] or null*/, int act, float* __restrict__ Gin) {
+  const long long total = (long long)batch * K;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / K), k = (int)(i - (long long)b * K);
+    float s = 0.f;
+    for (int o = 0; o < out; ++o) s += G[(long long)b * out + o] * W[(long long)k * out + o];
+    if (Ain != nullptr && act != 0) s *= dib_act_grad(act, Ain[i]);
+    Gin[i] = s;
+  }
+}
+
+// Two deterministic stages.  Stage 1: block c handles rows [c*rows_per_chunk, ...): partial[c][k*out+o] = sum_b a[b][k] g[b][o]
+// and partial[c][K*out + o] = sum_b g[b][o].  Stage 2: fixed-order sum over the chunks into the gradient (slab 0).
+__global__ void __launch_bounds__(256)
+dib_skinny_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ G, int batch, int K, int out,
+                        int rows_per_chunk, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int r0 = blockIdx.x * rows_per_chunk, r1 = min(batch, r0 + rows_per_chunk);
+  float* dst = partial + (long long)blockIdx.x * ((long long)K * out + out);
+  for (int o = 0; o < out; ++o) {
+    for (int k = threadIdx.x; k < K; k += 256) {
+      float s = 0.f;
+      for (int b = r0; b < r1; ++b) s += A[(long long)b * K + k] * G[(long long)b * out + o];
+      dst[(long long)k * out + o] = s;
+    }
+    float sb = 0.f;
+    for (int b = r0 + (int)threadIdx.x; b < r1; b += 256) sb += G[(long long)b * out + o];
+    const float tot = dib_block_sum_256(sb, red);
+    if (threadIdx.x == 0) dst[(long long)K * out + o] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+dib_skinny_wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int K, int out, float* __restrict__ dW,
+                               float* __restrict__ dB) {
+  const int n = K * out + out;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(long long)c * n + i];
+    if (i < K * out) dW[i] = s;
+    else dB[i - K * out] = s;
+  }
+}
