@@ -641,7 +641,7 @@ int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* gr
       // stage 1 per row chunk, stage 2 into slab 0 (the other slabs of this block stay zero), both fixed-order
       hipLaunchKernelGGL(dib_skinny_wgrad_kernel, dim3(m.skinny_chunks), dim3(256), 0, st, hin, gout, batch, win, l->out_dim,
                          m.skinny_rows, w + m.skinny_partial);
-      hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(cdiv((int64_t)win * l->out_dim + l->out_dim, 256)), dim3(256),
+      hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(win * l->out_dim + l->out_dim), dim3(256),
                          0, st, (const float*)(w + m.skinny_partial), m.skinny_chunks, win, l->out_dim,
                          gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
       hipLaunchKernelGGL(dib_skinny_dgrad_kernel, dim3(grid_for((int64_t)batch * win)), dim3(256), 0, st, gout, batch, win,

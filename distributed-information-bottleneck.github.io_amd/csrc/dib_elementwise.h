@@ -642,11 +642,13 @@ dib_skinny_wgrad_kernel(const float* __restrict__ A, const float* __restrict__ G
 __global__ void __launch_bounds__(256)
 dib_skinny_wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int K, int out, float* __restrict__ dW,
                                float* __restrict__ dB) {
-  const int n = K * out + out;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(long long)c * n + i];
-    if (i < K * out) dW[i] = s;
-    else dB[i - K * out] = s;
+  __shared__ float red[4];
+  const int n = K * out + out, i = blockIdx.x;  // one block per output element; fixed reduction tree => deterministic
+  float s = 0.f;
+  for (int c = threadIdx.x; c < nchunks; c += 256) s += partial[(long long)c * n + i];
+  const float tot = dib_block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    if (i < K * out) dW[i] = tot;
+    else dB[i - K * out] = tot;
   }
 }
