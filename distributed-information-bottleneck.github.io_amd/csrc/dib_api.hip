@@ -540,7 +540,7 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   const auto m = l->map(batch);
   float* w = (float*)ws;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)batch * l->sum_d)), dim3(256), 0, st, x, (long long)ldx,
+  hipLaunchKernelGGL(dib_posenc_kernel, dim3(cdiv(l->sum_d, 64), cdiv(batch, 64)), dim3(256), 0, st, x, (long long)ldx,
                      (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
@@ -785,7 +785,7 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
   float* w = (float*)ws;
   const int d = l->dims[feature];
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_posenc_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, st, x_f, (long long)d,
+  hipLaunchKernelGGL(dib_posenc_kernel, dim3(cdiv(d, 64), cdiv(n, 64)), dim3(256), 0, st, x_f, (long long)d,
                      (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;

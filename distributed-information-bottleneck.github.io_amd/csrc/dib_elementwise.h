@@ -15,13 +15,27 @@ __global__ void __launch_bounds__(256)
 dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restrict__ row_idx, long long row0,
                   int batch, const int4* __restrict__ colmap, int ncols, int n_blocks /*1 + n sinusoids*/,
                   float* __restrict__ P) {
-  const long long total = (long long)batch * ncols;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int b = (int)(i / ncols), c = (int)(i - (long long)b * ncols);
-    const long long row = row_idx ? (long long)row_idx[b] : row0 + b;
-    const float x = X[row * ldx + c];
-    const int4 cm = colmap[c];
+  // One block = 64 rows x 64 input columns.  The tile is read row-wise (coalesced along the sample-major X rows),
+  // transposed through LDS, and written with lanes <-> consecutive rows of ONE feature, so the feature-major P rows
+  // (width*4 bytes apart) are filled by neighbouring lanes instead of 4-byte stores scattered over 64 features.
+  __shared__ float T[64][65];
+  const int c0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = threadIdx.x + 256 * i, r = idx >> 6, c = idx & 63;
+    float v = 0.f;
+    if (b0 + r < batch && c0 + c < ncols) {
+      const long long row = row_idx ? (long long)row_idx[b0 + r] : row0 + b0 + r;
+      v = X[row * ldx + c0 + c];
+    }
+    T[r][c] = v;
+  }
+  __syncthreads();
+  const int r = threadIdx.x & 63, b = b0 + r;
+  if (b >= batch) return;
+  for (int c = threadIdx.x >> 6; c < 64 && c0 + c < ncols; c += 4) {
+    const int4 cm = colmap[c0 + c];
+    const float x = T[r][c];
     float* dst = P + (long long)cm.w * batch + (long long)b * (n_blocks * cm.z) + cm.y;
     dst[0] = x;
     float fr = 2.0f;
