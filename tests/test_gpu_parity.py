@@ -475,3 +475,37 @@ def test_science_level_si_circuit_information_allocation():
     mid = kl[450]                                                        # beta ~ 0.27
     assert mid[1] > 0.2 and mid[1] > mid[3] > max(mid[0], mid[2]), mid   # x1 kept longest, then x3, x0/x2 gone first
     assert kl[-1].sum() < 0.02 and abs(loss_bits[-1] - 0.811) < 0.05 and abs(acc[-1] - 0.75) < 1e-6
+
+
+def test_north_star_architecture_multi_step_trajectory():
+    """The exact BASELINE config-3 architecture (F=64 scalar features, encoder [128,128], E=32, integration [256,256],
+    1-unit logit; fused fwd/bwd + skinny output-layer kernels + split-batch wgrads + Keras-Adam) over 3 optimizer steps
+    at B=4096 against the float64 PyTorch-CPU restatement with the same counter-based noise: per-feature KL within
+    1e-3 nats (the BASELINE tolerance), loss and final parameters close."""
+    from dib_torch_cpu import TorchCpuDIB
+    from dib_amd.engine import HipEngine
+    spec = orc.DIBSpec([1] * 64, [128, 128], [256, 256], 1)
+    eng = HipEngine(**spec_kwargs(spec), init_seed=7)
+    p = flat_to_params(eng.blocks, eng.get_flat_params(), spec)
+    ref = TorchCpuDIB(spec, p, dtype=torch.float64)
+    B = 4096
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((B, 64)).astype(np.float32)
+    w = rng.standard_normal(8)
+    y = ((x[:, :8] @ w + 0.5 * x[:, 0] * x[:, 1]) > 0).astype(np.float32)[:, None]
+    xd, yd = eng.to_device(x), eng.to_device(y)
+    xt, yt = torch.tensor(x, dtype=torch.float64), torch.tensor(y, dtype=torch.float64)
+    beta, lr = 3e-2, 3e-4
+    eng.set_beta(beta)
+    eng.set_lr(lr)
+    for step in range(3):
+        eng.train_step(xd, yd, None, 0, B, 5, step, "bce_logits")
+        so = eng.step_out(B).cpu().numpy()
+        eng.adam_step()
+        eps = torch.tensor(orc.philox_normal_all(5, step, np.arange(B), 64, 32))
+        task, kl, _ = ref.train_step(xt, yt, eps, beta, "bce_logits", lr=lr)
+        assert np.abs(so[:64] / B - kl.numpy()).max() < 1e-3, (step, "per-feature KL")
+        assert abs(so[64] / B - task) < 2e-4 * (1 + abs(task)), (step, "task loss")
+    got = flat_to_params(eng.blocks, eng.get_flat_params(), spec)
+    for a, b in zip(got.tensors(), [t.detach().numpy() for t in ref.tensors()]):
+        assert np.abs(a - b).max() < 5e-5, "parameters after 3 Adam steps"
