@@ -177,7 +177,12 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
   if (c.count == 0) return DIB_OK;
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
-  const bool ni1 = (MODE == 2) && M <= 64, nj1 = N <= 64;   // narrow tiles for narrow outputs
+  bool ni1 = (MODE == 2) && M <= 64, nj1 = N <= 64;   // narrow tiles for narrow outputs
+  if (MODE == 2 && !ni1 && !nj1) {
+    // small weight gradients (e.g. a 256x256 layer): 128x128 tiles x splits do not fill 256 CUs -> 64-row tiles
+    const long long wgs = (long long)cdiv(M, 128) * cdiv(N, 128) * nsplit * c.count;
+    if (wgs < 256) ni1 = true;
+  }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(l, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
                                                    rows_per_split, split_stride, st)
