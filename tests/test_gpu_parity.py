@@ -509,3 +509,48 @@ def test_north_star_architecture_multi_step_trajectory():
     got = flat_to_params(eng.blocks, eng.get_flat_params(), spec)
     for a, b in zip(got.tensors(), [t.detach().numpy() for t in ref.tensors()]):
         assert np.abs(a - b).max() < 5e-5, "parameters after 3 Adam steps"
+
+
+def _random_spec(rng):
+    F = int(rng.integers(1, 6))
+    dims = [int(v) for v in rng.integers(1, 7, F)]
+    enc = [int(v) for v in rng.integers(1, 70, int(rng.integers(0, 4)))]
+    integ = [int(v) for v in rng.integers(1, 70, int(rng.integers(0, 3)))]
+    act = [None, "relu", "leaky_relu", "tanh", "sigmoid", "elu", "softplus"][int(rng.integers(0, 7))]
+    return orc.DIBSpec(dims, enc, integ, int(rng.integers(1, 6)), use_positional_encoding=bool(rng.integers(0, 2)),
+                       number_positional_encoding_frequencies=int(rng.integers(1, 6)), activation_fn=act,
+                       feature_embedding_dimension=int(rng.integers(1, 41)))
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_architectures_forward_backward(case):
+    """Seeded random architectures (ragged feature widths, 0-3 encoder layers, arbitrary unit counts / embedding widths /
+    activations / output widths, with and without positional encoding, arbitrary batch) through the general grouped-GEMM
+    path (or the fused kernels when they apply): predictions, per-feature KL and every gradient vs the oracle."""
+    rng = np.random.default_rng(1000 + case)
+    spec = _random_spec(rng)
+    eng, p = _engine(spec, seed=case)
+    F, E = spec.number_features, spec.feature_embedding_dimension
+    B = int(rng.integers(1, 200))
+    x = rng.standard_normal((B, sum(spec.feature_dimensionalities))).astype(np.float32)
+    if spec.output_dimensionality == 1:
+        kind, y = "bce_logits", rng.integers(0, 2, (B, 1)).astype(np.float32)
+    elif case % 2:
+        kind, y = "mse", rng.standard_normal((B, spec.output_dimensionality)).astype(np.float32)
+    else:
+        kind, y = "sparse_cce_logits", rng.integers(0, spec.output_dimensionality, (B, 1)).astype(np.float32)
+    beta = float(10 ** rng.uniform(-3, 0))
+    eng.set_beta(beta)
+    eng.train_step(eng.to_device(x), eng.to_device(y), None, 0, B, 21, case, kind)
+    eps = orc.philox_normal_all(21, case, np.arange(B), F, E)
+    c = orc.forward(spec, p, x.astype(np.float64), eps)
+    task, grads, _ = orc.backward(spec, p, x.astype(np.float64), y, c, beta, kind)
+    so = eng.step_out(B).cpu().numpy()
+    assert np.abs(eng.pred(B).cpu().numpy() - c.pred).max() <= 3e-4 * (1 + np.abs(c.pred).max()), spec
+    assert np.abs(so[:F] / B - c.kl).max() < 1e-3 * (1 + np.abs(c.kl).max()), spec
+    assert abs(so[F] / B - task) < 3e-4 * (1 + abs(task)), spec
+    gflat = eng.get_flat_grads()
+    gref = params_to_flat(eng.blocks, grads, eng.params.numel()).astype(np.float64)
+    for b in eng.blocks:
+        sl = slice(b["offset"], b["offset"] + b["rows"] * b["cols"])
+        assert np.abs(gflat[sl] - gref[sl]).max() <= 5e-4 * (np.abs(gref[sl]).max() + 1e-3), (spec, b)
