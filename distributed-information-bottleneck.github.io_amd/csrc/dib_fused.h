@@ -52,6 +52,8 @@ struct DibFusedCfg {
   static constexpr int T1 = H1 / 32, T2 = H2 / 32, T3 = N3 / 32;
 };
 
+typedef float dib_nt4 __attribute__((ext_vector_type(4)));  // native vector type for non-temporal 16-byte stores
+
 // C-fragment row of accumulator register r for lane-half h:  (r&3) + 8*(r>>2) + 4*h
 __device__ __forceinline__ int dib_crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -82,7 +84,9 @@ __device__ __forceinline__ void dib_store_tile(float* __restrict__ patch, const 
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering them
   if (rows_valid >= 32) {  // wave-uniform fast path: four unconditional 16-byte stores
 #pragma unroll
-    for (int pss = 0; pss < 4; ++pss) *reinterpret_cast<float4*>(dst + (long long)(rr + 8 * pss) * ld + cc) = v[pss];
+    for (int pss = 0; pss < 4; ++pss)
+      __builtin_nontemporal_store(dib_nt4{v[pss].x, v[pss].y, v[pss].z, v[pss].w},
+                                  reinterpret_cast<dib_nt4*>(dst + (long long)(rr + 8 * pss) * ld + cc));
   } else {
 #pragma unroll
     for (int pss = 0; pss < 4; ++pss)
