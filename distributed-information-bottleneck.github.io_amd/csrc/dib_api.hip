@@ -136,7 +136,7 @@ struct ProfScope {
   }
 };
 
-const char* kVersion = "dib_hip 0.1 (gfx950, fp32 MFMA grouped GEMM path)";
+const char* kVersion = "dib_hip 0.2 (gfx950: fused encoder-bank fwd/bwd + grouped fp32-MFMA GEMM)";
 
 int act_ok(int a) { return a >= 0 && a <= 6; }
 

@@ -13,13 +13,17 @@
 // Arithmetic is exact fp32 (the reference is fp32 end to end; gfx950 has no TF32/xf32): the
 // f32-input MFMA is bitwise an fmaf chain, peak 157.3 TFLOP/s = 64 FLOP/clk/SIMD.
 //
-// Tiling: (64*NI) x (64*NJ) x 32 block tile, 256 threads = 4 waves as 2x2, each wave NI x NJ MFMA tiles
+// Tiling: (64*NI) x (64*NJ) x BK block tile, 256 threads = 4 waves as 2x2, each wave NI x NJ MFMA tiles
 // of 32x32.  Operands are staged global -> registers -> LDS with the next tile's global loads in
-// flight during the MFMAs of the current one.  Two LDS images:
-//   KC ("k-contiguous", source rows run along k): T[ext][32+4]; a lane fetches 4 consecutive k
-//       with one ds_read_b128 and feeds 4 MFMAs (pitch 36 floats is conflict-free for b128).
-//   MC ("mn-contiguous", source rows run along m/n): T[32][ext+4]; one ds_read_b32 per MFMA,
+// flight during the MFMAs of the current one; BK = 64 for the 128x128 tile (a 32-deep MFMA phase is
+// shorter than the ~2 us HBM latency of the prefetch - measured +18 %), 32 for the narrow tiles.
+// Two LDS images:
+//   KC ("k-contiguous", source rows run along k): T[ext][BK+4]; a lane fetches 4 consecutive k
+//       with one ds_read_b128 and feeds 4 MFMAs (pitch BK+4 floats is conflict-free for b128).
+//   MC ("mn-contiguous", source rows run along m/n): T[BK][ext+4]; one ds_read_b32 per MFMA,
 //       32 consecutive floats per half-wave (conflict-free).
+// Forward / dgrad 128x128 tiles stage C through the idle operand LDS so global stores (and the dgrad's
+// activation-mask loads) are full-row float4 accesses.
 // Within an 8-deep k block q, MFMA step t contracts k = 8q + 4*(lane>>5) + t for BOTH operands
 // (any consistent permutation of k is legal), which is what makes the b128 fetch possible.
 //
