@@ -197,18 +197,18 @@ inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
-template <int H1, int H2, int E>
+template <int H1, int H2, int E, bool RELU>
 static int launch_fused_fwd(const DibFusedFwdArgs& a, int gx, int F, hipStream_t st) {
   using C = DibFusedCfg<H1, H2, E>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_fwd_kernel<H1, H2, E>,
+    hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_fwd_kernel<H1, H2, E, RELU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((dib_fused_encoder_fwd_kernel<H1, H2, E>), dim3(gx, F), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((dib_fused_encoder_fwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -228,26 +228,30 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   *gx_out = gx;
   ProfScope ps(kProfFusedFwd, st);
   switch (l->fused_id) {
-    case 0: return launch_fused_fwd<128, 128, 32>(a, gx, l->F, st);
-    case 1: return launch_fused_fwd<32, 32, 32>(a, gx, l->F, st);
-    case 2: return launch_fused_fwd<32, 32, 8>(a, gx, l->F, st);
-    case 3: return launch_fused_fwd<64, 64, 16>(a, gx, l->F, st);
+    case 0: return l->act == 1 ? launch_fused_fwd<128, 128, 32, true>(a, gx, l->F, st)
+                                : launch_fused_fwd<128, 128, 32, false>(a, gx, l->F, st);
+    case 1: return l->act == 1 ? launch_fused_fwd<32, 32, 32, true>(a, gx, l->F, st)
+                                : launch_fused_fwd<32, 32, 32, false>(a, gx, l->F, st);
+    case 2: return l->act == 1 ? launch_fused_fwd<32, 32, 8, true>(a, gx, l->F, st)
+                                : launch_fused_fwd<32, 32, 8, false>(a, gx, l->F, st);
+    case 3: return l->act == 1 ? launch_fused_fwd<64, 64, 16, true>(a, gx, l->F, st)
+                                : launch_fused_fwd<64, 64, 16, false>(a, gx, l->F, st);
     default: return DIB_E_UNSUPPORTED;
   }
 }
 
-template <int H1, int H2, int E>
+template <int H1, int H2, int E, bool RELU>
 static int launch_fused_bwd(const DibFusedBwdArgs& a, int gx, int F, hipStream_t st) {
   using C = DibFusedBwdCfg<H1, H2, E>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_bwd_kernel<H1, H2, E>,
+    hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_bwd_kernel<H1, H2, E, RELU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((dib_fused_encoder_bwd_kernel<H1, H2, E>), dim3(gx, F), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((dib_fused_encoder_bwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -272,8 +276,10 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   const int gx = fused_gx(l, batch);
   ProfScope ps(kProfFusedBwd, st);
   switch (l->fused_id) {
-    case 0: return launch_fused_bwd<128, 128, 32>(a, gx, l->F, st);
-    case 1: return launch_fused_bwd<32, 32, 32>(a, gx, l->F, st);
+    case 0: return l->act == 1 ? launch_fused_bwd<128, 128, 32, true>(a, gx, l->F, st)
+                                : launch_fused_bwd<128, 128, 32, false>(a, gx, l->F, st);
+    case 1: return l->act == 1 ? launch_fused_bwd<32, 32, 32, true>(a, gx, l->F, st)
+                                : launch_fused_bwd<32, 32, 32, false>(a, gx, l->F, st);
     default: return DIB_E_UNSUPPORTED;
   }
 }

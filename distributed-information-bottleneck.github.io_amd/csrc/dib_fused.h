@@ -57,12 +57,19 @@ typedef float dib_nt4 __attribute__((ext_vector_type(4)));  // native vector typ
 // C-fragment row of accumulator register r for lane-half h:  (r&3) + 8*(r>>2) + 4*h
 __device__ __forceinline__ int dib_crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// sigma = exp(logvar / 2) (reference models.py:108)
+__device__ __forceinline__ float dib_sigma(float lv) {
+  return __builtin_amdgcn_exp2f(0.72134752044448170f * lv);  // v_exp_f32: 2^(lv * log2(e)/2); exp(lv) = sigma^2
+}
+
 // Piecewise-linear activations only on the fused path (linear / relu / leaky_relu): act(v) = max(v,0) + slope*min(v,0)
 // is branch-free, so the hot loop stays straight-line code.  Other activations use the general GEMM path.
 __device__ __forceinline__ float dib_neg_slope(int act) { return act == 1 ? 0.f : (act == 2 ? 0.2f : 1.f); }
+// RELU (the reference default, train.py:37) is a compile-time specialisation: one v_max per element instead of three ops.
+template <bool RELU>
 __device__ __forceinline__ void dib_act_tile(float slope, dib_f32x16& v) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
+  for (int r = 0; r < 16; ++r) v[r] = RELU ? fmaxf(v[r], 0.f) : fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
 }
 
 // Write one 32(samples) x 32(units) tile held as a transposed-product C fragment to row-major global memory
@@ -94,7 +101,7 @@ __device__ __forceinline__ void dib_store_tile(float* __restrict__ patch, const 
   }
 }
 
-template <int H1, int H2, int E>
+template <int H1, int H2, int E, bool RELU>
 __global__ void __launch_bounds__(512)
 dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
   using C = DibFusedCfg<H1, H2, E>;
@@ -187,7 +194,7 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
           acc = DIB_MFMA(w.w, p[4 * g + 3], acc);
         }
       }
-      dib_act_tile(slope, acc);
+      dib_act_tile<RELU>(slope, acc);
       h1[jo] = acc;
     }
     // stash h1 (feature-major [F][B][H1]) for the backward pass
@@ -217,7 +224,7 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
           acc = DIB_MFMA(w.w, h1[ji][4 * g + 3], acc);
         }
       }
-      dib_act_tile(slope, acc);
+      dib_act_tile<RELU>(slope, acc);
       h2[jo] = acc;
     }
     {
@@ -277,10 +284,11 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       float4 mu = make_float4(o[t_mu][4 * g_mu], o[t_mu][4 * g_mu + 1], o[t_mu][4 * g_mu + 2], o[t_mu][4 * g_mu + 3]);
       float4 lv = make_float4(o[t_lv][4 * g_lv], o[t_lv][4 * g_lv + 1], o[t_lv][4 * g_lv + 2], o[t_lv][4 * g_lv + 3]);
       float4 u;
-      u.x = mu.x + expf(0.5f * lv.x) * eps[0];
-      u.y = mu.y + expf(0.5f * lv.y) * eps[1];
-      u.z = mu.z + expf(0.5f * lv.z) * eps[2];
-      u.w = mu.w + expf(0.5f * lv.w) * eps[3];
+      const float4 sg = make_float4(dib_sigma(lv.x), dib_sigma(lv.y), dib_sigma(lv.z), dib_sigma(lv.w));
+      u.x = mu.x + sg.x * eps[0];
+      u.y = mu.y + sg.y * eps[1];
+      u.z = mu.z + sg.z * eps[2];
+      u.w = mu.w + sg.w * eps[3];
       ut[t_mu][4 * g_mu] = u.x; ut[t_mu][4 * g_mu + 1] = u.y; ut[t_mu][4 * g_mu + 2] = u.z; ut[t_mu][4 * g_mu + 3] = u.w;
       if (valid) {
         if (E < 32) {  // narrow embeddings: direct 16-byte stores
@@ -288,8 +296,8 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
           *reinterpret_cast<float4*>(eo + E + e0) = lv;
           *reinterpret_cast<float4*>(up + e0) = u;
         }
-        klp += 0.5f * ((mu.x * mu.x + expf(lv.x) - lv.x - 1.f) + (mu.y * mu.y + expf(lv.y) - lv.y - 1.f) +
-                       (mu.z * mu.z + expf(lv.z) - lv.z - 1.f) + (mu.w * mu.w + expf(lv.w) - lv.w - 1.f));
+        klp += 0.5f * ((mu.x * mu.x + sg.x * sg.x - lv.x - 1.f) + (mu.y * mu.y + sg.y * sg.y - lv.y - 1.f) +
+                       (mu.z * mu.z + sg.z * sg.z - lv.z - 1.f) + (mu.w * mu.w + sg.w * sg.w - lv.w - 1.f));
       }
     }
     if (E >= 32) {  // full-line stores of (mu|logvar) [F][B][2E] and of u [B][F*E]
@@ -383,7 +391,7 @@ __device__ __forceinline__ dib_f32x16 dib_tile_to_frag(float* __restrict__ patch
   return c;
 }
 
-template <int H1, int H2, int E>
+template <int H1, int H2, int E, bool RELU>
 __global__ void __launch_bounds__(512)
 dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
   static_assert(E % 32 == 0, "fused backward: embedding dimension must be a multiple of 32");
@@ -468,12 +476,12 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const int e0 = 32 * t + 8 * gq + 4 * h;
-          float eps[4];
+          float eps[4] = {0.f, 0.f, 0.f, 0.f};
           dib_eps4(a.seed, nstep, (uint32_t)grow, (uint32_t)f, (uint32_t)(e0 >> 2), eps);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = 4 * gq + j;
-            const float s = expf(0.5f * lv[r]);
+            const float s = dib_sigma(lv[r]);
             dout[t][r] = g[r] + kb * mu[r];
             dout[t + E / 32][r] = g[r] * eps[j] * 0.5f * s + kb * 0.5f * (s * s - 1.f);
           }
@@ -516,7 +524,10 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
             acc = DIB_MFMA(w.w, dout[jt][4 * g + 3], acc);
           }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= ((hbits >> (16 * jo + r)) & 1ull) ? 1.f : slope;
+        for (int r = 0; r < 16; ++r) {
+          const bool on = (hbits >> (16 * jo + r)) & 1ull;
+          acc[r] = RELU ? (on ? acc[r] : 0.f) : acc[r] * (on ? 1.f : slope);
+        }
         dh2[jo] = acc;
         dib_store_tile(patch, acc, dg + 32 * jo, H2, rows_valid, lane);
       }
@@ -553,7 +564,7 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
           }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= (h1v[r] > 0.f ? 1.f : slope);
+        for (int r = 0; r < 16; ++r) acc[r] = RELU ? (h1v[r] > 0.f ? acc[r] : 0.f) : acc[r] * (h1v[r] > 0.f ? 1.f : slope);
         // dh1 tile -> LDS patch as row-major [m][n] (it never goes to HBM), then d(W1|b1) += [P|1]^T dh1 on 16x16x4 MFMAs:
         // step s contracts samples 4s..4s+3; B operand: lane (j, g) reads dh1[4s+g][16*half + j] from the patch.
 #pragma unroll
