@@ -235,12 +235,21 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       for (int jo = 0; jo < C::T2; ++jo) dib_store_tile(patch, h2[jo], dst + 32 * jo, H2, rows_valid, lane);
     }
     if (a.h2mask != nullptr && valid) {  // act'(h2) as one bit per unit: the fused backward needs nothing else of h2
-      unsigned long long bits = 0ull;
+      // h2 > 0  <=>  its bit pattern is a positive integer (+0 -> 0, negatives and -0 -> negative): v_med3_i32 clamps
+      // it to {0,1} and v_lshl_or_b32 shifts it in - 2 VALU ops per unit, no compare / SGPR round trip.  (Inline asm:
+      // the compiler otherwise canonicalises the clamp back into v_cmp + v_cndmask + v_or3 with one live constant
+      // register per bit, which cost 22 spilled VGPRs and 0.1 ms.)
+      unsigned int word[2] = {0u, 0u};
 #pragma unroll
-      for (int jo = 0; jo < C::T2; ++jo)
+      for (int w = 0; w < (C::T2 + 1) / 2; ++w)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bits |= (unsigned long long)(h2[jo][r] > 0.f ? 1 : 0) << (16 * jo + r);
-      a.h2mask[((long long)f * a.batch + b) * 2 + h] = bits;
+        for (int idx = min(31, 16 * C::T2 - 32 * w - 1); idx >= 0; --idx) {  // high bit first: word = (word << 1) | on
+          const int e = 32 * w + idx;
+          int on;
+          asm("v_med3_i32 %0, %1, 0, 1" : "=v"(on) : "v"(h2[e >> 4][e & 15]));
+          asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(word[w]) : "v"(word[w]), "v"(on));
+        }
+      a.h2mask[((long long)f * a.batch + b) * 2 + h] = ((unsigned long long)word[1] << 32) | word[0];
     }
 
     // ---- layer 3 (linear, reference models.py:78): out^T = W3^T h2^T + b3 ; rows [0,E) = mu, [E,2E) = logvar ----
@@ -525,8 +534,9 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
           }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const bool on = (hbits >> (16 * jo + r)) & 1ull;
-          acc[r] = RELU ? (on ? acc[r] : 0.f) : acc[r] * (on ? 1.f : slope);
+          const unsigned int word = (unsigned int)(hbits >> (32 * ((16 * jo) >> 5)));
+          const int keep = __builtin_amdgcn_sbfe(word, (16 * jo + r) & 31, 1);  // 0 or -1: v_bfe_i32 + v_and, no compare
+          acc[r] = RELU ? __int_as_float(__float_as_int(acc[r]) & keep) : acc[r] * (keep ? 1.f : slope);
         }
         dh2[jo] = acc;
         dib_store_tile(patch, acc, dg + 32 * jo, H2, rows_valid, lane);
