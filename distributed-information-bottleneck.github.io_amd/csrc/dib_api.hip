@@ -745,7 +745,7 @@ int dib_grads_finalize_part(dib_layout* l, int batch, int part, float* grads, vo
   }
   if (part != 1 && fused_bwd_ok(l)) {  // layer-1 weight/bias gradients: fixed-order sum of the fused kernel's partials
     ProfScope ps(kProfOther, (hipStream_t)stream);
-    hipLaunchKernelGGL(dib_dw1_reduce_kernel, dim3(l->F), dim3(256), 0, st, (const float*)(w + m.dw1_partial),
+    hipLaunchKernelGGL(dib_dw1_reduce_kernel, dim3(l->F, 16), dim3(256), 0, st, (const float*)(w + m.dw1_partial),
                        fused_gx(l, batch) * 8, l->F, l->enc_units[0], l->dev_fused_offs, l->dev_fused_offs + 3 * l->F,
                        l->dev_featmap, grads);
   }

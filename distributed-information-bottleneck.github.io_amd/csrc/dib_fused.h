@@ -604,15 +604,27 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
 }
 
 // grads[W1 block of feature f][k][n] = sum_p partial[p][f][k][n] (k < in_dim); grads[b1 block][n] = sum_p partial[p][f][in_dim][n]
+// grid (F, 16 rows k): one workgroup per (feature, row) so the F*(in_dim+1) rows reduce in parallel; the sum over the
+// partials keeps its fixed order (deterministic), 8 independent loads in flight per thread.
 __global__ void __launch_bounds__(256)
 dib_dw1_reduce_kernel(const float* __restrict__ partial, int nparts, int F, int H1, const long long* __restrict__ w_off,
                       const long long* __restrict__ b_off, const int4* __restrict__ featmap, float* __restrict__ grads) {
-  const int f = blockIdx.x;
+  const int f = blockIdx.x, k = blockIdx.y;
   const int in_dim = featmap[f].y;
-  for (int idx = threadIdx.x; idx < (in_dim + 1) * H1; idx += 256) {
-    const int k = idx / H1, n = idx - k * H1;
+  if (k > in_dim) return;
+  const long long pstride = (long long)F * 16 * H1;
+  for (int n = threadIdx.x; n < H1; n += 256) {
+    const float* src = partial + ((long long)f * 16 + k) * H1 + n;
     float s = 0.f;
-    for (int pz = 0; pz < nparts; ++pz) s += partial[(((long long)pz * F + f) * 16 + k) * H1 + n];
+    int pz = 0;
+    for (; pz + 8 <= nparts; pz += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(pz + u) * pstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; pz < nparts; ++pz) s += src[pz * pstride];
     if (k < in_dim) grads[w_off[f] + (long long)k * H1 + n] = s;
     else grads[b_off[f] + n] = s;
   }
