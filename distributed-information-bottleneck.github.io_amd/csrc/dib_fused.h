@@ -72,6 +72,13 @@ __device__ __forceinline__ void dib_act_tile(float slope, dib_f32x16& v) {
   for (int r = 0; r < 16; ++r) v[r] = RELU ? fmaxf(v[r], 0.f) : fmaxf(v[r], 0.f) + slope * fminf(v[r], 0.f);
 }
 
+// Row of the 32x36 patch that `lane` touches in pass pss of a row-major sweep (8 lanes x 16 B per row).  Each 16-lane
+// group gets rows r and r+8: 8 rows = 288 floats = 32 banks apart, so the two 128-byte row segments of a group fall
+// on disjoint halves of the 64 LDS banks (rows r, r+1 - 36 floats apart - collide on 4 banks).
+__device__ __forceinline__ int dib_patch_row(int lane, int pss) {
+  return (lane >> 4) + 8 * ((lane >> 3) & 1) + 4 * (pss & 1) + 16 * (pss >> 1);
+}
+
 // Write one 32(samples) x 32(units) tile held as a transposed-product C fragment to row-major global memory
 // with full 128-byte lines: C fragment -> wave-private LDS patch T[m][n] (4 ds_write_b128) -> each lane re-reads 4
 // consecutive units of one sample row (ds_read_b128) -> 16-byte global stores, 8 lanes per 128-byte row segment.
@@ -84,20 +91,21 @@ __device__ __forceinline__ void dib_store_tile(float* __restrict__ patch, const 
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<float4*>(patch + m * 36 + 8 * g + 4 * h) = make_float4(c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]);
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering them
-  const int rr = lane >> 3, cc = (lane & 7) * 4;
+  const int cc = (lane & 7) * 4;
   float4 v[4];
 #pragma unroll
-  for (int pss = 0; pss < 4; ++pss) v[pss] = *reinterpret_cast<const float4*>(patch + (rr + 8 * pss) * 36 + cc);
+  for (int pss = 0; pss < 4; ++pss) v[pss] = *reinterpret_cast<const float4*>(patch + dib_patch_row(lane, pss) * 36 + cc);
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering them
   if (rows_valid >= 32) {  // wave-uniform fast path: four unconditional 16-byte stores
 #pragma unroll
     for (int pss = 0; pss < 4; ++pss)
       __builtin_nontemporal_store(dib_nt4{v[pss].x, v[pss].y, v[pss].z, v[pss].w},
-                                  reinterpret_cast<dib_nt4*>(dst + (long long)(rr + 8 * pss) * ld + cc));
+                                  reinterpret_cast<dib_nt4*>(dst + (long long)dib_patch_row(lane, pss) * ld + cc));
   } else {
 #pragma unroll
     for (int pss = 0; pss < 4; ++pss)
-      if (rr + 8 * pss < rows_valid) *reinterpret_cast<float4*>(dst + (long long)(rr + 8 * pss) * ld + cc) = v[pss];
+      if (dib_patch_row(lane, pss) < rows_valid)
+        *reinterpret_cast<float4*>(dst + (long long)dib_patch_row(lane, pss) * ld + cc) = v[pss];
   }
 }
 
@@ -373,21 +381,21 @@ struct DibFusedBwdCfg {
 // issue the 4 coalesced 16-byte loads of one 32x32 row-major tile (rows clamped to the valid range)
 struct DibTile4 { float4 a, b, c, d; };
 __device__ __forceinline__ DibTile4 dib_tile_gload(const float* __restrict__ src, long long ld, int rows_valid, int lane) {
-  const int rr = lane >> 3, cc = (lane & 7) * 4;
+  const int cc = (lane & 7) * 4;
   DibTile4 t;
-  t.a = *reinterpret_cast<const float4*>(src + (long long)min(rr, rows_valid - 1) * ld + cc);
-  t.b = *reinterpret_cast<const float4*>(src + (long long)min(rr + 8, rows_valid - 1) * ld + cc);
-  t.c = *reinterpret_cast<const float4*>(src + (long long)min(rr + 16, rows_valid - 1) * ld + cc);
-  t.d = *reinterpret_cast<const float4*>(src + (long long)min(rr + 24, rows_valid - 1) * ld + cc);
+  t.a = *reinterpret_cast<const float4*>(src + (long long)min(dib_patch_row(lane, 0), rows_valid - 1) * ld + cc);
+  t.b = *reinterpret_cast<const float4*>(src + (long long)min(dib_patch_row(lane, 1), rows_valid - 1) * ld + cc);
+  t.c = *reinterpret_cast<const float4*>(src + (long long)min(dib_patch_row(lane, 2), rows_valid - 1) * ld + cc);
+  t.d = *reinterpret_cast<const float4*>(src + (long long)min(dib_patch_row(lane, 3), rows_valid - 1) * ld + cc);
   return t;
 }
 // row-major tile (already in registers) -> transposed-product C fragment, through the wave-private LDS patch
 __device__ __forceinline__ dib_f32x16 dib_tile_to_frag(float* __restrict__ patch, const DibTile4 t, int lane) {
-  const int rr = lane >> 3, cc = (lane & 7) * 4, m = lane & 31, h = lane >> 5;
-  *reinterpret_cast<float4*>(patch + rr * 36 + cc) = t.a;
-  *reinterpret_cast<float4*>(patch + (rr + 8) * 36 + cc) = t.b;
-  *reinterpret_cast<float4*>(patch + (rr + 16) * 36 + cc) = t.c;
-  *reinterpret_cast<float4*>(patch + (rr + 24) * 36 + cc) = t.d;
+  const int cc = (lane & 7) * 4, m = lane & 31, h = lane >> 5;
+  *reinterpret_cast<float4*>(patch + dib_patch_row(lane, 0) * 36 + cc) = t.a;
+  *reinterpret_cast<float4*>(patch + dib_patch_row(lane, 1) * 36 + cc) = t.b;
+  *reinterpret_cast<float4*>(patch + dib_patch_row(lane, 2) * 36 + cc) = t.c;
+  *reinterpret_cast<float4*>(patch + dib_patch_row(lane, 3) * 36 + cc) = t.d;
   __builtin_amdgcn_wave_barrier();  // LDS ops of one wave execute in order; keep the compiler from reordering them
   const float4 q0 = *reinterpret_cast<const float4*>(patch + m * 36 + 4 * h);
   const float4 q1 = *reinterpret_cast<const float4*>(patch + m * 36 + 8 + 4 * h);
@@ -508,7 +516,7 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
     float pa[8];
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) {
-      const int rl = 4 * s8 + lg;                                   // row within the wave's 32 samples
+      const int rl = 16 * (s8 >> 2) + (s8 & 3) + 4 * lg;            // row within the wave's 32 samples (see the dW1 MFMAs)
       const float v = Pf[(long long)min(wrow0 + rl, a.batch - 1) * in_dim + min(l15, in_dim - 1)];
       pa[s8] = (rl < rows_valid) ? (l15 < in_dim ? v : (l15 == in_dim ? 1.f : 0.f)) : 0.f;
     }
@@ -576,7 +584,7 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = RELU ? (h1v[r] > 0.f ? acc[r] : 0.f) : acc[r] * (h1v[r] > 0.f ? 1.f : slope);
         // dh1 tile -> LDS patch as row-major [m][n] (it never goes to HBM), then d(W1|b1) += [P|1]^T dh1 on 16x16x4 MFMAs:
-        // step s contracts samples 4s..4s+3; B operand: lane (j, g) reads dh1[4s+g][16*half + j] from the patch.
+        // step s contracts 4 samples (rows rl(s, g) below); B operand: lane (j, g) reads dh1[rl][16*half + j] from the patch.
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(patch + m * 36 + 8 * g + 4 * h) =
@@ -584,8 +592,10 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
-          const float b0 = patch[(4 * s8 + lg) * 36 + l15];
-          const float b1v = patch[(4 * s8 + lg) * 36 + 16 + l15];
+          // the 4 lane groups read rows 4 apart (144 floats = 16 banks): 4 x 16 floats on disjoint banks
+          const int rl = 16 * (s8 >> 2) + (s8 & 3) + 4 * lg;
+          const float b0 = patch[rl * 36 + l15];
+          const float b1v = patch[rl * 36 + 16 + l15];
           dw1[2 * jo] = DIB_MFMA16(pa[s8], b0, dw1[2 * jo]);
           dw1[2 * jo + 1] = DIB_MFMA16(pa[s8], b1v, dw1[2 * jo + 1]);
         }
