@@ -3,7 +3,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import dib_amd
 from dib_amd.engine import HipEngine
 from oracle import dib_oracle as orc
-eng = HipEngine([1] * 8, [128, 128], [256, 256], 1, device="cuda:0", init_seed=0, feature_embedding_dimension=32) if False else HipEngine([1] * 8, [128, 128], [256, 256], 1, device="cuda:0", init_seed=0)
+HipEngine([1] * 8, [128, 128], [256, 256], 1, device="cuda:0", init_seed=0)
 n = 4096
 got = eng.eps(None, 0, n, seed=12345, step=3).cpu().numpy()
 ref = orc.philox_normal_all(12345, 3, np.arange(n), got.shape[1], got.shape[2])
