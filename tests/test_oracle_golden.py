@@ -165,3 +165,67 @@ def test_infonce_oracle_similarity_properties(kind):
     b = rng.standard_normal((6, 5))
     l0 = orc.infonce_loss(a, b, kind, 1.0)
     assert l0 > 0 and abs(l0 - orc.infonce_loss(b, a, kind, 1.0)) < 1e-12  # symmetric in (X, Y)
+
+
+# ---- fixtures produced by executing the reference's own models.py source on a NumPy stand-in for TensorFlow
+#      (tests/golden/make_golden_models.py + tf_numpy_shim.py): pins the graph the reference builds ----
+_MODEL_CASES = [
+    dict(feature_dimensionalities=[1, 1, 1], feature_encoder_architecture=[8, 8], integration_network_architecture=[8],
+         output_dimensionality=1, feature_embedding_dimension=4),
+    dict(feature_dimensionalities=[2, 1, 3], feature_encoder_architecture=[6], integration_network_architecture=[5, 7],
+         output_dimensionality=3, use_positional_encoding=False, activation_fn="tanh", feature_embedding_dimension=3),
+    dict(feature_dimensionalities=[1, 4], feature_encoder_architecture=[5, 4, 3], integration_network_architecture=[],
+         output_dimensionality=2, number_positional_encoding_frequencies=3, activation_fn="leaky_relu",
+         feature_embedding_dimension=2, output_activation_fn="sigmoid"),
+]
+
+
+def _params_from_flat(spec, flat):
+    p = orc.glorot_uniform_init(spec, 0, dtype=np.float64)
+    off = 0
+    for t in p.tensors():
+        t[...] = flat[off: off + t.size].reshape(t.shape)
+        off += t.size
+    assert off == flat.size
+    return p
+
+
+@pytest.mark.parametrize("ci", range(len(_MODEL_CASES)))
+def test_forward_matches_reference_models_py_executed_on_numpy_backend(ci):
+    """oracle.forward vs reference models.py:96-123 (DistributedIBNet.call) run from its own source."""
+    g = np.load(os.path.join(GOLD, "models_forward.npz"))
+    spec = orc.DIBSpec(**_MODEL_CASES[ci])
+    p = _params_from_flat(spec, g[f"c{ci}_flat"])
+    c = orc.forward(spec, p, g[f"c{ci}_x"], g[f"c{ci}_eps"])
+    assert np.abs(c.pred - g[f"c{ci}_pred"]).max() < 1e-12
+    assert np.abs(c.kl - g[f"c{ci}_kl"]).max() < 1e-12                      # add_metric(KL{f}), models.py:115
+    beta = float(g[f"c{ci}_beta"])
+    assert abs(beta * c.kl.sum() - float(g[f"c{ci}_kl_loss"])) < 1e-12      # add_loss(beta * sum KL), models.py:118
+    assert float(g[f"c{ci}_beta_metric"]) == beta                           # add_metric(beta), models.py:121
+
+
+def test_positional_encoding_and_beta_ramp_match_reference_source():
+    g = np.load(os.path.join(GOLD, "models_forward.npz"))
+    got = orc.positional_encoding(g["posenc_x"], [2, 4, 8, 16])               # models.py:22-23 with models.py:70
+    assert np.abs(got - g["posenc_out"]).max() < 1e-15
+    b0, b1, n_pre, n_ann = g["anneal_args"]
+    ours = np.array([orc.beta_schedule(e, b0, b1, int(n_pre), int(n_ann)) for e in range(30)], dtype=np.float32)
+    # both sides evaluate the ramp in float32 (models.py:147-149); allow one float32 ulp for exp/log rounding order
+    assert np.all(np.abs(ours - g["anneal_betas"]) <= 2e-7 * np.abs(g["anneal_betas"]))
+    assert ours[0] == np.float32(1e-4) or abs(ours[0] - 1e-4) < 1e-10
+
+
+def test_similarities_and_mi_bounds_match_reference_utils_py_executed_on_numpy_backend():
+    """oracle.scaled_similarity vs utils.py:131-175 and oracle.mi_sandwich_bounds_batch vs utils.py:36-73, both run
+    from the reference's own source (tests/golden/make_golden_models.py)."""
+    g = np.load(os.path.join(GOLD, "models_forward.npz"))
+    for kind in ("l2sq", "l2", "l1", "linf", "cosine"):
+        got = orc.scaled_similarity(g["sim_e1"], g["sim_e2"], kind, 0.7)
+        assert np.abs(got - g[f"sim_{kind}"]).max() < 1e-12, kind
+    bounds = []
+    for i in range(g["mi_mus"].shape[0]):
+        mus, lvs = g["mi_mus"][i].astype(np.float64), g["mi_logvars"][i].astype(np.float64)   # utils.py:40-41 casts
+        u = mus + np.exp(lvs / 2.0) * g["mi_eps"][i]                                           # utils.py:44-45
+        bounds.append(orc.mi_sandwich_bounds_batch(mus, lvs, u))
+    got = np.mean(np.array(bounds), 0)                                                         # utils.py:73
+    assert np.abs(got - g["mi_bounds"]).max() < 1e-10, (got, g["mi_bounds"])
