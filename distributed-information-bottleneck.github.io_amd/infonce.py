@@ -33,6 +33,31 @@ class _BatchStream:
         return out
 
 
+def _dist():
+    """torch.distributed if a multi-rank process group is up (one process per GPU, RCCL), else None."""
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+
+
+def infonce_data_parallel(emb_x: torch.Tensor, emb_y: torch.Tensor, infonce_fn, dist=None):
+    """Symmetric InfoNCE of the GLOBAL batch when its rows are sharded over ranks (the negatives are in-batch, so the
+    [B,B] similarity needs every rank's embeddings - SURVEY 8(f) rank 1).  Each rank all-gathers both embedding sets
+    (rank order = row order of the global batch), evaluates loss and embedding gradients of the whole batch with
+    `infonce_fn(emb_x_all, emb_y_all) -> (loss, g_x_all, g_y_all)` (redundantly: B^2 D work, B <= a few thousand) and keeps
+    the gradient rows of its own shard.  Back-propagating those through the local encoders and all-reducing (sum) the
+    parameter gradients gives exactly the single-process gradient.  Returns (loss, g_x_local, g_y_local)."""
+    if dist is None:
+        return infonce_fn(emb_x, emb_y)
+    world, rank, b = dist.get_world_size(), dist.get_rank(), emb_x.shape[0]
+    ex = torch.empty((world * b, emb_x.shape[1]), dtype=emb_x.dtype, device=emb_x.device)
+    ey = torch.empty((world * b, emb_y.shape[1]), dtype=emb_y.dtype, device=emb_y.device)
+    dist.all_gather_into_tensor(ex, emb_x.contiguous())
+    dist.all_gather_into_tensor(ey, emb_y.contiguous())
+    loss, gx, gy = infonce_fn(ex, ey)
+    sl = slice(rank * b, (rank + 1) * b)
+    return loss, (None if gx is None else gx[sl]), (None if gy is None else gy[sl])
+
+
 def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, number_pretraining_epochs: int,
                 number_annealing_epochs: int, beta_start: float, beta_end: float, learning_rate: float,
                 y_encoder_architecture=(128, 128), shared_dimensionality: int = 64, similarity: str = 'l2',
@@ -55,18 +80,30 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
     epoch_steps = np.round(steps_per_epoch * np.arange(number_epochs)).astype(np.int32)  # train.py:236
     n_val_batches = nv // batch_size + 1                                                 # train.py:231-234
     stream, vstream = _BatchStream(n, batch_size, seed), _BatchStream(nv, batch_size, seed + 7)
-    B = batch_size
+    # data parallel (one process per GPU): every rank draws the same global batch (same seed) and takes its row shard;
+    # embeddings are all-gathered for the in-batch negatives, parameter gradients all-reduced (sum)
+    dist = _dist()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    assert batch_size % world == 0, "batch_size must be divisible by the number of ranks"
+    B = batch_size // world
 
     def eval_batch(xs, ys, rows_np, training, step):
-        idx = eng.to_device(rows_np.astype(np.int32), dtype=torch.int32)
+        idx = eng.to_device(rows_np[rank * B: (rank + 1) * B].astype(np.int32), dtype=torch.int32)
         eng.forward(xs, idx, 0, B, model.noise_seed, step)        # model(inps): noise always on (train.py:263-265)
         emb_x = eng.pred(B)
         emb_y = yenc.forward(ys.index_select(0, idx.long()))
-        loss, gx, gy = eng.infonce(emb_x, emb_y, similarity, temperature, want_grads=training)
+        loss, gx, gy = infonce_data_parallel(
+            emb_x, emb_y, lambda a, b: eng.infonce(a, b, similarity, temperature, want_grads=training), dist)
         kl = eng.step_out(B)[:F].clone() / B                       # kl_loss / beta (train.py:220)
+        if dist is not None:
+            dist.all_reduce(kl)
+            kl /= world
         if training:
-            eng.backward_from_pred_grad(gx, idx, 0, B, model.noise_seed, step)
+            eng.backward_from_pred_grad(gx, idx, 0, B, model.noise_seed, step, inv_global_batch=1.0 / batch_size)
             yenc.backward(gy)
+            if dist is not None:
+                dist.all_reduce(eng.grads)
+                dist.all_reduce(yenc.grads)
             eng.set_lr(learning_rate)
             eng.adam_step()                                        # one Keras Adam over all variables (train.py:196,219)
             yenc.adam_step(learning_rate)

@@ -67,3 +67,45 @@ def test_two_rank_fit_equals_single_process(tmp_path):
             continue
         assert np.allclose(r0[k], ref[k], rtol=1e-9, atol=1e-12), k
         assert np.allclose(r1[k], ref[k], rtol=1e-9, atol=1e-12), k
+
+
+def _run_infonce_dp(rank, world, port, out_dir):
+    """Data-parallel InfoNCE protocol (dib_amd.infonce.infonce_data_parallel) with a torch-CPU autograd loss standing in
+    for the device kernel: gathered loss = full-batch loss, concatenated local gradient rows = full-batch gradients."""
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dib_amd  # noqa: F401
+    from dib_amd.infonce import infonce_data_parallel
+
+    def infonce_cpu(ex, ey):  # symmetric CE over the -l2 similarity / T (reference train.py:203-214, utils.py:157-160)
+        ex = ex.clone().requires_grad_(True)
+        ey = ey.clone().requires_grad_(True)
+        sim = -torch.sqrt(torch.clamp((ex * ex).sum(1, keepdim=True) + (ey * ey).sum(1)[None] - 2 * ex @ ey.T, min=0) + 1e-9) / 0.5
+        tgt = torch.arange(ex.shape[0])
+        loss = torch.nn.functional.cross_entropy(sim, tgt) + torch.nn.functional.cross_entropy(sim.T, tgt)
+        gx, gy = torch.autograd.grad(loss, [ex, ey])
+        return loss.detach(), gx, gy
+
+    g = torch.Generator().manual_seed(0)
+    ex_all, ey_all = torch.randn(12, 5, generator=g, dtype=torch.float64), torch.randn(12, 5, generator=g, dtype=torch.float64)
+    b = 12 // world
+    sl = slice(rank * b, (rank + 1) * b)
+    loss, gx, gy = infonce_data_parallel(ex_all[sl], ey_all[sl], infonce_cpu, dist)
+    full_loss, fgx, fgy = infonce_cpu(ex_all, ey_all)
+    assert torch.allclose(loss, full_loss, rtol=0, atol=1e-14)
+    assert torch.allclose(gx, fgx[sl], rtol=0, atol=1e-14) and torch.allclose(gy, fgy[sl], rtol=0, atol=1e-14)
+    # without a process group the helper is the identity wrapper
+    l1, a1, b1 = infonce_data_parallel(ex_all, ey_all, infonce_cpu, None)
+    assert torch.equal(l1, full_loss) and torch.equal(a1, fgx) and torch.equal(b1, fgy)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_infonce_data_parallel_gather_protocol(tmp_path):
+    mp.spawn(_run_infonce_dp, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_run_infonce_dp, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
