@@ -89,6 +89,96 @@ __global__ void __launch_bounds__(256, 2) mfma_kernel(const float* __restrict__ 
   if (s == 12345.678f) out[tid] = s;  // keep the results alive
 }
 
+// ---- split-bf16 emulation of an fp32 product on the bf16 matrix pipe (planning numbers for a later round) ----
+// One "fp32-equivalent" 32x32x16 block = NPROD bf16 MFMAs (32x32x16) on hi / mid / lo pieces of the operands:
+//   NPROD = 1 plain bf16; 3: hi*hi + hi*lo + lo*hi (~2^-16 relative); 6: three-way split, all terms >= 2^-16 (~fp32).
+// SPLIT: the pieces are produced from fp32 registers with VALU ops inside the loop (what a kernel that receives fp32
+// activations has to do once per element); otherwise they are loop-invariant (weights split once).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 to_bf16(const f32x8 v) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)v[i];
+  return r;
+}
+__device__ __forceinline__ f32x8 to_f32(const bf16x8 v) {
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (float)v[i];
+  return r;
+}
+
+template <int NPROD, bool SPLIT>
+__global__ void __launch_bounds__(256, 2) bf16_kernel(const float* __restrict__ in, float* __restrict__ out, int iters) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  f32x8 a, b;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = in[(tid * 16 + i) & 0xFFFFF];
+    b[i] = in[(tid * 16 + 8 + i) & 0xFFFFF];
+  }
+  f32x16 acc[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  bf16x8 ah = to_bf16(a), bh = to_bf16(b);
+  bf16x8 am = to_bf16(a - to_f32(ah)), bm = to_bf16(b - to_f32(bh));
+  bf16x8 al = to_bf16(a - to_f32(ah) - to_f32(am)), bl = to_bf16(b - to_f32(bh) - to_f32(bm));
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      if (SPLIT) {  // the B operand arrives as fp32 (activations): split it now; perturb so it is not hoisted
+        b[n] += 1e-7f;
+        bh = to_bf16(b);
+        if (NPROD >= 3) bm = to_bf16(b - to_f32(bh));
+        if (NPROD >= 6) bl = to_bf16(b - to_f32(bh) - to_f32(bm));
+      }
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+      if (NPROD >= 3) {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+      }
+      if (NPROD >= 6) {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[n], 0, 0, 0);
+      }
+    }
+  }
+  float s = b[0];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[n][r];
+  if (s == 12345.678f) out[tid] = s;
+}
+
+template <int NPROD, bool SPLIT>
+static void run_bf16(const char* name, const float* in, float* out, int blocks, int iters) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((bf16_kernel<NPROD, SPLIT>), dim3(blocks), dim3(256), 0, 0, in, out, iters / 8);
+  hipDeviceSynchronize();
+  float sum = 0.f;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((bf16_kernel<NPROD, SPLIT>), dim3(blocks), dim3(256), 0, 0, in, out, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    sum += ms;
+  }
+  // fp32-equivalent FLOPs: one 32x32x16 block per NPROD MFMAs
+  const double blocks16 = (double)blocks * 4 * iters * 4;
+  printf("%-22s %8.3f ms  fp32-equivalent %7.1f TFLOP/s  (matrix-pipe %7.1f TFLOP/s)\n", name, sum / 5,
+         blocks16 * 32768.0 / (sum / 5 * 1e-3) / 1e12, blocks16 * NPROD * 32768.0 / (sum / 5 * 1e-3) / 1e12);
+}
+
 template <int NACC, int MODE>
 static void run(const char* name, const float* in, float* out, int blocks, int iters) {
   hipEvent_t e0, e1;
@@ -142,6 +232,11 @@ int main() {
   run<1, M_VALU8>("c1 +8valu/1", in, out, blocks, iters);
   run<4, M_SALU8>("+8 s_nop/16", in, out, blocks, iters);
   run<4, M_NONE>("chain4 again", in, out, blocks, iters);
+  run_bf16<1, false>("bf16 x1", in, out, blocks, iters * 2);
+  run_bf16<3, false>("bf16 x3 (presplit)", in, out, blocks, iters);
+  run_bf16<3, true>("bf16 x3 (+split B)", in, out, blocks, iters);
+  run_bf16<6, false>("bf16 x6 (presplit)", in, out, blocks, iters);
+  run_bf16<6, true>("bf16 x6 (+split B)", in, out, blocks, iters);
   hipFree(in);
   hipFree(out);
   return 0;
