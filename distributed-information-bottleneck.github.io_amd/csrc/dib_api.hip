@@ -220,8 +220,10 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap;
   a.n_blocks = l->n_blocks; a.act = l->act;
   a.h1 = w + m.enc_h[0]; a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.U = w + m.U;
-  a.kl_partial = w + m.kl_partial; a.F = l->F; a.seed = seed; a.step = step; a.deterministic = deterministic;
+  a.kl_partial = w + m.kl_partial; a.F = l->F; a.seed = seed; a.step = step;
+  a.deterministic = deterministic & DIB_FWD_DETERMINISTIC;
   a.h2mask = (unsigned long long*)(w + m.h2mask);
+  if (deterministic & DIB_FWD_INFERENCE) { a.h1 = nullptr; a.h2 = nullptr; a.h2mask = nullptr; }  // no backward follows
   a.step_dev = l->step_dev;
   const int n_tiles = cdiv(batch, 256);
   const int gx = std::max(1, std::min(n_tiles, cdiv(256, l->F)));
@@ -572,7 +574,7 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
                      w + m.kl_partial, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
-                     (unsigned long long)seed, (unsigned)step, deterministic, l->step_dev); }
+                     (unsigned long long)seed, (unsigned)step, deterministic & DIB_FWD_DETERMINISTIC, l->step_dev); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
   { ProfScope ps(kProfOther, (hipStream_t)stream);

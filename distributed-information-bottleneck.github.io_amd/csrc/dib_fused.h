@@ -205,8 +205,8 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       dib_act_tile<RELU>(slope, acc);
       h1[jo] = acc;
     }
-    // stash h1 (feature-major [F][B][H1]) for the backward pass
-    {
+    // stash h1 (feature-major [F][B][H1]) for the backward pass (skipped for inference: DIB_FWD_INFERENCE)
+    if (a.h1 != nullptr) {
       const int wrow0 = tile * 256 + wave * 32;
       const int rows_valid = min(32, a.batch - wrow0);
       float* dst = a.h1 + ((long long)f * a.batch + wrow0) * H1;
@@ -235,7 +235,7 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       dib_act_tile<RELU>(slope, acc);
       h2[jo] = acc;
     }
-    {
+    if (a.h2 != nullptr) {
       const int wrow0 = tile * 256 + wave * 32;
       const int rows_valid = min(32, a.batch - wrow0);
       float* dst = a.h2 + ((long long)f * a.batch + wrow0) * H2;

@@ -163,13 +163,15 @@ class HipEngine:
 
     # ---- the step -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, row_idx: Optional[torch.Tensor], row0: int, batch: int, seed: int, step: int,
-                deterministic: bool = False) -> None:
-        """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT]."""
+                deterministic: bool = False, inference: bool = False) -> None:
+        """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT].  inference=True: no backward
+        follows (validation / predict), the fused forward skips the stashes it would write for it."""
         ws = self.workspace(batch)
         st = self._stream()
         check(self.lib.dib_encoder_bank_fwd(self.layout, _ptr(x), x.stride(0), _ptr(row_idx), int(row0), batch,
                                             _ptr(self.params), int(seed), int(step) & 0xFFFFFFFF,
-                                            1 if deterministic else 0, _ptr(ws), st), "dib_encoder_bank_fwd")
+                                            (1 if deterministic else 0) | (2 if inference else 0), _ptr(ws), st),
+              "dib_encoder_bank_fwd")
         check(self.lib.dib_integration_fwd(self.layout, batch, _ptr(self.params), _ptr(ws), st), "dib_integration_fwd")
 
     def loss(self, loss_kind: str, y: torch.Tensor, row_idx, row0: int, batch: int, inv_global_batch: float) -> None:
@@ -225,7 +227,7 @@ class HipEngine:
                   inv_global_batch: Optional[float] = None) -> None:
         """validation: noise stays ON and the KL term is included (reference train.py:263-265)."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
-        self.forward(x, row_idx, row0, batch, seed, step)
+        self.forward(x, row_idx, row0, batch, seed, step, inference=True)
         self.loss(loss_kind, y, row_idx, row0, batch, inv)
         self.accumulate_metrics(batch, inv)
 

@@ -89,7 +89,7 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
 
     def eval_batch(xs, ys, rows_np, training, step):
         idx = eng.to_device(rows_np[rank * B: (rank + 1) * B].astype(np.int32), dtype=torch.int32)
-        eng.forward(xs, idx, 0, B, model.noise_seed, step)        # model(inps): noise always on (train.py:263-265)
+        eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training)  # noise always on (train.py:263-265)
         emb_x = eng.pred(B)
         emb_y = yenc.forward(ys.index_select(0, idx.long()))
         loss, gx, gy = infonce_data_parallel(

@@ -231,7 +231,7 @@ class DistributedIBNet:
         if x.dim() == 1:
             x = x.view(1, -1)
         B = x.shape[0]
-        eng.forward(x, None, 0, B, self.noise_seed, self._step)
+        eng.forward(x, None, 0, B, self.noise_seed, self._step, inference=True)  # not differentiable: forward_autograd is
         self._step += 1
         kl = eng.step_out(B)[: self.number_features].clone() / B
         self.last_kl = kl
@@ -283,7 +283,7 @@ class DistributedIBNet:
         outs = []
         for s0 in range(0, n, bs):
             b = min(bs, n - s0)
-            eng.forward(xd, None, s0, b, self.noise_seed, (1 << 30) + s0 // bs)
+            eng.forward(xd, None, s0, b, self.noise_seed, (1 << 30) + s0 // bs, inference=True)
             outs.append(eng.pred(b).clone())
         return torch.cat(outs, 0).cpu().numpy()
 

@@ -91,9 +91,13 @@ int dib_layout_wgrad_splits(const dib_layout* l, int batch);
  *   x       : dataset matrix [*, ldx]; the batch is rows row_idx[0..B) (or row0..row0+B if row_idx NULL)
  *   eps     : keyed by (seed, step, GLOBAL row id, feature, dim) - Philox4x32-10 + Box-Muller, see
  *             dib_philox_normal_ref; global row id = row_idx[b] (or row0 + b).
- *   deterministic != 0 : u = mu (no noise) - used by dib_encode_deterministic-style evaluation.
+ *   deterministic      : bit field.  DIB_FWD_DETERMINISTIC (1): u = mu (no noise) - dib_encode_deterministic-style
+ *             evaluation.  DIB_FWD_INFERENCE (2): no backward pass follows (validation / predict): the fused forward
+ *             skips the activation stashes it would write for it (h1, h2, act' bits: 70 % of its HBM writes).
  * Writes ws[ENC_OUT], ws[U] and the F local KL sums (sum over local rows, not yet divided) into
  * ws[STEP_OUT][0..F). */
+#define DIB_FWD_DETERMINISTIC 1
+#define DIB_FWD_INFERENCE 2
 int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32_t* row_idx, int64_t row0,
                          int batch, const float* params, uint64_t seed, uint32_t step, int deterministic,
                          void* ws, dib_stream_t stream);

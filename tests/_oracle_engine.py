@@ -58,7 +58,7 @@ class OracleEngine:
         eps = orc.philox_normal_all(seed, step, rows.astype(np.uint32), self.F, self.E)
         return rows, xb, orc.forward(self.spec, self.p, xb, eps)
 
-    def forward(self, x, row_idx, row0, batch, seed, step, deterministic=False):
+    def forward(self, x, row_idx, row0, batch, seed, step, deterministic=False, inference=False):
         _, _, c = self._fwd(x, row_idx, row0, batch, seed, step)
         self._pred, self._kl = c.pred, c.kl
 

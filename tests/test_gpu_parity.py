@@ -554,3 +554,28 @@ def test_random_architectures_forward_backward(case):
     for b in eng.blocks:
         sl = slice(b["offset"], b["offset"] + b["rows"] * b["cols"])
         assert np.abs(gflat[sl] - gref[sl]).max() <= 5e-4 * (np.abs(gref[sl]).max() + 1e-3), (spec, b)
+
+
+@pytest.mark.parametrize("name", ["tabular8_default", "boolean4_32x32", "pendulum_ragged"])
+def test_inference_forward_skips_stashes_but_not_results(name):
+    """DIB_FWD_INFERENCE (validation / predict): same prediction, (mu|logvar), u and KL sums bit for bit; a training
+    step afterwards is unaffected."""
+    spec = SPECS[name]
+    eng, _ = _engine(spec, seed=5)
+    rng = np.random.default_rng(1)
+    B = 300
+    x = eng.to_device(rng.standard_normal((B, sum(spec.feature_dimensionalities))).astype(np.float32))
+    eng.forward(x, None, 0, B, 3, 7)
+    ref = [eng.pred(B).clone(), eng.enc_out(B).clone(), eng.u(B).clone(), eng.step_out(B).clone()]
+    eng.forward(x, None, 0, B, 3, 7, inference=True)
+    got = [eng.pred(B), eng.enc_out(B), eng.u(B), eng.step_out(B)]
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    if spec.output_dimensionality == 1:
+        y = eng.to_device((rng.random((B, 1)) > 0.5).astype(np.float32))
+        eng.set_beta(0.1)
+        eng.train_step(x, y, None, 0, B, 3, 8, "bce_logits")
+        g1 = eng.grads.clone()
+        eng.forward(x, None, 0, B, 3, 9, inference=True)     # an evaluation in between must not disturb anything
+        eng.train_step(x, y, None, 0, B, 3, 8, "bce_logits")
+        assert torch.equal(g1, eng.grads)
