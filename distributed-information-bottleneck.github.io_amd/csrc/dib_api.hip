@@ -19,6 +19,9 @@ constexpr int64_t kAlign = 64;  // floats (256 B)
 #ifndef DIB_MAX_SPLITS
 #define DIB_MAX_SPLITS 32
 #endif
+#ifndef DIB_SPLIT_ROWS
+#define DIB_SPLIT_ROWS 512   // minimum batch rows per wgrad split: 8 K-tiles of 64 (measured: 2048 left mid-size batches with 16-256 workgroups)
+#endif
 inline int64_t align_up(int64_t v, int64_t a = kAlign) { return (v + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
@@ -83,8 +86,8 @@ struct dib_layout {
     m.kl_partial = take((int64_t)std::max(m.kl_blocks, 8 * 256) * F);  // fused fwd: <= 256 workgroups x 8 waves
     m.loss_blocks = cdiv(B, 256);
     m.loss_partial = take((int64_t)m.loss_blocks * 2);
-    // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= 1024 rows per split
-    int ns = std::min(DIB_MAX_SPLITS, std::max(1, B / 2048));
+    // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= DIB_SPLIT_ROWS rows per split
+    int ns = std::min(DIB_MAX_SPLITS, std::max(1, B / DIB_SPLIT_ROWS));
     int rps = cdiv(cdiv(B, ns), 32) * 32;
     ns = cdiv(B, rps);
     m.nsplit = ns;
@@ -178,6 +181,11 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
   bool ni1 = (MODE == 2) && M <= 64, nj1 = N <= 64;   // narrow tiles for narrow outputs
+  if (MODE != 2) {
+    // few 128-row tiles (small batches): 64-row tiles double the workgroup count (2 fit per CU at 128x128, 4 at 64x128)
+    const long long wgs = (long long)cdiv(M, 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
+    if (wgs < 512) ni1 = true;
+  }
   if (MODE == 2 && !ni1 && !nj1) {
     // small weight gradients (e.g. a 256x256 layer): 128x128 tiles x splits do not fill 256 CUs -> 64-row tiles
     const long long wgs = (long long)cdiv(M, 128) * cdiv(N, 128) * nsplit * c.count;

@@ -8,7 +8,7 @@ P=distributed-information-bottleneck.github.io_amd/libdib_hip.so
 for v in "$@"; do
   cp exp/lib_$v.so $P; touch $P
   [ -n "$EPSPREC" ] && timeout 60 python tools/eps_precision.py 2>&1 | tail -1
-  timeout 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/exp_$v.json 2> gpurun_out/exp_$v.err
+  timeout 120 python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline ${BATCH:+--batch $BATCH} > gpurun_out/exp_$v.json 2> gpurun_out/exp_$v.err
   python - <<PY
 import json
 d=json.load(open("gpurun_out/exp_$v.json"))
