@@ -185,11 +185,14 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
     // few 128-row tiles (small batches): 64-row tiles double the workgroup count (2 fit per CU at 128x128, 4 at 64x128)
     const long long wgs = (long long)cdiv(M, 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
     if (wgs < 512) ni1 = true;
+    // still a handful of workgroups (tiny batches: latency-bound K loops): halve the per-wave work once more
+    if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * c.count < 128) nj1 = true;
   }
   if (MODE == 2 && !ni1 && !nj1) {
     // small weight gradients (e.g. a 256x256 layer): 128x128 tiles x splits do not fill 256 CUs -> 64-row tiles
     const long long wgs = (long long)cdiv(M, 128) * cdiv(N, 128) * nsplit * c.count;
     if (wgs < 256) ni1 = true;
+    if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * nsplit * c.count < 128) nj1 = true;  // tiny batches
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(l, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
