@@ -579,3 +579,37 @@ def test_inference_forward_skips_stashes_but_not_results(name):
         eng.forward(x, None, 0, B, 3, 9, inference=True)     # an evaluation in between must not disturb anything
         eng.train_step(x, y, None, 0, B, 3, 8, "bce_logits")
         assert torch.equal(g1, eng.grads)
+
+
+def test_c_host_program_drives_a_training_step_through_the_c_abi():
+    """examples/c_abi_step.c: plain C11 + HIP runtime, no Python / torch in the process.  Its per-feature KL, task loss
+    and gradient checksums must equal what the Python engine computes from the same closed-form inputs."""
+    import subprocess
+    import __graft_entry__ as ge
+    exe = ge.build_c_example()
+    B = 300
+    out = subprocess.run([exe, str(B)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    vals = {ln.split()[0]: ln.split()[1:] for ln in out.stdout.splitlines() if ln and ln.split()[0] in
+            ("params", "KL", "task_loss", "grad_sum")}
+
+    def pattern(i0, n, scale):  # the C program's generator, float32 throughout
+        i = np.arange(i0, i0 + n, dtype=np.int64)
+        t = np.float32(0.37) * (i % 1009).astype(np.float32) + np.float32(0.001) * (i % 7919).astype(np.float32)
+        return (np.float32(scale) * np.sin(t.astype(np.float32))).astype(np.float32)
+
+    from dib_amd.engine import HipEngine
+    eng = HipEngine([1, 1, 1, 1], [32, 32], [64], 1, feature_embedding_dimension=32, device="cuda:0", init_seed=0)
+    assert int(vals["params"][0]) == eng.n_params
+    eng.set_flat_params(pattern(0, eng.n_params, 0.2))
+    x = pattern(12345, B * 4, 1.5).reshape(B, 4)
+    y = (pattern(777, B, 1.0) > 0).astype(np.float32)[:, None]
+    eng.set_beta(0.25)
+    eng.train_step(eng.to_device(x), eng.to_device(y), None, 0, B, 42, 3, "bce_logits")
+    so = eng.step_out(B).cpu().numpy()
+    kl_c = np.array([float(v) for v in vals["KL"]])
+    assert np.abs(kl_c - so[:4] / B).max() < 1e-5 * (1 + np.abs(kl_c).max())
+    assert abs(float(vals["task_loss"][0]) - so[4] / B) < 1e-5
+    g = eng.get_flat_grads().astype(np.float64)
+    assert abs(float(vals["grad_sum"][0]) - g.sum()) < 1e-4 * (1 + np.abs(g).sum())
+    assert abs(float(vals["grad_sum"][2]) - np.abs(g).sum()) < 1e-4 * (1 + np.abs(g).sum())
