@@ -49,6 +49,8 @@ def reduce_sum(x, axis=None, keepdims=False):
 
 
 def reduce_mean(x, axis=None):
+    if "Sym" in globals() and isinstance(x, Sym):
+        return Sym(lambda v: np.mean(v, axis=axis), (x,))
     return np.mean(x, axis=axis)
 
 
@@ -62,10 +64,24 @@ def cast(x, dtype):
 
 # ---- symbols used by the reference's utils.py:10-175 (MI sandwich bounds, InfoNCE similarities) ----
 float64 = np.float64
+int32 = np.int32
 
 
-def function(f):            # @tf.function: graph compilation is irrelevant to the values
-    return f
+def one_hot(indices, depth):
+    return np.eye(int(depth), dtype=np.float32)[np.asarray(indices)]
+
+
+def argsort(values):
+    return np.argsort(np.asarray(values), kind="stable")
+
+
+def squeeze(x):
+    return np.squeeze(np.asarray(x))
+
+
+
+def function(f=None, **kw):   # @tf.function / @tf.function(): graph compilation is irrelevant to the values
+    return f if f is not None else (lambda g: g)
 
 
 def shape(x):
@@ -158,23 +174,77 @@ _ACT = {None: lambda z: z, "linear": lambda z: z, "relu": lambda z: np.maximum(z
         "sigmoid": lambda z: 1.0 / (1.0 + np.exp(-z)), "leaky_relu": lambda z: np.where(z > 0, z, 0.2 * z)}
 
 
+ALL_LAYERS = []          # every layer instance in creation order (the fixture scripts inject weights by walking it)
+
+
+class Sym:
+    """Deferred value for the Keras functional API (tf.keras.Input ... tf.keras.Model(inp, out)): a node remembers the
+    function and the parent nodes it was produced from and is evaluated when the Model is called on real data."""
+
+    def __init__(self, fn=None, parents=()):
+        self.fn, self.parents = fn, tuple(parents)
+
+    def eval(self, feed, memo=None):
+        memo = {} if memo is None else memo
+        if id(self) in memo:
+            return memo[id(self)]
+        if self in feed:
+            v = feed[self]
+        else:
+            v = self.fn(*[q.eval(feed, memo) if isinstance(q, Sym) else q for q in self.parents])
+        memo[id(self)] = v
+        return v
+
+    __hash__ = object.__hash__
+
+
+def _has_sym(args):
+    return any(isinstance(a, Sym) or (isinstance(a, (list, tuple)) and any(isinstance(b, Sym) for b in a)) for a in args)
+
+
+def _defer(fn, args):
+    """Sym node computing fn(*args) where Syms (also inside one level of lists) are replaced by their values."""
+    flat, spec = [], []
+    for a in args:
+        if isinstance(a, (list, tuple)):
+            spec.append(len(a))
+            flat.extend(a)
+        else:
+            spec.append(None)
+            flat.append(a)
+
+    def run(*vals):
+        out, i = [], 0
+        for n in spec:
+            if n is None:
+                out.append(vals[i]); i += 1
+            else:
+                out.append(list(vals[i:i + n])); i += n
+        return fn(*out)
+    return Sym(run, flat)
+
+
 class Layer:
     def __init__(self, *a, **k):
-        pass
+        ALL_LAYERS.append(self)
 
-    def __call__(self, x):
-        return self.call(x)
+    def __call__(self, *args):
+        if _has_sym(args):
+            return _defer(self.call, args)
+        return self.call(*args)
 
 
 class Dense(Layer):
     """act(x @ kernel + bias), kernel [in, out] (Keras orientation); weights are injected by the fixture script."""
 
     def __init__(self, units, activation=None):
+        super().__init__()
         self.units, self.activation = units, activation
         self.kernel = self.bias = None
 
     def call(self, x):
-        return _ACT[self.activation](np.asarray(x) @ self.kernel + self.bias)
+        z = np.asarray(x) @ self.kernel + self.bias
+        return self.activation(z) if callable(self.activation) else _ACT[self.activation](z)
 
 
 class _Input:
@@ -184,15 +254,114 @@ class _Input:
 
 class Sequential:
     def __init__(self, layers):
-        self.layers = [l for l in layers if not isinstance(l, _Input)]
+        self.layers = [l for l in layers if not isinstance(l, (_Input, Sym))]
 
-    def __call__(self, x):
+    def __call__(self, x, training=None):
         for l in self.layers:
             x = l(x)
         return x
 
     def build(self, *a):
         return None
+
+    @property
+    def trainable_variables(self):
+        return []
+
+
+class LeakyReLU(Layer):
+    def __init__(self, alpha=0.3):
+        super().__init__()
+        self.alpha = alpha
+
+    def call(self, z):
+        return np.where(z > 0, z, self.alpha * z)
+
+
+class Add(Layer):
+    def call(self, values):
+        out = values[0]
+        for v in values[1:]:
+            out = out + v
+        return out
+
+
+class LayerNormalization(Layer):
+    """Keras default: normalise the last axis, epsilon 1e-3, trainable gamma / beta."""
+
+    def __init__(self, epsilon=1e-3):
+        super().__init__()
+        self.epsilon, self.gamma, self.beta = epsilon, None, None
+
+    def call(self, x):
+        mean = np.mean(x, -1, keepdims=True)
+        var = np.mean(np.square(x - mean), -1, keepdims=True)
+        return (x - mean) / np.sqrt(var + self.epsilon) * self.gamma + self.beta
+
+
+class MultiHeadAttention(Layer):
+    """Keras MultiHeadAttention(num_heads, key_dim) called as (query, value, key): per-head projections with biases,
+    softmax(q k^T / sqrt(key_dim)) v, output projection back to the query width.  Written head by head with plain
+    matrix products (deliberately not the einsum formulation of oracle/set_transformer_oracle.py)."""
+
+    def __init__(self, num_heads, key_dim):
+        super().__init__()
+        self.num_heads, self.key_dim = num_heads, key_dim
+        self.wq = self.bq = self.wk = self.bk = self.wv = self.bv = self.wo = self.bo = None
+
+    def call(self, query, value, key=None):
+        key = value if key is None else key
+        out = np.zeros(query.shape[:-1] + (self.wo.shape[-1],)) + self.bo
+        for h in range(self.num_heads):
+            q = query @ self.wq[:, h, :] + self.bq[h]
+            k = key @ self.wk[:, h, :] + self.bk[h]
+            v = value @ self.wv[:, h, :] + self.bv[h]
+            sc = (q @ np.swapaxes(k, -1, -2)) / np.sqrt(float(self.key_dim))
+            sc = sc - sc.max(-1, keepdims=True)
+            a = np.exp(sc)
+            a = a / a.sum(-1, keepdims=True)
+            out = out + (a @ v) @ self.wo[h]
+        return out
+
+
+class _FunctionalModel:
+    def __init__(self, inputs, outputs):
+        self.inputs, self.outputs = inputs, outputs
+
+    def __call__(self, x, training=None):
+        return self.outputs.eval({self.inputs: np.asarray(x)})
+
+    @property
+    def trainable_variables(self):
+        return []
+
+
+def _keras_input(shape):
+    return Sym()
+
+
+class _BinaryCrossentropy:
+    """Keras BinaryCrossentropy(from_logits=True): mean over the batch of max(z,0) - z*y + log(1 + exp(-|z|))."""
+
+    def __init__(self, from_logits=False):
+        assert from_logits
+
+    def __call__(self, y_true, y_pred):
+        z, y = np.asarray(y_pred, dtype=np.float64), np.asarray(y_true, dtype=np.float64).reshape(np.shape(y_pred))
+        return np.mean(np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z))))
+
+
+class _Adam:
+    def __init__(self, learning_rate=1e-3):
+        self.learning_rate = learning_rate
+
+
+class GradientTape:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class Model(Layer):
@@ -235,8 +404,21 @@ class FixedBatches:
         return self.batches[:n]
 
 
+class _ModelFactory(Model):
+    """tf.keras.Model is both a base class (models.py subclasses it) and, called as Model(inputs, outputs), the functional
+    constructor (set-transformer notebook)."""
+
+    def __new__(cls, *args, **kw):
+        if cls is _ModelFactory and len(args) == 2 and isinstance(args[0], Sym):
+            return _FunctionalModel(*args)
+        return super().__new__(cls)
+
+
 keras = types.SimpleNamespace(
-    layers=types.SimpleNamespace(Layer=Layer, Dense=Dense, Input=_Input),
-    Model=Model, Sequential=Sequential, callbacks=types.SimpleNamespace(Callback=Callback))
+    layers=types.SimpleNamespace(Layer=Layer, Dense=Dense, Input=_Input, LeakyReLU=LeakyReLU, Add=Add,
+                                 LayerNormalization=LayerNormalization, MultiHeadAttention=MultiHeadAttention),
+    Model=_ModelFactory, Sequential=Sequential, Input=_keras_input, callbacks=types.SimpleNamespace(Callback=Callback),
+    losses=types.SimpleNamespace(BinaryCrossentropy=_BinaryCrossentropy),
+    optimizers=types.SimpleNamespace(Adam=_Adam))
 
 abs = _abs  # noqa: A001 (tf.abs)
