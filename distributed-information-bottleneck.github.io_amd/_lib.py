@@ -107,6 +107,9 @@ SIGNATURES = {
     "dib_philox_normal_ref": (c_float, [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32]),
     "dib_profile_enable": (c_int, [c_int]),
     "dib_profile_summary": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
+    "dib_split_weights_bytes": (c_int64, [c_int, c_int]),
+    "dib_split_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dib_gemm_bf16x6": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "dib_gemm": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                          c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -12,6 +12,7 @@
 #include "dib_elementwise.h"
 #include "dib_gemm.h"
 #include "dib_fused.h"
+#include "dib_gemm_bf16x6.h"
 
 namespace {
 
@@ -928,6 +929,28 @@ float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t
   float out[4];
   dib_eps4(seed, step, row, feature, e >> 2, out);
   return out[e & 3];
+}
+
+int64_t dib_split_weights_bytes(int K, int N) {
+  if (K <= 0 || N <= 0) return DIB_E_ARG;
+  return 3ll * N * ((K + 31) / 32 * 32) * 2;
+}
+
+int dib_split_weights(const float* W, int K, int N, void* planes, dib_stream_t stream) {
+  if (!W || !planes || K <= 0 || N <= 0) return DIB_E_ARG;
+  const int Kp = (K + 31) / 32 * 32;
+  hipLaunchKernelGGL(dib_split_weights_kernel, dim3(grid_for((int64_t)N * Kp)), dim3(256), 0, (hipStream_t)stream, W, K, N, Kp,
+                     (__bf16*)planes);
+  return (int)hipGetLastError();
+}
+
+int dib_gemm_bf16x6(int M, int N, int K, const float* A, int lda, const void* planes, float* C, int ldc,
+                    const float* bias, int act, dib_stream_t stream) {
+  if (!A || !planes || !C || M <= 0 || N <= 0 || K <= 0 || !act_ok(act)) return DIB_E_ARG;
+  const int Kp = (K + 31) / 32 * 32;
+  hipLaunchKernelGGL(dib_gemm_bf16x6_kernel, dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, (hipStream_t)stream, A, lda,
+                     (const __bf16*)planes, Kp, C, ldc, bias, M, N, K, act);
+  return (int)hipGetLastError();
 }
 
 int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

@@ -1,0 +1,160 @@
+// dib_gemm_bf16x6.h - EXPERIMENTAL (not on the default path, not what bench.py measures): an fp32 GEMM whose products run
+// on the bf16 matrix pipe.  Every fp32 operand x is split exactly into three bf16 pieces x = hi + mid + lo (8 + 8 + 8
+// significand bits); a product a*b is the sum of the six piece products whose magnitude is >= 2^-16 |a b|
+//   hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi          (the three dropped terms are below fp32 resolution)
+// each of which is exact in fp32, accumulated in the fp32 MFMA accumulator (v_mfma_f32_32x32x16_bf16).  Measured
+// accuracy = plain fp32 (tools/split_bf16_accuracy.py: 1.7e-7 vs 3.8e-7 of max|C|); measured pipe rate 284 TFLOP/s
+// fp32-equivalent vs 154.5 for v_mfma_f32_32x32x2_f32 (tools/mfma_peak.hip).  This file is the first real kernel of that
+// kind: C[M,N] = act(A[M,K] @ W[K,N] + bias) for the integration network's forward (reference models.py:81-84,122).
+//
+//   W is prepared once per optimizer step by dib_split_weights_kernel: three bf16 planes, TRANSPOSED to [N][Kp] so that both
+//   operands are k-contiguous; A (activations) is split on the way into LDS.
+//   Tile 128 x 128 x 32, 256 threads = 4 waves (2 x 2), each wave 2 x 2 MFMA tiles; per 16-deep k step a wave issues
+//   12 ds_read_b128 (3 pieces x 2 tiles x {A,B}) and 24 MFMAs.  LDS rows are 32 bf16 + 8 pad = 80 bytes (conflict-free
+//   b128 reads).  The k assignment inside a 16-block is whatever the hardware uses for "8 elements per lane": A and B are
+//   fetched identically, so the contraction is correct for any such assignment.
+#pragma once
+#include "dib_gemm.h"
+
+typedef __bf16 dib_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dib_bf16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 [K][N] (Keras kernel) -> planes[3][N][Kp] bf16 (hi, mid, lo), Kp = K rounded up to 32, zero padded
+__global__ void __launch_bounds__(256)
+dib_split_weights_kernel(const float* __restrict__ W, int K, int N, int Kp, __bf16* __restrict__ planes) {
+  const long long total = (long long)N * Kp;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / Kp), k = (int)(i - (long long)n * Kp);
+    const float x = (k < K) ? W[(long long)k * N + n] : 0.f;
+    const __bf16 hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    planes[i] = hi;
+    planes[total + i] = mid;
+    planes[2 * total + i] = lo;
+  }
+}
+
+#define DIB_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__global__ void __launch_bounds__(256, 2)
+dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __restrict__ Wp /*[3][N][Kp]*/, int Kp,
+                       float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N, int K, int act) {
+  constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 8;   // bf16 elements per LDS row
+  __shared__ __attribute__((aligned(16))) __bf16 sA[3][BM * PITCH];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[3][BN * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const long long plane = (long long)N * Kp;
+
+  dib_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging maps: A tile 128 x 32 fp32 = 1024 float4 (4 per thread: row = tid/8 + 32p, k = 4*(tid%8));
+  //               B tile per plane 128 x 32 bf16 = 512 x 16 B (2 per thread: row = tid/4 + 64p, k = 8*(tid%4))
+  const int ar = tid >> 3, ak = (tid & 7) * 4, br = tid >> 2, bk = (tid & 3) * 8;
+  const bool avec = ((lda & 3) == 0) && ((reinterpret_cast<unsigned long long>(A) & 15) == 0);
+  float4 ra[4];
+  uint4 rb[3][2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = m0 + ar + 32 * p, k = k0 + ak;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M) {
+        const float* src = A + (long long)row * lda + k;
+        if (avec && k + 3 < K) v = *reinterpret_cast<const float4*>(src);
+        else {
+          if (k + 0 < K) v.x = src[0];
+          if (k + 1 < K) v.y = src[1];
+          if (k + 2 < K) v.z = src[2];
+          if (k + 3 < K) v.w = src[3];
+        }
+      }
+      ra[p] = v;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int n = n0 + br + 64 * p;
+        rb[pl][p] = (n < N) ? *reinterpret_cast<const uint4*>(Wp + pl * plane + (long long)n * Kp + k0 + bk) : make_uint4(0, 0, 0, 0);
+      }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float x[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w};
+      dib_bf16x4 hi, mid, lo;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        hi[c] = (__bf16)x[c];
+        const float r1 = x[c] - (float)hi[c];
+        mid[c] = (__bf16)r1;
+        lo[c] = (__bf16)(r1 - (float)mid[c]);
+      }
+      const int off = (ar + 32 * p) * PITCH + ak;
+      *reinterpret_cast<dib_bf16x4*>(&sA[0][off]) = hi;
+      *reinterpret_cast<dib_bf16x4*>(&sA[1][off]) = mid;
+      *reinterpret_cast<dib_bf16x4*>(&sA[2][off]) = lo;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(&sB[pl][(br + 64 * p) * PITCH + bk]) = rb[pl][p];
+  };
+
+  const int nkt = (K + BK - 1) / BK;
+  if (nkt > 0) gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      dib_bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          a[pl][t] = *reinterpret_cast<const dib_bf16x8*>(&sA[pl][(wm * 64 + t * 32 + l31) * PITCH + ks * 16 + h * 8]);
+          b[pl][t] = *reinterpret_cast<const dib_bf16x8*>(&sB[pl][(wn * 64 + t * 32 + l31) * PITCH + ks * 16 + h * 8]);
+        }
+      // six products per output tile, smallest first; consecutive MFMAs hit different accumulators
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
+        const int pa = (term == 0) ? 2 : (term == 1) ? 0 : (term == 2) ? 1 : (term == 3) ? 1 : (term == 4) ? 0 : 0;
+        const int pb = (term == 0) ? 0 : (term == 1) ? 2 : (term == 2) ? 1 : (term == 3) ? 0 : (term == 4) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = DIB_MFMA_BF16(a[pa][i], b[pb][j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < M) C[(long long)row * ldc + col] = dib_act(act, acc[i][j][r] + bv);
+      }
+    }
+}

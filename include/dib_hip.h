@@ -171,6 +171,15 @@ float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t
 int dib_profile_enable(int on);
 int dib_profile_summary(double* ms_by_category /*[15]*/, int* launches_by_category /*[15]*/);
 
+/* ---- EXPERIMENTAL: fp32 GEMM on the bf16 matrix pipe (csrc/dib_gemm_bf16x6.h) --------------------------------
+ * C[M,N] = act(A[M,K] @ W[K,N] + bias) with every product formed from six bf16 piece products (three-way exact
+ * split of both operands, fp32 accumulate): fp32 accuracy at ~1.8x the fp32-MFMA rate.  Not used by the training
+ * path or by bench.py; exposed so that it can be tested and measured.  `planes` = dib_split_weights output. */
+int64_t dib_split_weights_bytes(int K, int N);
+int dib_split_weights(const float* W, int K, int N, void* planes, dib_stream_t stream);
+int dib_gemm_bf16x6(int M, int N, int K, const float* A, int lda, const void* planes, float* C, int ldc,
+                    const float* bias, int act, dib_stream_t stream);
+
 /* ---- raw grouped GEMM (exposed for tests/benchmarks of the dominant kernel) ----------------
  * mode 0: C[M,N] = act(A[M,K] @ B[K,N] + bias)    mode 1: C[M,N] = (A[M,K] @ B[N,K]^T) * act'(aux)
  * mode 2: C[K... see DESIGN.md; single group, fp32 MFMA (v_mfma_f32_32x32x2_f32). */

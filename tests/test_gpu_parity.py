@@ -613,3 +613,40 @@ def test_c_host_program_drives_a_training_step_through_the_c_abi():
     g = eng.get_flat_grads().astype(np.float64)
     assert abs(float(vals["grad_sum"][0]) - g.sum()) < 1e-4 * (1 + np.abs(g).sum())
     assert abs(float(vals["grad_sum"][2]) - np.abs(g).sum()) < 1e-4 * (1 + np.abs(g).sum())
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 200, 150, "relu"), (128, 128, 32, None), (1, 5, 7, "tanh"), (1000, 256, 2048, "relu"),
+                                       (257, 129, 33, None)])
+def test_experimental_bf16x6_gemm_is_fp32_accurate(M, N, K, act):
+    """csrc/dib_gemm_bf16x6.h: an fp32 GEMM built from six bf16 piece products per element.  Its error against float64 must
+    be at the level of the plain fp32 MFMA path (not of bf16), incl. ragged edges, and A = identity must return W exactly."""
+    import ctypes
+    from dib_amd._lib import ACTIVATIONS, check, load_library
+    lib = load_library()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    Ad, Wd, bd = (torch.from_numpy(t).to(dev) for t in (A, W, b))
+    planes = torch.empty(int(lib.dib_split_weights_bytes(K, N)), dtype=torch.uint8, device=dev)
+    C = torch.empty((M, N), dtype=torch.float32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    check(lib.dib_split_weights(p(Wd), K, N, p(planes), st), "dib_split_weights")
+    check(lib.dib_gemm_bf16x6(M, N, K, p(Ad), K, p(planes), p(C), N, p(bd), ACTIVATIONS[act], st), "dib_gemm_bf16x6")
+    torch.cuda.synchronize()
+    z = A.astype(np.float64) @ W.astype(np.float64) + b
+    ref = {"relu": np.maximum(z, 0), None: z, "tanh": np.tanh(z)}[act]
+    err = np.abs(C.cpu().numpy() - ref).max()
+    assert err < 2e-6 * (1 + np.abs(z).max()), err            # bf16 alone would be ~1e-2
+    # exactness probe: identity x asymmetric W (every piece product is exact, sums of hi+mid+lo reproduce W bit for bit)
+    n = min(K, 96)
+    eye = torch.eye(n, dtype=torch.float32, device=dev)
+    Wn = Wd[:n].contiguous()
+    pl2 = torch.empty(int(lib.dib_split_weights_bytes(n, N)), dtype=torch.uint8, device=dev)
+    C2 = torch.empty((n, N), dtype=torch.float32, device=dev)
+    check(lib.dib_split_weights(p(Wn), n, N, p(pl2), st), "dib_split_weights")
+    check(lib.dib_gemm_bf16x6(n, N, n, p(eye), n, p(pl2), p(C2), N, None, 0, st), "dib_gemm_bf16x6")
+    torch.cuda.synchronize()
+    assert torch.equal(C2, Wn)
