@@ -63,9 +63,9 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
   //               B tile per plane 128 x 32 bf16 = 512 x 16 B (2 per thread: row = tid/4 + 64p, k = 8*(tid%4))
   const int ar = tid >> 3, ak = (tid & 7) * 4, br = tid >> 2, bk = (tid & 3) * 8;
   const bool avec = ((lda & 3) == 0) && ((reinterpret_cast<unsigned long long>(A) & 15) == 0);
-  float4 ra[4];
-  uint4 rb[3][2];
-  auto gload = [&](int k0) {
+  float4 ra0[4], ra1[4];   // activations are prefetched TWO K-tiles ahead (HBM latency ~2 us vs ~0.7 us of MFMAs per tile)
+  uint4 rb[3][2];          // weight planes (L2-resident) one tile ahead
+  auto gload_a = [&](float4 (&ra)[4], int k0) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = m0 + ar + 32 * p, k = k0 + ak;
@@ -82,6 +82,8 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
       }
       ra[p] = v;
     }
+  };
+  auto gload_b = [&](int k0) {
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -90,7 +92,7 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
         rb[pl][p] = (n < N) ? *reinterpret_cast<const uint4*>(Wp + pl * plane + (long long)n * Kp + k0 + bk) : make_uint4(0, 0, 0, 0);
       }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](const float4 (&ra)[4]) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const float x[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w};
@@ -114,11 +116,7 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
   };
 
   const int nkt = (K + BK - 1) / BK;
-  if (nkt > 0) gload(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    lstore();
-    __syncthreads();
-    if (kt + 1 < nkt) gload((kt + 1) * BK);
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       dib_bf16x8 a[3][2], b[3][2];
@@ -140,7 +138,24 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
           for (int j = 0; j < 2; ++j) acc[i][j] = DIB_MFMA_BF16(a[pa][i], b[pb][j], acc[i][j]);
       }
     }
+  };
+  if (nkt > 0) { gload_a(ra0, 0); gload_b(0); }
+  if (nkt > 1) gload_a(ra1, BK);
+  for (int kt = 0; kt < nkt; kt += 2) {   // unrolled by two so that the prefetch ring is addressed statically
+    lstore(ra0);
     __syncthreads();
+    if (kt + 2 < nkt) gload_a(ra0, (kt + 2) * BK);
+    if (kt + 1 < nkt) gload_b((kt + 1) * BK);
+    mfma_tile();
+    __syncthreads();
+    if (kt + 1 < nkt) {
+      lstore(ra1);
+      __syncthreads();
+      if (kt + 3 < nkt) gload_a(ra1, (kt + 3) * BK);
+      if (kt + 2 < nkt) gload_b((kt + 2) * BK);
+      mfma_tile();
+      __syncthreads();
+    }
   }
 
   // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
