@@ -65,7 +65,14 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
   const bool avec = ((lda & 3) == 0) && ((reinterpret_cast<unsigned long long>(A) & 15) == 0);
   float4 ra0[4], ra1[4];   // activations are prefetched TWO K-tiles ahead (HBM latency ~2 us vs ~0.7 us of MFMAs per tile)
   uint4 rb[3][2];          // weight planes (L2-resident) one tile ahead
+  const bool rows_in = m0 + BM <= M, cols_in = n0 + BN <= N;
   auto gload_a = [&](float4 (&ra)[4], int k0) {
+    if (avec && rows_in && k0 + BK <= K) {  // interior tile: four unconditional 16-byte loads
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        ra[p] = *reinterpret_cast<const float4*>(A + (long long)(m0 + ar + 32 * p) * lda + k0 + ak);
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int row = m0 + ar + 32 * p, k = k0 + ak;
@@ -84,6 +91,14 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
     }
   };
   auto gload_b = [&](int k0) {
+    if (cols_in) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          rb[pl][p] = *reinterpret_cast<const uint4*>(Wp + pl * plane + (long long)(n0 + br + 64 * p) * Kp + k0 + bk);
+      return;
+    }
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll

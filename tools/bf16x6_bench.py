@@ -36,7 +36,12 @@ def x6():
     check(lib.dib_gemm_bf16x6(M, N, K, p(A), K, p(planes), p(C2), N, p(b), 1, st), "x6")
 
 
-for name, fn in (("fp32 MFMA (dib_gemm mode 0)", fp32), ("bf16x6 (incl. weight split)", x6)):
+def x6_presplit():
+    check(lib.dib_gemm_bf16x6(M, N, K, p(A), K, p(planes), p(C2), N, p(b), 1, st), "x6")
+
+
+for name, fn in (("fp32 MFMA (dib_gemm mode 0)", fp32), ("bf16x6 (incl. weight split)", x6),
+                 ("bf16x6 (weights pre-split)", x6_presplit)):
     for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
