@@ -50,13 +50,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           os.path.join(CSRC, "dib_api.hip"), "-o", LIB_PATH + ".tmp"]
+           os.path.join(CSRC, "dib_api.hip"), "-o", LIB_PATH + f".tmp{os.getpid()}"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(LIB_PATH + f".tmp{os.getpid()}", LIB_PATH)  # per-process temp name: concurrent ranks cannot clobber each other
     return LIB_PATH
 
 

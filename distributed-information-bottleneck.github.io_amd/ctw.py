@@ -48,13 +48,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     cxx = shutil.which("g++") or shutil.which("c++")
     if cxx is None:
         raise RuntimeError("g++ not found: cannot build libdib_ctw.so")
-    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", SRC, "-o", LIB_PATH + ".tmp"]
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", SRC, "-o", LIB_PATH + f".tmp{os.getpid()}"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("g++ failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(LIB_PATH + f".tmp{os.getpid()}", LIB_PATH)  # per-process temp name: concurrent ranks cannot clobber each other
     return LIB_PATH
 
 
