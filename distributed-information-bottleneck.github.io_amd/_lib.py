@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
-SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h"]
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h"]
 
 # error codes (include/dib_hip.h)
 DIB_OK = 0
