@@ -948,7 +948,7 @@ int dib_gemm_bf16x6(int M, int N, int K, const float* A, int lda, const void* pl
                     const float* bias, int act, dib_stream_t stream) {
   if (!A || !planes || !C || M <= 0 || N <= 0 || K <= 0 || !act_ok(act)) return DIB_E_ARG;
   const int Kp = (K + 31) / 32 * 32;
-  hipLaunchKernelGGL(dib_gemm_bf16x6_kernel, dim3(cdiv(M, 128) * cdiv(N, 128)), dim3(256), 0, (hipStream_t)stream, A, lda,
+  hipLaunchKernelGGL(dib_gemm_bf16x6_kernel, dim3(8 * cdiv(cdiv(M, 128), 8) * cdiv(N, 128)), dim3(256), 0, (hipStream_t)stream, A, lda,
                      (const __bf16*)planes, Kp, C, ldc, bias, M, N, K, act);
   return (int)hipGetLastError();
 }

@@ -46,8 +46,12 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
   __shared__ __attribute__((aligned(16))) __bf16 sB[3][BN * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  // XCD-aware tile order (as dib_gemm_kernel): workgroup ids go round-robin over the 8 XCDs; all n-tiles of an m-tile run
+  // back to back on one XCD so that the activation tile comes from that XCD's L2 after its first read
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tn = slot % tiles_n, tm = (slot / tiles_n) * 8 + xcd;
+  if (tm >= tiles_m) return;  // block-uniform
   const int m0 = tm * BM, n0 = tn * BN;
   const long long plane = (long long)N * Kp;
 
