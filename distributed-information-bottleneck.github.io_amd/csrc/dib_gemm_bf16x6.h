@@ -78,7 +78,11 @@ dib_gemm_bf16x6_kernel(const float* __restrict__ A, int lda, const __bf16* __res
     if (avec && rows_in && k0 + BK <= K) {  // interior tile: four unconditional 16-byte loads
 #pragma unroll
       for (int p = 0; p < 4; ++p)
-        ra[p] = *reinterpret_cast<const float4*>(A + (long long)(m0 + ar + 32 * p) * lda + k0 + ak);
+      {  // streaming operand: non-temporal, so that it does not evict the (re-used) weight planes from L2
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(A + (long long)(m0 + ar + 32 * p) * lda + k0 + ak));
+        ra[p] = make_float4(v.x, v.y, v.z, v.w);
+      }
       return;
     }
 #pragma unroll
