@@ -76,6 +76,7 @@ SIGNATURES = {
     "dib_layout_upload_tables": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dib_layout_set_step_counter": (c_int, [c_void_p, c_void_p]),
     "dib_workspace_bytes": (c_int64, [c_void_p, c_int]),
+    "dib_workspace_init": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "dib_workspace_offset": (c_int64, [c_void_p, c_int, c_int]),
     "dib_layout_wgrad_splits": (c_int, [c_void_p, c_int]),
     "dib_encoder_bank_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_uint64,

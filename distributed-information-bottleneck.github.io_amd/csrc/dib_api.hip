@@ -203,22 +203,34 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
 #undef DIB_GO
 }
 
+__global__ void dib_write_desc_kernel(DibGemmGroup* dst, DibGemmGroup g) { *dst = g; }
+
 inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
   return (int)std::max<int64_t>(1, std::min<int64_t>((n + per_block - 1) / per_block, cap));
 }
 
 }  // namespace
 
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: track it per device ordinal (two engines on two
+// GPUs in one process are allowed).
+static bool dib_attr_needed(bool (&done)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (done[dev]) return false;
+  done[dev] = true;
+  return true;
+}
+
 template <int H1, int H2, int E, bool RELU>
 static int launch_fused_fwd(const DibFusedFwdArgs& a, int gx, int F, hipStream_t st) {
   using C = DibFusedCfg<H1, H2, E>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (dib_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_fwd_kernel<H1, H2, E, RELU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((dib_fused_encoder_fwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
   return (int)hipGetLastError();
@@ -258,12 +270,11 @@ template <int H1, int H2, int E, bool RELU>
 static int launch_fused_bwd(const DibFusedBwdArgs& a, int gx, int F, hipStream_t st) {
   using C = DibFusedBwdCfg<H1, H2, E>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};
+  if (dib_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_bwd_kernel<H1, H2, E, RELU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((dib_fused_encoder_bwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
   return (int)hipGetLastError();
@@ -519,6 +530,17 @@ int dib_layout_set_step_counter(dib_layout* l, const uint32_t* step_dev) {
 int64_t dib_workspace_bytes(const dib_layout* l, int batch) {
   if (!l || batch <= 0) return DIB_E_ARG;
   return l->map(batch).total * (int64_t)sizeof(float);
+}
+
+int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t stream) {
+  if (!l || !ws || batch <= 0) return DIB_E_ARG;
+  const auto m = l->map(batch);
+  if (m.nsplit <= 1) return DIB_OK;
+  // the split-batch weight-gradient slabs: dib_grads_finalize sums all nsplit slabs of every block, including the slabs
+  // a launch never writes (halved splits of narrow layers, slabs >= 1 of the skinny output layer, the layer-1 block
+  // under the fused backward, alignment gaps) - those must read as zero.  Nothing ever writes a non-zero there.
+  return (int)hipMemsetAsync((float*)ws + m.wgrad_partial, 0,
+                             (size_t)m.nsplit * (size_t)align_up(l->n_params, 4) * sizeof(float), (hipStream_t)stream);
 }
 
 int64_t dib_workspace_offset(const dib_layout* l, int batch, int which) {
@@ -959,8 +981,10 @@ int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float
   hipStream_t st = (hipStream_t)stream;
   DibGemmGroup g = make_group(Off(), lda, Off(), ldb, Off(), ldc, bias ? 0 : -1, Off(), ldaux, M, N, K);
   if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return DIB_E_ARG;  // operands must be 16-byte aligned
-  hipError_t e = hipMemcpyAsync(dev_desc, &g, sizeof(g), hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return (int)e;
+  // descriptor travels BY VALUE in a kernel argument and is written on the stream (capture-safe: no host-memory copy node
+  // pointing at this stack frame)
+  hipLaunchKernelGGL(dib_write_desc_kernel, dim3(1), dim3(1), 0, st, (DibGemmGroup*)dev_desc, g);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
   const DibGemmGroup* dg = (const DibGemmGroup*)dev_desc;
   const dim3 g1(8 * cdiv(tm, 8) * tn, 1, 1);

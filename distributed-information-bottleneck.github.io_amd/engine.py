@@ -71,7 +71,10 @@ class HipEngine:
             check(self.lib.dib_layout_upload_tables(self.layout, _ptr(self._tables), self._stream()),
                   "dib_layout_upload_tables")
             torch.cuda.synchronize(self.device)
-        self._ws: Dict[int, torch.Tensor] = {}
+        self._ws: Dict[int, torch.Tensor] = {}      # batch -> step workspace, insertion order = recency
+        self._ws_pinned = set()                     # batch sizes whose workspace a captured graph points into
+        self._ws_gen: Dict[int, int] = {}           # batch -> number of forwards that (re)wrote its activations
+        self._scratch: Optional[torch.Tensor] = None
         self.blocks = self._query_blocks()
         self.set_flat_params(self.glorot_uniform(init_seed))
 
@@ -87,18 +90,34 @@ class HipEngine:
         except Exception:
             pass
 
+    _WS_KEEP = 4  # unpinned step workspaces kept (train, tail, validation, validation tail)
+
     def workspace(self, batch: int) -> torch.Tensor:
-        ws = self._ws.get(batch)
+        """Step workspace for `batch` rows: true LRU over the most recent batch sizes.  A workspace whose raw pointer
+        is baked into a captured hipGraph is PINNED (capture_step_graph) and never evicted - freeing it would let the
+        caching allocator hand the memory to another tensor while graph replays still write to it."""
+        ws = self._ws.pop(batch, None)
         if ws is None:
             nbytes = int(self.lib.dib_workspace_bytes(self.layout, batch))
             if nbytes <= 0:
                 raise _lib.DibError(f"dib_workspace_bytes({batch}) -> {nbytes}")
-            # zero-filled: alignment gaps of the split-batch gradient slabs are summed by dib_grads_finalize
-            ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
-            if len(self._ws) >= 4:  # keep the most recent few batch sizes (train, tail, validation, ...)
-                self._ws.pop(next(iter(self._ws)))
-            self._ws[batch] = ws
+            # include/dib_hip.h contract: the split-batch gradient slabs that no launch writes must read as zero
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            check(self.lib.dib_workspace_init(self.layout, batch, _ptr(ws), self._stream()), "dib_workspace_init")
+            unpinned = [b for b in self._ws if b not in self._ws_pinned]
+            while len(unpinned) >= self._WS_KEEP:
+                self._ws.pop(unpinned.pop(0))  # least recently used first
+            self._ws_gen[batch] = self._ws_gen.get(batch, 0) + 1  # a fresh buffer holds nobody's activations
+        self._ws[batch] = ws  # (re)insert at the most-recent end
         return ws
+
+    def scratch(self, nbytes: int) -> torch.Tensor:
+        """Grow-only scratch for the evaluation helpers (encode_feature, MI bounds): they never touch the step
+        workspaces, so callbacks cannot evict or clobber a training workspace (or one a graph / autograd node owns)."""
+        n = (int(nbytes) + 3) // 4
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._scratch
 
     def ws_view(self, batch: int, which: int, numel: int) -> torch.Tensor:
         off = int(self.lib.dib_workspace_offset(self.layout, batch, which))
@@ -167,6 +186,7 @@ class HipEngine:
         """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT].  inference=True: no backward
         follows (validation / predict), the fused forward skips the stashes it would write for it."""
         ws = self.workspace(batch)
+        self._ws_gen[batch] += 1
         st = self._stream()
         check(self.lib.dib_encoder_bank_fwd(self.layout, _ptr(x), x.stride(0), _ptr(row_idx), int(row0), batch,
                                             _ptr(self.params), int(seed), int(step) & 0xFFFFFFFF,
@@ -253,6 +273,7 @@ class HipEngine:
         assert getattr(self, "step_dev", None) is not None, "call enable_step_counter() first"
         idx_stage = torch.zeros(batch, dtype=torch.int32, device=self.device)
         self.workspace(batch)
+        self._ws_pinned.add(batch)  # the graph bakes this workspace's pointer in: never evict it
         saved = (self.metrics_acc.clone(), self.grads.clone())
         # eager warm-up: loads modules / sets kernel attributes outside the capture; state is restored afterwards
         self.forward(x, idx_stage, 0, batch, seed, 0)
@@ -326,8 +347,9 @@ class HipEngine:
         xf = self.to_device(x_f).reshape(-1, self.dims[f])
         n = xf.shape[0]
         out = torch.empty((n, 2 * self.E), dtype=torch.float32, device=self.device)
+        ws = self.scratch(int(self.lib.dib_workspace_bytes(self.layout, n)))
         check(self.lib.dib_encode_deterministic(self.layout, int(f), _ptr(xf), n, _ptr(self.params), _ptr(out),
-                                                _ptr(self.workspace(n)), self._stream()), "dib_encode_deterministic")
+                                                _ptr(ws), self._stream()), "dib_encode_deterministic")
         return out
 
     def bhattacharyya(self, mu1, lv1, mu2, lv2) -> torch.Tensor:

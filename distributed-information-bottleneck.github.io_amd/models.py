@@ -417,24 +417,27 @@ class DistributedIBNet:
                     continue
                 lo = (gb * rank) // world
                 hi = (gb * (rank + 1)) // world
+                # Every rank issues the SAME collectives every step, rows or no rows (a tail batch with fewer rows than
+                # ranks leaves some ranks empty: they contribute zeros): bucket 1 (integration network) is all-reduced
+                # while the encoder-bank backward still runs, bucket 0 (encoder bank) after it.
                 pending = []
+                two_buckets = dist is not None and hasattr(eng, "part_range")
                 if hi > lo:
-                    overlap = None
-                    if dist is not None and hasattr(eng, "part_range"):
-                        # bucket 1 (integration network) is all-reduced while the encoder-bank backward still runs
-                        overlap = lambda g: pending.append(dist.all_reduce(g, async_op=True))
+                    overlap = (lambda g: pending.append(dist.all_reduce(g, async_op=True))) if two_buckets else None
                     eng.train_step(xd, yd, order_dev[s0 + lo: s0 + hi], 0, hi - lo, self.noise_seed, self._step, kind,
                                    inv_global_batch=1.0 / gb, on_integration_grads_ready=overlap)
                 else:
                     eng.grads.zero_()
-                if dist is not None:
-                    if pending:  # bucket 0 (encoder bank) after the backward; then wait for both
-                        off, cnt = eng.part_range(0)
+                    if two_buckets:
+                        off, cnt = eng.part_range(1)
                         pending.append(dist.all_reduce(eng.grads[off: off + cnt], async_op=True))
-                        for w in pending:
-                            w.wait()
-                    else:
-                        dist.all_reduce(eng.grads)
+                if two_buckets:
+                    off, cnt = eng.part_range(0)
+                    pending.append(dist.all_reduce(eng.grads[off: off + cnt], async_op=True))
+                    for w in pending:
+                        w.wait()
+                elif dist is not None:
+                    dist.all_reduce(eng.grads)
                 self._optimizer_step(eng)
                 self._step += 1
                 nsteps += 1
@@ -501,6 +504,9 @@ class _DIBFunction(torch.autograd.Function):
         eng.forward(x, idx, 0, B, model.noise_seed, step)
         ctx.model, ctx.idx, ctx.step, ctx.B = model, idx, step, B
         ctx.beta = float(model.beta.value())
+        # the activations the backward kernels re-read live in the engine's workspace for B rows: remember which forward
+        # wrote them so that backward() can refuse to run on a workspace another forward has overwritten since
+        ctx.ws_gen = eng._ws_gen.get(B) if hasattr(eng, "_ws_gen") else None
         kl = eng.step_out(B)[: model.number_features].sum() / B
         return eng.pred(B).clone(), (kl * ctx.beta).reshape(())
 
@@ -508,8 +514,16 @@ class _DIBFunction(torch.autograd.Function):
     def backward(ctx, g_pred, g_kl):
         model = ctx.model
         eng = model._ensure_engine()
-        # d/dparams of (beta * sum KL) scaled by the incoming gradient of the KL-loss output
-        eng.set_beta(ctx.beta * float(g_kl.item()) if g_kl is not None else 0.0)
+        if ctx.ws_gen is not None and eng._ws_gen.get(ctx.B) != ctx.ws_gen:
+            raise RuntimeError(
+                f"forward_autograd: another forward pass with batch size {ctx.B} ran between forward_autograd() and "
+                "backward(); it overwrote the stashed activations of this graph node.  Call backward() before the next "
+                "model(x) / predict / evaluate / forward_autograd of the same batch size.")
+        # d/dparams of (beta * sum KL) scaled by the incoming gradient of the KL-loss output - as a device scalar, no host sync
+        if g_kl is not None:
+            eng.beta_dev.copy_((g_kl.detach().to(torch.float32) * ctx.beta).reshape(1))
+        else:
+            eng.set_beta(0.0)
         eng.backward_from_pred_grad(g_pred.contiguous(), ctx.idx, 0, ctx.B, model.noise_seed, ctx.step,
                                     inv_global_batch=1.0 / ctx.B)
         eng.set_beta(float(model.beta.value()))

@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
   CHECK_DIB(dib_layout_upload_tables(l, tables, NULL));
   const int64_t ws_bytes = dib_workspace_bytes(l, B);
   CHECK_HIP(hipMalloc(&ws, (size_t)ws_bytes));
-  CHECK_HIP(hipMemset(ws, 0, (size_t)ws_bytes));
+  CHECK_DIB(dib_workspace_init(l, B, ws, 0)); /* include/dib_hip.h contract: once per (workspace, batch size) */
   CHECK_HIP(hipMalloc((void**)&params, (size_t)n * 4));
   CHECK_HIP(hipMalloc((void**)&grads, (size_t)n * 4));
   CHECK_HIP(hipMemset(grads, 0, (size_t)n * 4));

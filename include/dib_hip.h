@@ -79,8 +79,13 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
 /* hipGraph replay: when step_dev is non-NULL every kernel keys its noise with *step_dev (device uint32, bumped by the
  * caller between replays) instead of the by-value `step` arguments below; NULL restores the by-value behaviour. */
 int dib_layout_set_step_counter(dib_layout* l, const uint32_t* step_dev);
-/* workspace (activations, activation gradients, split-batch wgrad partials) for local batch B */
+/* workspace (activations, activation gradients, split-batch wgrad partials) for local batch B.
+ * CONTRACT: before its first use a workspace must either be zero-filled as a whole or be passed once to
+ * dib_workspace_init (which zeroes the only region that needs it: the split-batch weight-gradient slabs - for batch >= 1024
+ * dib_grads_finalize sums every slab of every parameter block, including slabs no launch writes).  The library never
+ * writes non-zero values into unwritten slabs, so one initialisation per (workspace, batch size) is enough. */
 int64_t dib_workspace_bytes(const dib_layout* l, int batch);
+int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t stream);
 int64_t dib_workspace_offset(const dib_layout* l, int batch, int which); /* byte offset, <0 on error */
 int dib_layout_wgrad_splits(const dib_layout* l, int batch);
 

@@ -46,53 +46,107 @@ class TorchCpuDIB:
             out += [w, b]
         return out
 
-    def forward(self, x: torch.Tensor, eps: torch.Tensor):
-        """reference models.py:96-123 with eps [B,F,E] injected."""
+    def _uniform(self) -> bool:
+        s = self.spec
+        return len(set(s.feature_dimensionalities)) == 1 and s.number_features > 1
+
+    def forward(self, x: torch.Tensor, eps: torch.Tensor, batched: bool = False, reduce_kl: str = "mean"):
+        """reference models.py:96-123 with eps [B,F,E] injected.
+
+        batched=False: the reference's own structure, a Python loop over F separate Dense chains (this is what the CPU
+        baseline times).  batched=True (features of equal width only): the SAME arithmetic with the F chains stacked into
+        torch.bmm calls - a faster checker for the full-size parity tests; test_torch_cpu_batched_equals_loop pins it on
+        the loop form.  reduce_kl: "mean" = models.py:111-112; "sum" = sum over the rows (callers that chunk the batch)."""
         s = self.spec
         E = s.feature_embedding_dimension
         act = _act(s.activation_fn)
-        feats = torch.split(x, list(s.feature_dimensionalities), dim=-1)
-        us, kls = [], []
-        for f in range(s.number_features):
-            h = feats[f]
+        red = torch.mean if reduce_kl == "mean" else torch.sum
+        if batched and self._uniform():
+            F, d = s.number_features, s.feature_dimensionalities[0]
+            h = x.view(x.shape[0], F, d).permute(1, 0, 2)                       # [F, B, d] (tf.split, models.py:101)
             if s.use_positional_encoding:
-                h = torch.cat([h] + [torch.sin(fr * h) for fr in self.freqs], -1)
-            n = len(self.enc_W[f])
+                h = torch.cat([h] + [torch.sin(fr * h) for fr in self.freqs], -1)  # models.py:22-23
+            n = len(self.enc_W[0])
             for l in range(n):
-                h = h @ self.enc_W[f][l] + self.enc_b[f][l]
+                W = torch.stack([self.enc_W[f][l] for f in range(F)])           # [F, in, out]
+                b = torch.stack([self.enc_b[f][l] for f in range(F)])[:, None, :]
+                h = torch.bmm(h, W) + b
                 if l < n - 1:
                     h = act(h)
-            mu, lv = h[:, :E], h[:, E:]
-            us.append(mu + torch.exp(lv / 2.0) * eps[:, f])
-            kls.append(torch.mean(torch.sum(0.5 * (mu * mu + torch.exp(lv) - lv - 1.0), -1)))
-        h = torch.cat(us, -1)
+            mu, lv = h[..., :E], h[..., E:]                                      # models.py:106
+            u = mu + torch.exp(lv / 2.0) * eps.permute(1, 0, 2)                  # models.py:108
+            kl = red(torch.sum(0.5 * (mu * mu + torch.exp(lv) - lv - 1.0), -1), -1)  # [F]   models.py:111-112
+            h = u.permute(1, 0, 2).reshape(x.shape[0], F * E)                    # tf.concat, models.py:122
+        else:
+            feats = torch.split(x, list(s.feature_dimensionalities), dim=-1)
+            us, kls = [], []
+            for f in range(s.number_features):
+                h = feats[f]
+                if s.use_positional_encoding:
+                    h = torch.cat([h] + [torch.sin(fr * h) for fr in self.freqs], -1)
+                n = len(self.enc_W[f])
+                for l in range(n):
+                    h = h @ self.enc_W[f][l] + self.enc_b[f][l]
+                    if l < n - 1:
+                        h = act(h)
+                mu, lv = h[:, :E], h[:, E:]
+                us.append(mu + torch.exp(lv / 2.0) * eps[:, f])
+                kls.append(red(torch.sum(0.5 * (mu * mu + torch.exp(lv) - lv - 1.0), -1)))
+            h = torch.cat(us, -1)
+            kl = torch.stack(kls)
         n = len(self.int_W)
         for l in range(n):
             h = h @ self.int_W[l] + self.int_b[l]
             h = act(h) if l < n - 1 else _act(s.output_activation_fn)(h)
-        return h, torch.stack(kls)
+        return h, kl
 
-    def loss(self, kind: str, y: torch.Tensor, pred: torch.Tensor):
+    def loss(self, kind: str, y: torch.Tensor, pred: torch.Tensor, reduction: str = "mean"):
         if kind == "bce_logits":
-            return torch.nn.functional.binary_cross_entropy_with_logits(pred, y.to(pred.dtype).view_as(pred))
+            return torch.nn.functional.binary_cross_entropy_with_logits(pred, y.to(pred.dtype).view_as(pred),
+                                                                        reduction=reduction)
         if kind == "mse":
-            return torch.mean((pred - y.to(pred.dtype).view_as(pred)) ** 2)
+            d = (pred - y.to(pred.dtype).view_as(pred)) ** 2
+            return torch.mean(d) if reduction == "mean" else torch.sum(d) / pred.shape[1]
         if kind == "sparse_cce_logits":
-            return torch.nn.functional.cross_entropy(pred, y.view(-1).long())
+            return torch.nn.functional.cross_entropy(pred, y.view(-1).long(), reduction=reduction)
         raise ValueError(kind)
 
-    def train_step(self, x, y, eps, beta: float, kind: str, lr: float = 3e-4):
-        pred, kl = self.forward(x, eps)
-        task = self.loss(kind, y, pred)
-        total = task + beta * kl.sum()
+    def loss_and_grads(self, x, y, eps, beta: float, kind: str, chunk: Optional[int] = None, batched: bool = False,
+                       want_grads: bool = True):
+        """L = mean_b loss + beta * sum_f KL_f (models.py:118) and dL/dparams, evaluated in row chunks (the batch mean is
+        linear, so the chunk gradients add up exactly): keeps the autograd tape of a 65536-row float64 batch out of
+        memory.  Returns (task loss, kl [F] detached, grads list | None, pred [B, out] detached)."""
+        B = x.shape[0]
+        chunk = B if not chunk else int(chunk)
         ps = self.tensors()
-        grads = torch.autograd.grad(total, ps)
+        acc = [torch.zeros_like(p) for p in ps] if want_grads else None
+        task_sum, kl_sum, preds = 0.0, torch.zeros(self.spec.number_features, dtype=self.dtype), []
+        for s0 in range(0, B, chunk):
+            sl = slice(s0, min(B, s0 + chunk))
+            with torch.set_grad_enabled(want_grads):
+                pred, kl = self.forward(x[sl], eps[sl], batched=batched, reduce_kl="sum")
+                task = self.loss(kind, y[sl], pred, reduction="sum")
+                total = (task + beta * kl.sum()) / B
+            if want_grads:
+                for a, g in zip(acc, torch.autograd.grad(total, ps)):
+                    a.add_(g)
+            task_sum += float(task.detach())
+            kl_sum += kl.detach()
+            preds.append(pred.detach())
+        return task_sum / B, kl_sum / B, acc, torch.cat(preds, 0)
+
+    def apply_adam(self, grads, lr: float = 3e-4, b1: float = 0.9, b2: float = 0.999, e: float = 1e-7):
+        """Keras Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps), eps = 1e-7."""
         self.t += 1
-        b1, b2, e = 0.9, 0.999, 1e-7
         lr_t = lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
         with torch.no_grad():
-            for p, g, m, v in zip(ps, grads, self.m, self.v):
+            for p, g, m, v in zip(self.tensors(), grads, self.m, self.v):
                 m.add_((1 - b1) * (g - m))
                 v.add_((1 - b2) * (g * g - v))
                 p.sub_(lr_t * m / (torch.sqrt(v) + e))
-        return float(task.detach()), kl.detach(), grads
+
+    def train_step(self, x, y, eps, beta: float, kind: str, lr: float = 3e-4, chunk: Optional[int] = None,
+                   batched: bool = False):
+        task, kl, grads, _ = self.loss_and_grads(x, y, eps, beta, kind, chunk=chunk, batched=batched)
+        self.apply_adam(grads, lr)
+        return task, kl, grads

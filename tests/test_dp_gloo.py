@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _run(rank, world, port, out_dir):
+def _run(rank, world, port, out_dir, n_rows=80):
     for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,6 +38,7 @@ def _run(rank, world, port, out_dir):
     x, y = orc.boolean_circuit_truth_table([0, 1, 2, 3, [0, 2, 0], [2, 4, 3], [0, 5, 1]], 4)
     x = np.tile(x, (5, 1)).astype(np.float32)
     y = np.tile(y, 5).astype(np.float32)
+    x, y = x[:n_rows], y[:n_rows]
     model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=1, shuffle_seed=2, init_seed=3)
     model._engine_factory = OracleEngine
     opt = dib_amd.optimizers.get("adam")
@@ -45,7 +46,7 @@ def _run(rank, world, port, out_dir):
     model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
     cb = dib_amd.InfoBottleneckAnnealingCallback(1e-3, 0.5, 1, 2)
     hist = model.fit(x, y, epochs=3, batch_size=32, callbacks=[cb], verbose=False, validation_data=(x[:30], y[:30]))
-    np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"), params=model._engine.get_flat_params(),
+    np.savez(os.path.join(out_dir, f"n{n_rows}_w{world}_r{rank}.npz"), params=model._engine.get_flat_params(),
              **{k: np.array(v) for k, v in hist.history.items()})
     if world > 1:
         dist.barrier()
@@ -57,9 +58,9 @@ def test_two_rank_fit_equals_single_process(tmp_path):
     out = str(tmp_path)
     _run(0, 1, _free_port(), out)
     mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
-    ref = np.load(os.path.join(out, "w1_r0.npz"))
-    r0 = np.load(os.path.join(out, "w2_r0.npz"))
-    r1 = np.load(os.path.join(out, "w2_r1.npz"))
+    ref = np.load(os.path.join(out, "n80_w1_r0.npz"))
+    r0 = np.load(os.path.join(out, "n80_w2_r0.npz"))
+    r1 = np.load(os.path.join(out, "n80_w2_r1.npz"))
     assert np.allclose(r0["params"], r1["params"], rtol=0, atol=0), "ranks diverged"
     assert np.allclose(r0["params"], ref["params"], rtol=1e-9, atol=1e-12)
     for k in ref.files:
@@ -67,6 +68,22 @@ def test_two_rank_fit_equals_single_process(tmp_path):
             continue
         assert np.allclose(r0[k], ref[k], rtol=1e-9, atol=1e-12), k
         assert np.allclose(r1[k], ref[k], rtol=1e-9, atol=1e-12), k
+
+
+@pytest.mark.timeout(300)
+def test_three_rank_fit_with_tail_batch_smaller_than_world(tmp_path):
+    """n % batch_size = 1 on 3 ranks: two ranks have NO rows in the tail batch.  Every rank must still issue the same
+    collectives (both gradient buckets) - a mismatch hangs RCCL (round-1 advisor finding) - and the result must equal
+    the single-process run."""
+    out = str(tmp_path)
+    _run(0, 1, _free_port(), out, 65)
+    mp.spawn(_run, args=(3, _free_port(), out, 65), nprocs=3, join=True)
+    ref = np.load(os.path.join(out, "n65_w1_r0.npz"))
+    rs = [np.load(os.path.join(out, f"n65_w3_r{r}.npz")) for r in range(3)]
+    for r in rs:
+        assert np.array_equal(r["params"], rs[0]["params"]), "ranks diverged"
+        for k in ref.files:
+            assert np.allclose(r[k], ref[k], rtol=1e-9, atol=1e-12), k
 
 
 def _run_infonce_dp(rank, world, port, out_dir):

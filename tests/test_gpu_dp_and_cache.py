@@ -1,0 +1,91 @@
+"""GPU tests of the data-parallel plumbing on RCCL (one rank: the driver's box has one GPU), of bench.py's launcher path on
+the GPU, and of the engine's workspace cache / autograd-bridge guards (round-1 advisor findings)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+@pytest.mark.timeout(900)
+def test_fit_under_rccl_one_rank_equals_single_process(tmp_path):
+    """fit() launched by torch.distributed.run (nccl = RCCL backend, world size 1): the two-bucket async all-reduce
+    sequence, the empty-tail-batch branch and the metric all-reduce run on the real communicator and reproduce the
+    plain single-process run bit for bit (a 1-rank sum all-reduce is the identity)."""
+    a, b = str(tmp_path / "single.npz"), str(tmp_path / "rccl.npz")
+    worker = os.path.join(HERE, "_dp_gpu_worker.py")
+    r = subprocess.run([sys.executable, worker, a], capture_output=True, text=True, timeout=400, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29731", worker, b], capture_output=True, text=True, timeout=400,
+                       env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    s, d = np.load(a), np.load(b)
+    assert set(s.files) == set(d.files)
+    for k in s.files:
+        assert np.array_equal(s[k], d[k]), k
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_launcher_reports_joined_ranks():
+    """bench.py under torch.distributed.run with one rank: RCCL path, `n_gpus` = ranks that joined the communicator."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29732", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+                        "--warmup", "1", "--blocks", "1", "--batch", "8192", "--no-cpu-baseline", "--no-extra"],
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["rccl_ranks_joined"] == 1 and out["scaling"] == "strong"
+    assert out["value"] > 0 and out["config"]["global_batch"] == 8192 and "roofline" in out
+
+
+def test_workspace_cache_is_lru_and_never_evicts_a_graph_workspace():
+    from dib_amd.engine import HipEngine
+    eng = HipEngine([1, 1], [32, 32], [16], 1, feature_embedding_dimension=32)
+    ws = {b: eng.workspace(b).data_ptr() for b in (8, 16, 24, 32)}
+    eng.workspace(8)                      # touch: 8 becomes most recent, 16 is now the LRU entry
+    eng.workspace(40)                     # evicts 16, not 8
+    assert 16 not in eng._ws and eng.workspace(8).data_ptr() == ws[8]
+    # a workspace referenced by a captured graph is pinned
+    x = torch.randn(64, 2, device=eng.device)
+    y = (x[:, :1] > 0).float()
+    eng.enable_step_counter(0)
+    graph, stage = eng.capture_step_graph(x, y, 48, "bce_logits", 1.0 / 48, 0, True)
+    p48 = eng.workspace(48).data_ptr()
+    for b in (50, 51, 52, 53, 54, 55):
+        eng.workspace(b)
+    assert 48 in eng._ws and eng.workspace(48).data_ptr() == p48
+    stage.copy_(torch.arange(48, dtype=torch.int32, device=eng.device))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.grads).all()
+    # evaluation helpers use their own scratch: no step workspace of that size appears
+    eng.encode_feature(0, np.zeros((77, 1), dtype=np.float32))
+    assert 77 not in eng._ws
+
+
+def test_autograd_bridge_refuses_clobbered_workspace():
+    import dib_amd
+    model = dib_amd.DistributedIBNet([1, 1, 1], [32, 32], [16], 1, feature_embedding_dimension=32)
+    x = torch.randn(20, 3)
+    pred, kl_loss = model.forward_autograd(x)
+    model(x)  # another forward with the same batch size overwrites the stashed activations
+    with pytest.raises(RuntimeError, match="overwrote the stashed activations"):
+        (pred.sum() + kl_loss).backward()
+    pred, kl_loss = model.forward_autograd(x)
+    model(torch.randn(21, 3))  # a different batch size has its own workspace: fine
+    (pred.sum() + 2.0 * kl_loss).backward()
+    assert torch.isfinite(model.flat_parameters.grad).all()

@@ -143,3 +143,40 @@ def test_torch_cpu_restatement_agrees_with_numpy_oracle():
     orc.adam_keras_step(p, g, st)
     for a, b in zip(m.tensors(), p.tensors()):
         assert np.allclose(a.detach().numpy(), b, atol=1e-12)
+
+
+def test_torch_cpu_batched_equals_loop():
+    """The full-size GPU parity tests use the feature-batched (bmm) + row-chunked form of the float64 PyTorch-CPU checker;
+    pin it on the reference-shaped per-feature loop form (models.py:105-122) and on the NumPy oracle."""
+    import torch
+    import dib_oracle as orc
+    from dib_torch_cpu import TorchCpuDIB
+    spec = orc.DIBSpec([1] * 6, [16, 12], [10], 1, feature_embedding_dimension=4)
+    p = orc.glorot_uniform_init(spec, 3)
+    rng = np.random.default_rng(0)
+    for t in p.tensors():
+        if t.ndim == 1:
+            t[:] = 0.1 * rng.standard_normal(t.shape)
+    B = 50
+    x = rng.standard_normal((B, 6))
+    y = (rng.random((B, 1)) > 0.5).astype(np.float64)
+    eps = rng.standard_normal((B, 6, 4))
+    xt, yt, et = torch.tensor(x), torch.tensor(y), torch.tensor(eps)
+    a = TorchCpuDIB(spec, p, dtype=torch.float64)
+    t0, k0, g0, p0 = a.loss_and_grads(xt, yt, et, 0.3, "bce_logits")
+    t1, k1, g1, p1 = a.loss_and_grads(xt, yt, et, 0.3, "bce_logits", chunk=16, batched=True)
+    assert abs(t0 - t1) < 1e-14 and torch.allclose(k0, k1, rtol=0, atol=1e-14) and torch.allclose(p0, p1, rtol=0, atol=1e-13)
+    for u, v in zip(g0, g1):
+        assert torch.allclose(u, v, rtol=0, atol=1e-14)
+    c = orc.forward(spec, p, x, eps)
+    task, grads, _ = orc.backward(spec, p, x, y, c, 0.3, "bce_logits")
+    assert abs(task - t1) < 1e-12 and np.abs(c.kl - k1.numpy()).max() < 1e-12
+    for u, v in zip(g1, [np.asarray(t) for f in range(6) for l in range(3) for t in (grads.enc_W[f][l], grads.enc_b[f][l])]
+                    + [np.asarray(t) for l in range(2) for t in (grads.int_W[l], grads.int_b[l])]):
+        assert np.abs(u.numpy() - v).max() < 1e-12
+    # train_step = loss_and_grads + Keras Adam, unchanged behaviour
+    b = TorchCpuDIB(spec, p, dtype=torch.float64)
+    b.train_step(xt, yt, et, 0.3, "bce_logits", lr=1e-3)
+    a.apply_adam(g1, 1e-3)
+    for u, v in zip(a.tensors(), b.tensors()):
+        assert torch.allclose(u, v, rtol=0, atol=1e-14)
