@@ -16,14 +16,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
-SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h"]
+INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h",
+           INCLUDE_ST]
 
 # error codes (include/dib_hip.h)
 DIB_OK = 0
 ACTIVATIONS = {None: 0, "linear": 0, "None": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "elu": 5,
                "softplus": 6}
+ACT_LEAKY_RELU_01 = 7  # tf.keras.layers.LeakyReLU(0.1) (include/dib_st.h)
 LOSS_KINDS = {"bce_logits": 0, "bce": 1, "sparse_cce_logits": 2, "mse": 3}
 WS_U, WS_PRED, WS_ENC_OUT, WS_G_U, WS_STEP_OUT, WS_G_PRED = range(6)
+WS_ENC_H0, WS_INT_H0 = 16, 32
 SIMILARITIES = {"l2sq": 0, "l2": 1, "l1": 2, "linf": 3, "cosine": 4}
 
 
@@ -115,6 +119,32 @@ SIGNATURES = {
                          c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
+# include/dib_st.h: building blocks of the per-particle set transformer
+SIGNATURES_ST = {
+    "dib_gemm_grouped": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
+    "dib_reduce_splits": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "dib_softmax_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "dib_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "dib_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "dib_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "dib_add_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    "dib_mean_pool_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dib_mean_pool_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dib_add_inplace": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "dib_act_grad_mul": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "dib_token_kl_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "dib_token_reparam_kl_fwd": (c_int, [c_void_p, c_int64, c_int, c_float, c_uint64, c_uint32, c_int64, c_int, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    "dib_token_reparam_kl_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_float, c_uint64, c_uint32,
+                                         c_int64, c_void_p, c_void_p]),
+    "dib_loss_rows_workspace_bytes": (c_int64, [c_int]),
+    "dib_loss_rows": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
+}
+
 
 def load_library(build_if_missing: bool = True):
     """dlopen libdib_hip.so and attach signatures.  Raises (no fallback) if it cannot be loaded."""
@@ -130,7 +160,7 @@ def load_library(build_if_missing: bool = True):
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_ST.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -13,6 +13,8 @@
 #include "dib_gemm.h"
 #include "dib_fused.h"
 #include "dib_gemm_bf16x6.h"
+#include "dib_st.h"
+#include "../../include/dib_st.h"
 
 namespace {
 
@@ -142,7 +144,7 @@ struct ProfScope {
 
 const char* kVersion = "dib_hip 0.2 (gfx950: fused encoder-bank fwd/bwd + grouped fp32-MFMA GEMM)";
 
-int act_ok(int a) { return a >= 0 && a <= 6; }
+int act_ok(int a) { return a >= 0 && a <= 7; }
 
 // Off = {fixed element offset, offset per batch row} : activations are feature-major [F][B][width]
 struct Off { int64_t fixed = 0, per_batch = 0; };
@@ -161,7 +163,7 @@ DibGemmGroup make_group(Off a, int lda, Off b, int ldb, Off c, int ldc, int64_t 
 }
 
 template <int MODE, int NI, int NJ>
-int launch_gemm_t(const dib_layout* l, const GemmCall& c, int M, int N, const float* A, const float* B, float* C,
+int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int N, const float* A, const float* B, float* C,
                   const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit,
                   int rows_per_split, long long split_stride, hipStream_t st) {
   const int tm = cdiv(M, 64 * NI), tn = cdiv(N, 64 * NJ);
@@ -169,14 +171,30 @@ int launch_gemm_t(const dib_layout* l, const GemmCall& c, int M, int N, const fl
   if (MODE == 2) grid = dim3(nsplit, tm * tn, c.count);
   else grid = dim3(8 * cdiv(tm, 8) * tn, 1, c.count);  // XCD-aware 1-D tile order, see dib_gemm.h
   constexpr int BK = (NI == 2 && NJ == 2) ? 64 : 32;  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
-  hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, l->dev_groups + c.first, A, B, C,
+  hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
                      bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride);
   return (int)hipGetLastError();
 }
 
+// Tile-rule knobs, overridable from the environment for A/B measurements on the GPU (tools/ab_bench.sh); the defaults
+// are the measured choices.
+struct Knobs {
+  int fwd_small_wgs = 512;   // forward/dgrad: below this many 128-row workgroups use 64-row tiles
+  int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
+  int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
+  Knobs() {
+    if (const char* e = std::getenv("DIB_FWD_SMALL_WGS")) fwd_small_wgs = std::atoi(e);
+    if (const char* e = std::getenv("DIB_L3_HALVE")) l3_halve = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FORCE_TILE0")) force_tile[0] = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FORCE_TILE1")) force_tile[1] = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FORCE_TILE2")) force_tile[2] = std::atoi(e);
+  }
+};
+inline const Knobs& knobs() { static Knobs k; return k; }
+
 template <int MODE>
-int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const float* B, float* C, const float* bias,
-                const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
+int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* A, const float* B, float* C,
+                const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
                 long long split_stride, hipStream_t st) {
   if (c.count == 0) return DIB_OK;
   const int M = c.max_m < 0 ? batch : c.max_m;
@@ -185,9 +203,11 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
   if (MODE != 2) {
     // few 128-row tiles (small batches): 64-row tiles double the workgroup count (2 fit per CU at 128x128, 4 at 64x128)
     const long long wgs = (long long)cdiv(M, 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
-    if (wgs < 512) ni1 = true;
-    // still a handful of workgroups (tiny batches: latency-bound K loops): halve the per-wave work once more
-    if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * c.count < 128) nj1 = true;
+    if (wgs < knobs().fwd_small_wgs) ni1 = true;
+    // still under two workgroups per CU: halve the per-wave work once more.  Forward GEMMs switch below 512 workgroups
+    // (measured at B = 8192: the integration forward on 512 64x64 tiles instead of 256 64x128 tiles, step -30 us); the
+    // dgrads measured no different and keep the round-1 threshold.
+    if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * c.count < (MODE == 0 ? 512 : 128)) nj1 = true;
   }
   if (MODE == 2 && !ni1 && !nj1) {
     // small weight gradients (e.g. a 256x256 layer): 128x128 tiles x splits do not fill 256 CUs -> 64-row tiles
@@ -195,8 +215,9 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
     if (wgs < 256) ni1 = true;
     if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * nsplit * c.count < 128) nj1 = true;  // tiny batches
   }
+  if (const int ft = knobs().force_tile[MODE]) { ni1 = ft / 10 == 1; nj1 = (ft % 10 == 1) || N <= 64; }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
-#define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(l, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
+#define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
                                                    rows_per_split, split_stride, st)
   if (ni1) return nj1 ? DIB_GO(1, 1) : DIB_GO(1, 2);
   return nj1 ? DIB_GO(2, 1) : DIB_GO(2, 2);
@@ -204,6 +225,14 @@ int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const fl
 }
 
 __global__ void dib_write_desc_kernel(DibGemmGroup* dst, DibGemmGroup g) { *dst = g; }
+
+template <int MODE>
+int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const float* B, float* C, const float* bias,
+                const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
+                long long split_stride, hipStream_t st) {
+  return launch_gemm<MODE>(l->dev_groups, c, A, B, C, bias, aux, bias_out, batch, act, nsplit, rows_per_split, split_stride,
+                           st);
+}
 
 inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
   return (int)std::max<int64_t>(1, std::min<int64_t>((n + per_block - 1) / per_block, cap));
@@ -236,6 +265,11 @@ static int launch_fused_fwd(const DibFusedFwdArgs& a, int gx, int F, hipStream_t
   return (int)hipGetLastError();
 }
 
+// Persistent grid of the fused kernels: gx workgroups per feature, each looping over batch tiles.  One workgroup fills a
+// CU (150 KB of LDS), so gx = floor(256 / F): the whole grid is co-resident.  (Rounding UP - the round-1 rule - gave F = 50
+// 6 x 50 = 300 workgroups on 256 CUs: a second, 17 %-full wave of workgroups doubled the kernel time.)
+static int fused_gx(const dib_layout* l, int batch) { return std::max(1, std::min(cdiv(batch, 256), std::max(1, 256 / l->F))); }
+
 static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w, const float* x, int64_t ldx,
                              const int32_t* row_idx, int64_t row0, int batch, const float* params, uint64_t seed,
                              uint32_t step, int deterministic, hipStream_t st, int* gx_out) {
@@ -249,8 +283,7 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.h2mask = (unsigned long long*)(w + m.h2mask);
   if (deterministic & DIB_FWD_INFERENCE) { a.h1 = nullptr; a.h2 = nullptr; a.h2mask = nullptr; }  // no backward follows
   a.step_dev = l->step_dev;
-  const int n_tiles = cdiv(batch, 256);
-  const int gx = std::max(1, std::min(n_tiles, cdiv(256, l->F)));
+  const int gx = fused_gx(l, batch);
   *gx_out = gx;
   ProfScope ps(kProfFusedFwd, st);
   switch (l->fused_id) {
@@ -287,7 +320,7 @@ static bool fused_bwd_ok(const dib_layout* l) {
     if (l->in_dim[f] > 15) return false;  // row in_dim of the 16-row d(W1|b1) tile carries the bias gradient
   return true;
 }
-static int fused_gx(const dib_layout* l, int batch) { return std::max(1, std::min(cdiv(batch, 256), cdiv(256, l->F))); }
+
 
 static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params,
                              const float* beta_dev, float inv_bg, const int32_t* row_idx, int64_t row0, uint64_t seed,
@@ -554,7 +587,10 @@ int64_t dib_workspace_offset(const dib_layout* l, int batch, int which) {
     case DIB_WS_G_U: o = m.g_u; break;
     case DIB_WS_STEP_OUT: o = m.step_out; break;
     case DIB_WS_G_PRED: o = m.g_pred; break;
-    default: return DIB_E_ARG;
+    default:
+      if (which >= DIB_WS_ENC_H0 && which < DIB_WS_ENC_H0 + l->n_enc) o = m.enc_h[which - DIB_WS_ENC_H0];
+      else if (which >= DIB_WS_INT_H0 && which < DIB_WS_INT_H0 + l->n_int) o = m.int_h[which - DIB_WS_INT_H0];
+      else return DIB_E_ARG;
   }
   return o * (int64_t)sizeof(float);
 }
@@ -658,12 +694,8 @@ int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, 
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2), dim3(256), 0, st, w + m.loss_partial, m.loss_blocks, 2,
-                     w + m.step_out + l->F); }
-  rc = (int)hipGetLastError();
-  if (rc) return rc;
-  { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_set_scalar_kernel, dim3(1), dim3(1), 0, st, w + m.step_out + l->F + 2, (float)batch); }
+  hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), m.loss_blocks,
+                     (float)batch, w + m.step_out + l->F); }
   return (int)hipGetLastError();
 }
 
@@ -741,7 +773,8 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
     const float* hin = ly == 0 ? w + m.P : w + m.enc_h[ly - 1];
     // narrow outputs (the 2E-wide last layer) run 128x64 tiles at 4 workgroups/CU: half as many, twice as long batch
     // splits fill the chip in one wave (measured 0.88 -> 0.71 ms); the unused slabs of these blocks stay zero.
-    const bool halve = l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 16 && (m.nsplit % 2) == 0;
+    // (only from 32 splits = 16384 rows up: at B = 8192 the 16 -> 8 split halving measured 117 vs 103 us)
+    const bool halve = knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
     rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0,
                         halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, st);
     if (rc) return rc;
@@ -810,11 +843,7 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
   hipStream_t st = (hipStream_t)stream;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
-                     lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale); }
-  int rc = (int)hipGetLastError();
-  if (rc) return rc;
-  { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev); }
+                     lr_dev, (long long*)t_dev, beta1, beta2, eps, grad_scale); }
   return (int)hipGetLastError();
 }
 
@@ -997,6 +1026,165 @@ int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float
   else  // single split over the whole contraction; bias (if given) receives the column sums of B
     hipLaunchKernelGGL((dib_gemm_kernel<2, 2, 2, 32>), dim3(1, tm * tn, 1), dim3(256), 0, st, dg, A, B, C,
                        (const float*)nullptr, aux, (float*)bias, 0, act, tm, tn, K, 0ll);
+  return (int)hipGetLastError();
+}
+
+
+// ---- set-transformer building blocks (include/dib_st.h) ----------------------------------------------------------------
+static_assert(sizeof(dib_gemm_desc) == sizeof(DibGemmGroup), "public descriptor must mirror the kernel's group struct");
+
+int dib_gemm_grouped(int mode, int n_groups, const dib_gemm_desc* dev_desc, int max_m, int max_n, const float* A,
+                     const float* B, float* C, const float* bias, const float* aux, float* bias_out, int act, int nsplit,
+                     int rows_per_split, int64_t split_stride, dib_stream_t stream) {
+  if (!dev_desc || !A || !B || !C || n_groups <= 0 || max_m <= 0 || max_n <= 0 || mode < 0 || mode > 2 || !act_ok(act))
+    return DIB_E_ARG;
+  if (mode == 2 && (nsplit <= 0 || rows_per_split <= 0)) return DIB_E_ARG;
+  GemmCall c;
+  c.first = 0; c.count = n_groups; c.max_m = max_m; c.max_n = max_n;
+  const DibGemmGroup* g = reinterpret_cast<const DibGemmGroup*>(dev_desc);
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case 0: return launch_gemm<0>(g, c, A, B, C, bias, aux, nullptr, 0, act, 1, 0, 0, st);
+    case 1: return launch_gemm<1>(g, c, A, B, C, nullptr, aux, nullptr, 0, act, 1, 0, 0, st);
+    default: return launch_gemm<2>(g, c, A, B, C, nullptr, nullptr, bias_out, 0, 0, nsplit, rows_per_split,
+                                   (long long)split_stride, st);
+  }
+}
+
+int dib_softmax_rows_fwd(float* S, int64_t rows, int P, int ld, float scale, dib_stream_t stream) {
+  if (!S || rows <= 0 || P <= 0 || ld < P) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_softmax_rows_fwd_kernel, dim3(grid_for(rows, 4, 4096)), dim3(256), 0, (hipStream_t)stream, S,
+                     (long long)rows, P, ld, scale);
+  return (int)hipGetLastError();
+}
+
+int dib_softmax_rows_bwd(const float* Pm, float* dP, int64_t rows, int P, int ld, float scale, dib_stream_t stream) {
+  if (!Pm || !dP || rows <= 0 || P <= 0 || ld < P) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_softmax_rows_bwd_kernel, dim3(grid_for(rows, 4, 4096)), dim3(256), 0, (hipStream_t)stream, Pm, dP,
+                     (long long)rows, P, ld, scale);
+  return (int)hipGetLastError();
+}
+
+static int ln_grid(int64_t T, int D) { return grid_for(T, D <= 32 ? 8 : 4, 512); }
+
+int dib_add_layernorm_fwd(const float* a, const float* b, int64_t T, int D, const float* gamma, const float* beta,
+                          float eps, float* y, float* xhat, float* rstd, dib_stream_t stream) {
+  if (!a || !b || !gamma || !beta || !y || !xhat || !rstd || T <= 0 || D <= 0) return DIB_E_ARG;
+  if (D > 256) return DIB_E_UNSUPPORTED;
+  if (D <= 32)
+    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<32>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       (long long)T, D, gamma, beta, eps, y, xhat, rstd);
+  else
+    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<64>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       (long long)T, D, gamma, beta, eps, y, xhat, rstd);
+  return (int)hipGetLastError();
+}
+
+int64_t dib_add_layernorm_bwd_workspace_bytes(int64_t T, int D) {
+  if (T <= 0 || D <= 0 || D > 256) return DIB_E_ARG;
+  return (int64_t)ln_grid(T, D) * 4 * (D <= 32 ? 2 : 1) * 2 * D * (int64_t)sizeof(float);
+}
+
+int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t T, int D,
+                          float* ds, float* dgamma_dbeta, void* ws, dib_stream_t stream) {
+  if (!dy || !xhat || !rstd || !gamma || !ds || !dgamma_dbeta || !ws || T <= 0 || D <= 0) return DIB_E_ARG;
+  if (D > 256) return DIB_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ln_grid(T, D);
+  float* partial = (float*)ws;
+  if (D <= 32)
+    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<32>, dim3(grid), dim3(256), 0, st, dy, xhat, rstd, gamma, (long long)T, D,
+                       ds, partial);
+  else
+    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, dy, xhat, rstd, gamma, (long long)T, D,
+                       ds, partial);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  // [gamma gradient (D) | beta gradient (D)] = fixed-order column sums of the per-slot partials
+  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2 * D), dim3(256), 0, st, (const float*)partial,
+                     grid * 4 * (D <= 32 ? 2 : 1), 2 * D, dgamma_dbeta);
+  return (int)hipGetLastError();
+}
+
+int dib_mean_pool_fwd(const float* x, int B, int P, int D, float* out, dib_stream_t stream) {
+  if (!x || !out || B <= 0 || P <= 0 || D <= 0) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_mean_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, B, P, D, out);
+  return (int)hipGetLastError();
+}
+
+int dib_mean_pool_bwd(const float* g, int B, int P, int D, float* dx, dib_stream_t stream) {
+  if (!g || !dx || B <= 0 || P <= 0 || D <= 0) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_mean_pool_bwd_kernel, dim3(grid_for((int64_t)B * P * D)), dim3(256), 0, (hipStream_t)stream, g, B, P,
+                     D, dx);
+  return (int)hipGetLastError();
+}
+
+int dib_add_inplace(float* dst, const float* src, int64_t n, dib_stream_t stream) {
+  if (!dst || !src || n <= 0) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, (long long)n);
+  return (int)hipGetLastError();
+}
+
+int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* out, dib_stream_t stream) {
+  if (!g || !y || !out || n <= 0 || !act_ok(act)) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_act_grad_mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, y, act, (long long)n, out);
+  return (int)hipGetLastError();
+}
+
+int64_t dib_token_kl_workspace_bytes(int64_t T, int E) {
+  if (T <= 0 || E <= 0 || (E + 3) / 4 > 256) return DIB_E_ARG;
+  return (int64_t)cdiv(T, std::max(1, 256 / ((E + 3) / 4))) * (int64_t)sizeof(float);
+}
+
+int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logvar_offset, uint64_t seed, uint32_t step,
+                             int64_t row0, int deterministic, float* u, float* kl_sum, void* ws, dib_stream_t stream) {
+  if (!enc_out || !u || !kl_sum || !ws || T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256) return DIB_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = cdiv(T, std::max(1, 256 / ((E + 3) / 4)));
+  hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(blocks, 1), dim3(256), 0, st, enc_out, u, (float*)ws, (const int*)nullptr,
+                     (long long)row0, (int)T, 1, E, (unsigned long long)seed, (unsigned)step, deterministic ? 1 : 0,
+                     (const unsigned*)nullptr, logvar_offset);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, 1, kl_sum);
+  return (int)hipGetLastError();
+}
+
+int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, int64_t T, int E, float logvar_offset,
+                             const float* beta_dev, float inv_batch, uint64_t seed, uint32_t step, int64_t row0,
+                             float* d_enc_out, dib_stream_t stream) {
+  if (!enc_out || !g_u || !beta_dev || !d_enc_out || T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256)
+    return DIB_E_ARG;
+  const int blocks = cdiv(T, std::max(1, 256 / ((E + 3) / 4)));
+  hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, enc_out, g_u, d_enc_out,
+                     beta_dev, inv_batch, (const int*)nullptr, (long long)row0, (int)T, 1, E, (unsigned long long)seed,
+                     (unsigned)step, (const unsigned*)nullptr, logvar_offset);
+  return (int)hipGetLastError();
+}
+
+int64_t dib_loss_rows_workspace_bytes(int batch) {
+  if (batch <= 0) return DIB_E_ARG;
+  return (int64_t)cdiv(batch, 256) * 2 * (int64_t)sizeof(float);
+}
+
+int dib_loss_rows(int loss_kind, const float* pred, int out_dim, const float* y, int64_t ldy, int batch,
+                  float inv_global_batch, float* g_pred, float* out3, void* ws, dib_stream_t stream) {
+  if (!pred || !y || !g_pred || !out3 || !ws || batch <= 0 || out_dim <= 0) return DIB_E_ARG;
+  if (loss_kind < 0 || loss_kind > 3) return DIB_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = cdiv(batch, 256);
+  hipLaunchKernelGGL(dib_loss_kernel, dim3(blocks), dim3(256), 0, st, loss_kind, pred, out_dim, y, (long long)ldy,
+                     (const int*)nullptr, 0ll, batch, inv_global_batch, 0, g_pred, (float*)ws);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)ws, blocks, (float)batch, out3);
+  return (int)hipGetLastError();
+}
+
+int dib_reduce_splits(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream) {
+  if (!partial || !out || n <= 0 || nsplit <= 0 || (n & 3) || (stride & 3)) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial,
+                     (long long)n, nsplit, (long long)stride, out);
   return (int)hipGetLastError();
 }
 

@@ -74,6 +74,7 @@ __device__ __forceinline__ float dib_act(int act, float z) {
     case 4: return 1.0f / (1.0f + expf(-z));
     case 5: return z > 0.0f ? z : expm1f(z);
     case 6: return fmaxf(z, 0.0f) + log1pf(expf(-fabsf(z)));
+    case 7: return z > 0.0f ? z : 0.1f * z;   // tf.keras.layers.LeakyReLU(0.1) of the set-transformer notebook
     default: return z;
   }
 }
@@ -86,6 +87,7 @@ __device__ __forceinline__ float dib_act_grad(int act, float y) {
     case 4: return y * (1.0f - y);
     case 5: return y > 0.0f ? 1.0f : y + 1.0f;
     case 6: return 1.0f - expf(-y);
+    case 7: return y > 0.0f ? 1.0f : 0.1f;
     default: return 1.0f;
   }
 }

@@ -55,7 +55,8 @@ dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restr
 __global__ void __launch_bounds__(256)
 dib_reparam_kl_fwd_kernel(const float* __restrict__ enc_out, float* __restrict__ U, float* __restrict__ kl_partial,
                           const int* __restrict__ row_idx, long long row0, int batch, int F, int E,
-                          unsigned long long seed, unsigned step, int deterministic, const unsigned* step_dev) {
+                          unsigned long long seed, unsigned step, int deterministic, const unsigned* step_dev,
+                          float lv_off = 0.f /* set transformer: logvar += -3 before sampling / KL */) {
   __shared__ float red[4];
   if (step_dev) step = step_dev[0];
   const int E4 = (E + 3) >> 2;
@@ -73,7 +74,8 @@ dib_reparam_kl_fwd_kernel(const float* __restrict__ enc_out, float* __restrict__
     if (!deterministic) dib_eps4(seed, step, (uint32_t)grow, (uint32_t)f, (uint32_t)q, eps);
     if ((E & 3) == 0) {
       const float4 mu = *reinterpret_cast<const float4*>(mu_p);
-      const float4 lv = *reinterpret_cast<const float4*>(lv_p);
+      float4 lv = *reinterpret_cast<const float4*>(lv_p);
+      lv.x += lv_off; lv.y += lv_off; lv.z += lv_off; lv.w += lv_off;
       float4 u;
       u.x = mu.x + expf(0.5f * lv.x) * eps[0];
       u.y = mu.y + expf(0.5f * lv.y) * eps[1];
@@ -85,7 +87,7 @@ dib_reparam_kl_fwd_kernel(const float* __restrict__ enc_out, float* __restrict__
     } else {
       for (int j = 0; j < 4; ++j) {
         if (4 * q + j < E) {
-          const float mu = mu_p[j], lv = lv_p[j];
+          const float mu = mu_p[j], lv = lv_p[j] + lv_off;
           u_p[j] = mu + expf(0.5f * lv) * eps[j];
           klp += 0.5f * (mu * mu + expf(lv) - lv - 1.f);
         }
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(256)
 dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __restrict__ GU,
                           float* __restrict__ dout, const float* __restrict__ beta_dev, float inv_bg,
                           const int* __restrict__ row_idx, long long row0, int batch, int F, int E,
-                          unsigned long long seed, unsigned step, const unsigned* step_dev) {
+                          unsigned long long seed, unsigned step, const unsigned* step_dev, float lv_off = 0.f) {
   if (step_dev) step = step_dev[0];
   const int E4 = (E + 3) >> 2;
   const int rows_per_block = 256 / E4;
@@ -130,7 +132,8 @@ dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __rest
   dib_eps4(seed, step, (uint32_t)grow, (uint32_t)f, (uint32_t)q, eps);
   if ((E & 3) == 0) {
     const float4 mu = *reinterpret_cast<const float4*>(enc_out + o);
-    const float4 lv = *reinterpret_cast<const float4*>(enc_out + o + E);
+    float4 lv = *reinterpret_cast<const float4*>(enc_out + o + E);
+    lv.x += lv_off; lv.y += lv_off; lv.z += lv_off; lv.w += lv_off;
     const float4 gu = *reinterpret_cast<const float4*>(gu_p);
     float4 dm, dl;
     dm.x = gu.x + kb * mu.x; dm.y = gu.y + kb * mu.y; dm.z = gu.z + kb * mu.z; dm.w = gu.w + kb * mu.w;
@@ -143,7 +146,7 @@ dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __rest
   } else {
     for (int j = 0; j < 4; ++j) {
       if (4 * q + j < E) {
-        const float mu = enc_out[o + j], lv = enc_out[o + E + j], gu = gu_p[j];
+        const float mu = enc_out[o + j], lv = enc_out[o + E + j] + lv_off, gu = gu_p[j];
         dout[o + j] = gu + kb * mu;
         dout[o + E + j] = gu * eps[j] * 0.5f * expf(0.5f * lv) + kb * 0.5f * (expf(lv) - 1.f);
       }
@@ -282,13 +285,18 @@ dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsp
 // ---------------------------------------------------------------------------------------------
 // Keras Adam (reference train.py:128-129 tf.keras.optimizers.get('adam')):
 //   m += (1-b1)(g-m); v += (1-b2)(g^2-v); theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)
-// t = *t_dev + 1 (device counter, bumped by dib_bump_counter_kernel afterwards).
+// t = *t_dev + 1.  The device step counter is bumped INSIDE this kernel by the last workgroup to finish (one launch less
+// per step): t_dev is an int64 whose low word is the step count and whose high word is used as the arrival counter - it
+// is back to 0 when the kernel ends, so the host still reads a plain int64 step count.  Every workgroup reads t at its
+// start and arrives at its end, so nobody can observe the bumped value within the launch.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 dib_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                long long n, const float* __restrict__ lr_dev, const long long* __restrict__ t_dev, float b1,
+                long long n, const float* __restrict__ lr_dev, long long* __restrict__ t_dev, float b1,
                 float b2, float eps, float gscale) {
-  const float t = (float)(t_dev[0] + 1);
+  const int t_old = reinterpret_cast<const int*>(t_dev)[0];  // uniform address: one scalar load per wave (a volatile load here
+                                                             // serialised 556 k uncached reads of one word: +40 us)
+  const float t = (float)(t_old + 1);
   const float lr_t = lr_dev[0] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
   const long long n4 = n >> 2;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
@@ -319,9 +327,30 @@ dib_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
     v[i] = vv;
     p[i] -= lr_t * mm / (sqrtf(vv) + eps);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* arrive = reinterpret_cast<unsigned*>(t_dev) + 1;
+    if (atomicAdd(arrive, 1u) == gridDim.x - 1) {  // last workgroup: everyone has read t_old
+      *arrive = 0u;
+      reinterpret_cast<int*>(t_dev)[0] = t_old + 1;
+    }
+  }
 }
 
-__global__ void dib_bump_counter_kernel(long long* t) { t[0] += 1; }
+// loss second stage: step_out[F] = task-loss sum, step_out[F+1] = #correct (fixed-order sums of the per-block partials),
+// step_out[F+2] = rows.  grid = 2 workgroups.
+__global__ void __launch_bounds__(256)
+dib_loss_finalize_kernel(const float* __restrict__ partial, int nblocks, float rows, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int f = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[(long long)i * 2 + f];
+  const float tot = dib_block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    out[f] = tot;
+    if (f == 0) out[2] = rows;
+  }
+}
 
 __global__ void __launch_bounds__(256)
 dib_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, long long n, const float* __restrict__ lr_dev,

@@ -336,6 +336,16 @@ class HipEngine:
         return self.ws_view(batch, _lib.WS_ENC_OUT, batch * self.F * 2 * self.E).view(self.F, batch, 2 * self.E) \
             .permute(1, 0, 2)
 
+    def enc_h(self, batch: int, layer: int) -> torch.Tensor:
+        """post-activation output of encoder hidden layer `layer` as stashed by the training forward: [F, B, units]."""
+        w = self.enc_units[layer]
+        return self.ws_view(batch, _lib.WS_ENC_H0 + layer, batch * self.F * w).view(self.F, batch, w)
+
+    def int_h(self, batch: int, layer: int) -> torch.Tensor:
+        """post-activation output of integration hidden layer `layer`: [B, units]."""
+        w = self.int_units[layer]
+        return self.ws_view(batch, _lib.WS_INT_H0 + layer, batch * w).view(batch, w)
+
     def g_u(self, batch: int) -> torch.Tensor:
         return self.ws_view(batch, _lib.WS_G_U, batch * self.F * self.E).view(batch, self.F * self.E)
 

@@ -1,0 +1,627 @@
+"""Per-particle Distributed-IB set transformer on the MI355X-native path (BASELINE config 5).
+
+Host-side mirror of the reference notebook
+    complex_systems/InfoDecomp_Amorphous_plasticity_per_particle_measurements_and_set_transformer.ipynb, code cell 8:
+`particle_encoder` (PositionalEncoding -> Dense(128, LeakyReLU(0.1)) x2 -> Dense(2*32), shared by all particles), the
+`train_step` bottleneck (logvar - 3, reparameterised sample, KL summed over (particle, dim) and averaged over the batch),
+`set_transformer` (6 x [MultiHeadAttention(12, 128)(x, x, x) -> Add -> LayerNormalization -> Dense(128, relu),
+Dense(32, relu) -> Add -> LayerNormalization], tf.reduce_mean over the particle axis, Dense(256, LeakyReLU(0.1)), Dense(1)),
+BCE-from-logits + beta * KL, Keras Adam, the linear learning-rate warm-up and the per-STEP log ramp of beta of the
+notebook's training loop.  Same names and argument meaning as the notebook's variables.
+
+Every FLOP runs in libdib_hip.so through the C ABI of include/dib_st.h: all matrix products (encoder, q/k/v/output
+projections, the per-(neighbourhood, head) Q K^T, P V and their four backward products, feed-forward, head, every weight
+gradient) on the grouped fp32-MFMA GEMM (`dib_gemm_grouped`, 12 x batch groups per launch for the attention products),
+softmax / Add+LayerNorm / mean-pool / reparameterisation+KL / loss / Adam as HBM-bound row kernels.  PyTorch only owns the
+device memory.  There is no CPU fallback.
+
+Parameters live in one flat fp32 buffer in Keras variable-creation order (`param_shapes`, the order of
+`particle_encoder.trainable_variables + set_transformer.trainable_variables`), every block 16-byte aligned.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from ctypes import c_void_p
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+DESC = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("c_off", "<i8"), ("bias_off", "<i8"), ("aux_off", "<i8"),
+                 ("a_boff", "<i8"), ("b_boff", "<i8"), ("c_boff", "<i8"), ("aux_boff", "<i8"),
+                 ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"), ("ldaux", "<i4"),
+                 ("flags", "<i4")])
+assert DESC.itemsize == 104  # include/dib_st.h: dib_gemm_desc
+
+ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, _lib.ACT_LEAKY_RELU_01
+LOSS_BCE_LOGITS = 0
+
+
+def _ptr(t: Optional[torch.Tensor], off: int = 0):
+    return c_void_p(t.data_ptr() + 4 * off) if t is not None else c_void_p(0)
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def convert_to_per_particle_feature_set(particle_positions, types, number_particles_to_use=60):
+    """Notebook cell 6: per-particle features (x, x^2, r, log r, log x^2, unit vector, one-hot type), nearest particles
+    first.  Host-side data preparation (NumPy), done once per dataset."""
+    pos = np.asarray(particle_positions, dtype=np.float32)
+    types = np.asarray(types).astype(np.int32)
+    one_hot = np.eye(2, dtype=np.float32)[types - 1]
+    radii = np.sqrt(np.sum(np.square(pos), -1, keepdims=True) + np.float32(1e-10)).astype(np.float32)
+    unit = pos / radii
+    feats = np.concatenate([pos, pos ** 2, radii, np.log(radii + np.float32(1e-3)), np.log(pos ** 2 + np.float32(1e-3)),
+                            unit, one_hot], -1).astype(np.float32)
+    if number_particles_to_use > 0:
+        order = np.argsort(np.squeeze(radii, -1), kind="stable")
+        feats = feats[order][:number_particles_to_use]
+    return feats
+
+
+class _Gemm:
+    """One grouped-GEMM launch: a device descriptor table + base tensors."""
+
+    def __init__(self, mode, descs, A, B, C, bias=None, aux=None, bias_out=None, act=0, nsplit=1, rows_per_split=0,
+                 split_stride=0):
+        self.mode, self.n = mode, len(descs)
+        self.max_m = int(max(d["M"] for d in descs))
+        self.max_n = int(max(d["N"] for d in descs))
+        arr = np.zeros(len(descs), dtype=DESC)
+        for i, d in enumerate(descs):
+            for k, v in d.items():
+                arr[i][k] = v
+        self.host = arr
+        self.dev = None
+        self.A, self.B, self.C, self.bias, self.aux, self.bias_out = A, B, C, bias, aux, bias_out
+        self.act, self.nsplit, self.rps, self.stride = act, nsplit, rows_per_split, split_stride
+
+    def upload(self, device):
+        self.dev = torch.from_numpy(self.host.view(np.uint8).copy()).to(device)
+
+    def run(self, lib, stream):
+        check(lib.dib_gemm_grouped(self.mode, self.n, _ptr(self.dev), self.max_m, self.max_n, _ptr(self.A), _ptr(self.B),
+                                   _ptr(self.C), _ptr(self.bias), _ptr(self.aux), _ptr(self.bias_out), self.act, self.nsplit,
+                                   self.rps, self.stride, stream), "dib_gemm_grouped")
+
+
+def _d(a_off, lda, b_off, ldb, c_off, ldc, M, N, K, bias_off=-1, aux_off=0, ldaux=0):
+    return dict(a_off=a_off, b_off=b_off, c_off=c_off, bias_off=bias_off, aux_off=aux_off, M=M, N=N, K=K, lda=lda, ldb=ldb,
+                ldc=ldc, ldaux=ldaux)
+
+
+class SetTransformerDIB:
+    """`particle_encoder` + `set_transformer` + `train_step` of the notebook as one device-resident object."""
+
+    def __init__(self, particle_feature_dimensions: int = 12, number_positional_encoding_frequencies: int = 5,
+                 particle_encoder_arch_spec: Sequence[int] = (128, 128), bottleneck_dimension: int = 32, key_dim: int = 128,
+                 number_heads_per_mha: int = 12, number_attention_blocks: int = 6,
+                 ff_arch_per_block: Sequence[int] = (128, 32), final_processing_arch: Sequence[int] = (256,),
+                 output_dimensionality: int = 1, logvar_initialization: float = -3.0, layer_norm_epsilon: float = 1e-3,
+                 *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.lib = _lib.load_library()
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.particle_feature_dimensions = int(particle_feature_dimensions)
+        self.number_positional_encoding_frequencies = int(number_positional_encoding_frequencies)
+        self.particle_encoder_arch_spec = [int(u) for u in particle_encoder_arch_spec]
+        self.bottleneck_dimension = int(bottleneck_dimension)
+        self.key_dim, self.number_heads_per_mha = int(key_dim), int(number_heads_per_mha)
+        self.number_attention_blocks = int(number_attention_blocks)
+        self.ff_arch_per_block = [int(u) for u in ff_arch_per_block]
+        assert self.ff_arch_per_block[-1] == self.bottleneck_dimension, "the feed-forward block must return to the model width"
+        self.final_processing_arch = [int(u) for u in final_processing_arch]
+        self.output_dimensionality = int(output_dimensionality)
+        self.logvar_initialization = float(logvar_initialization)
+        self.layer_norm_epsilon = float(layer_norm_epsilon)
+        self.noise_seed = int(noise_seed)
+        assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
+        # ---- flat parameter layout (Keras creation order) ----
+        self.shapes = self.param_shapes()
+        self.offsets: Dict[str, int] = {}
+        o = 0
+        for name, shp in self.shapes.items():
+            self.offsets[name] = o
+            o = _align4(o + int(np.prod(shp)))
+        self.n_alloc = o
+        self.n_params = int(sum(int(np.prod(s)) for s in self.shapes.values()))
+        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
+        self.params, self.grads, self.adam_m, self.adam_v = z(o), z(o), z(o), z(o)
+        self.beta_dev = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.lr_dev = torch.full((1,), 1e-4, dtype=torch.float32, device=self.device)
+        self.t_dev = z(1, torch.int64)
+        self.set_params(self.init_params(init_seed))
+        self._plans: Dict[Tuple[int, int], dict] = {}
+        self._step = 0
+        self.last = {}
+
+    # ---- parameters ---------------------------------------------------------------------------------------------
+    def param_shapes(self) -> Dict[str, tuple]:
+        """Keras creation order.  Kernels [in, out]; MultiHeadAttention kernels [dim, heads, key_dim] / [heads, key_dim, dim]."""
+        s: Dict[str, tuple] = {}
+        d_in = self.particle_feature_dimensions * self.number_positional_encoding_frequencies
+        for l, u in enumerate(self.particle_encoder_arch_spec + [2 * self.bottleneck_dimension]):
+            s[f"enc{l}_w"], s[f"enc{l}_b"] = (d_in, u), (u,)
+            d_in = u
+        D, H, K = self.bottleneck_dimension, self.number_heads_per_mha, self.key_dim
+        for b in range(self.number_attention_blocks):
+            for nm in ("q", "k", "v"):
+                s[f"blk{b}_{nm}_w"], s[f"blk{b}_{nm}_b"] = (D, H, K), (H, K)
+            s[f"blk{b}_o_w"], s[f"blk{b}_o_b"] = (H, K, D), (D,)
+            s[f"blk{b}_ln1_g"], s[f"blk{b}_ln1_b"] = (D,), (D,)
+            d = D
+            for l, u in enumerate(self.ff_arch_per_block):
+                s[f"blk{b}_ff{l}_w"], s[f"blk{b}_ff{l}_b"] = (d, u), (u,)
+                d = u
+            s[f"blk{b}_ln2_g"], s[f"blk{b}_ln2_b"] = (D,), (D,)
+        d = D
+        for l, u in enumerate(self.final_processing_arch):
+            s[f"fin{l}_w"], s[f"fin{l}_b"] = (d, u), (u,)
+            d = u
+        s["out_w"], s["out_b"] = (d, self.output_dimensionality), (self.output_dimensionality,)
+        return s
+
+    def init_params(self, seed: int = 0) -> Dict[str, np.ndarray]:
+        """Keras defaults: glorot-uniform kernels (receptive-field fan convention for the attention einsum kernels), zero
+        biases, LayerNormalization gamma = 1, beta = 0."""
+        rng = np.random.default_rng(seed)
+        p = {}
+        for name, shp in self.shapes.items():
+            if name.endswith("_g"):
+                a = np.ones(shp)
+            elif name.endswith("_b"):
+                a = np.zeros(shp)
+            else:
+                if len(shp) == 2:
+                    fan_in, fan_out = shp
+                elif "_o_w" in name:
+                    fan_in, fan_out = shp[0] * shp[1], shp[2]
+                else:
+                    fan_in, fan_out = shp[0], shp[1] * shp[2]
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                a = rng.uniform(-lim, lim, size=shp)
+            p[name] = a.astype(np.float32)
+        return p
+
+    def set_params(self, p: Dict[str, np.ndarray]) -> None:
+        flat = np.zeros(self.n_alloc, dtype=np.float32)
+        for name, shp in self.shapes.items():
+            a = np.asarray(p[name], dtype=np.float32).reshape(-1)
+            assert a.size == int(np.prod(shp)), name
+            flat[self.offsets[name]: self.offsets[name] + a.size] = a
+        self.params.copy_(torch.from_numpy(flat))
+
+    def _unflatten(self, t: torch.Tensor) -> Dict[str, np.ndarray]:
+        flat = t.detach().cpu().numpy()
+        return {name: flat[self.offsets[name]: self.offsets[name] + int(np.prod(shp))].reshape(shp).copy()
+                for name, shp in self.shapes.items()}
+
+    def get_params(self) -> Dict[str, np.ndarray]:
+        return self._unflatten(self.params)
+
+    def get_grads(self) -> Dict[str, np.ndarray]:
+        return self._unflatten(self.grads)
+
+    @property
+    def trainable_variables(self) -> List[torch.Tensor]:
+        """particle_encoder.trainable_variables + set_transformer.trainable_variables: views into the flat buffer."""
+        return [self.params[self.offsets[n]: self.offsets[n] + int(np.prod(s))].view(*s) for n, s in self.shapes.items()]
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.t_dev.zero_()
+
+    # ---- plan: workspace map + descriptor tables for a (batch, particles) shape ------------------------------------------
+    def _stream(self):
+        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _plan(self, B: int, P: int) -> dict:
+        key = (B, P)
+        if key in self._plans:
+            return self._plans[key]
+        D, H, K = self.bottleneck_dimension, self.number_heads_per_mha, self.key_dim
+        HK, T = H * K, B * P
+        ldS = _align4(P)
+        F0 = self.particle_feature_dimensions
+        pe_w = F0 * self.number_positional_encoding_frequencies
+        enc_units = self.particle_encoder_arch_spec + [2 * D]
+        ff = self.ff_arch_per_block
+        off: Dict[str, int] = {}
+        o = 0
+
+        def take(name, n):
+            nonlocal o
+            off[name] = o
+            o = _align4(o + int(n)) + 0
+            return off[name]
+
+        take("feats", T * F0)
+        take("pe", T * pe_w)
+        for l, u in enumerate(enc_units):
+            take(f"enc_h{l}", T * u)                # last one = enc_out (mu | raw logvar)
+        take("x0", T * D)                           # u = sampled embeddings
+        for b in range(self.number_attention_blocks):
+            for nm in ("q", "k", "v", "ctx"):
+                take(f"b{b}_{nm}", T * HK)
+            take(f"b{b}_S", B * H * P * ldS)        # attention probabilities
+            take(f"b{b}_mha", T * D)
+            take(f"b{b}_xhat1", T * D); take(f"b{b}_rstd1", T); take(f"b{b}_h", T * D)
+            d = D
+            for l, u in enumerate(ff):
+                take(f"b{b}_ff{l}", T * u)
+            take(f"b{b}_xhat2", T * D); take(f"b{b}_rstd2", T); take(f"b{b}_x", T * D)
+        take("pool", B * D)
+        for l, u in enumerate(self.final_processing_arch):
+            take(f"fin{l}", B * u)
+        take("pred", B * self.output_dimensionality)
+        take("g_pred", B * self.output_dimensionality)
+        take("out3", 4)
+        take("kl_sum", 4)
+        # backward scratch (reused by every block)
+        for l, u in enumerate(self.final_processing_arch):
+            take(f"g_fin{l}", B * u)
+        take("g_pool", B * D)
+        take("g_x", T * D); take("g_s", T * D); take("g_z", T * D); take("g_h", T * D)
+        for l, u in enumerate(ff[:-1]):
+            take(f"g_ff{l}", T * u)
+        for nm in ("q", "k", "v", "ctx"):
+            take(f"g_{nm}", T * HK)
+        take("g_S", B * H * P * ldS)
+        for nm in ("q", "k", "v"):
+            take(f"g_x{nm}", T * D)
+        for l, u in enumerate(enc_units):
+            take(f"g_enc_h{l}", T * u)
+        ln_ws = int(self.lib.dib_add_layernorm_bwd_workspace_bytes(T, D)) // 4
+        take("ln_ws", ln_ws)
+        take("kl_ws", int(self.lib.dib_token_kl_workspace_bytes(T, D)) // 4 + 4)
+        take("loss_ws", int(self.lib.dib_loss_rows_workspace_bytes(B)) // 4 + 4)
+        ws = torch.zeros(o, dtype=torch.float32, device=self.device)
+
+        # weight-gradient target: contraction over T tokens is split into slabs when T is large (fixed-order reduce)
+        nsplit = max(1, min(32, T // 1024))
+        rps = ((T + nsplit - 1) // nsplit + 31) // 32 * 32
+        nsplit = (T + rps - 1) // rps
+        slabs = torch.zeros(nsplit * self.n_alloc, dtype=torch.float32, device=self.device) if nsplit > 1 else None
+        gt = slabs if nsplit > 1 else self.grads
+        po = self.offsets
+
+        def dense_fwd(x, kin, w, b, y, kout, act, M):
+            return _Gemm(0, [_d(off[x], kin, po[w], kout, off[y], kout, M, kout, kin, bias_off=po[b])], ws, self.params, ws,
+                         bias=self.params, act=act)
+
+        def dense_dgrad(dy, kout, w, dx, kin, M, aux=None, act=0):
+            return _Gemm(1, [_d(off[dy], kout, po[w], kout, off[dx], kin, M, kin, kout,
+                                aux_off=off[aux] if aux else 0, ldaux=kin)], ws, self.params, ws,
+                         aux=ws if aux else None, act=act if aux else 0)
+
+        def dense_wgrad(x, kin, dy, kout, w, b, M, split=True):
+            ns, r = (nsplit, rps) if split else (1, max(M, 1))
+            return _Gemm(2, [_d(off[x], kin, off[dy], kout, po[w], kout, kin, kout, M, bias_off=po[b])], ws, ws, gt,
+                         bias_out=gt, nsplit=ns, rows_per_split=r, split_stride=self.n_alloc)
+
+        g: Dict[str, _Gemm] = {}
+        # particle encoder (shared by all particles): [T, 60] -> 128 -> 128 -> 64
+        kin, src = pe_w, "pe"
+        for l, u in enumerate(enc_units):
+            act = ACT_LEAKY01 if l < len(enc_units) - 1 else ACT_NONE
+            g[f"enc{l}_fwd"] = dense_fwd(src, kin, f"enc{l}_w", f"enc{l}_b", f"enc_h{l}", u, act, T)
+            g[f"enc{l}_wgrad"] = dense_wgrad(src, kin, f"g_enc_h{l}", u, f"enc{l}_w", f"enc{l}_b", T)
+            if l > 0:
+                g[f"enc{l}_dgrad"] = dense_dgrad(f"g_enc_h{l}", u, f"enc{l}_w", f"g_enc_h{l - 1}", kin, T, aux=f"enc_h{l - 1}",
+                                                 act=ACT_LEAKY01)
+            kin, src = u, f"enc_h{l}"
+        bh = [(b_, h_) for b_ in range(B) for h_ in range(H)]
+        for b in range(self.number_attention_blocks):
+            xin = "x0" if b == 0 else f"b{b - 1}_x"
+            pre = f"blk{b}_"
+            # q, k, v projections: 3 groups
+            g[f"b{b}_qkv_fwd"] = _Gemm(0, [_d(off[xin], D, po[pre + nm + "_w"], HK, off[f"b{b}_{nm}"], HK, T, HK, D,
+                                              bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, self.params, ws,
+                                       bias=self.params)
+            # scores S_bh = Q_bh K_bh^T (scale folded into the softmax)
+            g[f"b{b}_qk"] = _Gemm(1, [_d(off[f"b{b}_q"] + bi * P * HK + hi * K, HK, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
+                                         off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, P, P, K) for bi, hi in bh], ws, ws, ws)
+            # ctx_bh = P_bh V_bh
+            g[f"b{b}_pv"] = _Gemm(0, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
+                                         off[f"b{b}_ctx"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
+            g[f"b{b}_o_fwd"] = dense_fwd(f"b{b}_ctx", HK, pre + "o_w", pre + "o_b", f"b{b}_mha", D, ACT_NONE, T)
+            d, src = D, f"b{b}_h"
+            for l, u in enumerate(ff):
+                g[f"b{b}_ff{l}_fwd"] = dense_fwd(src, d, pre + f"ff{l}_w", pre + f"ff{l}_b", f"b{b}_ff{l}", u, ACT_RELU, T)
+                d, src = u, f"b{b}_ff{l}"
+            # ---- backward ----
+            # feed-forward: g_z = dL/d(pre-activation of the last ff layer)
+            nff = len(ff)
+            gy, ky = "g_z", ff[-1]
+            for l in range(nff - 1, -1, -1):
+                kin_l = D if l == 0 else ff[l - 1]
+                src_l = f"b{b}_h" if l == 0 else f"b{b}_ff{l - 1}"
+                g[f"b{b}_ff{l}_wgrad"] = dense_wgrad(src_l, kin_l, gy, ky, pre + f"ff{l}_w", pre + f"ff{l}_b", T)
+                if l > 0:
+                    g[f"b{b}_ff{l}_dgrad"] = dense_dgrad(gy, ky, pre + f"ff{l}_w", f"g_ff{l - 1}", kin_l, T, aux=src_l, act=ACT_RELU)
+                    gy, ky = f"g_ff{l - 1}", kin_l
+                else:
+                    g[f"b{b}_ff0_dgrad"] = dense_dgrad(gy, ky, pre + "ff0_w", "g_h", D, T)
+            # attention output projection
+            g[f"b{b}_o_wgrad"] = dense_wgrad(f"b{b}_ctx", HK, "g_s", D, pre + "o_w", pre + "o_b", T)
+            g[f"b{b}_o_dgrad"] = dense_dgrad("g_s", D, pre + "o_w", "g_ctx", HK, T)
+            g[f"b{b}_dv"] = _Gemm(2, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off["g_ctx"] + bi * P * HK + hi * K, HK,
+                                         off["g_v"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
+                                  nsplit=1, rows_per_split=max(P, 1))
+            g[f"b{b}_dp"] = _Gemm(1, [_d(off["g_ctx"] + bi * P * HK + hi * K, HK, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
+                                         off["g_S"] + (bi * H + hi) * P * ldS, ldS, P, P, K) for bi, hi in bh], ws, ws, ws)
+            g[f"b{b}_dq"] = _Gemm(0, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
+                                         off["g_q"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
+            g[f"b{b}_dk"] = _Gemm(2, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_q"] + bi * P * HK + hi * K, HK,
+                                         off["g_k"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
+                                  nsplit=1, rows_per_split=max(P, 1))
+            g[f"b{b}_qkv_wgrad"] = _Gemm(2, [_d(off[xin], D, off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, D, HK, T,
+                                                bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, ws, gt, bias_out=gt,
+                                         nsplit=nsplit, rows_per_split=rps, split_stride=self.n_alloc)
+            g[f"b{b}_qkv_dgrad"] = _Gemm(1, [_d(off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, off[f"g_x{nm}"], D, T, D, HK)
+                                             for nm in "qkv"], ws, self.params, ws)
+        # head: pooled [B, D] -> Dense(256, LeakyReLU(0.1)) -> Dense(out)
+        d, src = D, "pool"
+        for l, u in enumerate(self.final_processing_arch):
+            g[f"fin{l}_fwd"] = dense_fwd(src, d, f"fin{l}_w", f"fin{l}_b", f"fin{l}", u, ACT_LEAKY01, B)
+            d, src = u, f"fin{l}"
+        g["out_fwd"] = dense_fwd(src, d, "out_w", "out_b", "pred", self.output_dimensionality, ACT_NONE, B)
+        g["out_wgrad"] = dense_wgrad(src, d, "g_pred", self.output_dimensionality, "out_w", "out_b", B, split=False)
+        nfin = len(self.final_processing_arch)
+        if nfin:
+            g["out_dgrad"] = dense_dgrad("g_pred", self.output_dimensionality, "out_w", f"g_fin{nfin - 1}", d, B,
+                                         aux=f"fin{nfin - 1}", act=ACT_LEAKY01)
+        else:
+            g["out_dgrad"] = dense_dgrad("g_pred", self.output_dimensionality, "out_w", "g_pool", d, B)
+        for l in range(nfin - 1, -1, -1):
+            kin_l = D if l == 0 else self.final_processing_arch[l - 1]
+            src_l = "pool" if l == 0 else f"fin{l - 1}"
+            u = self.final_processing_arch[l]
+            g[f"fin{l}_wgrad"] = dense_wgrad(src_l, kin_l, f"g_fin{l}", u, f"fin{l}_w", f"fin{l}_b", B, split=False)
+            if l > 0:
+                g[f"fin{l}_dgrad"] = dense_dgrad(f"g_fin{l}", u, f"fin{l}_w", f"g_fin{l - 1}", kin_l, B, aux=src_l, act=ACT_LEAKY01)
+            else:
+                g["fin0_dgrad"] = dense_dgrad(f"g_fin{l}", u, "fin0_w", "g_pool", D, B)
+        for gg in g.values():
+            gg.upload(self.device)
+        plan = dict(B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
+                    enc_units=enc_units)
+        self._plans[key] = plan
+        return plan
+
+    def _view(self, plan, name, *shape):
+        o = plan["off"][name]
+        return plan["ws"][o: o + int(np.prod(shape))].view(*shape)
+
+    # ---- forward (notebook train_step, forward part) -------------------------------------------------------------------
+    def forward(self, batch_inp, step: Optional[int] = None, deterministic: bool = False, row0: int = 0,
+                embs_reparam=None) -> torch.Tensor:
+        """embs = particle_encoder(batch_inp); logvar - 3; reparameterised sample; kl; loci_prediction = set_transformer(u).
+        batch_inp [B, P, particle_feature_dimensions].  Returns the logits [B, out]; self.last holds kl (device scalar).
+        embs_reparam [B, P, bottleneck] (optional): use these sampled embeddings instead of the library's counter-based
+        noise (the notebook evaluates `set_transformer(tf.random.normal(...))` on its own samples; also how the golden
+        fixture, which carries its own noise, is replayed)."""
+        x = batch_inp if isinstance(batch_inp, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(batch_inp, dtype=np.float32))
+        x = x.to(device=self.device, dtype=torch.float32).contiguous()
+        B, P, F0 = x.shape
+        assert F0 == self.particle_feature_dimensions
+        pl = self._plan(B, P)
+        lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
+        T, D = pl["T"], self.bottleneck_dimension
+        step = self._step if step is None else int(step)
+        self._view(pl, "feats", T, F0).copy_(x.view(T, F0))
+        check(lib.dib_positional_encoding(_ptr(ws, off["feats"]), F0, T, F0, self.number_positional_encoding_frequencies,
+                                          _ptr(ws, off["pe"]), st), "dib_positional_encoding")
+        ne = len(pl["enc_units"])
+        for l in range(ne):
+            g[f"enc{l}_fwd"].run(lib, st)
+        check(lib.dib_token_reparam_kl_fwd(_ptr(ws, off[f"enc_h{ne - 1}"]), T, D, self.logvar_initialization, self.noise_seed,
+                                           step & 0xFFFFFFFF, int(row0), 1 if deterministic else 0, _ptr(ws, off["x0"]),
+                                           _ptr(ws, off["kl_sum"]), _ptr(ws, off["kl_ws"]), st), "dib_token_reparam_kl_fwd")
+        if embs_reparam is not None:
+            er = embs_reparam if isinstance(embs_reparam, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(embs_reparam, dtype=np.float32))
+            self._view(pl, "x0", T, D).copy_(er.to(device=self.device, dtype=torch.float32).reshape(T, D))
+        scale = 1.0 / math.sqrt(self.key_dim)
+        H = self.number_heads_per_mha
+        for b in range(self.number_attention_blocks):
+            xin = "x0" if b == 0 else f"b{b - 1}_x"
+            pre = f"blk{b}_"
+            g[f"b{b}_qkv_fwd"].run(lib, st)
+            g[f"b{b}_qk"].run(lib, st)
+            check(lib.dib_softmax_rows_fwd(_ptr(ws, off[f"b{b}_S"]), B * H * P, P, pl["ldS"], scale, st), "dib_softmax_rows_fwd")
+            g[f"b{b}_pv"].run(lib, st)
+            g[f"b{b}_o_fwd"].run(lib, st)
+            check(lib.dib_add_layernorm_fwd(_ptr(ws, off[xin]), _ptr(ws, off[f"b{b}_mha"]), T, D,
+                                            _ptr(self.params, self.offsets[pre + "ln1_g"]), _ptr(self.params, self.offsets[pre + "ln1_b"]),
+                                            self.layer_norm_epsilon, _ptr(ws, off[f"b{b}_h"]), _ptr(ws, off[f"b{b}_xhat1"]),
+                                            _ptr(ws, off[f"b{b}_rstd1"]), st), "dib_add_layernorm_fwd")
+            for l in range(len(self.ff_arch_per_block)):
+                g[f"b{b}_ff{l}_fwd"].run(lib, st)
+            last_ff = f"b{b}_ff{len(self.ff_arch_per_block) - 1}"
+            check(lib.dib_add_layernorm_fwd(_ptr(ws, off[f"b{b}_h"]), _ptr(ws, off[last_ff]), T, D,
+                                            _ptr(self.params, self.offsets[pre + "ln2_g"]), _ptr(self.params, self.offsets[pre + "ln2_b"]),
+                                            self.layer_norm_epsilon, _ptr(ws, off[f"b{b}_x"]), _ptr(ws, off[f"b{b}_xhat2"]),
+                                            _ptr(ws, off[f"b{b}_rstd2"]), st), "dib_add_layernorm_fwd")
+        xl = "x0" if self.number_attention_blocks == 0 else f"b{self.number_attention_blocks - 1}_x"
+        check(lib.dib_mean_pool_fwd(_ptr(ws, off[xl]), B, P, D, _ptr(ws, off["pool"]), st), "dib_mean_pool_fwd")
+        for l in range(len(self.final_processing_arch)):
+            g[f"fin{l}_fwd"].run(lib, st)
+        g["out_fwd"].run(lib, st)
+        self.last = dict(plan=pl, step=step, row0=int(row0), B=B, P=P,
+                         kl=self._view(pl, "kl_sum", 1) / B)   # "sum over dimension and particles, avg over batch"
+        return self._view(pl, "pred", B, self.output_dimensionality)
+
+    # ---- loss + backward ----------------------------------------------------------------------------------------------
+    def loss_and_backward(self, is_loci, inv_global_batch: Optional[float] = None) -> None:
+        """bce_losses = mean BCE(is_loci, logits); loss = bce_losses + beta_var * kl; tape.gradient(loss, variables).
+        Gradients land in self.grads; self.last gets bce (device scalar)."""
+        pl = self.last["plan"]
+        B, P, T = self.last["B"], self.last["P"], pl["T"]
+        lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
+        D, H = self.bottleneck_dimension, self.number_heads_per_mha
+        y = is_loci if isinstance(is_loci, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(is_loci, dtype=np.float32))
+        y = y.to(device=self.device, dtype=torch.float32).reshape(B, -1).contiguous()
+        inv = 1.0 / B if inv_global_batch is None else float(inv_global_batch)
+        gt = pl["gt"]
+        if pl["nsplit"] == 1:
+            self.grads.zero_()  # blocks are overwritten; alignment gaps stay zero
+        check(lib.dib_loss_rows(LOSS_BCE_LOGITS, _ptr(ws, off["pred"]), self.output_dimensionality, _ptr(y), y.stride(0), B, inv,
+                                _ptr(ws, off["g_pred"]), _ptr(ws, off["out3"]), _ptr(ws, off["loss_ws"]), st), "dib_loss_rows")
+        # head
+        g["out_wgrad"].run(lib, st)
+        g["out_dgrad"].run(lib, st)
+        for l in range(len(self.final_processing_arch) - 1, -1, -1):
+            g[f"fin{l}_wgrad"].run(lib, st)
+            g[f"fin{l}_dgrad"].run(lib, st)
+        check(lib.dib_mean_pool_bwd(_ptr(ws, off["g_pool"]), B, P, D, _ptr(ws, off["g_x"]), st), "dib_mean_pool_bwd")
+        scale = 1.0 / math.sqrt(self.key_dim)
+        nff = len(self.ff_arch_per_block)
+        for b in range(self.number_attention_blocks - 1, -1, -1):
+            pre = f"blk{b}_"
+            # x_out = LN2(h + ff): g_x -> g_s (gradient of both addends), d(gamma2, beta2)
+            check(lib.dib_add_layernorm_bwd(_ptr(ws, off["g_x"]), _ptr(ws, off[f"b{b}_xhat2"]), _ptr(ws, off[f"b{b}_rstd2"]),
+                                            _ptr(self.params, self.offsets[pre + "ln2_g"]), T, D, _ptr(ws, off["g_s"]),
+                                            _ptr(gt, self.offsets[pre + "ln2_g"]), _ptr(ws, off["ln_ws"]), st),
+                  "dib_add_layernorm_bwd")
+            # feed-forward branch: mask of its last relu, then the Dense chain backwards
+            check(lib.dib_act_grad_mul(_ptr(ws, off["g_s"]), _ptr(ws, off[f"b{b}_ff{nff - 1}"]), ACT_RELU, T * D,
+                                       _ptr(ws, off["g_z"]), st), "dib_act_grad_mul")
+            for l in range(nff - 1, -1, -1):
+                g[f"b{b}_ff{l}_wgrad"].run(lib, st)
+                g[f"b{b}_ff{l}_dgrad"].run(lib, st)
+            check(lib.dib_add_inplace(_ptr(ws, off["g_h"]), _ptr(ws, off["g_s"]), T * D, st), "dib_add_inplace")  # + residual
+            # h = LN1(x + mha): g_h -> g_s, d(gamma1, beta1)
+            check(lib.dib_add_layernorm_bwd(_ptr(ws, off["g_h"]), _ptr(ws, off[f"b{b}_xhat1"]), _ptr(ws, off[f"b{b}_rstd1"]),
+                                            _ptr(self.params, self.offsets[pre + "ln1_g"]), T, D, _ptr(ws, off["g_s"]),
+                                            _ptr(gt, self.offsets[pre + "ln1_g"]), _ptr(ws, off["ln_ws"]), st),
+                  "dib_add_layernorm_bwd")
+            # multi-head attention
+            g[f"b{b}_o_wgrad"].run(lib, st)
+            g[f"b{b}_o_dgrad"].run(lib, st)
+            g[f"b{b}_dv"].run(lib, st)
+            g[f"b{b}_dp"].run(lib, st)
+            check(lib.dib_softmax_rows_bwd(_ptr(ws, off[f"b{b}_S"]), _ptr(ws, off["g_S"]), B * H * P, P, pl["ldS"], scale, st),
+                  "dib_softmax_rows_bwd")
+            g[f"b{b}_dq"].run(lib, st)
+            g[f"b{b}_dk"].run(lib, st)
+            g[f"b{b}_qkv_wgrad"].run(lib, st)
+            g[f"b{b}_qkv_dgrad"].run(lib, st)
+            # g_x (input of the block) = residual + the three projection inputs
+            check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xq"]), T * D, st), "dib_add_inplace")
+            check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xk"]), T * D, st), "dib_add_inplace")
+            check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xv"]), T * D, st), "dib_add_inplace")
+            self._view(pl, "g_x", T * D).copy_(self._view(pl, "g_s", T * D))
+        # bottleneck: d(mu | raw logvar), beta * KL included
+        ne = len(pl["enc_units"])
+        check(lib.dib_token_reparam_kl_bwd(_ptr(ws, off[f"enc_h{ne - 1}"]), _ptr(ws, off["g_x"]), T, D, self.logvar_initialization,
+                                           _ptr(self.beta_dev), inv, self.noise_seed, self.last["step"] & 0xFFFFFFFF,
+                                           self.last["row0"], _ptr(ws, off[f"g_enc_h{ne - 1}"]), st), "dib_token_reparam_kl_bwd")
+        for l in range(ne - 1, -1, -1):
+            g[f"enc{l}_wgrad"].run(lib, st)
+            if l > 0:
+                g[f"enc{l}_dgrad"].run(lib, st)
+        if pl["nsplit"] > 1:
+            check(lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_alloc, pl["nsplit"], self.n_alloc, _ptr(self.grads), st),
+                  "dib_reduce_splits")
+        out3 = self._view(pl, "out3", 3)
+        self.last["bce"] = out3[0:1] * inv
+        self.last["correct"] = out3[1:2]
+
+    def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7) -> None:
+        check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v), self.n_alloc,
+                                     _ptr(self.lr_dev), _ptr(self.t_dev), beta_1, beta_2, epsilon, 1.0, self._stream()),
+              "dib_adam_step")
+
+    def train_step(self, batch_inp, is_loci, training: bool = True):
+        """The notebook's `train_step(batch_inp, is_loci, training=True)`: returns bce_losses (device scalar tensor [1])."""
+        self.forward(batch_inp)
+        self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
+        if training:
+            self.adam_step()
+        self._step += 1
+        return self.last["bce"]
+
+    def _loss_only(self, is_loci):
+        pl = self.last["plan"]
+        B = self.last["B"]
+        y = is_loci if isinstance(is_loci, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(is_loci, dtype=np.float32))
+        y = y.to(device=self.device, dtype=torch.float32).reshape(B, -1).contiguous()
+        ws, off = pl["ws"], pl["off"]
+        check(self.lib.dib_loss_rows(LOSS_BCE_LOGITS, _ptr(ws, off["pred"]), self.output_dimensionality, _ptr(y), y.stride(0), B,
+                                     1.0 / B, _ptr(ws, off["g_pred"]), _ptr(ws, off["out3"]), _ptr(ws, off["loss_ws"]),
+                                     self._stream()), "dib_loss_rows")
+        out3 = self._view(pl, "out3", 3)
+        self.last["bce"] = out3[0:1] / B
+        self.last["correct"] = out3[1:2]
+
+    # ---- the notebook's evaluation helpers ---------------------------------------------------------------------------------
+    def particle_encoder(self, feats) -> torch.Tensor:
+        """particle_encoder(features): [..., particle_feature_dimensions] -> [..., 2 * bottleneck] (mu | raw logvar)."""
+        x = feats if isinstance(feats, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32))
+        x = x.to(device=self.device, dtype=torch.float32)
+        lead = x.shape[:-1]
+        x = x.reshape(1, -1, self.particle_feature_dimensions).contiguous()
+        pl = self._plan(1, x.shape[1])
+        lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
+        T, F0 = pl["T"], self.particle_feature_dimensions
+        self._view(pl, "feats", T, F0).copy_(x.view(T, F0))
+        check(lib.dib_positional_encoding(_ptr(ws, off["feats"]), F0, T, F0, self.number_positional_encoding_frequencies,
+                                          _ptr(ws, off["pe"]), st), "dib_positional_encoding")
+        ne = len(pl["enc_units"])
+        for l in range(ne):
+            g[f"enc{l}_fwd"].run(lib, st)
+        return self._view(pl, f"enc_h{ne - 1}", T, 2 * self.bottleneck_dimension).clone().view(*lead, 2 * self.bottleneck_dimension)
+
+    # ---- the notebook's training loop ------------------------------------------------------------------------------------
+    @staticmethod
+    def learning_rate_schedule(step: int, learning_rate: float, number_training_steps: int) -> float:
+        """min(step / number_linear_ramp_lr_steps, 1) * learning_rate, number_linear_ramp_lr_steps = number_training_steps // 10."""
+        return min(step / max(number_training_steps // 10, 1), 1) * learning_rate
+
+    @staticmethod
+    def beta_schedule(step: int, beta_start: float, beta_end: float, number_training_steps: int) -> float:
+        """np.exp(np.log(beta_start) + float(step) / number_training_steps * (np.log(beta_end) - np.log(beta_start)))."""
+        return float(np.exp(np.log(beta_start) + float(step) / number_training_steps * (np.log(beta_end) - np.log(beta_start))))
+
+    def fit(self, particle_features_train, loci_train, number_training_steps=25_000, learning_rate=1e-4, beta_start=2e-6,
+            beta_end=2e-1, batch_size=32, particle_features_val=None, loci_val=None, eval_every=None, batch_seed=0,
+            verbose=False):
+        """The notebook's loop: per step ramp the learning rate, anneal beta, draw `batch_size` neighbourhoods with
+        replacement, train_step; every `eval_every` steps evaluate BCE and accuracy (sign of the logit) on the validation
+        neighbourhoods.  Returns dict(bce_series_val, acc_series_val, bce_series_train)."""
+        xtr = torch.from_numpy(np.ascontiguousarray(particle_features_train, dtype=np.float32)).to(self.device)
+        ytr = torch.from_numpy(np.ascontiguousarray(loci_train, dtype=np.float32).reshape(-1, 1)).to(self.device)
+        rng = np.random.default_rng(batch_seed)
+        eval_every = eval_every or max(number_training_steps // 200, 1)
+        hist = dict(bce_series_val=[], acc_series_val=[], bce_series_train=[], eval_steps=[])
+        for step in range(number_training_steps):
+            self.lr_dev.fill_(self.learning_rate_schedule(step, learning_rate, number_training_steps))
+            self.beta_dev.fill_(self.beta_schedule(step, beta_start, beta_end, number_training_steps))
+            batch_inds = torch.from_numpy(rng.choice(xtr.shape[0], size=batch_size, replace=True)).to(self.device)
+            bce = self.train_step(xtr[batch_inds], ytr[batch_inds])
+            if step % eval_every == 0:
+                hist["bce_series_train"].append(float(bce.item()))
+                if particle_features_val is not None:
+                    bces, right, n = [], 0.0, 0
+                    xv = np.asarray(particle_features_val, dtype=np.float32)
+                    yv = np.asarray(loci_val, dtype=np.float32).reshape(-1, 1)
+                    for s0 in range(0, xv.shape[0], batch_size):
+                        xb, yb = xv[s0: s0 + batch_size], yv[s0: s0 + batch_size]
+                        bces.append(float(self.train_step(xb, yb, training=False).item()))
+                        pred = self.forward(xb).cpu().numpy()   # a second sampled pass, as in the notebook
+                        right += float((np.sign(pred) == (yb * 2 - 1)).sum())
+                        n += len(xb)
+                    hist["bce_series_val"].append(float(np.mean(bces)))
+                    hist["acc_series_val"].append(right / n)
+                    hist["eval_steps"].append(step)
+                    if verbose:
+                        print(f"Step: {step}, acc : {right / n:.4f}")
+        return hist

@@ -54,7 +54,10 @@ enum { DIB_WS_U = 0,        /* [B, F*E]  sampled embeddings, models.py:108,122 *
        DIB_WS_ENC_OUT = 2,  /* [F][B][2E] feature-major (mu|logvar) per feature, models.py:106 */
        DIB_WS_G_U = 3,      /* [B, F*E]  dL/du */
        DIB_WS_STEP_OUT = 4, /* [F+3]     per-step scalars: KL_f local sums, task-loss sum, #correct, rows */
-       DIB_WS_G_PRED = 5    /* [B, out]  dL/dpred */ };
+       DIB_WS_G_PRED = 5,   /* [B, out]  dL/dpred */
+       DIB_WS_ENC_H0 = 16,  /* + l: [F][B][units_l] feature-major post-activation output of encoder hidden layer l (training
+                               forward only; the backward's act' choices are exactly `value > 0`) */
+       DIB_WS_INT_H0 = 32   /* + l: [B][units_l] post-activation output of integration hidden layer l */ };
 
 const char* dib_version(void);
 const char* dib_error_string(int code);

@@ -1,0 +1,87 @@
+/* dib_st.h - C ABI of the building blocks of the per-particle Distributed-IB SET TRANSFORMER on MI355X (part of
+ * libdib_hip.so; conventions as in dib_hip.h: extern "C", raw device pointers + sizes, int return codes, never allocates
+ * or synchronises, enqueues on the caller's stream, capture-safe).
+ *
+ * Reference (BASELINE config 5):
+ *   complex_systems/InfoDecomp_Amorphous_plasticity_per_particle_measurements_and_set_transformer.ipynb, code cell 8 -
+ *   particle encoder `tf.keras.Sequential([PositionalEncoding, Dense(128, LeakyReLU(0.1)) x2, Dense(2*32)])`, the
+ *   `train_step` bottleneck (logvar - 3, reparameterised sample, KL summed over (particle, dim)), six blocks of
+ *   MultiHeadAttention(12, 128)(x, x, x) -> Add -> LayerNormalization -> Dense(128, relu), Dense(32, relu) -> Add ->
+ *   LayerNormalization, tf.reduce_mean over the particle axis, Dense(256, LeakyReLU(0.1)), Dense(1), BCE-from-logits.
+ * The host-side mirror of that notebook cell is dib_amd/set_transformer.py; these are the device entry points it drives.
+ */
+#ifndef DIB_ST_H
+#define DIB_ST_H
+#include "dib_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIB_ACT_LEAKY_RELU_01 7 /* tf.keras.layers.LeakyReLU(0.1) (the string 'leaky_relu' of the other notebooks is 0.2 = 2) */
+
+/* One GEMM of a grouped launch.  Offsets are in ELEMENTS relative to the base pointers of dib_gemm_grouped; *_boff are
+ * reserved (set 0).  bias_off < 0: no bias (mode 0) / no bias gradient (mode 2). */
+typedef struct dib_gemm_desc {
+  int64_t a_off, b_off, c_off, bias_off, aux_off;
+  int64_t a_boff, b_boff, c_boff, aux_boff;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldaux;
+  int32_t flags;
+} dib_gemm_desc;
+
+/* n_groups independent fp32-MFMA GEMMs in one launch (blockIdx.z = group); dev_desc is a DEVICE array.
+ *   mode 0: C[M,N] = act(A[M,K] @ B[K,N] + bias[N])              Dense forward / P @ V
+ *   mode 1: C[M,N] = (A[M,K] @ B[N,K]^T) * act'(aux[M,N])        Dense dgrad (B = Keras kernel [in=N, out=K]) / Q @ K^T
+ *   mode 2: C[M,N] = A[K,M]^T @ B[K,N]; bias_out[N] = column sums of B (groups with bias_off >= 0)   weight gradients,
+ *           P^T @ dO, dS^T @ Q.  The contraction is split over nsplit slabs of rows_per_split rows written split_stride
+ *           elements apart (nsplit = 1: directly into C); reduce with dib_reduce_splits.
+ * max_m / max_n: largest M / N over the groups (tile-shape rule). */
+int dib_gemm_grouped(int mode, int n_groups, const dib_gemm_desc* dev_desc, int max_m, int max_n, const float* A,
+                     const float* B, float* C, const float* bias, const float* aux, float* bias_out, int act, int nsplit,
+                     int rows_per_split, int64_t split_stride, dib_stream_t stream);
+int dib_reduce_splits(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream);
+
+/* Keras MultiHeadAttention softmax over the key axis, in place: S[row][0..P) <- softmax(scale * S[row][0..P)); rows are ld
+ * floats apart.  Backward (in place on dP): dS = scale * P * (dP - sum_j dP_j P_j), the gradient w.r.t. the unscaled q.k. */
+int dib_softmax_rows_fwd(float* S, int64_t rows, int P, int ld, float scale, dib_stream_t stream);
+int dib_softmax_rows_bwd(const float* P_probs, float* dP, int64_t rows, int P, int ld, float scale, dib_stream_t stream);
+
+/* tf.keras.layers.Add()([a, b]) -> LayerNormalization(epsilon): y = (s - mean)/sqrt(var + eps) * gamma + beta over the last
+ * axis (D <= 256); xhat [T, D] and rstd [T] are stashed for the backward.  Backward: ds [T, D] (gradient of BOTH addends)
+ * and dgamma_dbeta = [dgamma (D) | dbeta (D)] (contiguous, Keras variable order gamma, beta). */
+int dib_add_layernorm_fwd(const float* a, const float* b, int64_t T, int D, const float* gamma, const float* beta,
+                          float eps, float* y, float* xhat, float* rstd, dib_stream_t stream);
+int64_t dib_add_layernorm_bwd_workspace_bytes(int64_t T, int D);
+int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t T, int D,
+                          float* ds, float* dgamma_dbeta, void* ws, dib_stream_t stream);
+
+/* tf.reduce_mean(x, axis=-2): x [B, P, D] -> out [B, D]; backward dx = g / P broadcast over the particle axis */
+int dib_mean_pool_fwd(const float* x, int B, int P, int D, float* out, dib_stream_t stream);
+int dib_mean_pool_bwd(const float* g, int B, int P, int D, float* dx, dib_stream_t stream);
+int dib_add_inplace(float* dst, const float* src, int64_t n, dib_stream_t stream);
+/* out = g * act'(y), y = post-activation values (activation ids of dib_hip.h + DIB_ACT_LEAKY_RELU_01) */
+int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* out, dib_stream_t stream);
+
+/* The notebook's bottleneck on T = batch * particles tokens: enc_out [T, 2E] = (mu | raw logvar);
+ *   logvar = raw + logvar_offset (-3); u = mu + exp(logvar/2) * eps; kl_sum = sum_{token, dim} 0.5 (mu^2 + e^logvar - logvar - 1)
+ * (the caller divides by the number of neighbourhoods: "sum over dimension and particles, avg over batch").  eps is the
+ * library's counter-based noise keyed by (seed, step, row0 + token, feature 0, dim).  Backward:
+ *   d_enc_out = (g_u + k mu | g_u eps sigma / 2 + k (e^logvar - 1)/2), k = beta_dev[0] * inv_batch. */
+int64_t dib_token_kl_workspace_bytes(int64_t T, int E);
+int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logvar_offset, uint64_t seed, uint32_t step,
+                             int64_t row0, int deterministic, float* u, float* kl_sum, void* ws, dib_stream_t stream);
+int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, int64_t T, int E, float logvar_offset,
+                             const float* beta_dev, float inv_batch, uint64_t seed, uint32_t step, int64_t row0,
+                             float* d_enc_out, dib_stream_t stream);
+
+/* Keras loss on plain buffers (DIB_LOSS_* of dib_hip.h): out3 = {sum of per-row losses, #correct, rows};
+ * g_pred = d(mean loss)/d(pred) * (inv_global_batch * batch). */
+int64_t dib_loss_rows_workspace_bytes(int batch);
+int dib_loss_rows(int loss_kind, const float* pred, int out_dim, const float* y, int64_t ldy, int batch,
+                  float inv_global_batch, float* g_pred, float* out3, void* ws, dib_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -24,6 +24,25 @@ def _act(name: Optional[str]):
             "elu": torch.nn.functional.elu, "softplus": torch.nn.functional.softplus}[name]
 
 
+class _MaskedReLU(torch.autograd.Function):
+    """relu(z) whose backward uses a GIVEN subgradient choice (mask) instead of its own `z > 0`.  ReLU' is discontinuous:
+    a float32 device and this float64 restatement legitimately disagree about the sign of a pre-activation that sits
+    within round-off of 0, and at B = 65536 a handful of the 10^8 units always do - each flips one sample's whole
+    contribution to a weight-gradient column (1e-3 of the column's scale).  The full-size parity tests therefore compare
+    gradients under the device's own choices and separately prove that those differ from the float64 choices only where
+    the pre-activation is at round-off level."""
+
+    @staticmethod
+    def forward(ctx, z, mask):
+        ctx.save_for_backward(mask)
+        return torch.relu(z)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask.to(g.dtype), None
+
+
 class TorchCpuDIB:
     def __init__(self, spec: orc.DIBSpec, params: orc.DIBParams, dtype=torch.float32):
         self.spec, self.dtype = spec, dtype
@@ -50,13 +69,17 @@ class TorchCpuDIB:
         s = self.spec
         return len(set(s.feature_dimensionalities)) == 1 and s.number_features > 1
 
-    def forward(self, x: torch.Tensor, eps: torch.Tensor, batched: bool = False, reduce_kl: str = "mean"):
+    def forward(self, x: torch.Tensor, eps: torch.Tensor, batched: bool = False, reduce_kl: str = "mean", masks=None,
+                pre_out=None):
         """reference models.py:96-123 with eps [B,F,E] injected.
 
         batched=False: the reference's own structure, a Python loop over F separate Dense chains (this is what the CPU
         baseline times).  batched=True (features of equal width only): the SAME arithmetic with the F chains stacked into
         torch.bmm calls - a faster checker for the full-size parity tests; test_torch_cpu_batched_equals_loop pins it on
-        the loop form.  reduce_kl: "mean" = models.py:111-112; "sum" = sum over the rows (callers that chunk the batch)."""
+        the loop form.  reduce_kl: "mean" = models.py:111-112; "sum" = sum over the rows (callers that chunk the batch).
+        masks (batched relu only): {"enc": [bool [F,B,units] per hidden layer], "int": [bool [B,units] per hidden layer]} -
+        the backward then uses these act' choices (_MaskedReLU).  pre_out: optional dict that receives the float64
+        PRE-activations ("enc": [...], "int": [...]) so a caller can check where the choices differ."""
         s = self.spec
         E = s.feature_embedding_dimension
         act = _act(s.activation_fn)
@@ -72,7 +95,9 @@ class TorchCpuDIB:
                 b = torch.stack([self.enc_b[f][l] for f in range(F)])[:, None, :]
                 h = torch.bmm(h, W) + b
                 if l < n - 1:
-                    h = act(h)
+                    if pre_out is not None:
+                        pre_out.setdefault("enc", []).append(h.detach())
+                    h = _MaskedReLU.apply(h, masks["enc"][l]) if masks is not None else act(h)
             mu, lv = h[..., :E], h[..., E:]                                      # models.py:106
             u = mu + torch.exp(lv / 2.0) * eps.permute(1, 0, 2)                  # models.py:108
             kl = red(torch.sum(0.5 * (mu * mu + torch.exp(lv) - lv - 1.0), -1), -1)  # [F]   models.py:111-112
@@ -97,7 +122,12 @@ class TorchCpuDIB:
         n = len(self.int_W)
         for l in range(n):
             h = h @ self.int_W[l] + self.int_b[l]
-            h = act(h) if l < n - 1 else _act(s.output_activation_fn)(h)
+            if l < n - 1 and pre_out is not None:
+                pre_out.setdefault("int", []).append(h.detach())
+            if l < n - 1 and masks is not None:
+                h = _MaskedReLU.apply(h, masks["int"][l])
+            else:
+                h = act(h) if l < n - 1 else _act(s.output_activation_fn)(h)
         return h, kl
 
     def loss(self, kind: str, y: torch.Tensor, pred: torch.Tensor, reduction: str = "mean"):
@@ -112,10 +142,13 @@ class TorchCpuDIB:
         raise ValueError(kind)
 
     def loss_and_grads(self, x, y, eps, beta: float, kind: str, chunk: Optional[int] = None, batched: bool = False,
-                       want_grads: bool = True):
+                       want_grads: bool = True, masks=None, boundary=None):
         """L = mean_b loss + beta * sum_f KL_f (models.py:118) and dL/dparams, evaluated in row chunks (the batch mean is
         linear, so the chunk gradients add up exactly): keeps the autograd tape of a 65536-row float64 batch out of
-        memory.  Returns (task loss, kl [F] detached, grads list | None, pred [B, out] detached)."""
+        memory.  Returns (task loss, kl [F] detached, grads list | None, pred [B, out] detached).
+        masks: see forward().  boundary: optional dict; with masks given it receives, per hidden layer, the number of units
+        whose given choice differs from the float64 `z > 0` and the largest |z| among those ("enc_l0", "int_l1", ...)."""
+        assert masks is None or (batched and self._uniform() and self.spec.activation_fn == "relu")
         B = x.shape[0]
         chunk = B if not chunk else int(chunk)
         ps = self.tensors()
@@ -123,8 +156,19 @@ class TorchCpuDIB:
         task_sum, kl_sum, preds = 0.0, torch.zeros(self.spec.number_features, dtype=self.dtype), []
         for s0 in range(0, B, chunk):
             sl = slice(s0, min(B, s0 + chunk))
+            mk, pre = None, None
+            if masks is not None:
+                mk = {"enc": [m[:, sl] for m in masks["enc"]], "int": [m[sl] for m in masks["int"]]}
+                pre = {} if boundary is not None else None
             with torch.set_grad_enabled(want_grads):
-                pred, kl = self.forward(x[sl], eps[sl], batched=batched, reduce_kl="sum")
+                pred, kl = self.forward(x[sl], eps[sl], batched=batched, reduce_kl="sum", masks=mk, pre_out=pre)
+            if pre:
+                for net in ("enc", "int"):
+                    for l, z in enumerate(pre.get(net, [])):
+                        diff = (z > 0) != mk[net][l]
+                        cnt, worst = boundary.get(f"{net}_l{l}", (0, 0.0))
+                        boundary[f"{net}_l{l}"] = (cnt + int(diff.sum()), max(worst, float(z[diff].abs().max()) if diff.any() else 0.0))
+            with torch.set_grad_enabled(want_grads):
                 task = self.loss(kind, y[sl], pred, reduction="sum")
                 total = (task + beta * kl.sum()) / B
             if want_grads:

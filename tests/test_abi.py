@@ -27,6 +27,12 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in dib_hip.h but not exported"
     assert declared == set(mod.SIGNATURES), declared ^ set(mod.SIGNATURES)
+    hdr_st = open(os.path.join(ROOT, "include", "dib_st.h")).read()
+    declared_st = set(re.findall(r"^(?:int|void|int64_t|float|const char\*)\s+(dib_[a-z0-9_]+)\s*\(", hdr_st, re.M))
+    assert len(declared_st) >= 12
+    for name in declared_st:
+        assert hasattr(lib, name), f"{name} declared in dib_st.h but not exported"
+    assert declared_st == set(mod.SIGNATURES_ST), declared_st ^ set(mod.SIGNATURES_ST)
     assert b"gfx950" in lib.dib_version()
     assert lib.dib_error_string(-2) == b"shape mismatch"
 

@@ -41,7 +41,7 @@ def _device_eps(eng, rows, seed, step, check_rows=96):
     eps = eng.eps(idx, 0, len(rows), seed, step).cpu()
     pick = np.random.default_rng(step).choice(len(rows), size=min(check_rows, len(rows)), replace=False)
     ref = orc.philox_normal_all(seed, step & 0xFFFFFFFF, rows[pick].astype(np.uint32), eng.F, eng.E)
-    assert np.abs(eps[pick].numpy() - ref).max() < 1e-5, "device Philox noise != oracle Philox noise"
+    assert np.abs(eps[pick].numpy() - ref).max() < 1e-5 * (1 + np.abs(ref).max()), "device Philox noise != oracle Philox noise"
     return eps.to(torch.float64)
 
 
@@ -67,11 +67,22 @@ def _single_step_check(F, B, seed):
     gflat = eng.get_flat_grads().astype(np.float64)
     pred = eng.pred(B).cpu().numpy().astype(np.float64)
 
+    # the device's act' choices (value > 0 of the stashed post-activations): ReLU' is discontinuous, see _MaskedReLU
+    masks = {"enc": [(eng.enc_h(B, l) > 0).cpu() for l in range(2)], "int": [(eng.int_h(B, l) > 0).cpu() for l in range(2)]}
+
     ref = TorchCpuDIB(spec, p, dtype=torch.float64)
     eps = _device_eps(eng, np.arange(B), nseed, step)
+    boundary = {}
     task, kl, grads, rpred = ref.loss_and_grads(torch.tensor(x, dtype=torch.float64), torch.tensor(y, dtype=torch.float64),
-                                                eps, beta, "bce_logits", chunk=CHUNK, batched=True)
+                                                eps, beta, "bce_logits", chunk=CHUNK, batched=True, masks=masks,
+                                                boundary=boundary)
     kl = kl.numpy()
+    # the device's choices differ from the float64 `z > 0` only on a vanishing set of units whose pre-activation is at
+    # float32 round-off level
+    print("act' choices differing from float64 (count, max |pre-activation|):", boundary)
+    for key, (cnt, worst) in boundary.items():
+        units = (F if key.startswith("enc") else 1) * B * (128 if key.startswith("enc") else 256)
+        assert cnt <= 2e-5 * units and worst < 2e-5, (key, cnt, worst)
     assert np.abs(so[:F] / B - kl).max() < 1e-3, ("per-feature KL (nats)", np.abs(so[:F] / B - kl).max())
     assert abs(so[F] / B - task) < 2e-4 * (1 + abs(task)), ("task loss", so[F] / B, task)
     assert so[F + 2] == B
