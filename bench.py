@@ -368,6 +368,9 @@ def main():
                                    "launches": per[dom]["launches"], "flops_per_launch": per[dom]["flops_per_launch"]}
                 out["roofline_by_kernel"] = per
                 out["mfma_kernels_ms_per_step"] = round(sum(v["ms_per_step"] for v in per.values()), 4)
+            rest = {n: round(ms / args.steps, 4) for n, (ms, cnt) in prof.items() if n not in fl and cnt}
+            if rest:  # tile shapes the rule picks at other batch sizes (no per-symbol FLOP split for them)
+                out["other_timed_kernels_ms_per_step"] = rest
         if "roofline" not in out:
             out["roofline"] = dict(out["step_roofline"], traffic=None)
         if world == 1 and not args.no_extra:

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
 INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
-SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h",
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h", "dib_attn.h",
            INCLUDE_ST]
 
 # error codes (include/dib_hip.h)
@@ -126,6 +126,10 @@ SIGNATURES_ST = {
     "dib_reduce_splits": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "dib_softmax_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "dib_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "dib_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_void_p,
+                                  c_void_p]),
+    "dib_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
+                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     "dib_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int64, c_int]),
@@ -140,6 +144,9 @@ SIGNATURES_ST = {
                                          c_void_p, c_void_p, c_void_p]),
     "dib_token_reparam_kl_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_float, c_uint64, c_uint32,
                                          c_int64, c_void_p, c_void_p]),
+    "dib_mi_probe_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "dib_mi_probe_bounds": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_uint64, c_uint32, c_uint32, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_loss_rows_workspace_bytes": (c_int64, [c_int]),
     "dib_loss_rows": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p,
                               c_void_p]),

@@ -14,6 +14,7 @@
 #include "dib_fused.h"
 #include "dib_gemm_bf16x6.h"
 #include "dib_st.h"
+#include "dib_attn.h"
 #include "../../include/dib_st.h"
 
 namespace {
@@ -170,7 +171,10 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
   dim3 grid;
   if (MODE == 2) grid = dim3(nsplit, tm * tn, c.count);
   else grid = dim3(8 * cdiv(tm, 8) * tn, 1, c.count);  // XCD-aware 1-D tile order, see dib_gemm.h
-  constexpr int BK = (NI == 2 && NJ == 2) ? 64 : 32;  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
+#ifndef DIB_BK11
+#define DIB_BK11 32
+#endif
+  constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : 32);  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
   hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
                      bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride);
   return (int)hipGetLastError();
@@ -843,7 +847,11 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
   hipStream_t st = (hipStream_t)stream;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
-                     lr_dev, (long long*)t_dev, beta1, beta2, eps, grad_scale); }
+                     lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale); }
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  { ProfScope ps(kProfOther, (hipStream_t)stream);
+  hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev); }
   return (int)hipGetLastError();
 }
 
@@ -1125,6 +1133,35 @@ int dib_add_inplace(float* dst, const float* src, int64_t n, dib_stream_t stream
   return (int)hipGetLastError();
 }
 
+int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,
+                      float scale, float* o, float* lse, dib_stream_t stream) {
+  if (!q || !k || !v || !o || !lse || B <= 0 || P <= 0 || H <= 0 || ld < (int64_t)H * key_dim || (ld & 3)) return DIB_E_ARG;
+  if (key_dim != kAttnD) return DIB_E_UNSUPPORTED;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) != 0) return DIB_E_ARG;
+  DibAttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.P = P; a.H = H; a.ld = ld; a.scale = scale;
+  hipLaunchKernelGGL(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int dib_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                      int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk, float* dv,
+                      float* delta_ws, dib_stream_t stream) {
+  if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !delta_ws || B <= 0 || P <= 0 || H <= 0 ||
+      ld < (int64_t)H * key_dim || (ld & 3))
+    return DIB_E_ARG;
+  if (key_dim != kAttnD) return DIB_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dib_attn_delta_kernel, dim3(cdiv((int64_t)B * P * H, 4)), dim3(256), 0, st, o, d_o, (long long)ld, B, P, H,
+                     delta_ws);
+  DibAttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.delta = delta_ws; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.P = P; a.H = H; a.ld = ld; a.scale = scale;
+  hipLaunchKernelGGL(dib_attn_bwd_dq_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(dib_attn_bwd_dkv_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
 int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* out, dib_stream_t stream) {
   if (!g || !y || !out || n <= 0 || !act_ok(act)) return DIB_E_ARG;
   hipLaunchKernelGGL(dib_act_grad_mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, y, act, (long long)n, out);
@@ -1160,6 +1197,38 @@ int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, int64_t T, 
                      beta_dev, inv_batch, (const int*)nullptr, (long long)row0, (int)T, 1, E, (unsigned long long)seed,
                      (unsigned)step, (const unsigned*)nullptr, logvar_offset);
   return (int)hipGetLastError();
+}
+
+int64_t dib_mi_probe_workspace_bytes(int n_probes, int n_data, int E) {
+  if (n_probes <= 0 || n_data <= 0 || E <= 0) return DIB_E_ARG;
+  return (int64_t)sizeof(double) * ((2ll * E + 1) * ((int64_t)n_probes + n_data));
+}
+
+int dib_mi_probe_bounds(const float* enc_probe, int n_probes, const float* enc_data, int n_data, int E, float logvar_offset,
+                        uint64_t seed, uint32_t step, uint32_t feature, double* lower_rows, double* upper_rows,
+                        double* u_probe_out, void* ws, dib_stream_t stream) {
+  if (!enc_probe || !enc_data || !lower_rows || !upper_rows || !ws || n_probes <= 0 || n_data <= 0 || E <= 0) return DIB_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  double* is_p = (double*)ws;
+  double* u_p = is_p + (int64_t)n_probes * E;
+  double* c_p = u_p + (int64_t)n_probes * E;
+  double* is_d = c_p + n_probes;
+  double* u_d = is_d + (int64_t)n_data * E;
+  double* c_d = u_d + (int64_t)n_data * E;
+  hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n_probes, 256)), dim3(256), 0, st, enc_probe, n_probes, E,
+                     (unsigned long long)seed, (unsigned)step, (unsigned)feature, is_p, u_p, c_p, logvar_offset);
+  hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n_data, 256)), dim3(256), 0, st, enc_data, n_data, E,
+                     (unsigned long long)seed, (unsigned)step, (unsigned)feature + 1u, is_d, u_d, c_d, logvar_offset);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(dib_mi_probe_rows_kernel, dim3(n_probes), dim3(256), 0, st, enc_probe, (const double*)u_p,
+                     (const double*)is_p, (const double*)c_p, enc_data, (const double*)is_d, (const double*)c_d, n_data, E,
+                     lower_rows, upper_rows);
+  rc = (int)hipGetLastError();
+  if (rc) return rc;
+  if (u_probe_out)
+    return (int)hipMemcpyAsync(u_probe_out, u_p, (size_t)n_probes * E * sizeof(double), hipMemcpyDeviceToDevice, st);
+  return DIB_OK;
 }
 
 int64_t dib_loss_rows_workspace_bytes(int batch) {

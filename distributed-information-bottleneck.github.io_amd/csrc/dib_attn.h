@@ -1,0 +1,390 @@
+// dib_attn.h - flash-style self-attention over the particle axis for the per-particle Distributed-IB set transformer
+// (reference notebook ...per_particle_measurements_and_set_transformer.ipynb, cell 8:
+// `tf.keras.layers.MultiHeadAttention(number_heads_per_mha, key_dim)(x, x, x)`, 12 heads x key_dim 128; BASELINE config 5
+// asks for 4096 particles per neighbourhood).  Exact fp32 on v_mfma_f32_32x32x2_f32.
+//
+// The [P, P] score matrix of a (neighbourhood, head) never exists in HBM (at P = 4096 it is 805 MB per block and
+// neighbourhood): keys / values stream through LDS in tiles of 32, softmax is computed online, the backward pass
+// recomputes the probabilities from the stashed per-query log-sum-exp.
+//
+//   forward   dib_attn_fwd_kernel : one wave = 32 queries (workgroup = 128 queries of one (neighbourhood, head)).
+//             S^T = K Q^T is evaluated TRANSPOSED (rows = keys, columns = queries): lane (j, h) then holds 16 keys of ONE
+//             query j, so the row maximum / sum are register reductions plus one cross-half shuffle, and the probability
+//             tile P^T is - register for register - the B operand of O^T += V^T P^T (contraction index = key
+//             (r&3) + 8(r>>2) + 4h = the C-fragment row of register r): probabilities never touch LDS.
+//   backward  dib_attn_bwd_dq_kernel  (same structure; dQ^T += K^T dS^T, dS^T = P^T (dP^T - delta))
+//             dib_attn_bwd_dkv_kernel (one wave = 32 keys, loops over query tiles; S = Q K^T evaluated UNtransposed so that
+//             P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS, contraction index = query)
+//             Two kernels instead of one with atomics: every gradient element has exactly one writer (deterministic).
+//   delta     dib_attn_delta_kernel : delta[q] = sum_d dO[q][d] O[q][d]
+//
+// Layout: q, k, v, o and their gradients are [tokens, ld] row-major with head h at columns [h*128, (h+1)*128)
+// (ld = heads * 128), token = neighbourhood * P + particle; lse / delta are [neighbourhood][head][P].
+// Operand fetch follows dib_gemm.h: "KC" = a [rows][128+4] LDS image read along k with one ds_read_b128 per 4 MFMAs, "MC"
+// = the same image read along rows with ds_read_b32; MFMA step t of k-block q contracts k = 8q + 4*(lane>>5) + t.
+#pragma once
+#include "dib_common.h"
+#include "dib_gemm.h"
+
+constexpr int kAttnD = 128;          // key_dim (= value dim) of the notebook's MultiHeadAttention
+constexpr int kAttnPitch = kAttnD + 4;
+constexpr int kAttnTile = 32;        // keys (fwd, dq) / queries (dkv) per LDS tile
+
+struct DibAttnArgs {
+  const float* q; const float* k; const float* v;   // [T, ld]
+  float* o;                                         // fwd out [T, ld]
+  float* lse;                                       // [B][H][P]  fwd out / bwd in
+  const float* d_o;                                 // bwd: dL/do [T, ld]
+  const float* delta;                               // bwd: [B][H][P]
+  float* dq; float* dk; float* dv;                  // bwd out [T, ld]
+  int P, H; long long ld; float scale;
+};
+
+// 32 rows x 128 floats of a [T, ld] matrix (rows row0.. clamped to row_max) -> registers (4 float4 per thread, 256 threads)
+__device__ __forceinline__ void dib_attn_gload(float4 (&r)[4], const float* __restrict__ base, long long ld, int row0,
+                                               int row_max, int tid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = min(row0 + (tid >> 5) + 8 * p, row_max);
+    r[p] = *reinterpret_cast<const float4*>(base + (long long)row * ld + (tid & 31) * 4);
+  }
+}
+__device__ __forceinline__ void dib_attn_lstore(float* __restrict__ T, const float4 (&r)[4], int tid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    *reinterpret_cast<float4*>(T + ((tid >> 5) + 8 * p) * kAttnPitch + (tid & 31) * 4) = r[p];
+}
+// KC fragment: 4 consecutive k of row (l31) for k-block q   |   MC fragment: rows 8q+4h+t (t = 0..3), column c
+__device__ __forceinline__ float4 dib_attn_kc(const float* __restrict__ T, int q, int l31, int h) {
+  return *reinterpret_cast<const float4*>(T + l31 * kAttnPitch + q * 8 + h * 4);
+}
+__device__ __forceinline__ float4 dib_attn_mc(const float* __restrict__ T, int q, int c, int h) {
+  const float* p = T + (q * 8 + h * 4) * kAttnPitch + c;
+  return make_float4(p[0], p[kAttnPitch], p[2 * kAttnPitch], p[3 * kAttnPitch]);
+}
+// the 32 x 128 row block of one token range held as the B operand of a transposed product: lane (j, h) keeps
+// X[row j][8q + 4h + t] in f[q] (t = x, y, z, w)
+__device__ __forceinline__ void dib_attn_rowfrag(float4 (&f)[16], const float* __restrict__ base, long long ld, int row,
+                                                 int h, float mul) {
+  const float* src = base + (long long)row * ld + 4 * h;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float4 v = *reinterpret_cast<const float4*>(src + 8 * q);
+    f[q] = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
+  }
+}
+// store a transposed accumulator (lane = row j of the output, registers = 128 columns) as row-major [row][128]
+__device__ __forceinline__ void dib_attn_store_rows(float* __restrict__ base, long long ld, int row, bool ok, int h,
+                                                    const dib_f32x16 (&acc)[4], float mul) {
+  if (!ok) return;
+  float* dst = base + (long long)row * ld + 4 * h;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(dst + 32 * dt + 8 * g) =
+          make_float4(acc[dt][4 * g] * mul, acc[dt][4 * g + 1] * mul, acc[dt][4 * g + 2] * mul, acc[dt][4 * g + 3] * mul);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: grid (ceil(P / 128), H, B), 256 threads
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_attn_fwd_kernel(DibAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[kAttnTile * kAttnPitch];
+  __shared__ __attribute__((aligned(16))) float Vs[kAttnTile * kAttnPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z, P = a.P;
+  const long long tok0 = (long long)b * P;
+  const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
+  const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
+  const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
+  const int qrow = blockIdx.x * 128 + wave * 32 + l31;          // this lane's query
+  const bool q_ok = qrow < P;
+  const bool wave_ok = blockIdx.x * 128 + wave * 32 < P;        // wave has at least one real query
+
+  float4 qf[16];
+  dib_attn_rowfrag(qf, Qb, a.ld, min(qrow, P - 1), h, a.scale);
+  dib_f32x16 acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
+  float4 rk[4], rv[4];
+  dib_attn_gload(rk, Kb, a.ld, 0, P - 1, tid);
+  dib_attn_gload(rv, Vb, a.ld, 0, P - 1, tid);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    dib_attn_lstore(Ks, rk, tid);
+    dib_attn_lstore(Vs, rv, tid);
+    __syncthreads();
+    if (kt + 1 < n_tiles) {
+      dib_attn_gload(rk, Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+      dib_attn_gload(rv, Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+    }
+    if (wave_ok) {
+      // S^T[key][query] = sum_d K[key][d] (scale Q[query][d])
+      dib_f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 kk = dib_attn_kc(Ks, q, l31, h);
+        s = DIB_MFMA(kk.x, qf[q].x, s);
+        s = DIB_MFMA(kk.y, qf[q].y, s);
+        s = DIB_MFMA(kk.z, qf[q].z, s);
+        s = DIB_MFMA(kk.w, qf[q].w, s);
+      }
+      // online softmax over this tile's keys (register r <-> key kt*32 + (r&3) + 8(r>>2) + 4h)
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * kAttnTile + (r & 3) + 8 * (r >> 2) + 4 * h;
+        s[r] = key < P ? s[r] : -INFINITY;
+        mloc = fmaxf(mloc, s[r]);
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_run, mloc);          // finite: every tile holds at least one real key
+      const float alpha = __expf(m_run - m_new);       // first tile: exp(-inf) = 0
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __expf(s[r] - m_new);
+        psum += s[r];
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+      // O^T[d][query] += sum_key V[key][d] P^T[key][query]
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 vv = dib_attn_mc(Vs, q, 32 * dt + l31, h);
+          acc[dt] = DIB_MFMA(vv.x, s[4 * q + 0], acc[dt]);
+          acc[dt] = DIB_MFMA(vv.y, s[4 * q + 1], acc[dt]);
+          acc[dt] = DIB_MFMA(vv.z, s[4 * q + 2], acc[dt]);
+          acc[dt] = DIB_MFMA(vv.w, s[4 * q + 3], acc[dt]);
+        }
+    }
+    __syncthreads();
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  dib_attn_store_rows(a.o + tok0 * a.ld + head * kAttnD, a.ld, qrow, q_ok && wave_ok, h, acc, inv);
+  if (q_ok && wave_ok && h == 0) a.lse[((long long)b * a.H + head) * P + qrow] = m_run + __logf(l_tot);
+}
+
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d] : grid (ceil(T*H / 4)), one wave per (token, head)
+__global__ void __launch_bounds__(256)
+dib_attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, long long ld, int B, int P, int H,
+                      float* __restrict__ delta) {
+  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long total = (long long)B * P * H;
+  if (item >= total) return;
+  const int lane = threadIdx.x & 63;
+  const long long tok = item / H;
+  const int head = (int)(item % H);
+  const float* po = o + tok * ld + head * kAttnD;
+  const float* pd = d_o + tok * ld + head * kAttnD;
+  float s = po[lane] * pd[lane] + po[lane + 64] * pd[lane + 64];
+  s = dib_wave_sum(s);
+  if (lane == 0) {
+    const long long b = tok / P, p = tok % P;
+    delta[(b * H + head) * P + p] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dQ: grid (ceil(P / 128), H, B).  Per key tile: S^T = K Q^T, P^T = exp(S^T - lse), dP^T = V dO^T,
+// dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T ; dQ = scale * dQ^T^T.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_attn_bwd_dq_kernel(DibAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[kAttnTile * kAttnPitch];
+  __shared__ __attribute__((aligned(16))) float Vs[kAttnTile * kAttnPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z, P = a.P;
+  const long long tok0 = (long long)b * P;
+  const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
+  const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
+  const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
+  const float* dOb = a.d_o + tok0 * a.ld + head * kAttnD;
+  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+  const bool q_ok = qrow < P;
+  const bool wave_ok = blockIdx.x * 128 + wave * 32 < P;
+  const int qc = min(qrow, P - 1);
+  float4 qf[16], gf[16];
+  dib_attn_rowfrag(qf, Qb, a.ld, qc, h, a.scale);
+  dib_attn_rowfrag(gf, dOb, a.ld, qc, h, 1.0f);
+  const float lse = a.lse[((long long)b * a.H + head) * P + qc];
+  const float dlt = a.delta[((long long)b * a.H + head) * P + qc];
+  dib_f32x16 acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+
+  const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
+  float4 rk[4], rv[4];
+  dib_attn_gload(rk, Kb, a.ld, 0, P - 1, tid);
+  dib_attn_gload(rv, Vb, a.ld, 0, P - 1, tid);
+  for (int kt = 0; kt < n_tiles; ++kt) {
+    dib_attn_lstore(Ks, rk, tid);
+    dib_attn_lstore(Vs, rv, tid);
+    __syncthreads();
+    if (kt + 1 < n_tiles) {
+      dib_attn_gload(rk, Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+      dib_attn_gload(rv, Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+    }
+    if (wave_ok) {
+      dib_f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 kk = dib_attn_kc(Ks, q, l31, h);
+        s = DIB_MFMA(kk.x, qf[q].x, s);
+        s = DIB_MFMA(kk.y, qf[q].y, s);
+        s = DIB_MFMA(kk.z, qf[q].z, s);
+        s = DIB_MFMA(kk.w, qf[q].w, s);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 vv = dib_attn_kc(Vs, q, l31, h);
+        dp = DIB_MFMA(vv.x, gf[q].x, dp);
+        dp = DIB_MFMA(vv.y, gf[q].y, dp);
+        dp = DIB_MFMA(vv.z, gf[q].z, dp);
+        dp = DIB_MFMA(vv.w, gf[q].w, dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * kAttnTile + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float p = key < P ? __expf(s[r] - lse) : 0.f;
+        s[r] = p * (dp[r] - dlt);                      // dS^T (w.r.t. the scaled score)
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 kk = dib_attn_mc(Ks, q, 32 * dt + l31, h);
+          acc[dt] = DIB_MFMA(kk.x, s[4 * q + 0], acc[dt]);
+          acc[dt] = DIB_MFMA(kk.y, s[4 * q + 1], acc[dt]);
+          acc[dt] = DIB_MFMA(kk.z, s[4 * q + 2], acc[dt]);
+          acc[dt] = DIB_MFMA(kk.w, s[4 * q + 3], acc[dt]);
+        }
+    }
+    __syncthreads();
+  }
+  dib_attn_store_rows(a.dq + tok0 * a.ld + head * kAttnD, a.ld, qrow, q_ok && wave_ok, h, acc, a.scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dK / dV: grid (ceil(P / 128), H, B); one wave = 32 keys, query tiles of 32 stream through LDS.
+//   S[query][key] = (scale Q) K^T, P = exp(S - lse[query]), dP = dO V^T, dS = P (dP - delta[query]),
+//   dV^T[d][key] += sum_query dO[query][d] P[query][key],  dK^T[d][key] += sum_query (scale Q)[query][d] dS[query][key]
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+dib_attn_bwd_dkv_kernel(DibAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Qs[kAttnTile * kAttnPitch];   // scaled Q tile
+  __shared__ __attribute__((aligned(16))) float Gs[kAttnTile * kAttnPitch];   // dO tile
+  __shared__ float Ls[kAttnTile], Ds[kAttnTile];                              // lse / delta of the tile's queries
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z, P = a.P;
+  const long long tok0 = (long long)b * P;
+  const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
+  const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
+  const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
+  const float* dOb = a.d_o + tok0 * a.ld + head * kAttnD;
+  const float* lse_b = a.lse + ((long long)b * a.H + head) * P;
+  const float* dlt_b = a.delta + ((long long)b * a.H + head) * P;
+  const int krow = blockIdx.x * 128 + wave * 32 + l31;          // this lane's key
+  const bool k_ok = krow < P;
+  const bool wave_ok = blockIdx.x * 128 + wave * 32 < P;
+  const int kc = min(krow, P - 1);
+  float4 kf[16], vf[16];
+  dib_attn_rowfrag(kf, Kb, a.ld, kc, h, 1.0f);
+  dib_attn_rowfrag(vf, Vb, a.ld, kc, h, 1.0f);
+  dib_f32x16 dv[4], dk[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
+
+  const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
+  float4 rq[4], rg[4];
+  float rl = 0.f, rd = 0.f;
+  dib_attn_gload(rq, Qb, a.ld, 0, P - 1, tid);
+  dib_attn_gload(rg, dOb, a.ld, 0, P - 1, tid);
+  if (tid < kAttnTile) { rl = lse_b[min(tid, P - 1)]; rd = dlt_b[min(tid, P - 1)]; }
+  for (int qt = 0; qt < n_tiles; ++qt) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { rq[p].x *= a.scale; rq[p].y *= a.scale; rq[p].z *= a.scale; rq[p].w *= a.scale; }
+    dib_attn_lstore(Qs, rq, tid);
+    dib_attn_lstore(Gs, rg, tid);
+    if (tid < kAttnTile) { Ls[tid] = rl; Ds[tid] = rd; }
+    __syncthreads();
+    if (qt + 1 < n_tiles) {
+      dib_attn_gload(rq, Qb, a.ld, (qt + 1) * kAttnTile, P - 1, tid);
+      dib_attn_gload(rg, dOb, a.ld, (qt + 1) * kAttnTile, P - 1, tid);
+      if (tid < kAttnTile) {
+        rl = lse_b[min((qt + 1) * kAttnTile + tid, P - 1)];
+        rd = dlt_b[min((qt + 1) * kAttnTile + tid, P - 1)];
+      }
+    }
+    if (wave_ok) {
+      // S[query][key] and dP[query][key]: A = query-tile rows (KC), B = this lane's key row
+      dib_f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 qq = dib_attn_kc(Qs, q, l31, h);
+        s = DIB_MFMA(qq.x, kf[q].x, s);
+        s = DIB_MFMA(qq.y, kf[q].y, s);
+        s = DIB_MFMA(qq.z, kf[q].z, s);
+        s = DIB_MFMA(qq.w, kf[q].w, s);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 gg = dib_attn_kc(Gs, q, l31, h);
+        dp = DIB_MFMA(gg.x, vf[q].x, dp);
+        dp = DIB_MFMA(gg.y, vf[q].y, dp);
+        dp = DIB_MFMA(gg.z, vf[q].z, dp);
+        dp = DIB_MFMA(gg.w, vf[q].w, dp);
+      }
+      // register r <-> query qt*32 + (r&3) + 8(r>>2) + 4h ; lane <-> key
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = k_ok && (qt * kAttnTile + ql < P);
+        const float p = ok ? __expf(s[r] - Ls[ql]) : 0.f;
+        dp[r] = p * (dp[r] - Ds[ql]);                  // dS
+        s[r] = p;                                      // P
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 gg = dib_attn_mc(Gs, q, 32 * dt + l31, h);
+          dv[dt] = DIB_MFMA(gg.x, s[4 * q + 0], dv[dt]);
+          dv[dt] = DIB_MFMA(gg.y, s[4 * q + 1], dv[dt]);
+          dv[dt] = DIB_MFMA(gg.z, s[4 * q + 2], dv[dt]);
+          dv[dt] = DIB_MFMA(gg.w, s[4 * q + 3], dv[dt]);
+          const float4 qq = dib_attn_mc(Qs, q, 32 * dt + l31, h);
+          dk[dt] = DIB_MFMA(qq.x, dp[4 * q + 0], dk[dt]);
+          dk[dt] = DIB_MFMA(qq.y, dp[4 * q + 1], dk[dt]);
+          dk[dt] = DIB_MFMA(qq.z, dp[4 * q + 2], dk[dt]);
+          dk[dt] = DIB_MFMA(qq.w, dp[4 * q + 3], dk[dt]);
+        }
+    }
+    __syncthreads();
+  }
+  dib_attn_store_rows(a.dv + tok0 * a.ld + head * kAttnD, a.ld, krow, k_ok && wave_ok, h, dv, 1.0f);
+  dib_attn_store_rows(a.dk + tok0 * a.ld + head * kAttnD, a.ld, krow, k_ok && wave_ok, h, dk, 1.0f);  // Q tile was pre-scaled
+}

@@ -285,18 +285,15 @@ dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsp
 // ---------------------------------------------------------------------------------------------
 // Keras Adam (reference train.py:128-129 tf.keras.optimizers.get('adam')):
 //   m += (1-b1)(g-m); v += (1-b2)(g^2-v); theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps)
-// t = *t_dev + 1.  The device step counter is bumped INSIDE this kernel by the last workgroup to finish (one launch less
-// per step): t_dev is an int64 whose low word is the step count and whose high word is used as the arrival counter - it
-// is back to 0 when the kernel ends, so the host still reads a plain int64 step count.  Every workgroup reads t at its
-// start and arrives at its end, so nobody can observe the bumped value within the launch.
+// t = *t_dev + 1 (device counter, bumped by dib_bump_counter_kernel afterwards).  (Bumping it inside this kernel through a
+// last-workgroup-done arrival counter was tried in round 2 and reverted: 2173 workgroups x one atomicAdd on one word
+// serialise at ~11 ns each - the kernel went from 14 to 35 us to save a 4.5 us launch.)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 dib_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                long long n, const float* __restrict__ lr_dev, long long* __restrict__ t_dev, float b1,
+                long long n, const float* __restrict__ lr_dev, const long long* __restrict__ t_dev, float b1,
                 float b2, float eps, float gscale) {
-  const int t_old = reinterpret_cast<const int*>(t_dev)[0];  // uniform address: one scalar load per wave (a volatile load here
-                                                             // serialised 556 k uncached reads of one word: +40 us)
-  const float t = (float)(t_old + 1);
+  const float t = (float)(t_dev[0] + 1);
   const float lr_t = lr_dev[0] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
   const long long n4 = n >> 2;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
@@ -327,15 +324,9 @@ dib_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
     v[i] = vv;
     p[i] -= lr_t * mm / (sqrtf(vv) + eps);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned* arrive = reinterpret_cast<unsigned*>(t_dev) + 1;
-    if (atomicAdd(arrive, 1u) == gridDim.x - 1) {  // last workgroup: everyone has read t_old
-      *arrive = 0u;
-      reinterpret_cast<int*>(t_dev)[0] = t_old + 1;
-    }
-  }
 }
+
+__global__ void dib_bump_counter_kernel(long long* t) { t[0] += 1; }
 
 // loss second stage: step_out[F] = task-loss sum, step_out[F+1] = #correct (fixed-order sums of the per-block partials),
 // step_out[F+2] = rows.  grid = 2 workgroups.
@@ -396,7 +387,7 @@ dib_bhattacharyya_kernel(const float* __restrict__ mu1, const float* __restrict_
 __global__ void __launch_bounds__(256)
 dib_mi_prep_kernel(const float* __restrict__ enc_out /*[N][2E]*/, int n, int E, unsigned long long seed, unsigned step,
                    unsigned feature, double* __restrict__ inv_sigma /*[N][E]*/, double* __restrict__ u /*[N][E]*/,
-                   double* __restrict__ cj /*[N]*/) {
+                   double* __restrict__ cj /*[N]*/, float lv_off = 0.f /* set transformer: logvar - 3 */) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const float* mu = enc_out + (long long)j * 2 * E;
@@ -407,7 +398,7 @@ dib_mi_prep_kernel(const float* __restrict__ enc_out /*[N][2E]*/, int n, int E, 
     dib_eps4(seed, step, (uint32_t)j, feature, (uint32_t)q, eps);
     for (int t = 0; t < 4 && 4 * q + t < E; ++t) {
       const int e = 4 * q + t;
-      const double l = (double)lv[e];
+      const double l = (double)lv[e] + (double)lv_off;
       const double sd = exp(0.5 * l);
       inv_sigma[(long long)j * E + e] = 1.0 / sd;
       u[(long long)j * E + e] = (double)mu[e] + sd * (double)eps[t];
@@ -469,6 +460,63 @@ dib_mi_rows_kernel(const float* __restrict__ enc_out, int n, int E, const double
     const double logn = log((double)n);
     lower_rows[i] = lii - (lse_all - logn);
     upper_rows[i] = lii - (lse_off - logn);
+  }
+}
+
+
+// Per-particle information map of the set-transformer notebook (probe-grid MI bounds, cell 8 "Now use probe points along
+// with a bunch of real points ..."): M probe Gaussians with one sample u_i each, N data Gaussians,
+//   lii = log p(u_i | probe_i),  lij = log p(u_i | data_j)
+//   lower_i = lii - ( LSE(lii, li1 .. liN) - log(N + 1) )       infonce_per (N + 1 terms in the mean)
+//   upper_i = lii - ( LSE(li1 .. liN)      - log N )            loo_per
+// float64 with a log-sum-exp (the notebook's exp-then-log underflows for separated Gaussians).  One workgroup per probe.
+__global__ void __launch_bounds__(256)
+dib_mi_probe_rows_kernel(const float* __restrict__ enc_probe, const double* __restrict__ u_probe,
+                         const double* __restrict__ is_probe, const double* __restrict__ c_probe,
+                         const float* __restrict__ enc_data, const double* __restrict__ is_data,
+                         const double* __restrict__ c_data, int n_data, int E, double* __restrict__ lower_rows,
+                         double* __restrict__ upper_rows) {
+  __shared__ double smx[256], ssm[256];
+  const int i = blockIdx.x;
+  const double* ui = u_probe + (long long)i * E;
+  double mx = -1.0e300, sm = 0.0;
+  for (int j = threadIdx.x; j < n_data; j += 256) {
+    const float* mu = enc_data + (long long)j * 2 * E;
+    const double* is = is_data + (long long)j * E;
+    double q = 0.0;
+    for (int e = 0; e < E; ++e) {
+      const double d = (ui[e] - (double)mu[e]) * is[e];
+      q = fma(d, d, q);
+    }
+    dib_lse_add(mx, sm, c_data[j] - 0.5 * q);
+  }
+  smx[threadIdx.x] = mx;
+  ssm[threadIdx.x] = sm;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double m1 = smx[threadIdx.x], m2 = smx[threadIdx.x + s];
+      const double s1 = ssm[threadIdx.x], s2 = ssm[threadIdx.x + s];
+      const double m = m1 > m2 ? m1 : m2;
+      smx[threadIdx.x] = m;
+      ssm[threadIdx.x] = s1 * exp(m1 - m) + s2 * exp(m2 - m);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float* mu = enc_probe + (long long)i * 2 * E;
+    const double* is = is_probe + (long long)i * E;
+    double q = 0.0;
+    for (int e = 0; e < E; ++e) {
+      const double d = (ui[e] - (double)mu[e]) * is[e];
+      q = fma(d, d, q);
+    }
+    const double lii = c_probe[i] - 0.5 * q;
+    const double lse_data = (ssm[0] > 0.0) ? smx[0] + log(ssm[0]) : -INFINITY;
+    const double mall = lii > lse_data ? lii : lse_data;
+    const double lse_all = mall + log(exp(lii - mall) + exp(lse_data - mall));
+    lower_rows[i] = lii - (lse_all - log((double)n_data + 1.0));
+    upper_rows[i] = lii - (lse_data - log((double)n_data));
   }
 }
 

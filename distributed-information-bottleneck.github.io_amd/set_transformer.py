@@ -45,6 +45,10 @@ def _ptr(t: Optional[torch.Tensor], off: int = 0):
     return c_void_p(t.data_ptr() + 4 * off) if t is not None else c_void_p(0)
 
 
+def _ptr8(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
 def _align4(n: int) -> int:
     return (n + 3) // 4 * 4
 
@@ -104,7 +108,9 @@ class SetTransformerDIB:
                  number_heads_per_mha: int = 12, number_attention_blocks: int = 6,
                  ff_arch_per_block: Sequence[int] = (128, 32), final_processing_arch: Sequence[int] = (256,),
                  output_dimensionality: int = 1, logvar_initialization: float = -3.0, layer_norm_epsilon: float = 1e-3,
-                 *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None):
+                 *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto"):
+        """attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
+        grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" = flash whenever key_dim == 128."""
         if not torch.cuda.is_available():
             raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.lib = _lib.load_library()
@@ -122,6 +128,11 @@ class SetTransformerDIB:
         self.logvar_initialization = float(logvar_initialization)
         self.layer_norm_epsilon = float(layer_norm_epsilon)
         self.noise_seed = int(noise_seed)
+        if attention not in ("auto", "flash", "gemm"):
+            raise ValueError(f"attention={attention!r}")
+        if attention == "flash" and self.key_dim != 128:
+            raise ValueError("attention='flash' needs key_dim == 128 (the notebook's value)")
+        self.attention_impl = "flash" if (attention == "flash" or (attention == "auto" and self.key_dim == 128)) else "gemm"
         assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
         # ---- flat parameter layout (Keras creation order) ----
         self.shapes = self.param_shapes()
@@ -251,7 +262,10 @@ class SetTransformerDIB:
         for b in range(self.number_attention_blocks):
             for nm in ("q", "k", "v", "ctx"):
                 take(f"b{b}_{nm}", T * HK)
-            take(f"b{b}_S", B * H * P * ldS)        # attention probabilities
+            if self.attention_impl == "gemm":
+                take(f"b{b}_S", B * H * P * ldS)    # attention probabilities (stashed for the backward)
+            else:
+                take(f"b{b}_lse", B * H * P)        # per-query log-sum-exp (the flash backward recomputes the rest)
             take(f"b{b}_mha", T * D)
             take(f"b{b}_xhat1", T * D); take(f"b{b}_rstd1", T); take(f"b{b}_h", T * D)
             d = D
@@ -274,7 +288,10 @@ class SetTransformerDIB:
             take(f"g_ff{l}", T * u)
         for nm in ("q", "k", "v", "ctx"):
             take(f"g_{nm}", T * HK)
-        take("g_S", B * H * P * ldS)
+        if self.attention_impl == "gemm":
+            take("g_S", B * H * P * ldS)
+        else:
+            take("attn_delta", B * H * P)
         for nm in ("q", "k", "v"):
             take(f"g_x{nm}", T * D)
         for l, u in enumerate(enc_units):
@@ -286,7 +303,9 @@ class SetTransformerDIB:
         ws = torch.zeros(o, dtype=torch.float32, device=self.device)
 
         # weight-gradient target: contraction over T tokens is split into slabs when T is large (fixed-order reduce)
-        nsplit = max(1, min(32, T // 1024))
+        # (from 512 tokens up: with one slab the q/k/v and output-projection wgrads of the reference size, 1600 tokens, ran on
+        # 12-36 workgroups looping over all rows - 110-137 us each, the top entries of the first profile)
+        nsplit = max(1, min(32, T // 256))
         rps = ((T + nsplit - 1) // nsplit + 31) // 32 * 32
         nsplit = (T + rps - 1) // rps
         slabs = torch.zeros(nsplit * self.n_alloc, dtype=torch.float32, device=self.device) if nsplit > 1 else None
@@ -326,12 +345,15 @@ class SetTransformerDIB:
             g[f"b{b}_qkv_fwd"] = _Gemm(0, [_d(off[xin], D, po[pre + nm + "_w"], HK, off[f"b{b}_{nm}"], HK, T, HK, D,
                                               bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, self.params, ws,
                                        bias=self.params)
+            gemm_attn = self.attention_impl == "gemm"
             # scores S_bh = Q_bh K_bh^T (scale folded into the softmax)
-            g[f"b{b}_qk"] = _Gemm(1, [_d(off[f"b{b}_q"] + bi * P * HK + hi * K, HK, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
-                                         off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, P, P, K) for bi, hi in bh], ws, ws, ws)
+            if gemm_attn:
+                g[f"b{b}_qk"] = _Gemm(1, [_d(off[f"b{b}_q"] + bi * P * HK + hi * K, HK, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
+                                           off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, P, P, K) for bi, hi in bh], ws, ws, ws)
             # ctx_bh = P_bh V_bh
-            g[f"b{b}_pv"] = _Gemm(0, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
-                                         off[f"b{b}_ctx"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
+            if gemm_attn:
+                g[f"b{b}_pv"] = _Gemm(0, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
+                                           off[f"b{b}_ctx"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
             g[f"b{b}_o_fwd"] = dense_fwd(f"b{b}_ctx", HK, pre + "o_w", pre + "o_b", f"b{b}_mha", D, ACT_NONE, T)
             d, src = D, f"b{b}_h"
             for l, u in enumerate(ff):
@@ -353,16 +375,20 @@ class SetTransformerDIB:
             # attention output projection
             g[f"b{b}_o_wgrad"] = dense_wgrad(f"b{b}_ctx", HK, "g_s", D, pre + "o_w", pre + "o_b", T)
             g[f"b{b}_o_dgrad"] = dense_dgrad("g_s", D, pre + "o_w", "g_ctx", HK, T)
-            g[f"b{b}_dv"] = _Gemm(2, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off["g_ctx"] + bi * P * HK + hi * K, HK,
-                                         off["g_v"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
-                                  nsplit=1, rows_per_split=max(P, 1))
-            g[f"b{b}_dp"] = _Gemm(1, [_d(off["g_ctx"] + bi * P * HK + hi * K, HK, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
-                                         off["g_S"] + (bi * H + hi) * P * ldS, ldS, P, P, K) for bi, hi in bh], ws, ws, ws)
-            g[f"b{b}_dq"] = _Gemm(0, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
-                                         off["g_q"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
-            g[f"b{b}_dk"] = _Gemm(2, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_q"] + bi * P * HK + hi * K, HK,
-                                         off["g_k"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
-                                  nsplit=1, rows_per_split=max(P, 1))
+            if gemm_attn:
+                g[f"b{b}_dv"] = _Gemm(2, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off["g_ctx"] + bi * P * HK + hi * K, HK,
+                                           off["g_v"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
+                                    nsplit=1, rows_per_split=max(P, 1))
+            if gemm_attn:
+                g[f"b{b}_dp"] = _Gemm(1, [_d(off["g_ctx"] + bi * P * HK + hi * K, HK, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
+                                           off["g_S"] + (bi * H + hi) * P * ldS, ldS, P, P, K) for bi, hi in bh], ws, ws, ws)
+            if gemm_attn:
+                g[f"b{b}_dq"] = _Gemm(0, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
+                                           off["g_q"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
+            if gemm_attn:
+                g[f"b{b}_dk"] = _Gemm(2, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_q"] + bi * P * HK + hi * K, HK,
+                                           off["g_k"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
+                                    nsplit=1, rows_per_split=max(P, 1))
             g[f"b{b}_qkv_wgrad"] = _Gemm(2, [_d(off[xin], D, off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, D, HK, T,
                                                 bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, ws, gt, bias_out=gt,
                                          nsplit=nsplit, rows_per_split=rps, split_stride=self.n_alloc)
@@ -435,9 +461,15 @@ class SetTransformerDIB:
             xin = "x0" if b == 0 else f"b{b - 1}_x"
             pre = f"blk{b}_"
             g[f"b{b}_qkv_fwd"].run(lib, st)
-            g[f"b{b}_qk"].run(lib, st)
-            check(lib.dib_softmax_rows_fwd(_ptr(ws, off[f"b{b}_S"]), B * H * P, P, pl["ldS"], scale, st), "dib_softmax_rows_fwd")
-            g[f"b{b}_pv"].run(lib, st)
+            if self.attention_impl == "gemm":
+                g[f"b{b}_qk"].run(lib, st)
+                check(lib.dib_softmax_rows_fwd(_ptr(ws, off[f"b{b}_S"]), B * H * P, P, pl["ldS"], scale, st), "dib_softmax_rows_fwd")
+                g[f"b{b}_pv"].run(lib, st)
+            else:
+                HK = H * self.key_dim
+                check(lib.dib_attention_fwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]), B, P, H,
+                                            self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]), st),
+                      "dib_attention_fwd")
             g[f"b{b}_o_fwd"].run(lib, st)
             check(lib.dib_add_layernorm_fwd(_ptr(ws, off[xin]), _ptr(ws, off[f"b{b}_mha"]), T, D,
                                             _ptr(self.params, self.offsets[pre + "ln1_g"]), _ptr(self.params, self.offsets[pre + "ln1_b"]),
@@ -506,12 +538,19 @@ class SetTransformerDIB:
             # multi-head attention
             g[f"b{b}_o_wgrad"].run(lib, st)
             g[f"b{b}_o_dgrad"].run(lib, st)
-            g[f"b{b}_dv"].run(lib, st)
-            g[f"b{b}_dp"].run(lib, st)
-            check(lib.dib_softmax_rows_bwd(_ptr(ws, off[f"b{b}_S"]), _ptr(ws, off["g_S"]), B * H * P, P, pl["ldS"], scale, st),
-                  "dib_softmax_rows_bwd")
-            g[f"b{b}_dq"].run(lib, st)
-            g[f"b{b}_dk"].run(lib, st)
+            if self.attention_impl == "gemm":
+                g[f"b{b}_dv"].run(lib, st)
+                g[f"b{b}_dp"].run(lib, st)
+                check(lib.dib_softmax_rows_bwd(_ptr(ws, off[f"b{b}_S"]), _ptr(ws, off["g_S"]), B * H * P, P, pl["ldS"], scale, st),
+                      "dib_softmax_rows_bwd")
+                g[f"b{b}_dq"].run(lib, st)
+                g[f"b{b}_dk"].run(lib, st)
+            else:
+                HK = H * self.key_dim
+                check(lib.dib_attention_bwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
+                                            _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]), B, P, H,
+                                            self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
+                                            _ptr(ws, off["attn_delta"]), st), "dib_attention_bwd")
             g[f"b{b}_qkv_wgrad"].run(lib, st)
             g[f"b{b}_qkv_dgrad"].run(lib, st)
             # g_x (input of the block) = residual + the three projection inputs
@@ -568,17 +607,83 @@ class SetTransformerDIB:
         x = feats if isinstance(feats, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32))
         x = x.to(device=self.device, dtype=torch.float32)
         lead = x.shape[:-1]
-        x = x.reshape(1, -1, self.particle_feature_dimensions).contiguous()
-        pl = self._plan(1, x.shape[1])
-        lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
-        T, F0 = pl["T"], self.particle_feature_dimensions
-        self._view(pl, "feats", T, F0).copy_(x.view(T, F0))
+        x = x.reshape(-1, self.particle_feature_dimensions).contiguous()
+        T, F0 = x.shape[0], self.particle_feature_dimensions
+        pl = self._encoder_plan(T)
+        lib, st, ws, off = self.lib, self._stream(), pl["ws"], pl["off"]
+        ws[off["feats"]: off["feats"] + T * F0].view(T, F0).copy_(x)
         check(lib.dib_positional_encoding(_ptr(ws, off["feats"]), F0, T, F0, self.number_positional_encoding_frequencies,
                                           _ptr(ws, off["pe"]), st), "dib_positional_encoding")
-        ne = len(pl["enc_units"])
-        for l in range(ne):
-            g[f"enc{l}_fwd"].run(lib, st)
-        return self._view(pl, f"enc_h{ne - 1}", T, 2 * self.bottleneck_dimension).clone().view(*lead, 2 * self.bottleneck_dimension)
+        for gg in pl["g"]:
+            gg.run(lib, st)
+        E2 = 2 * self.bottleneck_dimension
+        o = off[f"enc_h{len(pl['g']) - 1}"]
+        return ws[o: o + T * E2].view(T, E2).clone().view(*lead, E2)
+
+    def _encoder_plan(self, T: int) -> dict:
+        """Encoder-only workspace + GEMM descriptors for `particle_encoder` on T particles (no attention buffers)."""
+        key = ("enc", T)
+        if key in self._plans:
+            return self._plans[key]
+        F0 = self.particle_feature_dimensions
+        pe_w = F0 * self.number_positional_encoding_frequencies
+        units = self.particle_encoder_arch_spec + [2 * self.bottleneck_dimension]
+        off, o = {}, 0
+        for name, n in [("feats", T * F0), ("pe", T * pe_w)] + [(f"enc_h{l}", T * u) for l, u in enumerate(units)]:
+            off[name] = o
+            o = _align4(o + n)
+        ws = torch.zeros(o, dtype=torch.float32, device=self.device)
+        gs, kin, src = [], pe_w, "pe"
+        for l, u in enumerate(units):
+            act = ACT_LEAKY01 if l < len(units) - 1 else ACT_NONE
+            gs.append(_Gemm(0, [_d(off[src], kin, self.offsets[f"enc{l}_w"], u, off[f"enc_h{l}"], u, T, u, kin,
+                                   bias_off=self.offsets[f"enc{l}_b"])], ws, self.params, ws, bias=self.params, act=act))
+            kin, src = u, f"enc_h{l}"
+        for gg in gs:
+            gg.upload(self.device)
+        # keep at most a few encoder plans (evaluation batches come in a handful of sizes)
+        enc_keys = [k for k in self._plans if k[0] == "enc"]
+        if len(enc_keys) >= 4:
+            self._plans.pop(enc_keys[0])
+        self._plans[key] = dict(ws=ws, off=off, g=gs)
+        return self._plans[key]
+
+    def probe_info_bounds(self, probe_features, data_features, seed: int = 0, step: int = 0, return_samples: bool = False):
+        """One pass of the notebook's probe-grid estimator: per-probe (infonce_per, loo_per) in nats for probe particles
+        `probe_features` [M, particle_feature_dimensions] against the data particles `data_features`
+        [N, particle_feature_dimensions] (both encoded by `particle_encoder`, logvar - 3), on the device in float64."""
+        ep = self.particle_encoder(probe_features).reshape(-1, 2 * self.bottleneck_dimension).contiguous()
+        ed = self.particle_encoder(data_features).reshape(-1, 2 * self.bottleneck_dimension).contiguous()
+        M, N, E = ep.shape[0], ed.shape[0], self.bottleneck_dimension
+        ws = torch.empty(int(self.lib.dib_mi_probe_workspace_bytes(M, N, E)) // 8, dtype=torch.float64, device=self.device)
+        rows = torch.empty((2, M), dtype=torch.float64, device=self.device)
+        u = torch.empty((M, E), dtype=torch.float64, device=self.device) if return_samples else None
+        check(self.lib.dib_mi_probe_bounds(_ptr8(ep), M, _ptr8(ed), N, E, self.logvar_initialization, int(seed),
+                                           int(step) & 0xFFFFFFFF, 0, _ptr8(rows[0]), _ptr8(rows[1]), _ptr8(u), _ptr8(ws),
+                                           self._stream()), "dib_mi_probe_bounds")
+        return (rows[0], rows[1], u, ep, ed) if return_samples else (rows[0], rows[1])
+
+    def information_map(self, particle_positions_probe, type_id: int, particle_features_val, num_eval_batches: int = 16,
+                        eval_batch_size_probe_grid: int = 512, number_probes_to_eval_at_a_time: int = 100, seed: int = 0):
+        """The notebook's per-particle information map for one particle type: for every probe position on the grid, the
+        average over `num_eval_batches` random data batches (eval_batch_size_probe_grid neighbourhoods each, all their
+        particles) of the lower / upper MI bounds.  Returns info_bounds_grid [n_probes, 2] (nats)."""
+        pos = np.asarray(particle_positions_probe, dtype=np.float32)
+        types = (type_id + 1) * np.ones(pos.shape[0], dtype=np.float32)
+        features = convert_to_per_particle_feature_set(pos, types, number_particles_to_use=-1)
+        xv = np.asarray(particle_features_val, dtype=np.float32)
+        rng = np.random.default_rng(seed)
+        lo_acc = torch.zeros(pos.shape[0], dtype=torch.float64, device=self.device)
+        up_acc = torch.zeros_like(lo_acc)
+        for probe_ind_start in range(0, pos.shape[0], number_probes_to_eval_at_a_time):
+            sl = slice(probe_ind_start, min(pos.shape[0], probe_ind_start + number_probes_to_eval_at_a_time))
+            for b in range(num_eval_batches):
+                batch_inds = rng.choice(xv.shape[0], size=eval_batch_size_probe_grid, replace=True)
+                batch_particles = xv[batch_inds].reshape(-1, self.particle_feature_dimensions)
+                lo, up = self.probe_info_bounds(features[sl], batch_particles, seed=seed, step=probe_ind_start * 131 + b)
+                lo_acc[sl] += lo
+                up_acc[sl] += up
+        return torch.stack([lo_acc, up_acc], -1).cpu().numpy() / num_eval_batches
 
     # ---- the notebook's training loop ------------------------------------------------------------------------------------
     @staticmethod

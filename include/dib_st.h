@@ -47,6 +47,16 @@ int dib_reduce_splits(const float* partial, int64_t n, int nsplit, int64_t strid
 int dib_softmax_rows_fwd(float* S, int64_t rows, int P, int ld, float scale, dib_stream_t stream);
 int dib_softmax_rows_bwd(const float* P_probs, float* dP, int64_t rows, int P, int ld, float scale, dib_stream_t stream);
 
+/* Flash-style self-attention over the particle axis, Keras MultiHeadAttention(heads, key_dim = 128)(x, x, x) semantics:
+ * o[b, p, h, :] = sum_q softmax_q(scale * q[b, p, h, :] . k[b, q, h, :]) v[b, q, h, :].  q, k, v, o (and gradients) are
+ * [B * P, ld] row-major, head h in columns [h * 128, (h + 1) * 128), 16-byte aligned.  The [P, P] scores never reach HBM
+ * (online softmax forward, recomputation from lse [B, H, P] backward); deterministic (no atomics).  delta_ws: B * H * P floats. */
+int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,
+                      float scale, float* o, float* lse, dib_stream_t stream);
+int dib_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                      int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk, float* dv,
+                      float* delta_ws, dib_stream_t stream);
+
 /* tf.keras.layers.Add()([a, b]) -> LayerNormalization(epsilon): y = (s - mean)/sqrt(var + eps) * gamma + beta over the last
  * axis (D <= 256); xhat [T, D] and rstd [T] are stashed for the backward.  Backward: ds [T, D] (gradient of BOTH addends)
  * and dgamma_dbeta = [dgamma (D) | dbeta (D)] (contiguous, Keras variable order gamma, beta). */
@@ -74,6 +84,16 @@ int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logva
 int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, int64_t T, int E, float logvar_offset,
                              const float* beta_dev, float inv_batch, uint64_t seed, uint32_t step, int64_t row0,
                              float* d_enc_out, dib_stream_t stream);
+
+/* Per-particle information map (notebook cell 8, "Now use probe points along with a bunch of real points to get the info
+ * for points on a grid"): enc_probe [M, 2E] / enc_data [N, 2E] = particle_encoder outputs (mu | raw logvar), logvar_offset
+ * = -3.  One sample u_i ~ N(mu_i, sigma_i) per probe from the library's counter-based noise (seed, step, row = probe
+ * index, feature); per probe lower = infonce_per (mean over the probe's own and the N data conditionals), upper = loo_per
+ * (mean over the N data conditionals), nats, float64 with a log-sum-exp.  u_probe_out [M, E] (optional) returns the samples. */
+int64_t dib_mi_probe_workspace_bytes(int n_probes, int n_data, int E);
+int dib_mi_probe_bounds(const float* enc_probe, int n_probes, const float* enc_data, int n_data, int E, float logvar_offset,
+                        uint64_t seed, uint32_t step, uint32_t feature, double* lower_rows, double* upper_rows,
+                        double* u_probe_out, void* ws, dib_stream_t stream);
 
 /* Keras loss on plain buffers (DIB_LOSS_* of dib_hip.h): out3 = {sum of per-row losses, #correct, rows};
  * g_pred = d(mean loss)/d(pred) * (inv_global_batch * batch). */

@@ -232,3 +232,22 @@ def flops_per_neighbourhood(spec: SetTransformerSpec, particles: int) -> int:
         fl += 2 * d * u
         d = u
     return fl
+
+
+def probe_info_bounds(mus_probes, logvars_probes, sampled_u_probes, mus_data, logvars_data):
+    """Per-probe InfoNCE lower / leave-one-out upper bounds (nats) of the notebook's per-particle information map
+    (nb: "Now use probe points along with a bunch of real points to get the info for points on a grid", inner loop):
+      p_ii = N(u_i; mu_i, sigma_i) for the probe's own Gaussian, p_ij = N(u_i; mu_j, sigma_j) over the N data Gaussians,
+      infonce_i = log(p_ii / mean([p_ii, p_i1 .. p_iN]))   (N + 1 terms),   loo_i = log(p_ii / mean_j p_ij)   (N terms).
+    Literal float64 restatement (exp then log, like the notebook).  logvars already include the -3 offset."""
+    mp, lp = np.asarray(mus_probes, np.float64), np.asarray(logvars_probes, np.float64)
+    md, ld = np.asarray(mus_data, np.float64), np.asarray(logvars_data, np.float64)
+    u = np.asarray(sampled_u_probes, np.float64)
+    E = mp.shape[-1]
+    norm = (2.0 * np.pi) ** (E / 2.0)
+    p_ii = np.exp(-np.sum(((u - mp) / np.exp(lp / 2.0)) ** 2, -1) / 2.0 - np.sum(lp, -1) / 2.0) / norm
+    d = (u[:, None, :] - md[None, :, :]) / np.exp(ld / 2.0)[None, :, :]
+    p_ij = np.exp(-np.sum(d ** 2, -1) / 2.0 - np.sum(ld, -1)[None, :] / 2.0) / norm
+    infonce = np.log(p_ii / np.mean(np.concatenate([p_ii[:, None], p_ij], -1), axis=1))
+    loo = np.log(p_ii / np.mean(p_ij, axis=1))
+    return infonce, loo

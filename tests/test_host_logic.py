@@ -180,3 +180,36 @@ def test_torch_cpu_batched_equals_loop():
     a.apply_adam(g1, 1e-3)
     for u, v in zip(a.tensors(), b.tensors()):
         assert torch.allclose(u, v, rtol=0, atol=1e-14)
+
+
+def test_compression_matrix_figure_content_matches_reference_function(monkeypatch, tmp_path):
+    """SaveCompressionMatricesCallback / visualization.save_compression_matrices: the CONTENT of the PNG (matrix handed to
+    imshow, side-plot arrays) against what the reference's own function draws (visualization.py:14-81 executed with a
+    recording matplotlib stand-in, tests/golden/make_golden_compression.py) - not just that a file appears."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from plt_recorder import Recorder
+    from make_golden_compression import fake_encoder
+    import dib_amd
+    from dib_amd import visualization
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "compression_matrix_figure.npz"))
+    # (a) fewer than 10 unique raw values: histogram mode, deterministic
+    rec = Recorder()
+    monkeypatch.setattr(visualization, "_plt", lambda: rec)
+    m = visualization.save_compression_matrices(fake_encoder, g["inp_a"], str(tmp_path / "a.png"), inp_features_raw=g["raw_a"],
+                                                feature_label="Feature 3")
+    c = rec.content()
+    assert np.abs(m - g["a_matrix"]).max() < 1e-12 and np.abs(c[((1, 1), "imshow")][0] - g["a_matrix"]).max() < 1e-12
+    assert np.array_equal(c[((1, 0), "barh")][0], g["a_barh_y"]) and np.allclose(c[((1, 0), "barh")][1], g["a_barh_w"], atol=1e-15)
+    assert np.array_equal(c[((0, 1), "bar")][0], g["a_bar_x"]) and np.allclose(c[((0, 1), "bar")][1], g["a_bar_h"], atol=1e-15)
+    assert rec.saved == [str(tmp_path / "a.png")]
+    # (b) continuous feature: 128 random rows sorted by raw value (same np.random stream as the reference)
+    rec = Recorder()
+    monkeypatch.setattr(visualization, "_plt", lambda: rec)
+    np.random.seed(123)
+    m = visualization.save_compression_matrices(fake_encoder, g["inp_b"], str(tmp_path / "b.png"), inp_features_raw=g["raw_b"])
+    c = rec.content()
+    assert np.abs(m - g["b_matrix_intent"]).max() < 1e-12, "matrix of the sorted random selection (reference intent, defect A14 fixed)"
+    assert np.abs(m - g["b_matrix_literal"]).max() > 1e-3    # the reference literally draws the first 128 dataset rows
+    assert np.array_equal(c[((1, 0), "plot")][0], g["b_left_x"]) and np.array_equal(c[((1, 0), "plot")][1], g["b_left_y"])
+    assert np.array_equal(c[((0, 1), "plot")][0], g["b_top_x"]) and np.array_equal(c[((0, 1), "plot")][1], g["b_top_y"])

@@ -102,3 +102,14 @@ def test_schedules():
     assert sto.learning_rate_schedule(2500, 1e-4, 25000) == 1e-4 == sto.learning_rate_schedule(20000, 1e-4, 25000)
     assert sto.beta_schedule(0, 2e-6, 2e-1, 25000) == pytest.approx(2e-6)
     assert sto.beta_schedule(12500, 2e-6, 2e-1, 25000) == pytest.approx(np.sqrt(2e-6 * 2e-1))
+
+
+def test_probe_grid_bounds_match_the_notebook_statements_executed():
+    """oracle.probe_info_bounds against the notebook's own inner-loop statements run on the NumPy TF stand-in
+    (tests/golden/make_golden_probe_grid.py)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "probe_grid_bounds.npz"))
+    u = g["mus_probes"] + np.exp(g["logvars_probes"] / 2.0) * g["eps"]
+    assert np.abs(u - g["sampled_u_probes"]).max() < 1e-14
+    lo, up = sto.probe_info_bounds(g["mus_probes"], g["logvars_probes"], u, g["mus_data"], g["logvars_data"])
+    assert np.abs(lo - g["infonce_per"]).max() < 1e-11 and np.abs(up - g["loo_per"]).max() < 1e-10
+    assert (lo <= np.log(41) + 1e-12).all() and (lo <= up + 1e-12).all()
