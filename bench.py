@@ -387,6 +387,38 @@ def main():
                                     "value": round(sps4, 1), "unit": "samples/s", "ms_per_step": round(1e3 * m4 / k4, 4),
                                     "steps": k4, "batch": w4.gb, "params": w4.eng.n_params, "flops_per_sample": fl4,
                                     "step_roofline_frac": round(sps4 * fl4 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        if world == 1 and not args.no_extra:
+            # BASELINE config 5: per-particle set-transformer DIB, 4096 particles per neighbourhood, 3-D positions
+            # (16 derived per-particle features), the notebook's architecture; one step = fwd + KL + BCE + bwd + Adam
+            try:
+                torch.cuda.empty_cache()
+                from dib_amd import SetTransformerDIB
+                nb, npart, nfeat = 4, 4096, 16
+                st = SetTransformerDIB(particle_feature_dimensions=nfeat)
+                rng = np.random.default_rng(5)
+                xs = torch.from_numpy(rng.standard_normal((nb, npart, nfeat)).astype(np.float32)).to(dev)
+                ys = torch.from_numpy((rng.random((nb, 1)) > 0.5).astype(np.float32)).to(dev)
+                st.beta_dev.fill_(1e-3)
+                for _ in range(2):
+                    st.train_step(xs, ys)
+                torch.cuda.synchronize()
+                t5 = time.perf_counter()
+                for _ in range(4):
+                    st.train_step(xs, ys)
+                torch.cuda.synchronize()
+                dt5 = (time.perf_counter() - t5) / 4
+                D, H, K = 32, 12, 128
+                per_blk = 3 * 2 * D * H * K * npart + 4 * H * K * npart * npart + 2 * H * K * D * npart + 2 * (D * 128 + 128 * D) * npart
+                fwd = 2 * (nfeat * 5 * 128 + 128 * 128 + 128 * 64) * npart + 6 * per_blk
+                extra["config5_set_transformer"] = {
+                    "workload": f"BASELINE config 5: per-particle set-transformer DIB, {nb} neighbourhoods x {npart} particles x "
+                                f"{nfeat} features (3-D positions), 6 x [MHA 12 x 128, Add+LN, FF, Add+LN], fp32",
+                    "value": round(nb / dt5, 2), "unit": "neighbourhoods/s", "ms_per_step": round(1e3 * dt5, 2),
+                    "algorithmic_TFLOPs": round(3 * fwd * nb / dt5 / 1e12, 2), "attention": st.attention_impl,
+                    "params": st.n_params}
+                del st, xs, ys
+            except Exception as e:  # noqa: BLE001 - the extra line must never take the headline down
+                extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

@@ -110,7 +110,10 @@ class SetTransformerDIB:
                  output_dimensionality: int = 1, logvar_initialization: float = -3.0, layer_norm_epsilon: float = 1e-3,
                  *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto"):
         """attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
-        grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" = flash whenever key_dim == 128."""
+        grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" (per batch shape, key_dim == 128):
+        flash for short sets (P <= 128: measured 3.4 vs 4.1 ms/step at the notebook's 32 x 50) and whenever the stashed
+        probabilities of all blocks would exceed `score_budget_bytes` (default 16 GB: 32 neighbourhoods x 4096 particles
+        would need 155 GB), else gemm (measured 20-35 % faster at P = 2048-4096 while it fits)."""
         if not torch.cuda.is_available():
             raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.lib = _lib.load_library()
@@ -132,6 +135,8 @@ class SetTransformerDIB:
             raise ValueError(f"attention={attention!r}")
         if attention == "flash" and self.key_dim != 128:
             raise ValueError("attention='flash' needs key_dim == 128 (the notebook's value)")
+        self.attention = attention
+        self.score_budget_bytes = 16 << 30
         self.attention_impl = "flash" if (attention == "flash" or (attention == "auto" and self.key_dim == 128)) else "gemm"
         assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
         # ---- flat parameter layout (Keras creation order) ----
@@ -241,6 +246,11 @@ class SetTransformerDIB:
         D, H, K = self.bottleneck_dimension, self.number_heads_per_mha, self.key_dim
         HK, T = H * K, B * P
         ldS = _align4(P)
+        if self.attention == "auto" and self.key_dim == 128:
+            score_bytes = 4 * B * H * P * ldS * (self.number_attention_blocks + 1)
+            impl = "flash" if (P <= 128 or score_bytes > self.score_budget_bytes) else "gemm"
+        else:
+            impl = self.attention_impl
         F0 = self.particle_feature_dimensions
         pe_w = F0 * self.number_positional_encoding_frequencies
         enc_units = self.particle_encoder_arch_spec + [2 * D]
@@ -262,7 +272,7 @@ class SetTransformerDIB:
         for b in range(self.number_attention_blocks):
             for nm in ("q", "k", "v", "ctx"):
                 take(f"b{b}_{nm}", T * HK)
-            if self.attention_impl == "gemm":
+            if impl == "gemm":
                 take(f"b{b}_S", B * H * P * ldS)    # attention probabilities (stashed for the backward)
             else:
                 take(f"b{b}_lse", B * H * P)        # per-query log-sum-exp (the flash backward recomputes the rest)
@@ -288,7 +298,7 @@ class SetTransformerDIB:
             take(f"g_ff{l}", T * u)
         for nm in ("q", "k", "v", "ctx"):
             take(f"g_{nm}", T * HK)
-        if self.attention_impl == "gemm":
+        if impl == "gemm":
             take("g_S", B * H * P * ldS)
         else:
             take("attn_delta", B * H * P)
@@ -345,7 +355,7 @@ class SetTransformerDIB:
             g[f"b{b}_qkv_fwd"] = _Gemm(0, [_d(off[xin], D, po[pre + nm + "_w"], HK, off[f"b{b}_{nm}"], HK, T, HK, D,
                                               bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, self.params, ws,
                                        bias=self.params)
-            gemm_attn = self.attention_impl == "gemm"
+            gemm_attn = impl == "gemm"
             # scores S_bh = Q_bh K_bh^T (scale folded into the softmax)
             if gemm_attn:
                 g[f"b{b}_qk"] = _Gemm(1, [_d(off[f"b{b}_q"] + bi * P * HK + hi * K, HK, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
@@ -418,7 +428,7 @@ class SetTransformerDIB:
                 g["fin0_dgrad"] = dense_dgrad(f"g_fin{l}", u, "fin0_w", "g_pool", D, B)
         for gg in g.values():
             gg.upload(self.device)
-        plan = dict(B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
+        plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
                     enc_units=enc_units)
         self._plans[key] = plan
         return plan
@@ -461,7 +471,7 @@ class SetTransformerDIB:
             xin = "x0" if b == 0 else f"b{b - 1}_x"
             pre = f"blk{b}_"
             g[f"b{b}_qkv_fwd"].run(lib, st)
-            if self.attention_impl == "gemm":
+            if pl["impl"] == "gemm":
                 g[f"b{b}_qk"].run(lib, st)
                 check(lib.dib_softmax_rows_fwd(_ptr(ws, off[f"b{b}_S"]), B * H * P, P, pl["ldS"], scale, st), "dib_softmax_rows_fwd")
                 g[f"b{b}_pv"].run(lib, st)
@@ -487,6 +497,7 @@ class SetTransformerDIB:
         for l in range(len(self.final_processing_arch)):
             g[f"fin{l}_fwd"].run(lib, st)
         g["out_fwd"].run(lib, st)
+        self.attention_impl = pl["impl"]   # what this batch shape ran on (reporting)
         self.last = dict(plan=pl, step=step, row0=int(row0), B=B, P=P,
                          kl=self._view(pl, "kl_sum", 1) / B)   # "sum over dimension and particles, avg over batch"
         return self._view(pl, "pred", B, self.output_dimensionality)
@@ -538,7 +549,7 @@ class SetTransformerDIB:
             # multi-head attention
             g[f"b{b}_o_wgrad"].run(lib, st)
             g[f"b{b}_o_dgrad"].run(lib, st)
-            if self.attention_impl == "gemm":
+            if pl["impl"] == "gemm":
                 g[f"b{b}_dv"].run(lib, st)
                 g[f"b{b}_dp"].run(lib, st)
                 check(lib.dib_softmax_rows_bwd(_ptr(ws, off[f"b{b}_S"]), _ptr(ws, off["g_S"]), B * H * P, P, pl["ldS"], scale, st),
@@ -580,25 +591,55 @@ class SetTransformerDIB:
               "dib_adam_step")
 
     def train_step(self, batch_inp, is_loci, training: bool = True):
-        """The notebook's `train_step(batch_inp, is_loci, training=True)`: returns bce_losses (device scalar tensor [1])."""
-        self.forward(batch_inp)
-        self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
+        """The notebook's `train_step(batch_inp, is_loci, training=True)`: returns bce_losses (device scalar tensor [1]).
+
+        Data parallel (BASELINE config 5 shards the neighbourhoods over the GPUs of a node): when torch.distributed is
+        initialised every rank calls train_step with the SAME global batch; rank r takes neighbourhoods
+        [r*B/N, (r+1)*B/N), the noise is keyed by the global token index (results independent of N), the flat gradient
+        buffer is all-reduced (RCCL over xGMI with the nccl backend), every rank applies the same Adam update."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            self.forward(batch_inp)
+            self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
+            if training:
+                self.adam_step()
+            self._step += 1
+            return self.last["bce"]
+        rank, world = dist.get_rank(), dist.get_world_size()
+        B, P = int(batch_inp.shape[0]), int(batch_inp.shape[1])
+        lo, hi = (B * rank) // world, (B * (rank + 1)) // world
+        stats = torch.zeros(2, dtype=torch.float32, device=self.device)   # [bce sum / B, kl sum / B] of the local rows
+        if hi > lo:
+            self.forward(batch_inp[lo:hi], row0=lo * P)
+            if training:
+                self.loss_and_backward(is_loci[lo:hi], inv_global_batch=1.0 / B)
+            else:
+                self._loss_only(is_loci[lo:hi], inv_global_batch=1.0 / B)
+            stats[0:1] = self.last["bce"]
+            stats[1:2] = self.last["kl"] * ((hi - lo) / B)
+        elif training:
+            self.grads.zero_()
+        if training:
+            dist.all_reduce(self.grads)        # every rank issues the same collectives, rows or no rows
+        dist.all_reduce(stats)
         if training:
             self.adam_step()
         self._step += 1
+        self.last["bce"], self.last["kl"] = stats[0:1], stats[1:2]
         return self.last["bce"]
 
-    def _loss_only(self, is_loci):
+    def _loss_only(self, is_loci, inv_global_batch: Optional[float] = None):
         pl = self.last["plan"]
         B = self.last["B"]
+        inv = 1.0 / B if inv_global_batch is None else float(inv_global_batch)
         y = is_loci if isinstance(is_loci, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(is_loci, dtype=np.float32))
         y = y.to(device=self.device, dtype=torch.float32).reshape(B, -1).contiguous()
         ws, off = pl["ws"], pl["off"]
         check(self.lib.dib_loss_rows(LOSS_BCE_LOGITS, _ptr(ws, off["pred"]), self.output_dimensionality, _ptr(y), y.stride(0), B,
-                                     1.0 / B, _ptr(ws, off["g_pred"]), _ptr(ws, off["out3"]), _ptr(ws, off["loss_ws"]),
+                                     inv, _ptr(ws, off["g_pred"]), _ptr(ws, off["out3"]), _ptr(ws, off["loss_ws"]),
                                      self._stream()), "dib_loss_rows")
         out3 = self._view(pl, "out3", 3)
-        self.last["bce"] = out3[0:1] / B
+        self.last["bce"] = out3[0:1] * inv
         self.last["correct"] = out3[1:2]
 
     # ---- the notebook's evaluation helpers ---------------------------------------------------------------------------------

@@ -198,3 +198,41 @@ def test_probe_grid_information_bounds_match_oracle():
     grid = m.information_map(rng.uniform(-3, 3, (25, 2)), 0, data.reshape(40, 10, 12), num_eval_batches=2,
                              eval_batch_size_probe_grid=8, number_probes_to_eval_at_a_time=10)
     assert grid.shape == (25, 2) and np.isfinite(grid[:, 0]).all() and (grid[:, 0] <= grid[:, 1] + 1e-9).all()
+
+
+def test_data_parallel_shards_reproduce_the_full_batch_gradient():
+    """The DP contract of train_step (neighbourhoods sharded over ranks, noise keyed by the GLOBAL token index,
+    inv_global_batch = 1/B): the shard gradients sum to the full-batch gradient, the shard KL / BCE to the full values."""
+    spec = sto.SetTransformerSpec(number_attention_blocks=2)
+    B, P = 6, 17
+    m, _ = _model(spec, seed=8)
+    rng = np.random.default_rng(9)
+    feats = rng.standard_normal((B, P, 12)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32)
+    m.beta_dev.fill_(0.05)
+    m.forward(feats, step=3)
+    m.loss_and_backward(y)
+    g_full, kl_full, bce_full = m.grads.clone(), float(m.last["kl"].item()), float(m.last["bce"].item())
+    acc, kl, bce = torch.zeros_like(g_full), 0.0, 0.0
+    for lo, hi in ((0, 2), (2, 6)):
+        m.forward(feats[lo:hi], step=3, row0=lo * P)
+        m.loss_and_backward(y[lo:hi], inv_global_batch=1.0 / B)
+        acc += m.grads
+        kl += float(m.last["kl"].item()) * (hi - lo) / B
+        bce += float(m.last["bce"].item())
+    assert (acc - g_full).abs().max() <= 2e-5 * g_full.abs().max()
+    assert abs(kl - kl_full) < 1e-4 * max(1.0, abs(kl_full)) and abs(bce - bce_full) < 1e-5
+
+
+def test_fit_loop_runs_the_notebook_schedule():
+    """A few steps of the notebook's loop (lr warm-up, per-step beta, random neighbourhood batches, validation pass)."""
+    spec = sto.SetTransformerSpec(number_attention_blocks=1)
+    m, _ = _model(spec, seed=2)
+    rng = np.random.default_rng(0)
+    xtr = rng.standard_normal((40, 10, 12)).astype(np.float32)
+    ytr = (xtr[:, :, 0].mean(1) > 0).astype(np.float32)
+    hist = m.fit(xtr, ytr, number_training_steps=12, learning_rate=1e-3, beta_start=2e-6, beta_end=2e-1, batch_size=8,
+                 particle_features_val=xtr[:16], loci_val=ytr[:16], eval_every=4)
+    assert len(hist["bce_series_val"]) == 3 and np.isfinite(hist["bce_series_val"]).all()
+    assert all(0.0 <= a <= 1.0 for a in hist["acc_series_val"])
+    assert abs(float(m.lr_dev.item()) - 1e-3) < 1e-9 and int(m.t_dev.item()) == 12
