@@ -419,6 +419,23 @@ def main():
                 del st, xs, ys
             except Exception as e:  # noqa: BLE001 - the extra line must never take the headline down
                 extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and not args.no_extra:
+            # opt-in mode, separately labelled (never the headline): the integration network's two hidden-layer FORWARD
+            # products evaluated as six bf16 piece products per fp32 product on the bf16 matrix pipe (fp32-accurate, see
+            # csrc/dib_gemm_bf16x6.h); everything else unchanged.  Same workload, same protocol, its own process.
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", "2",
+                                    "--blocks", "1", "--batch", str(args.batch), "--no-cpu-baseline", "--no-extra",
+                                    "--no-kernel-timing"], env=dict(os.environ, DIB_GEMM_MODE="bf16x6"), capture_output=True,
+                                   text=True, timeout=300)
+                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                extra["bf16x6_integration_fwd"] = {
+                    "value": j["value"], "unit": "samples/s", "ms_per_step": j["ms_per_step"],
+                    "dtype": "f32, with the 2 integration forward GEMMs fp32-emulated on the bf16 MFMA pipe (bf16x6: 6 exact "
+                             "piece products per product, fp32 accumulate); DIB_GEMM_MODE=bf16x6",
+                    "roofline_note": "those GEMMs: bf16 MFMA peak 2500 / 6 = 417 TFLOP/s fp32-equivalent ceiling"}
+            except Exception as e:  # noqa: BLE001
+                extra["bf16x6_integration_fwd"] = {"error": f"{type(e).__name__}: {e}"}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

@@ -59,12 +59,13 @@ struct dib_layout {
   const long long* dev_fused_offs = nullptr;
   const int4* dev_featmap = nullptr;
   const unsigned* step_dev = nullptr;  // optional device-resident noise step (dib_layout_set_step_counter)
+  bool bf16x6 = false;                 // DIB_GEMM_MODE=bf16x6: integration forward GEMMs on the bf16 pipe (fp32-emulated)
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
-    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, skinny_partial, total;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, skinny_partial, bf16_planes, total;
     int skinny_chunks, skinny_rows;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
@@ -107,6 +108,15 @@ struct dib_layout {
       const int win = n_int == 0 ? F * E : int_units[n_int - 1];
       m.skinny_partial = take(out_dim <= 8 ? (int64_t)m.skinny_chunks * ((int64_t)win * out_dim + out_dim) : 0);
     }  // [F][B][2] x 64-bit act'(h2) masks (fused fwd -> fused bwd)
+    {  // DIB_GEMM_MODE=bf16x6: three bf16 planes [N][Kp] of the largest integration hidden-layer kernel
+      int64_t need = 0;
+      if (bf16x6)
+        for (int ly = 0; ly < n_int; ++ly) {
+          const int64_t K = ly == 0 ? (int64_t)F * E : int_units[ly - 1];
+          need = std::max<int64_t>(need, 3ll * int_units[ly] * ((K + 31) / 32 * 32) * 2 / 4 + 4);
+        }
+      m.bf16_planes = take(need);
+    }
     m.total = o;
     return m;
   }
@@ -481,6 +491,7 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
   // fused encoder-bank path: two hidden layers, instantiated (H1,H2,E), encoder inputs <= 16 wide
   {
     static const int kFused[][3] = {{128, 128, 32}, {32, 32, 32}, {32, 32, 8}, {64, 64, 16}};
+    if (const char* gm = std::getenv("DIB_GEMM_MODE")) l->bf16x6 = std::strcmp(gm, "bf16x6") == 0;
     const char* dis = std::getenv("DIB_DISABLE_FUSED");
     bool in_ok = true;
     for (int f = 0; f < F; ++f) in_ok = in_ok && l->in_dim[f] <= 16;
@@ -674,6 +685,17 @@ int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws,
       ProfScope ps(kProfOther, st);
       hipLaunchKernelGGL(dib_skinny_fwd_kernel, dim3(grid_for((int64_t)batch * 64, 256, 2048)), dim3(256), 0, st, A, batch,
                          win, params + l->int_w_off[ly], params + l->int_b_off[ly], l->out_dim, act, C);
+      rc = (int)hipGetLastError();
+    } else if (l->bf16x6 && ly < LI - 1 && batch >= 128) {
+      // opt-in mode: the hidden layers' forward products as six bf16 piece products per fp32 product (dib_gemm_bf16x6.h):
+      // split this step's kernel into three transposed bf16 planes, then the 128x128x32 bf16-MFMA GEMM
+      const int K = ly == 0 ? l->F * l->E : l->int_width[ly - 1], N = l->int_width[ly], Kp = (K + 31) / 32 * 32;
+      __bf16* planes = (__bf16*)(w + m.bf16_planes);
+      ProfScope ps(kProfOther, st);
+      hipLaunchKernelGGL(dib_split_weights_kernel, dim3(grid_for((int64_t)N * Kp)), dim3(256), 0, st, params + l->int_w_off[ly], K,
+                         N, Kp, planes);
+      hipLaunchKernelGGL(dib_gemm_bf16x6_kernel, dim3(8 * cdiv(cdiv(batch, 128), 8) * cdiv(N, 128)), dim3(256), 0, st, A, K,
+                         (const __bf16*)planes, Kp, C, N, params + l->int_b_off[ly], batch, N, K, act);
       rc = (int)hipGetLastError();
     } else {
       rc = launch_gemm<0>(l, l->int_fwd[ly], A, params, C, params, nullptr, nullptr, batch, act, 1, 0, 0, st);
@@ -1061,15 +1083,21 @@ int dib_gemm_grouped(int mode, int n_groups, const dib_gemm_desc* dev_desc, int 
 
 int dib_softmax_rows_fwd(float* S, int64_t rows, int P, int ld, float scale, dib_stream_t stream) {
   if (!S || rows <= 0 || P <= 0 || ld < P) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_softmax_rows_fwd_kernel, dim3(grid_for(rows, 4, 4096)), dim3(256), 0, (hipStream_t)stream, S,
-                     (long long)rows, P, ld, scale);
+  const dim3 grid(grid_for(rows, 4, 8192));
+  hipStream_t st = (hipStream_t)stream;
+#define DIB_SM(R) hipLaunchKernelGGL(dib_softmax_rows_fwd_kernel<R>, grid, dim3(256), 0, st, S, (long long)rows, P, ld, scale)
+  if (P <= 64) DIB_SM(1); else if (P <= 256) DIB_SM(4); else if (P <= 1024) DIB_SM(16); else if (P <= 4096) DIB_SM(64); else DIB_SM(0);
+#undef DIB_SM
   return (int)hipGetLastError();
 }
 
 int dib_softmax_rows_bwd(const float* Pm, float* dP, int64_t rows, int P, int ld, float scale, dib_stream_t stream) {
   if (!Pm || !dP || rows <= 0 || P <= 0 || ld < P) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_softmax_rows_bwd_kernel, dim3(grid_for(rows, 4, 4096)), dim3(256), 0, (hipStream_t)stream, Pm, dP,
-                     (long long)rows, P, ld, scale);
+  const dim3 grid(grid_for(rows, 4, 8192));
+  hipStream_t st = (hipStream_t)stream;
+#define DIB_SM(R) hipLaunchKernelGGL(dib_softmax_rows_bwd_kernel<R>, grid, dim3(256), 0, st, Pm, dP, (long long)rows, P, ld, scale)
+  if (P <= 64) DIB_SM(1); else if (P <= 256) DIB_SM(4); else if (P <= 1024) DIB_SM(16); else if (P <= 4096) DIB_SM(64); else DIB_SM(0);
+#undef DIB_SM
   return (int)hipGetLastError();
 }
 

@@ -24,28 +24,56 @@ __device__ __forceinline__ float dib_group_sum(float v) {
 }
 
 // ---- softmax over the key axis (Keras MultiHeadAttention: softmax(q k^T / sqrt(key_dim))) -------------------------
-// S: [rows][ld], the first P entries of a row are scores; in place: S <- softmax(scale * S).  One wave per row.
+// S: [rows][ld], the first P entries of a row are scores; in place: S <- softmax(scale * S).  One wave per row; rows of up
+// to 64 * RPL entries are held in registers between the passes (one HBM read + one write per element instead of three
+// reads and two writes - at 4096 particles the score tensor is 805 MB per block and neighbourhood, so this kernel IS its
+// HBM traffic); longer rows fall back to re-reading.
+template <int RPL>   // register entries per lane; RPL = 0: rows longer than 64 * 64, streamed
 __global__ void __launch_bounds__(256)
 dib_softmax_rows_fwd_kernel(float* __restrict__ S, long long rows, int P, int ld, float scale) {
   const int lane = threadIdx.x & 63;
   for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
     float* s = S + row * ld;
-    float m = -INFINITY;
-    for (int j = lane; j < P; j += 64) m = fmaxf(m, s[j]);
-    m = dib_wave_max(m);
-    float sum = 0.f;
-    for (int j = lane; j < P; j += 64) {
-      const float e = expf(scale * (s[j] - m));
-      s[j] = e;
-      sum += e;
+    if (RPL > 0) {
+      float v[RPL > 0 ? RPL : 1];
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < RPL; ++c) {
+        const int j = lane + 64 * c;
+        v[c] = j < P ? s[j] : -INFINITY;
+        m = fmaxf(m, v[c]);
+      }
+      m = dib_wave_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < RPL; ++c) {
+        v[c] = expf(scale * (v[c] - m));   // exp(-inf) = 0 for the padding
+        sum += v[c];
+      }
+      const float inv = 1.0f / dib_wave_sum(sum);
+#pragma unroll
+      for (int c = 0; c < RPL; ++c) {
+        const int j = lane + 64 * c;
+        if (j < P) s[j] = v[c] * inv;
+      }
+    } else {
+      float m = -INFINITY;
+      for (int j = lane; j < P; j += 64) m = fmaxf(m, s[j]);
+      m = dib_wave_max(m);
+      float sum = 0.f;
+      for (int j = lane; j < P; j += 64) {
+        const float e = expf(scale * (s[j] - m));
+        s[j] = e;
+        sum += e;
+      }
+      const float inv = 1.0f / dib_wave_sum(sum);
+      for (int j = lane; j < P; j += 64) s[j] *= inv;
     }
-    sum = dib_wave_sum(sum);
-    const float inv = 1.0f / sum;
-    for (int j = lane; j < P; j += 64) s[j] *= inv;
   }
 }
 
 // backward, in place on dP: dS = scale * P * (dP - sum_j dP_j P_j)   (gradient w.r.t. the UNSCALED scores q k^T)
+template <int RPL>
 __global__ void __launch_bounds__(256)
 dib_softmax_rows_bwd_kernel(const float* __restrict__ Pm, float* __restrict__ dP, long long rows, int P, int ld,
                             float scale) {
@@ -53,10 +81,28 @@ dib_softmax_rows_bwd_kernel(const float* __restrict__ Pm, float* __restrict__ dP
   for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
     const float* p = Pm + row * ld;
     float* d = dP + row * ld;
-    float dot = 0.f;
-    for (int j = lane; j < P; j += 64) dot += d[j] * p[j];
-    dot = dib_wave_sum(dot);
-    for (int j = lane; j < P; j += 64) d[j] = scale * p[j] * (d[j] - dot);
+    if (RPL > 0) {
+      float pv[RPL > 0 ? RPL : 1], dv[RPL > 0 ? RPL : 1];
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < RPL; ++c) {
+        const int j = lane + 64 * c;
+        pv[c] = j < P ? p[j] : 0.f;
+        dv[c] = j < P ? d[j] : 0.f;
+        dot += dv[c] * pv[c];
+      }
+      dot = dib_wave_sum(dot);
+#pragma unroll
+      for (int c = 0; c < RPL; ++c) {
+        const int j = lane + 64 * c;
+        if (j < P) d[j] = scale * pv[c] * (dv[c] - dot);
+      }
+    } else {
+      float dot = 0.f;
+      for (int j = lane; j < P; j += 64) dot += d[j] * p[j];
+      dot = dib_wave_sum(dot);
+      for (int j = lane; j < P; j += 64) d[j] = scale * p[j] * (d[j] - dot);
+    }
   }
 }
 

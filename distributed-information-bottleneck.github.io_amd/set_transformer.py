@@ -112,8 +112,8 @@ class SetTransformerDIB:
         """attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
         grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" (per batch shape, key_dim == 128):
         flash for short sets (P <= 128: measured 3.4 vs 4.1 ms/step at the notebook's 32 x 50) and whenever the stashed
-        probabilities of all blocks would exceed `score_budget_bytes` (default 16 GB: 32 neighbourhoods x 4096 particles
-        would need 155 GB), else gemm (measured 20-35 % faster at P = 2048-4096 while it fits)."""
+        probabilities of all blocks would exceed `score_budget_bytes` (default 96 GB, a third of the MI355X's HBM: 32
+        neighbourhoods x 4096 particles would need 180 GB), else gemm (measured 20-35 % faster at P = 2048-4096 while it fits)."""
         if not torch.cuda.is_available():
             raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.lib = _lib.load_library()
@@ -136,7 +136,7 @@ class SetTransformerDIB:
         if attention == "flash" and self.key_dim != 128:
             raise ValueError("attention='flash' needs key_dim == 128 (the notebook's value)")
         self.attention = attention
-        self.score_budget_bytes = 16 << 30
+        self.score_budget_bytes = 96 << 30
         self.attention_impl = "flash" if (attention == "flash" or (attention == "auto" and self.key_dim == 128)) else "gemm"
         assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
         # ---- flat parameter layout (Keras creation order) ----

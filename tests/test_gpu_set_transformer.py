@@ -80,6 +80,7 @@ SPECS = {
     "reference_size_flash": (sto.SetTransformerSpec(), 32, 50, "flash"),
     # several 128-query workgroups, a partial last key tile and a partial last query wave
     "flash_multi_tile": (sto.SetTransformerSpec(number_attention_blocks=1, number_heads_per_mha=3), 2, 300, "flash"),
+    "gemm_multi_tile": (sto.SetTransformerSpec(number_attention_blocks=1, number_heads_per_mha=3), 2, 300, "gemm"),
     "flash_33": (sto.SetTransformerSpec(number_attention_blocks=1, number_heads_per_mha=2), 3, 33, "flash"),
 }
 
