@@ -14,7 +14,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
+LIB_PATH = os.path.join(_HERE, "libdib_hip.so")   # (tools/ab_bench.sh swaps experiment builds in under this name)
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
 INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
 SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h", "dib_attn.h",
@@ -128,6 +128,7 @@ SIGNATURES_ST = {
     "dib_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "dib_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_void_p,
                                   c_void_p]),
+    "dib_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dib_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,

@@ -1172,22 +1172,43 @@ int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int
   return (int)hipGetLastError();
 }
 
+int64_t dib_attention_bwd_workspace_bytes(int B, int P, int H) {
+  if (B <= 0 || P <= 0 || H <= 0) return DIB_E_ARG;
+  const int64_t nkb = cdiv(P, 128);
+  return (int64_t)sizeof(float) * ((int64_t)B * H * P + (nkb > 1 ? (int64_t)B * H * nkb * P * kAttnD : 0) + 64);
+}
+
 int dib_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                       int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk, float* dv,
-                      float* delta_ws, dib_stream_t stream) {
-  if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !delta_ws || B <= 0 || P <= 0 || H <= 0 ||
+                      void* ws, dib_stream_t stream) {
+  if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !ws || B <= 0 || P <= 0 || H <= 0 ||
       ld < (int64_t)H * key_dim || (ld & 3))
     return DIB_E_ARG;
   if (key_dim != kAttnD) return DIB_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  float* delta = (float*)ws;
+  float* part = delta + (((int64_t)B * H * P + 63) / 64) * 64;
+  const int nkb = cdiv(P, 128);
   hipLaunchKernelGGL(dib_attn_delta_kernel, dim3(cdiv((int64_t)B * P * H, 4)), dim3(256), 0, st, o, d_o, (long long)ld, B, P, H,
-                     delta_ws);
+                     delta);
   DibAttnArgs a{};
-  a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.delta = delta_ws; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
   a.P = P; a.H = H; a.ld = ld; a.scale = scale;
-  hipLaunchKernelGGL(dib_attn_bwd_dq_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(dib_attn_bwd_dkv_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, st, a);
-  return (int)hipGetLastError();
+  const size_t lds = (size_t)DibAttnBwdLds * sizeof(float);
+  static bool attr_set[64] = {};
+  if (dib_attr_needed(attr_set)) {
+    hipError_t e = hipFuncSetAttribute((const void*)dib_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(dib_attn_bwd_kernel, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  if (nkb > 1) {
+    hipLaunchKernelGGL(dib_attn_dq_reduce_kernel, dim3(grid_for((int64_t)B * H * P * (kAttnD / 4))), dim3(256), 0, st,
+                       (const float*)part, B, P, H, nkb, (long long)ld, scale, dq);
+    rc = (int)hipGetLastError();
+  }
+  return rc;
 }
 
 int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* out, dib_stream_t stream) {

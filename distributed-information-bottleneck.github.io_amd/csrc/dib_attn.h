@@ -12,10 +12,10 @@
 //             query j, so the row maximum / sum are register reductions plus one cross-half shuffle, and the probability
 //             tile P^T is - register for register - the B operand of O^T += V^T P^T (contraction index = key
 //             (r&3) + 8(r>>2) + 4h = the C-fragment row of register r): probabilities never touch LDS.
-//   backward  dib_attn_bwd_dq_kernel  (same structure; dQ^T += K^T dS^T, dS^T = P^T (dP^T - delta))
-//             dib_attn_bwd_dkv_kernel (one wave = 32 keys, loops over query tiles; S = Q K^T evaluated UNtransposed so that
-//             P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS, contraction index = query)
-//             Two kernels instead of one with atomics: every gradient element has exactly one writer (deterministic).
+//   backward  dib_attn_bwd_kernel (one wave = 32 keys, loops over query tiles; S = Q K^T evaluated UNtransposed so that
+//             P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS, contraction index = query; the dQ
+//             contribution of the workgroup's 128 keys goes through an LDS transpose of dS into a per-key-block partial
+//             buffer) + dib_attn_dq_reduce_kernel: no atomics, one writer per element, fixed summation order.
 //   delta     dib_attn_delta_kernel : delta[q] = sum_d dO[q][d] O[q][d]
 //
 // Layout: q, k, v, o and their gradients are [tokens, ld] row-major with head h at columns [h*128, (h+1)*128)
@@ -89,7 +89,10 @@ __device__ __forceinline__ void dib_attn_store_rows(float* __restrict__ base, lo
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: grid (ceil(P / 128), H, B), 256 threads
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+#ifndef DIB_ATTN_FWD_WAVES
+#define DIB_ATTN_FWD_WAVES 3   // measured (tools/attn_bench.py, 4 x 4096 x 12 heads): 3 waves/SIMD 4.26 ms = 97 TFLOP/s, 2 waves/SIMD 4.98 ms
+#endif
+__global__ void __launch_bounds__(256, DIB_ATTN_FWD_WAVES)   // workgroups per CU = waves per SIMD (2: <= 256 registers, 3: <= 168)
 dib_attn_fwd_kernel(DibAttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[kAttnTile * kAttnPitch];
   __shared__ __attribute__((aligned(16))) float Vs[kAttnTile * kAttnPitch];
@@ -125,52 +128,76 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
       dib_attn_gload(rv, Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
     }
     if (wave_ok) {
-      // S^T[key][query] = sum_d K[key][d] (scale Q[query][d])
+      // S^T[key][query] = sum_d K[key][d] (scale Q[query][d]); the K fragment of step q + 1 is fetched before the MFMAs of
+      // step q are issued (one LDS latency per tile instead of one per 4 MFMAs)
       dib_f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      float4 kk = dib_attn_kc(Ks, 0, l31, h);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float4 kk = dib_attn_kc(Ks, q, l31, h);
+        const float4 kn = dib_attn_kc(Ks, q < 15 ? q + 1 : 15, l31, h);
         s = DIB_MFMA(kk.x, qf[q].x, s);
         s = DIB_MFMA(kk.y, qf[q].y, s);
         s = DIB_MFMA(kk.z, qf[q].z, s);
         s = DIB_MFMA(kk.w, qf[q].w, s);
+        kk = kn;
       }
       // online softmax over this tile's keys (register r <-> key kt*32 + (r&3) + 8(r>>2) + 4h)
-      float mloc = -INFINITY;
+      if (kt == n_tiles - 1) {   // only the last tile can hold keys beyond P
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * kAttnTile + (r & 3) + 8 * (r >> 2) + 4 * h;
-        s[r] = key < P ? s[r] : -INFINITY;
-        mloc = fmaxf(mloc, s[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * kAttnTile + (r & 3) + 8 * (r >> 2) + 4 * h;
+          s[r] = key < P ? s[r] : -INFINITY;
+        }
       }
+      float mloc = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-      const float m_new = fmaxf(m_run, mloc);          // finite: every tile holds at least one real key
-      const float alpha = __expf(m_run - m_new);       // first tile: exp(-inf) = 0
+      // Lazy rescale: the running reference m_run only moves when the tile maximum exceeds it by more than kLazy (then
+      // exp(s - m_run) <= e^kLazy, harmless in fp32).  The 64 accumulator registers live in AGPRs, so a rescale is 64 x
+      // (read, multiply, write back) in front of the P V MFMAs that depend on them - with the eager form that was paid on
+      // every key tile; now on the first tile and the (rare) tiles where some query's maximum jumps.  lse stays exact.
+      constexpr float kLazy = 6.0f;
+      const bool moved = mloc > m_run + kLazy;         // m_run = -inf on the first tile: always true
+      const float m_new = moved ? mloc : m_run;
+      if (__any(moved)) {
+        const float alpha = __expf(m_run - m_new);     // 1 for the lanes that did not move, 0 on the first tile
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+      }
+      m_run = m_new;
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s[r] = __expf(s[r] - m_new);
         psum += s[r];
       }
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
+      l_run += psum;
+      // O^T[d][query] += sum_key V[key][d] P^T[key][query]: the four d-tile fragments of the NEXT key block are in flight
+      // while the 16 MFMAs of the current one (four independent accumulators) issue
+      float4 vv[4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+      for (int dt = 0; dt < 4; ++dt) vv[dt] = dib_attn_mc(Vs, 0, 32 * dt + l31, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
-      // O^T[d][query] += sum_key V[key][d] P^T[key][query]
+      for (int q = 0; q < 4; ++q) {
+        float4 vn[4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt) vn[dt] = dib_attn_mc(Vs, q < 3 ? q + 1 : 3, 32 * dt + l31, h);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 vv = dib_attn_mc(Vs, q, 32 * dt + l31, h);
-          acc[dt] = DIB_MFMA(vv.x, s[4 * q + 0], acc[dt]);
-          acc[dt] = DIB_MFMA(vv.y, s[4 * q + 1], acc[dt]);
-          acc[dt] = DIB_MFMA(vv.z, s[4 * q + 2], acc[dt]);
-          acc[dt] = DIB_MFMA(vv.w, s[4 * q + 3], acc[dt]);
+        for (int dt = 0; dt < 4; ++dt) {
+          acc[dt] = DIB_MFMA(vv[dt].x, s[4 * q + 0], acc[dt]);
+          acc[dt] = DIB_MFMA(vv[dt].y, s[4 * q + 1], acc[dt]);
+          acc[dt] = DIB_MFMA(vv[dt].z, s[4 * q + 2], acc[dt]);
+          acc[dt] = DIB_MFMA(vv[dt].w, s[4 * q + 3], acc[dt]);
         }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vv[dt] = vn[dt];
+      }
     }
     __syncthreads();
   }
@@ -201,99 +228,29 @@ dib_attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// backward, dQ: grid (ceil(P / 128), H, B).  Per key tile: S^T = K Q^T, P^T = exp(S^T - lse), dP^T = V dO^T,
-// dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T ; dQ = scale * dQ^T^T.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-dib_attn_bwd_dq_kernel(DibAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ks[kAttnTile * kAttnPitch];
-  __shared__ __attribute__((aligned(16))) float Vs[kAttnTile * kAttnPitch];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y, b = blockIdx.z, P = a.P;
-  const long long tok0 = (long long)b * P;
-  const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
-  const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
-  const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
-  const float* dOb = a.d_o + tok0 * a.ld + head * kAttnD;
-  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
-  const bool q_ok = qrow < P;
-  const bool wave_ok = blockIdx.x * 128 + wave * 32 < P;
-  const int qc = min(qrow, P - 1);
-  float4 qf[16], gf[16];
-  dib_attn_rowfrag(qf, Qb, a.ld, qc, h, a.scale);
-  dib_attn_rowfrag(gf, dOb, a.ld, qc, h, 1.0f);
-  const float lse = a.lse[((long long)b * a.H + head) * P + qc];
-  const float dlt = a.delta[((long long)b * a.H + head) * P + qc];
-  dib_f32x16 acc[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
-
-  const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
-  float4 rk[4], rv[4];
-  dib_attn_gload(rk, Kb, a.ld, 0, P - 1, tid);
-  dib_attn_gload(rv, Vb, a.ld, 0, P - 1, tid);
-  for (int kt = 0; kt < n_tiles; ++kt) {
-    dib_attn_lstore(Ks, rk, tid);
-    dib_attn_lstore(Vs, rv, tid);
-    __syncthreads();
-    if (kt + 1 < n_tiles) {
-      dib_attn_gload(rk, Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
-      dib_attn_gload(rv, Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
-    }
-    if (wave_ok) {
-      dib_f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float4 kk = dib_attn_kc(Ks, q, l31, h);
-        s = DIB_MFMA(kk.x, qf[q].x, s);
-        s = DIB_MFMA(kk.y, qf[q].y, s);
-        s = DIB_MFMA(kk.z, qf[q].z, s);
-        s = DIB_MFMA(kk.w, qf[q].w, s);
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float4 vv = dib_attn_kc(Vs, q, l31, h);
-        dp = DIB_MFMA(vv.x, gf[q].x, dp);
-        dp = DIB_MFMA(vv.y, gf[q].y, dp);
-        dp = DIB_MFMA(vv.z, gf[q].z, dp);
-        dp = DIB_MFMA(vv.w, gf[q].w, dp);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * kAttnTile + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float p = key < P ? __expf(s[r] - lse) : 0.f;
-        s[r] = p * (dp[r] - dlt);                      // dS^T (w.r.t. the scaled score)
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 kk = dib_attn_mc(Ks, q, 32 * dt + l31, h);
-          acc[dt] = DIB_MFMA(kk.x, s[4 * q + 0], acc[dt]);
-          acc[dt] = DIB_MFMA(kk.y, s[4 * q + 1], acc[dt]);
-          acc[dt] = DIB_MFMA(kk.z, s[4 * q + 2], acc[dt]);
-          acc[dt] = DIB_MFMA(kk.w, s[4 * q + 3], acc[dt]);
-        }
-    }
-    __syncthreads();
-  }
-  dib_attn_store_rows(a.dq + tok0 * a.ld + head * kAttnD, a.ld, qrow, q_ok && wave_ok, h, acc, a.scale);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// backward, dK / dV: grid (ceil(P / 128), H, B); one wave = 32 keys, query tiles of 32 stream through LDS.
-//   S[query][key] = (scale Q) K^T, P = exp(S - lse[query]), dP = dO V^T, dS = P (dP - delta[query]),
+// backward: ONE kernel, grid (ceil(P / 128), H, B), 256 threads, dynamic LDS (DibAttnBwdLds floats).
+// A workgroup owns 128 keys (one wave = 32 keys, lane = key); query tiles of 32 stream through LDS.  Per query tile:
+//   S[query][key] = (scale Q) K^T, P = exp(S - lse[query]), dP = dO V^T, dS = P (dP - delta[query])      (lane = key)
 //   dV^T[d][key] += sum_query dO[query][d] P[query][key],  dK^T[d][key] += sum_query (scale Q)[query][d] dS[query][key]
+//   dQ contribution of these 128 keys: every wave drops its dS tile TRANSPOSED into an LDS patch; after a barrier wave w
+//   computes the d-tile w of  dQ^T[d][query] = sum_{128 keys} K^T[d][key] dS^T[key][query]  (K block resident in LDS) and
+//   writes it to the per-key-block partial buffer  part[b][h][key block][query][128].
+// dib_attn_dq_reduce_kernel then sums the key-block partials in a fixed order (x scale).  Every gradient element has one
+// writer and a fixed summation order (deterministic), S and dP are computed ONCE per tile pair: 5 tile products where the
+// separate dQ and dK/dV kernels of the first version needed 7.
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int kAttnPatch = 32 * 36;
+constexpr int DibAttnBwdLds = 2 * kAttnTile * kAttnPitch + 128 * kAttnPitch + 4 * kAttnPatch + 2 * kAttnTile;
+
 __global__ void __launch_bounds__(256)
-dib_attn_bwd_dkv_kernel(DibAttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float Qs[kAttnTile * kAttnPitch];   // scaled Q tile
-  __shared__ __attribute__((aligned(16))) float Gs[kAttnTile * kAttnPitch];   // dO tile
-  __shared__ float Ls[kAttnTile], Ds[kAttnTile];                              // lse / delta of the tile's queries
+dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;                                   // [32][132] scaled Q tile
+  float* Gs = Qs + kAttnTile * kAttnPitch;           // [32][132] dO tile
+  float* Kblk = Gs + kAttnTile * kAttnPitch;         // [128][132] this workgroup's keys (A operand of the dQ product)
+  float* patches = Kblk + 128 * kAttnPitch;          // [4 waves][32 queries][36]: dS^T tiles
+  float* Ls = patches + 4 * kAttnPatch;              // lse / delta of the tile's queries
+  float* Ds = Ls + kAttnTile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z, P = a.P;
   const long long tok0 = (long long)b * P;
@@ -310,52 +267,63 @@ dib_attn_bwd_dkv_kernel(DibAttnArgs a) {
   float4 kf[16], vf[16];
   dib_attn_rowfrag(kf, Kb, a.ld, kc, h, 1.0f);
   dib_attn_rowfrag(vf, Vb, a.ld, kc, h, 1.0f);
+  // the workgroup's 128 key rows -> LDS (rows beyond P are clamped: their dS is 0)
+#pragma unroll 4
+  for (int p = 0; p < 16; ++p) {
+    const int rl = (tid >> 5) + 8 * p;
+    const int row = min(blockIdx.x * 128 + rl, P - 1);
+    *reinterpret_cast<float4*>(Kblk + rl * kAttnPitch + (tid & 31) * 4) =
+        *reinterpret_cast<const float4*>(Kb + (long long)row * a.ld + (tid & 31) * 4);
+  }
   dib_f32x16 dv[4], dk[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dv[dt][r] = 0.f; dk[dt][r] = 0.f; }
+  float* my_patch = patches + wave * kAttnPatch;
+  // dQ output of this workgroup: direct (one key block: P <= 128) or partial buffer slice
+  float* dq_out = (n_key_blocks > 1)
+                      ? dq_part + ((((long long)b * a.H + head) * n_key_blocks + blockIdx.x) * P) * kAttnD
+                      : a.dq + tok0 * a.ld + head * kAttnD;
+  const long long dq_ld = (n_key_blocks > 1) ? kAttnD : a.ld;
+  const float dq_mul = (n_key_blocks > 1) ? 1.0f : a.scale;
 
   const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
   float4 rq[4], rg[4];
-  float rl = 0.f, rd = 0.f;
+  float rl_ = 0.f, rd_ = 0.f;
   dib_attn_gload(rq, Qb, a.ld, 0, P - 1, tid);
   dib_attn_gload(rg, dOb, a.ld, 0, P - 1, tid);
-  if (tid < kAttnTile) { rl = lse_b[min(tid, P - 1)]; rd = dlt_b[min(tid, P - 1)]; }
+  if (tid < kAttnTile) { rl_ = lse_b[min(tid, P - 1)]; rd_ = dlt_b[min(tid, P - 1)]; }
   for (int qt = 0; qt < n_tiles; ++qt) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) { rq[p].x *= a.scale; rq[p].y *= a.scale; rq[p].z *= a.scale; rq[p].w *= a.scale; }
     dib_attn_lstore(Qs, rq, tid);
     dib_attn_lstore(Gs, rg, tid);
-    if (tid < kAttnTile) { Ls[tid] = rl; Ds[tid] = rd; }
+    if (tid < kAttnTile) { Ls[tid] = rl_; Ds[tid] = rd_; }
     __syncthreads();
     if (qt + 1 < n_tiles) {
       dib_attn_gload(rq, Qb, a.ld, (qt + 1) * kAttnTile, P - 1, tid);
       dib_attn_gload(rg, dOb, a.ld, (qt + 1) * kAttnTile, P - 1, tid);
       if (tid < kAttnTile) {
-        rl = lse_b[min((qt + 1) * kAttnTile + tid, P - 1)];
-        rd = dlt_b[min((qt + 1) * kAttnTile + tid, P - 1)];
+        rl_ = lse_b[min((qt + 1) * kAttnTile + tid, P - 1)];
+        rd_ = dlt_b[min((qt + 1) * kAttnTile + tid, P - 1)];
       }
     }
+    dib_f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     if (wave_ok) {
-      // S[query][key] and dP[query][key]: A = query-tile rows (KC), B = this lane's key row
-      dib_f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      // S[query][key] and dP[query][key]: A = query-tile rows (KC), B = this lane's key row; fragments one step ahead
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float4 qq = dib_attn_kc(Qs, q, l31, h);
+        const float4 qq = dib_attn_kc(Qs, q, l31, h), gg = dib_attn_kc(Gs, q, l31, h);
         s = DIB_MFMA(qq.x, kf[q].x, s);
-        s = DIB_MFMA(qq.y, kf[q].y, s);
-        s = DIB_MFMA(qq.z, kf[q].z, s);
-        s = DIB_MFMA(qq.w, kf[q].w, s);
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float4 gg = dib_attn_kc(Gs, q, l31, h);
         dp = DIB_MFMA(gg.x, vf[q].x, dp);
+        s = DIB_MFMA(qq.y, kf[q].y, s);
         dp = DIB_MFMA(gg.y, vf[q].y, dp);
+        s = DIB_MFMA(qq.z, kf[q].z, s);
         dp = DIB_MFMA(gg.z, vf[q].z, dp);
+        s = DIB_MFMA(qq.w, kf[q].w, s);
         dp = DIB_MFMA(gg.w, vf[q].w, dp);
       }
       // register r <-> query qt*32 + (r&3) + 8(r>>2) + 4h ; lane <-> key
@@ -367,24 +335,85 @@ dib_attn_bwd_dkv_kernel(DibAttnArgs a) {
         dp[r] = p * (dp[r] - Ds[ql]);                  // dS
         s[r] = p;                                      // P
       }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 gg = dib_attn_mc(Gs, q, 32 * dt + l31, h);
-          dv[dt] = DIB_MFMA(gg.x, s[4 * q + 0], dv[dt]);
-          dv[dt] = DIB_MFMA(gg.y, s[4 * q + 1], dv[dt]);
-          dv[dt] = DIB_MFMA(gg.z, s[4 * q + 2], dv[dt]);
-          dv[dt] = DIB_MFMA(gg.w, s[4 * q + 3], dv[dt]);
-          const float4 qq = dib_attn_mc(Qs, q, 32 * dt + l31, h);
-          dk[dt] = DIB_MFMA(qq.x, dp[4 * q + 0], dk[dt]);
-          dk[dt] = DIB_MFMA(qq.y, dp[4 * q + 1], dk[dt]);
-          dk[dt] = DIB_MFMA(qq.z, dp[4 * q + 2], dk[dt]);
-          dk[dt] = DIB_MFMA(qq.w, dp[4 * q + 3], dk[dt]);
-        }
     }
-    __syncthreads();
+    // dS^T into this wave's patch: patch[query][key] (zeros from a wave without keys)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) my_patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = dp[r];
+    if (wave_ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 gv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Gs, q, 32 * dt + l31, h);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = DIB_MFMA(gv[dt].x, s[4 * q + 0], dv[dt]);
+          dv[dt] = DIB_MFMA(gv[dt].y, s[4 * q + 1], dv[dt]);
+          dv[dt] = DIB_MFMA(gv[dt].z, s[4 * q + 2], dv[dt]);
+          dv[dt] = DIB_MFMA(gv[dt].w, s[4 * q + 3], dv[dt]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Qs, q, 32 * dt + l31, h);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dk[dt] = DIB_MFMA(gv[dt].x, dp[4 * q + 0], dk[dt]);
+          dk[dt] = DIB_MFMA(gv[dt].y, dp[4 * q + 1], dk[dt]);
+          dk[dt] = DIB_MFMA(gv[dt].z, dp[4 * q + 2], dk[dt]);
+          dk[dt] = DIB_MFMA(gv[dt].w, dp[4 * q + 3], dk[dt]);
+        }
+      }
+    }
+    __syncthreads();   // all four dS^T patches are in LDS; nobody reads Qs / Gs any more
+    {
+      // dQ^T[d = 32*wave + .][query] over the workgroup's 128 keys: A = K block (MC), B = dS^T patches (b128 along keys)
+      dib_f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ds4 = *reinterpret_cast<const float4*>(patches + kw * kAttnPatch + l31 * 36 + 8 * g + 4 * h);
+          const float4 kk = dib_attn_mc(Kblk + kw * 32 * kAttnPitch, g, 32 * wave + l31, h);
+          dq = DIB_MFMA(kk.x, ds4.x, dq);
+          dq = DIB_MFMA(kk.y, ds4.y, dq);
+          dq = DIB_MFMA(kk.z, ds4.z, dq);
+          dq = DIB_MFMA(kk.w, ds4.w, dq);
+        }
+      // dq[r] = dQ^T[d = 32*wave + (r&3) + 8(r>>2) + 4h][query l31]
+      const int qrow = qt * kAttnTile + l31;
+      if (qrow < P) {
+        float* dst = dq_out + (long long)qrow * dq_ld + 32 * wave + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4*>(dst + 8 * g) =
+              make_float4(dq[4 * g] * dq_mul, dq[4 * g + 1] * dq_mul, dq[4 * g + 2] * dq_mul, dq[4 * g + 3] * dq_mul);
+      }
+    }
   }
   dib_attn_store_rows(a.dv + tok0 * a.ld + head * kAttnD, a.ld, krow, k_ok && wave_ok, h, dv, 1.0f);
   dib_attn_store_rows(a.dk + tok0 * a.ld + head * kAttnD, a.ld, krow, k_ok && wave_ok, h, dk, 1.0f);  // Q tile was pre-scaled
+}
+
+// dq[token][head cols] = scale * sum_{key blocks, fixed order} part[b][h][kb][query][128]
+__global__ void __launch_bounds__(256)
+dib_attn_dq_reduce_kernel(const float* __restrict__ part, int B, int P, int H, int n_key_blocks, long long ld, float scale,
+                          float* __restrict__ dq) {
+  const long long total4 = (long long)B * H * P * (kAttnD / 4);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+    const int c4 = (int)(i % (kAttnD / 4));
+    const long long row = i / (kAttnD / 4);            // (b*H + head)*P + query
+    const int qy = (int)(row % P);
+    const long long bh = row / P;
+    const float4* src = reinterpret_cast<const float4*>(part + ((bh * n_key_blocks) * P + qy) * kAttnD) + c4;
+    float4 sacc = src[0];
+    for (int kb = 1; kb < n_key_blocks; ++kb) {
+      const float4 v = src[(long long)kb * P * (kAttnD / 4)];
+      sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+    }
+    const long long b = bh / H;
+    const int head = (int)(bh % H);
+    *reinterpret_cast<float4*>(dq + (b * P + qy) * ld + head * kAttnD + 4 * c4) =
+        make_float4(sacc.x * scale, sacc.y * scale, sacc.z * scale, sacc.w * scale);
+  }
 }

@@ -208,11 +208,28 @@ dib_add_layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restri
 // ---- mean over the particle axis (notebook: x = tf.reduce_mean(x, axis=-2)) ------------------------------------------
 __global__ void __launch_bounds__(256)
 dib_mean_pool_fwd_kernel(const float* __restrict__ X, int B, int P, int D, float* __restrict__ out) {
+  // one workgroup per neighbourhood; thread = (particle lane, column): 256 / D particle lanes stride over the particles,
+  // fixed-order LDS reduction over the lanes (the first version walked all P particles in one thread per column: 0.93 ms
+  // at 4096 particles)
+  __shared__ float red[256];
   const int b = blockIdx.x;
-  for (int d = threadIdx.x; d < D; d += 256) {
+  if (D <= 256 && 256 % D == 0) {
+    const int lanes = 256 / D, pl = threadIdx.x / D, d = threadIdx.x % D;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += X[((long long)b * P + p) * D + d];
-    out[(long long)b * D + d] = s / (float)P;
+    for (int p = pl; p < P; p += lanes) s += X[((long long)b * P + p) * D + d];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (pl == 0) {
+      float t = 0.f;
+      for (int l = 0; l < lanes; ++l) t += red[l * D + d];
+      out[(long long)b * D + d] = t / (float)P;
+    }
+  } else {
+    for (int d = threadIdx.x; d < D; d += 256) {
+      float s = 0.f;
+      for (int p = 0; p < P; ++p) s += X[((long long)b * P + p) * D + d];
+      out[(long long)b * D + d] = s / (float)P;
+    }
   }
 }
 __global__ void __launch_bounds__(256)

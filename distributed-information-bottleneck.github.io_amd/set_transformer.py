@@ -301,7 +301,7 @@ class SetTransformerDIB:
         if impl == "gemm":
             take("g_S", B * H * P * ldS)
         else:
-            take("attn_delta", B * H * P)
+            take("attn_delta", int(self.lib.dib_attention_bwd_workspace_bytes(B, P, H)) // 4)   # delta + dQ key-block partials
         for nm in ("q", "k", "v"):
             take(f"g_x{nm}", T * D)
         for l, u in enumerate(enc_units):

@@ -50,12 +50,14 @@ int dib_softmax_rows_bwd(const float* P_probs, float* dP, int64_t rows, int P, i
 /* Flash-style self-attention over the particle axis, Keras MultiHeadAttention(heads, key_dim = 128)(x, x, x) semantics:
  * o[b, p, h, :] = sum_q softmax_q(scale * q[b, p, h, :] . k[b, q, h, :]) v[b, q, h, :].  q, k, v, o (and gradients) are
  * [B * P, ld] row-major, head h in columns [h * 128, (h + 1) * 128), 16-byte aligned.  The [P, P] scores never reach HBM
- * (online softmax forward, recomputation from lse [B, H, P] backward); deterministic (no atomics).  delta_ws: B * H * P floats. */
+ * (online softmax forward, recomputation from lse [B, H, P] backward); deterministic (no atomics: the dQ contributions of
+ * the 128-key blocks go through a partial buffer inside `ws` and a fixed-order reduce).  ws: dib_attention_bwd_workspace_bytes. */
 int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,
                       float scale, float* o, float* lse, dib_stream_t stream);
+int64_t dib_attention_bwd_workspace_bytes(int B, int P, int H);
 int dib_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                       int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk, float* dv,
-                      float* delta_ws, dib_stream_t stream);
+                      void* ws, dib_stream_t stream);
 
 /* tf.keras.layers.Add()([a, b]) -> LayerNormalization(epsilon): y = (s - mean)/sqrt(var + eps) * gamma + beta over the last
  * axis (D <= 256); xhat [T, D] and rstd [T] are stashed for the backward.  Backward: ds [T, D] (gradient of BOTH addends)
