@@ -242,7 +242,7 @@ dib_attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o
 constexpr int kAttnPatch = 32 * 36;
 constexpr int DibAttnBwdLds = 2 * kAttnTile * kAttnPitch + 128 * kAttnPitch + 4 * kAttnPatch + 2 * kAttnTile;
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 1)
 dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Qs = lds;                                   // [32][132] scaled Q tile
@@ -264,8 +264,11 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
   const bool k_ok = krow < P;
   const bool wave_ok = blockIdx.x * 128 + wave * 32 < P;
   const int kc = min(krow, P - 1);
-  float4 kf[16], vf[16];
-  dib_attn_rowfrag(kf, Kb, a.ld, kc, h, 1.0f);
+  // V row fragment resident in registers (B operand of dP = dO V^T); the K row fragment (B operand of S = Q K^T) is read
+  // from the workgroup's K block in LDS instead - it is there for the dQ product anyway, and 64 registers fewer end the
+  // spilling (48 -> 0) and leave room to fetch every LDS fragment one step ahead of its MFMAs (one wave per SIMD: nobody
+  // else hides that latency)
+  float4 vf[16];
   dib_attn_rowfrag(vf, Vb, a.ld, kc, h, 1.0f);
   // the workgroup's 128 key rows -> LDS (rows beyond P are clamped: their dS is 0)
 #pragma unroll 4
@@ -313,18 +316,23 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     if (wave_ok) {
-      // S[query][key] and dP[query][key]: A = query-tile rows (KC), B = this lane's key row; fragments one step ahead
+      // S[query][key] and dP[query][key]: A = query-tile rows (KC), B = this lane's key row (K from the LDS block, V from
+      // registers); the three LDS fragments of step q + 1 are in flight during the 8 MFMAs of step q
+      const float* Kw = Kblk + wave * 32 * kAttnPitch;
+      float4 qq = dib_attn_kc(Qs, 0, l31, h), gg = dib_attn_kc(Gs, 0, l31, h), kk = dib_attn_kc(Kw, 0, l31, h);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float4 qq = dib_attn_kc(Qs, q, l31, h), gg = dib_attn_kc(Gs, q, l31, h);
-        s = DIB_MFMA(qq.x, kf[q].x, s);
+        const int qn_ = q < 15 ? q + 1 : 15;
+        const float4 qn = dib_attn_kc(Qs, qn_, l31, h), gn = dib_attn_kc(Gs, qn_, l31, h), kn = dib_attn_kc(Kw, qn_, l31, h);
+        s = DIB_MFMA(qq.x, kk.x, s);
         dp = DIB_MFMA(gg.x, vf[q].x, dp);
-        s = DIB_MFMA(qq.y, kf[q].y, s);
+        s = DIB_MFMA(qq.y, kk.y, s);
         dp = DIB_MFMA(gg.y, vf[q].y, dp);
-        s = DIB_MFMA(qq.z, kf[q].z, s);
+        s = DIB_MFMA(qq.z, kk.z, s);
         dp = DIB_MFMA(gg.z, vf[q].z, dp);
-        s = DIB_MFMA(qq.w, kf[q].w, s);
+        s = DIB_MFMA(qq.w, kk.w, s);
         dp = DIB_MFMA(gg.w, vf[q].w, dp);
+        qq = qn; gg = gn; kk = kn;
       }
       // register r <-> query qt*32 + (r&3) + 8(r>>2) + 4h ; lane <-> key
 #pragma unroll
@@ -340,11 +348,13 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
 #pragma unroll
     for (int r = 0; r < 16; ++r) my_patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = dp[r];
     if (wave_ok) {
+      float4 gv[4], qv[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Gs, 0, 32 * dt + l31, h);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float4 gv[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Gs, q, 32 * dt + l31, h);
+        for (int dt = 0; dt < 4; ++dt) qv[dt] = dib_attn_mc(Qs, q, 32 * dt + l31, h);   // in flight during the dV MFMAs
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           dv[dt] = DIB_MFMA(gv[dt].x, s[4 * q + 0], dv[dt]);
@@ -352,14 +362,16 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
           dv[dt] = DIB_MFMA(gv[dt].z, s[4 * q + 2], dv[dt]);
           dv[dt] = DIB_MFMA(gv[dt].w, s[4 * q + 3], dv[dt]);
         }
+        if (q < 3) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Qs, q, 32 * dt + l31, h);
+          for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Gs, q + 1, 32 * dt + l31, h);   // in flight during the dK MFMAs
+        }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dk[dt] = DIB_MFMA(gv[dt].x, dp[4 * q + 0], dk[dt]);
-          dk[dt] = DIB_MFMA(gv[dt].y, dp[4 * q + 1], dk[dt]);
-          dk[dt] = DIB_MFMA(gv[dt].z, dp[4 * q + 2], dk[dt]);
-          dk[dt] = DIB_MFMA(gv[dt].w, dp[4 * q + 3], dk[dt]);
+          dk[dt] = DIB_MFMA(qv[dt].x, dp[4 * q + 0], dk[dt]);
+          dk[dt] = DIB_MFMA(qv[dt].y, dp[4 * q + 1], dk[dt]);
+          dk[dt] = DIB_MFMA(qv[dt].z, dp[4 * q + 2], dk[dt]);
+          dk[dt] = DIB_MFMA(qv[dt].w, dp[4 * q + 3], dk[dt]);
         }
       }
     }
@@ -369,17 +381,20 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
       dib_f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      float4 ds4 = *reinterpret_cast<const float4*>(patches + l31 * 36 + 4 * h);
+      float4 kk4 = dib_attn_mc(Kblk, 0, 32 * wave + l31, h);
 #pragma unroll
-      for (int kw = 0; kw < 4; ++kw)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 ds4 = *reinterpret_cast<const float4*>(patches + kw * kAttnPatch + l31 * 36 + 8 * g + 4 * h);
-          const float4 kk = dib_attn_mc(Kblk + kw * 32 * kAttnPitch, g, 32 * wave + l31, h);
-          dq = DIB_MFMA(kk.x, ds4.x, dq);
-          dq = DIB_MFMA(kk.y, ds4.y, dq);
-          dq = DIB_MFMA(kk.z, ds4.z, dq);
-          dq = DIB_MFMA(kk.w, ds4.w, dq);
-        }
+      for (int st = 0; st < 16; ++st) {   // st = 4 * key wave + g
+        const int sn = st < 15 ? st + 1 : 15;
+        const float4 dsn = *reinterpret_cast<const float4*>(patches + (sn >> 2) * kAttnPatch + l31 * 36 + 8 * (sn & 3) + 4 * h);
+        const float4 kn4 = dib_attn_mc(Kblk + (sn >> 2) * 32 * kAttnPitch, sn & 3, 32 * wave + l31, h);
+        dq = DIB_MFMA(kk4.x, ds4.x, dq);
+        dq = DIB_MFMA(kk4.y, ds4.y, dq);
+        dq = DIB_MFMA(kk4.z, ds4.z, dq);
+        dq = DIB_MFMA(kk4.w, ds4.w, dq);
+        ds4 = dsn;
+        kk4 = kn4;
+      }
       // dq[r] = dQ^T[d = 32*wave + (r&3) + 8(r>>2) + 4h][query l31]
       const int qrow = qt * kAttnTile + l31;
       if (qrow < P) {
