@@ -379,13 +379,13 @@ def main():
             del wl
             torch.cuda.empty_cache()
             w4 = Workload(50, dev, 0, 1, None, "strong", args.batch, args.dp_buckets)
-            m4, t4 = w4.measure(2, max(4, args.steps // 2), 1, dev)
             k4 = max(4, args.steps // 2)
+            m4, t4 = w4.measure(3, k4, 3, dev)   # median of 3 blocks, like the headline
             fl4 = gemm_flops_per_sample(50)
             sps4 = k4 * w4.gb / m4
             extra["config4_F50"] = {"workload": "BASELINE config 4: 50 shell features (synthetic N(0,1)), same architecture",
                                     "value": round(sps4, 1), "unit": "samples/s", "ms_per_step": round(1e3 * m4 / k4, 4),
-                                    "steps": k4, "batch": w4.gb, "params": w4.eng.n_params, "flops_per_sample": fl4,
+                                    "steps": k4, "blocks_ms_per_step": [round(1e3 * t / k4, 4) for t in t4], "batch": w4.gb, "params": w4.eng.n_params, "flops_per_sample": fl4,
                                     "step_roofline_frac": round(sps4 * fl4 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_extra:
             # BASELINE config 5: per-particle set-transformer DIB, 4096 particles per neighbourhood, 3-D positions

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY - CPU restatement of the per-particle Distributed-IB set transformer of the reference's
-amorphous-plasticity notebook (BASELINE config 5).  GROUNDWORK: no HIP path exists for this model
-yet; this oracle (PyTorch-CPU float64 with autograd for the backward) and its fixtures are what the kernels of a later
-round will be checked against.  Nothing in the product imports it.
+amorphous-plasticity notebook (BASELINE config 5): PyTorch-CPU float64 with autograd for the backward.
+It is the checker of the HIP path (dib_amd/set_transformer.py, include/dib_st.h; tests/test_gpu_set_transformer.py) and
+nothing in the product imports it.
 
 Reference: complex_systems/InfoDecomp_Amorphous_plasticity_per_particle_measurements_and_set_transformer.ipynb, code
 cell 8 ("Create the particle encoder and the set transformer" ... `train_step`), cell 6

@@ -1,7 +1,7 @@
-"""GROUNDWORK for SURVEY 8(f) rank 3 (per-particle set-transformer DIB, BASELINE config 5): the CPU oracle
-(oracle/set_transformer_oracle.py) against fixtures produced by executing the reference notebook's own model-building and
-train_step code on the NumPy stand-in for TensorFlow (tests/golden/make_golden_set_transformer.py).  No HIP path exists for
-this model yet - these tests pin what a later round's kernels will be checked against."""
+"""SURVEY 8(f) rank 3 (per-particle set-transformer DIB, BASELINE config 5): the CPU oracle
+(oracle/set_transformer_oracle.py) against fixtures produced by executing the reference notebook's own model-building,
+train_step and probe-grid code on the NumPy stand-in for TensorFlow (tests/golden/make_golden_set_transformer.py,
+make_golden_probe_grid.py).  These tests pin the checker that tests/test_gpu_set_transformer.py holds the HIP path to."""
 import os
 import sys
 
