@@ -89,6 +89,11 @@ SIGNATURES = {
     "dib_loss_fwd_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p,
                                  c_void_p]),
     "dib_integration_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_output_head_fused_supported": (c_int, [c_void_p, c_int]),
+    "dib_integration_fwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dib_output_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
+    "dib_integration_bwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                      c_uint64, c_uint32, c_void_p, c_void_p]),
     "dib_grads_finalize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -90,7 +90,7 @@ struct dib_layout {
     m.kl_blocks = cdiv(B, rpb);
     m.kl_partial = take((int64_t)std::max(m.kl_blocks, 8 * 256) * F);  // fused fwd: <= 256 workgroups x 8 waves
     m.loss_blocks = cdiv(B, 256);
-    m.loss_partial = take((int64_t)m.loss_blocks * 2);
+    m.loss_partial = take((int64_t)std::max(m.loss_blocks, 512) * 2);  // also the fused output head's per-workgroup partials (<= 512)
     // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= DIB_SPLIT_ROWS rows per split
     int ns = std::min(DIB_MAX_SPLITS, std::max(1, B / DIB_SPLIT_ROWS));
     int rps = cdiv(cdiv(B, ns), 32) * 32;
@@ -668,7 +668,8 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   return (int)hipGetLastError();
 }
 
-int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream) {
+static int integration_fwd_impl(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream,
+                                bool with_output_layer) {
   if (!l || !params || !ws || batch <= 0) return DIB_E_ARG;
   if (!l->dev_groups) return DIB_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -676,6 +677,7 @@ int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws,
   float* w = (float*)ws;
   const int LI = l->n_int + 1;
   for (int ly = 0; ly < LI; ++ly) {
+    if (ly == LI - 1 && !with_output_layer) break;
     const float* A = ly == 0 ? w + m.U : w + m.int_h[ly - 1];
     float* C = ly == LI - 1 ? w + m.pred : w + m.int_h[ly];
     const int act = ly == LI - 1 ? l->out_act : l->act;  // reference models.py:82-83
@@ -705,6 +707,14 @@ int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws,
   return DIB_OK;
 }
 
+int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream) {
+  return integration_fwd_impl(l, batch, params, ws, stream, true);
+}
+
+int dib_integration_fwd_hidden(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream) {
+  return integration_fwd_impl(l, batch, params, ws, stream, false);
+}
+
 // ---- loss + backward ----------------------------------------------------------------------------
 int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
                      int batch, float inv_global_batch, void* ws, dib_stream_t stream) {
@@ -729,7 +739,8 @@ static inline float* wgrad_target(const dib_layout::WsMap& m, float* w, float* g
   return m.nsplit > 1 ? w + m.wgrad_partial : grads;
 }
 
-int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* grads, void* ws, dib_stream_t stream) {
+static int integration_bwd_impl(dib_layout* l, int batch, const float* params, float* grads, void* ws, dib_stream_t stream,
+                                bool with_output_layer) {
   if (!l || !params || !grads || !ws || batch <= 0) return DIB_E_ARG;
   if (!l->dev_groups) return DIB_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -739,6 +750,7 @@ int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* gr
   const long long sstride = align_up(l->n_params, 4);
   const int LI = l->n_int + 1;
   for (int ly = LI - 1; ly >= 0; --ly) {
+    if (ly == LI - 1 && !with_output_layer) continue;  // done by dib_output_head_fused
     const float* gout = ly == LI - 1 ? w + m.g_pred : w + m.g_int_h[ly];
     const float* hin = ly == 0 ? w + m.U : w + m.int_h[ly - 1];
     float* gin = ly == 0 ? w + m.g_u : w + m.g_int_h[ly - 1];
@@ -768,6 +780,55 @@ int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* gr
     if (rc) return rc;
   }
   return DIB_OK;
+}
+
+int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* grads, void* ws, dib_stream_t stream) {
+  return integration_bwd_impl(l, batch, params, grads, ws, stream, true);
+}
+
+int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, float* grads, void* ws, dib_stream_t stream) {
+  return integration_bwd_impl(l, batch, params, grads, ws, stream, false);
+}
+
+// fused 1-unit output head of a training step: supported for out_dim == 1, linear output activation, BCE-from-logits or
+// MSE, at least one integration hidden layer whose width is a multiple of 4 and <= 1024
+int dib_output_head_fused_supported(const dib_layout* l, int loss_kind) {
+  if (!l) return 0;
+  if (const char* e = std::getenv("DIB_DISABLE_FUSED_HEAD")) if (e[0] == '1') return 0;  // A/B switch
+  if (l->out_dim != 1 || l->out_act != DIB_ACT_LINEAR || l->n_int < 1) return 0;
+  if (loss_kind != DIB_LOSS_BCE_LOGITS && loss_kind != DIB_LOSS_MSE) return 0;
+  const int K = l->int_width[l->n_int - 1];
+  return (K % 4 == 0 && K <= 1024) ? 1 : 0;
+}
+
+int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
+                          int batch, float inv_global_batch, const float* params, float* grads, void* ws,
+                          dib_stream_t stream) {
+  if (!l || !y || !params || !grads || !ws || batch <= 0) return DIB_E_ARG;
+  if (!dib_output_head_fused_supported(l, loss_kind)) return DIB_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  float* gt = wgrad_target(m, w, grads);
+  const int ly = l->n_int, K = l->int_width[ly - 1];
+  const int nblk = m.skinny_chunks, rpb = m.skinny_rows;
+  const float* A = w + m.int_h[ly - 1];
+  {
+    ProfScope ps(kProfOther, st);
+#define DIB_HEAD(NC) hipLaunchKernelGGL(dib_head_fused_kernel<NC>, dim3(nblk), dim3(256), 0, st, loss_kind, A, batch, K,      \
+                                        params + l->int_w_off[ly], params + l->int_b_off[ly], y, (long long)ldy,                 \
+                                        (const int*)row_idx, (long long)row0, inv_global_batch, l->act, rpb, w + m.pred,          \
+                                        w + m.g_pred, w + m.g_int_h[ly - 1], w + m.skinny_partial, w + m.loss_partial)
+    if (K <= 256) DIB_HEAD(1); else if (K <= 512) DIB_HEAD(2); else DIB_HEAD(4);
+#undef DIB_HEAD
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(K + 1), dim3(256), 0, st, (const float*)(w + m.skinny_partial), nblk,
+                       K, 1, gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
+    hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), nblk, (float)batch,
+                       w + m.step_out + l->F);
+  }
+  return (int)hipGetLastError();
 }
 
 int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,

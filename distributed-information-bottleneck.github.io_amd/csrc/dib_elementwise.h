@@ -743,3 +743,89 @@ dib_skinny_wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, i
     else dB[i - K * out] = tot;
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Fused 1-unit output head of a training step (reference models.py:83 Dense(out) + the compiled Keras loss + its part of
+// tape.gradient): for every row ONE pass over the last hidden activation a[b][0..K):
+//   z = a.w + bias  -> pred ;  loss / accuracy terms ;  g = dloss/dz * inv_bg -> g_pred ;
+//   g_a[b][k] = g * w[k] * act'(a[b][k])            (dgrad into the last hidden layer)
+//   dW[k] += a[b][k] * g ,  db += g                  (per-workgroup partials, fixed-order reduce afterwards)
+// instead of four launches (skinny fwd, loss, skinny wgrad, skinny dgrad) that each re-read a or g.  One wave per row,
+// a lane holds the float4 columns lane, lane + 64, ... (K <= 1024, K % 4 == 0); rows of a workgroup in a fixed order.
+// partial_w: [gridDim.x][K + 1] (layout of dib_skinny_wgrad_reduce_kernel), partial_l: [gridDim.x][2] (dib_loss_finalize).
+// ---------------------------------------------------------------------------------------------
+template <int NC>   // float4 columns per lane = ceil(K / 256)
+__global__ void __launch_bounds__(256)
+dib_head_fused_kernel(int kind, const float* __restrict__ A, int batch, int K, const float* __restrict__ W,
+                      const float* __restrict__ bias, const float* __restrict__ Y, long long ldy,
+                      const int* __restrict__ row_idx, long long row0, float inv_bg, int act, int rows_per_block,
+                      float* __restrict__ pred, float* __restrict__ g_pred, float* __restrict__ g_a,
+                      float* __restrict__ partial_w, float* __restrict__ partial_l) {
+  __shared__ float redw[4][1024 + 4];
+  __shared__ float redl[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K4 = K >> 2;
+  float4 w4[NC], pw[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = lane + 64 * c;
+    w4[c] = j < K4 ? reinterpret_cast<const float4*>(W)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    pw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float b0 = bias ? bias[0] : 0.f;
+  float pb = 0.f, lsum = 0.f, correct = 0.f;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(batch, r0 + rows_per_block);
+  for (int b = r0 + wave; b < r1; b += 4) {
+    const float4* a = reinterpret_cast<const float4*>(A + (long long)b * K);
+    float4 av[NC];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int j = lane + 64 * c;
+      av[c] = j < K4 ? a[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      dot += av[c].x * w4[c].x + av[c].y * w4[c].y + av[c].z * w4[c].z + av[c].w * w4[c].w;
+    }
+    const float z = dib_wave_sum(dot) + b0;
+    const long long row = row_idx ? (long long)row_idx[b] : row0 + b;
+    const float yy = Y[row * ldy];
+    float l, gg;
+    if (kind == 0) {  // Keras BinaryCrossentropy(from_logits=True), same expressions as dib_loss_kernel
+      l = fmaxf(z, 0.f) - z * yy + log1pf(expf(-fabsf(z)));
+      gg = 1.0f / (1.0f + expf(-z)) - yy;
+    } else {          // 'mse'
+      const float d = z - yy;
+      l = d * d;
+      gg = 2.f * d;
+    }
+    gg *= inv_bg;
+    if (lane == 0) {
+      pred[b] = z;
+      g_pred[b] = gg;
+      lsum += l;
+      correct += ((z > 0.5f ? 1.f : 0.f) == yy) ? 1.f : 0.f;
+      pb += gg;
+    }
+    float4* ga = reinterpret_cast<float4*>(g_a + (long long)b * K);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int j = lane + 64 * c;
+      if (j < K4) {
+        ga[j] = make_float4(gg * w4[c].x * dib_act_grad(act, av[c].x), gg * w4[c].y * dib_act_grad(act, av[c].y),
+                            gg * w4[c].z * dib_act_grad(act, av[c].z), gg * w4[c].w * dib_act_grad(act, av[c].w));
+        pw[c].x += av[c].x * gg; pw[c].y += av[c].y * gg; pw[c].z += av[c].z * gg; pw[c].w += av[c].w * gg;
+      }
+    }
+  }
+  // fixed-order sum of the four waves' partials
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int j = lane + 64 * c;
+    if (j < K4) *reinterpret_cast<float4*>(&redw[wave][4 * j]) = pw[c];
+  }
+  if (lane == 0) { redw[wave][K] = pb; redl[wave][0] = lsum; redl[wave][1] = correct; }
+  __syncthreads();
+  float* dst = partial_w + (long long)blockIdx.x * (K + 1);
+  for (int i = threadIdx.x; i <= K; i += 256) dst[i] = redw[0][i] + redw[1][i] + redw[2][i] + redw[3][i];
+  if (threadIdx.x < 2) partial_l[2 * blockIdx.x + threadIdx.x] = redl[0][threadIdx.x] + redl[1][threadIdx.x] + redl[2][threadIdx.x] + redl[3][threadIdx.x];
+}

@@ -75,6 +75,7 @@ class HipEngine:
         self._ws_pinned = set()                     # batch sizes whose workspace a captured graph points into
         self._ws_gen: Dict[int, int] = {}           # batch -> number of forwards that (re)wrote its activations
         self._scratch: Optional[torch.Tensor] = None
+        self._fused_head: Dict[int, bool] = {}      # loss kind -> dib_output_head_fused_supported
         self.blocks = self._query_blocks()
         self.set_flat_params(self.glorot_uniform(init_seed))
 
@@ -182,7 +183,7 @@ class HipEngine:
 
     # ---- the step -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, row_idx: Optional[torch.Tensor], row0: int, batch: int, seed: int, step: int,
-                deterministic: bool = False, inference: bool = False) -> None:
+                deterministic: bool = False, inference: bool = False, hidden_only: bool = False) -> None:
         """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT].  inference=True: no backward
         follows (validation / predict), the fused forward skips the stashes it would write for it."""
         ws = self.workspace(batch)
@@ -192,7 +193,11 @@ class HipEngine:
                                             _ptr(self.params), int(seed), int(step) & 0xFFFFFFFF,
                                             (1 if deterministic else 0) | (2 if inference else 0), _ptr(ws), st),
               "dib_encoder_bank_fwd")
-        check(self.lib.dib_integration_fwd(self.layout, batch, _ptr(self.params), _ptr(ws), st), "dib_integration_fwd")
+        if hidden_only:  # the output layer is evaluated by the fused head together with the loss (train_step)
+            check(self.lib.dib_integration_fwd_hidden(self.layout, batch, _ptr(self.params), _ptr(ws), st),
+                  "dib_integration_fwd_hidden")
+        else:
+            check(self.lib.dib_integration_fwd(self.layout, batch, _ptr(self.params), _ptr(ws), st), "dib_integration_fwd")
 
     def loss(self, loss_kind: str, y: torch.Tensor, row_idx, row0: int, batch: int, inv_global_batch: float) -> None:
         ws = self.workspace(batch)
@@ -207,14 +212,14 @@ class HipEngine:
         return off.value, cnt.value
 
     def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float,
-                 on_integration_grads_ready=None) -> None:
+                 on_integration_grads_ready=None, hidden_only: bool = False) -> None:
         """Backward pass.  The integration-network gradients (bucket 1) are final right after dib_integration_bwd;
         `on_integration_grads_ready(grads_slice)` is called at that point so a data-parallel caller can start their
         all-reduce while the encoder-bank backward (the bulk of the step) is still running."""
         ws = self.workspace(batch)
         st = self._stream()
-        check(self.lib.dib_integration_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st),
-              "dib_integration_bwd")
+        fn = self.lib.dib_integration_bwd_hidden if hidden_only else self.lib.dib_integration_bwd
+        check(fn(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st), "dib_integration_bwd")
         if on_integration_grads_ready is not None:
             check(self.lib.dib_grads_finalize_part(self.layout, batch, 1, _ptr(self.grads), _ptr(ws), st),
                   "dib_grads_finalize_part")
@@ -237,9 +242,18 @@ class HipEngine:
         """fwd + loss + bwd for the local rows; grads (partial sums over local rows / B_global) land in
         self.grads, ready for the data-parallel all-reduce(sum) and the optimizer step."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
-        self.forward(x, row_idx, row0, batch, seed, step)
-        self.loss(loss_kind, y, row_idx, row0, batch, inv)
-        self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready)
+        kind = LOSS_KINDS[loss_kind]
+        fused_head = self._fused_head.get(kind)
+        if fused_head is None:
+            fused_head = self._fused_head[kind] = bool(self.lib.dib_output_head_fused_supported(self.layout, kind))
+        self.forward(x, row_idx, row0, batch, seed, step, hidden_only=fused_head)
+        if fused_head:  # output Dense(1) + loss + its backward in one pass over the last hidden activation
+            check(self.lib.dib_output_head_fused(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
+                                                 float(inv), _ptr(self.params), _ptr(self.grads), _ptr(self.workspace(batch)),
+                                                 self._stream()), "dib_output_head_fused")
+        else:
+            self.loss(loss_kind, y, row_idx, row0, batch, inv)
+        self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=fused_head)
         if accumulate:
             self.accumulate_metrics(batch, inv)
 

@@ -121,6 +121,21 @@ int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, 
                      int64_t row0, int batch, float inv_global_batch, void* ws, dib_stream_t stream);
 int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* grads, void* ws,
                         dib_stream_t stream);
+/* Fused 1-unit output head of a TRAINING step (one pass over the last hidden activation instead of four launches):
+ *   dib_integration_fwd_hidden  = dib_integration_fwd without the output layer (models.py:83)
+ *   dib_output_head_fused       = output Dense(1) forward -> ws[PRED], the loss (dib_loss_fwd_bwd's accounting into
+ *                                 ws[STEP_OUT]) and the output layer's backward (its weight / bias gradient, ws[G_PRED], the
+ *                                 gradient of the last hidden layer)
+ *   dib_integration_bwd_hidden  = dib_integration_bwd without the output layer
+ * Same results as the unfused sequence fwd -> dib_loss_fwd_bwd -> bwd.  dib_output_head_fused_supported: out_dim 1, linear
+ * output, BCE-from-logits or MSE, >= 1 hidden layer of width % 4 == 0 and <= 1024; otherwise use the unfused sequence. */
+int dib_output_head_fused_supported(const dib_layout* l, int loss_kind);
+int dib_integration_fwd_hidden(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream);
+int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
+                          int batch, float inv_global_batch, const float* params, float* grads, void* ws,
+                          dib_stream_t stream);
+int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, float* grads, void* ws,
+                               dib_stream_t stream);
 int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
                          float inv_global_batch, const int32_t* row_idx, int64_t row0, uint64_t seed,
                          uint32_t step, void* ws, dib_stream_t stream);

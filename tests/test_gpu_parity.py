@@ -650,3 +650,29 @@ def test_experimental_bf16x6_gemm_is_fp32_accurate(M, N, K, act):
     check(lib.dib_gemm_bf16x6(n, N, n, p(eye), n, p(pl2), p(C2), N, None, 0, st), "dib_gemm_bf16x6")
     torch.cuda.synchronize()
     assert torch.equal(C2, Wn)
+
+
+@pytest.mark.parametrize("kind,B", [("bce_logits", 300), ("mse", 37), ("bce_logits", 8192 + 5)])
+def test_fused_output_head_equals_the_unfused_sequence(kind, B):
+    """dib_output_head_fused (output Dense(1) + loss + its backward in one pass, what train_step uses) against the separate
+    dib_integration_fwd -> dib_loss_fwd_bwd -> dib_integration_bwd sequence: same predictions, loss sums, accuracy and
+    gradients (different summation order only)."""
+    spec = orc.DIBSpec([1] * 6, [32, 32], [256, 64], 1, feature_embedding_dimension=32)
+    eng, _ = _engine(spec, 3)
+    kind_id = {"bce_logits": 0, "mse": 3}[kind]
+    assert eng.lib.dib_output_head_fused_supported(eng.layout, kind_id) == 1
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, 6)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32) if kind == "bce_logits" else rng.standard_normal((B, 1)).astype(np.float32)
+    xd, yd = eng.to_device(x), eng.to_device(y)
+    eng.set_beta(0.1)
+    eng.train_step(xd, yd, None, 0, B, 2, 3, kind, accumulate=False)            # fused head
+    g_f, so_f, pred_f = eng.grads.clone(), eng.step_out(B).clone(), eng.pred(B).clone()
+    eng.forward(xd, None, 0, B, 2, 3)                                            # unfused sequence
+    eng.loss(kind, yd, None, 0, B, 1.0 / B)
+    eng.backward(None, 0, B, 2, 3, 1.0 / B)
+    g_u, so_u, pred_u = eng.grads, eng.step_out(B), eng.pred(B)
+    assert torch.equal(pred_f, pred_u) or (pred_f - pred_u).abs().max() < 1e-6
+    assert (so_f - so_u).abs().max() <= 1e-5 * (1 + so_u.abs().max())
+    assert so_f[6 + 1] == so_u[6 + 1] and so_f[6 + 2] == B                       # accuracy count, rows
+    assert (g_f - g_u).abs().max() <= 2e-5 * g_u.abs().max()
