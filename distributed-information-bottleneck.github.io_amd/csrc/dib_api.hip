@@ -60,6 +60,10 @@ struct dib_layout {
   const int4* dev_featmap = nullptr;
   const unsigned* step_dev = nullptr;  // optional device-resident noise step (dib_layout_set_step_counter)
   bool bf16x6 = false;                 // DIB_GEMM_MODE=bf16x6: integration forward GEMMs on the bf16 pipe (fp32-emulated)
+  // fork / join inside dib_encoder_bank_bwd: the HBM-bound narrow wgrad runs beside the MFMA-bound one (created with the
+  // descriptor tables, i.e. outside any stream capture; the fork-join itself is capturable)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
@@ -196,12 +200,16 @@ struct Knobs {
   int fwd_small_wgs = 512;   // forward/dgrad: below this many 128-row workgroups use 64-row tiles
   int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
   int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
+  int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
+                             // OFF: measured slower (same box, B = 65536: 8.44-8.50 vs 8.37 ms; B = 8192: 1.345 vs 1.313 ms) -
+                             // the two kernels together ask for 5.8 TB/s of HBM and evict each other's L2 lines
   Knobs() {
     if (const char* e = std::getenv("DIB_FWD_SMALL_WGS")) fwd_small_wgs = std::atoi(e);
     if (const char* e = std::getenv("DIB_L3_HALVE")) l3_halve = std::atoi(e);
     if (const char* e = std::getenv("DIB_FORCE_TILE0")) force_tile[0] = std::atoi(e);
     if (const char* e = std::getenv("DIB_FORCE_TILE1")) force_tile[1] = std::atoi(e);
     if (const char* e = std::getenv("DIB_FORCE_TILE2")) force_tile[2] = std::atoi(e);
+    if (const char* e = std::getenv("DIB_CONCURRENT_WGRAD")) concurrent_wgrad = std::atoi(e);
   }
 };
 inline const Knobs& knobs() { static Knobs k; return k; }
@@ -512,7 +520,13 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
   return DIB_OK;
 }
 
-void dib_layout_destroy(dib_layout* l) { delete l; }
+void dib_layout_destroy(dib_layout* l) {
+  if (!l) return;
+  if (l->ev_fork) (void)hipEventDestroy(l->ev_fork);
+  if (l->ev_join) (void)hipEventDestroy(l->ev_join);
+  if (l->side) (void)hipStreamDestroy(l->side);
+  delete l;
+}
 
 int64_t dib_layout_param_count(const dib_layout* l) { return l ? l->n_params : DIB_E_ARG; }
 
@@ -562,6 +576,14 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
   char* fmp = fo + align_up((int64_t)l->fused_offs.size() * sizeof(long long), 256);
   e = hipMemcpyAsync(fmp, l->featmap.data(), l->featmap.size() * sizeof(int4), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
+  if (!l->side) {  // host-side objects only (no device memory): a second stream + two events for the wgrad fork / join
+    if (hipStreamCreateWithFlags(&l->side, hipStreamNonBlocking) != hipSuccess) l->side = nullptr;
+    if (l->side && (hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess)) {
+      (void)hipStreamDestroy(l->side);
+      l->side = nullptr;
+    }
+  }
   l->dev_groups = (const DibGemmGroup*)base;
   l->dev_colmap = (const int4*)cm;
   l->dev_fused_offs = (const long long*)fo;
@@ -854,6 +876,12 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   }
   if (rc) return rc;
   const int LE = l->n_enc + 1;
+  // Optional fork / join (DIB_CONCURRENT_WGRAD=1, default off - measured slower, see Knobs): the last layer's weight gradient
+  // (N = 2E <= 64 columns: HBM-bound, 4.5 TB/s with the matrix pipe 2/3 busy) is independent of the other layers' and can run
+  // on the layout's side stream beside the MFMA-bound wide wgrad that follows it on the caller's stream; the caller's stream
+  // waits for it before this entry returns its work.  Never while the per-kernel event timing of bench.py is on.
+  const bool fork = fused && knobs().concurrent_wgrad && l->side && !g_prof.on && LE >= 3 && l->enc_wgrad[LE - 1].max_n <= 64 &&
+                    batch >= 4096;
   for (int ly = LE - 1; ly >= 0; --ly) {
     if (fused && ly == 0) break;  // d(W1|b1) is produced inside the fused kernel and reduced in dib_grads_finalize
     const float* gout = ly == LE - 1 ? w + m.dout : w + m.g_enc_h[ly];
@@ -862,15 +890,23 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
     // splits fill the chip in one wave (measured 0.88 -> 0.71 ms); the unused slabs of these blocks stay zero.
     // (only from 32 splits = 16384 rows up: at B = 8192 the 16 -> 8 split halving measured 117 vs 103 us)
     const bool halve = knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
+    hipStream_t lst = st;
+    if (fork && ly == LE - 1) {
+      if (hipEventRecord(l->ev_fork, st) != hipSuccess || hipStreamWaitEvent(l->side, l->ev_fork, 0) != hipSuccess)
+        return DIB_E_ARG;
+      lst = l->side;
+    }
     rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0,
-                        halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, st);
+                        halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, lst);
     if (rc) return rc;
+    if (fork && ly == LE - 1 && hipEventRecord(l->ev_join, l->side) != hipSuccess) return DIB_E_ARG;
     if (ly >= 1 && !fused) {
       rc = launch_gemm<1>(l, l->enc_dgrad[ly], gout, params, w + m.g_enc_h[ly - 1], nullptr, hin, nullptr, batch,
                           l->act, 1, 0, 0, st);
       if (rc) return rc;
     }
   }
+  if (fork && hipStreamWaitEvent(st, l->ev_join, 0) != hipSuccess) return DIB_E_ARG;
   return DIB_OK;
 }
 
