@@ -188,7 +188,10 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 #ifndef DIB_BK11
 #define DIB_BK11 32
 #endif
-  constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : 32);  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
+#ifndef DIB_BK212
+#define DIB_BK212 32
+#endif
+  constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
   hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
                      bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride);
   return (int)hipGetLastError();
@@ -663,8 +666,12 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   const auto m = l->map(batch);
   float* w = (float*)ws;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_posenc_kernel, dim3(cdiv(l->sum_d, 64), cdiv(batch, 64)), dim3(256), 0, st, x, (long long)ldx,
-                     (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P); }
+  if ((long long)cdiv(l->sum_d, 64) * cdiv(batch, 64) >= 512)
+    hipLaunchKernelGGL(dib_posenc_kernel<64>, dim3(cdiv(l->sum_d, 64), cdiv(batch, 64)), dim3(256), 0, st, x, (long long)ldx,
+                       (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P);
+  else
+    hipLaunchKernelGGL(dib_posenc_kernel<16>, dim3(cdiv(l->sum_d, 64), cdiv(batch, 16)), dim3(256), 0, st, x, (long long)ldx,
+                       (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   if (l->fused_id >= 0) {  // one launch: positional encoding + 3 layers + reparameterisation + KL
@@ -994,7 +1001,7 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
   float* w = (float*)ws;
   const int d = l->dims[feature];
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_posenc_kernel, dim3(cdiv(d, 64), cdiv(n, 64)), dim3(256), 0, st, x_f, (long long)d,
+  hipLaunchKernelGGL(dib_posenc_kernel<64>, dim3(cdiv(d, 64), cdiv(n, 64)), dim3(256), 0, st, x_f, (long long)d,
                      (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;

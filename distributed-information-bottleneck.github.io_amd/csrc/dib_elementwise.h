@@ -11,17 +11,19 @@
 // P is feature-major and ragged: P_f = P + poff*batch is a dense [batch, n_blocks*d_f] matrix and
 // P_f[b, j*d_f + c_local] = (j==0 ? x : sin(2^j * x)),  x = X[row(b), c]
 // ---------------------------------------------------------------------------------------------
+template <int ROWS>   // batch rows per workgroup tile: 64, or 16 for mid-size batches (more workgroups: at B = 8192 the 64-row
+                      // tiling is 128 workgroups of sinf-bound work on 256 CUs)
 __global__ void __launch_bounds__(256)
 dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restrict__ row_idx, long long row0,
                   int batch, const int4* __restrict__ colmap, int ncols, int n_blocks /*1 + n sinusoids*/,
                   float* __restrict__ P) {
-  // One block = 64 rows x 64 input columns.  The tile is read row-wise (coalesced along the sample-major X rows),
+  // One block = ROWS rows x 64 input columns.  The tile is read row-wise (coalesced along the sample-major X rows),
   // transposed through LDS, and written with lanes <-> consecutive rows of ONE feature, so the feature-major P rows
   // (width*4 bytes apart) are filled by neighbouring lanes instead of 4-byte stores scattered over 64 features.
-  __shared__ float T[64][65];
-  const int c0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  __shared__ float T[ROWS][65];
+  const int c0 = blockIdx.x * 64, b0 = blockIdx.y * ROWS;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < ROWS / 4; ++i) {
     const int idx = threadIdx.x + 256 * i, r = idx >> 6, c = idx & 63;
     float v = 0.f;
     if (b0 + r < batch && c0 + c < ncols) {
@@ -31,9 +33,9 @@ dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restr
     T[r][c] = v;
   }
   __syncthreads();
-  const int r = threadIdx.x & 63, b = b0 + r;
+  const int r = threadIdx.x & (ROWS - 1), b = b0 + r;
   if (b >= batch) return;
-  for (int c = threadIdx.x >> 6; c < 64 && c0 + c < ncols; c += 4) {
+  for (int c = threadIdx.x / ROWS; c < 64 && c0 + c < ncols; c += 256 / ROWS) {
     const int4 cm = colmap[c0 + c];
     const float x = T[r][c];
     float* dst = P + (long long)cm.w * batch + (long long)b * (n_blocks * cm.z) + cm.y;

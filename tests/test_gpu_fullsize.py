@@ -12,6 +12,8 @@ per-feature loop by tests/test_host_logic.py::test_torch_cpu_batched_equals_loop
 from the device generator (134 M normals per step take ~15 s in the NumPy Philox); it is spot-checked against the
 oracle's Philox on random rows in every test, and pinned in full by test_eps_matches_oracle_and_host_ref.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -24,6 +26,16 @@ pytestmark = pytest.mark.gpu
 
 ENC, INTEG, E = [128, 128], [256, 256], 32
 CHUNK = 8192
+
+
+@pytest.fixture(autouse=True)
+def _bounded_cpu_threads():
+    """The float64 checker is 64-way batched matmuls on 8192-row chunks: on a 256-core host the default thread count
+    oversubscribes them (22 s per 65536-row step measured); a bounded pool is faster."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    yield
+    torch.set_num_threads(n)
 
 
 def _synthetic(n, F, seed):
