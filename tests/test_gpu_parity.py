@@ -6,6 +6,7 @@ gradient's max-abs.
 """
 import ctypes
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -113,7 +114,9 @@ def test_eps_matches_oracle_and_host_ref():
 @pytest.mark.parametrize("B", [1, 37, 300])
 def test_forward_backward_parity(name, B):
     spec = SPECS[name]
-    eng, p = _engine(spec, seed=hash(name) % 1000)
+    # (zlib.crc32, not hash(): str hashes are salted per process, and with a different parameter seed every run the odd run hit
+    # a ReLU unit within round-off of 0 - one flipped unit moves a gradient column by ~1/sqrt(B) of its scale)
+    eng, p = _engine(spec, seed=zlib.crc32(name.encode()) % 1000)
     F, E = spec.number_features, spec.feature_embedding_dimension
     rng = np.random.default_rng(B)
     n = B + 11
