@@ -94,7 +94,7 @@ def flops_by_kernel(F=64):
         "dib_gemm_kernel<2, 2, 1, 32>": fl(*enc[2]) * F,                                  # encoder layer-3 wgrad (N = 64)
         "dib_skinny_{fwd,dgrad,wgrad}_kernel": 3 * fl(*integ[2]),                         # 256 -> 1 output layer (HBM-bound)
         "dib_gemm_kernel<2, 2, 2, 64>": fl(*integ[0]) + fl(*enc[1]) * F,                  # wgrads with M, N >= 128
-        "dib_gemm_kernel<2, 1, 2, 32>": fl(*integ[1]),                                    # integration 256 x 256 wgrad: 64-row tiles
+        "dib_gemm_kernel<2, 1, 2, 64>": fl(*integ[1]),                                    # integration 256 x 256 wgrad: 64-row tiles
     }
     assert sum(out.values()) == gemm_flops_per_sample(F)
     return out

@@ -189,7 +189,7 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 #define DIB_BK11 32
 #endif
 #ifndef DIB_BK212
-#define DIB_BK212 32
+#define DIB_BK212 64   // 64x128 wgrad tile (the 256x256 integration layer): 0.136 -> 0.124 ms with 64-deep K-tiles (same-box A/B)
 #endif
   constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
   hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,

@@ -26,6 +26,9 @@
 // activation-mask loads) are full-row float4 accesses.
 // Within an 8-deep k block q, MFMA step t contracts k = 8q + 4*(lane>>5) + t for BOTH operands
 // (any consistent permutation of k is legal), which is what makes the b128 fetch possible.
+// (Round 2 tried the analogous trick on the mn axis for the MC operands - sub-tile t of a wave takes rows 2*lane + t, so
+// that the two sub-tiles' values of one k come from ONE ds_read_b64 instead of two ds_read_b32; parity-green, but the big
+// wgrad went 1.89 -> 1.98 ms and the forward 0.74 -> 0.76 ms: reverted.)
 //
 // Activation matrices are FEATURE-MAJOR in HBM ([F][B][width]: each group's operand is a dense
 // row-major matrix; group offsets therefore scale with the batch: off = x_off + x_boff * batch),
@@ -100,25 +103,9 @@ struct DibStage {
       return make_float4(p[0], p[MC_PITCH], p[2 * MC_PITCH], p[3 * MC_PITCH]);
     }
   }
-  // MC image, TWO 32-wide sub-tiles at once with the INTERLEAVED assignment: lane l31 of sub-tile i owns element
-  // mn_base + 2*l31 + i, so its two operand values of one k are adjacent in LDS: one ds_read_b64 instead of two
-  // ds_read_b32 (which 32 rows / columns form an MFMA tile is free as long as the epilogue uses the same assignment).
-  static __device__ __forceinline__ void frag2(const float* __restrict__ T, int mn_base, int q, int l31, int h, float4& f0,
-                                               float4& f1) {
-    const float* p = T + (q * 8 + h * 4) * MC_PITCH + mn_base + 2 * l31;
-    const float2 v0 = *reinterpret_cast<const float2*>(p);
-    const float2 v1 = *reinterpret_cast<const float2*>(p + MC_PITCH);
-    const float2 v2 = *reinterpret_cast<const float2*>(p + 2 * MC_PITCH);
-    const float2 v3 = *reinterpret_cast<const float2*>(p + 3 * MC_PITCH);
-    f0 = make_float4(v0.x, v1.x, v2.x, v3.x);
-    f1 = make_float4(v0.y, v1.y, v2.y, v3.y);
-  }
 };
 
 #define DIB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-#ifndef DIB_MC_B64
-#define DIB_MC_B64 1
-#endif
 
 template <int MODE, int NI, int NJ, int BK>
 __global__ void __launch_bounds__(256, 2)  // >= 2 workgroups per CU: keep VGPR+AGPR <= 256
@@ -129,11 +116,6 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
   constexpr bool A_KC = (MODE != 2);
   constexpr bool B_KC = (MODE == 1);
   constexpr int BM = 64 * NI, BN = 64 * NJ;
-  // interleaved sub-tile assignment (one ds_read_b64 per k for both sub-tiles) for MC operands with two sub-tiles per wave:
-  // local element of sub-tile t, lane-index x:  interleaved 2*x + t,  else 32*t + x
-  constexpr bool A_IL = DIB_MC_B64 && !A_KC && NI == 2, B_IL = DIB_MC_B64 && !B_KC && NJ == 2;
-#define DIB_AROW(i, x) (A_IL ? 2 * (x) + (i) : 32 * (i) + (x))
-#define DIB_BCOL(j, x) (B_IL ? 2 * (x) + (j) : 32 * (j) + (x))
   using SA = DibStage<A_KC, BM, BK>;
   using SB = DibStage<B_KC, BN, BK>;
   __shared__ __attribute__((aligned(16))) float smem[SA::FLOATS + SB::FLOATS];
@@ -207,16 +189,10 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
         float4 a[NI], b[NJ];
-        if (A_IL) SA::frag2(As, wm * 32 * NI, q, l31, h, a[0], a[NI - 1]);
-        else {
 #pragma unroll
-          for (int i = 0; i < NI; ++i) a[i] = SA::frag(As, wm * 32 * NI + i * 32, q, l31, h);
-        }
-        if (B_IL) SB::frag2(Bs, wn * 32 * NJ, q, l31, h, b[0], b[NJ - 1]);
-        else {
+        for (int i = 0; i < NI; ++i) a[i] = SA::frag(As, wm * 32 * NI + i * 32, q, l31, h);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) b[j] = SB::frag(Bs, wn * 32 * NJ + j * 32, q, l31, h);
-        }
+        for (int j = 0; j < NJ; ++j) b[j] = SB::frag(Bs, wn * 32 * NJ + j * 32, q, l31, h);
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -245,7 +221,7 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            smem[(wm * 64 + DIB_AROW(i, (r & 3) + 8 * (r >> 2) + 4 * h)) * CP + wn * 64 + DIB_BCOL(j, l31)] = acc[i][j][r];
+            smem[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CP + wn * 64 + j * 32 + l31] = acc[i][j][r];
     }
     __syncthreads();
     float* Cg = Cbase + g.c_off + g.c_boff * batch;
@@ -298,21 +274,21 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     for (int i = 0; i < NI; ++i) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int colc = n0 + wn * 32 * NJ + DIB_BCOL(j, l31);
+        const int colc = n0 + wn * 32 * NJ + j * 32 + l31;
         if (colc < N) {
           float bv = 0.f;
           if (MODE == 0 && bias != nullptr && g.bias_off >= 0) bv = bias[g.bias_off + colc];
-          const int rbase = m0 + wm * 32 * NI;  // + DIB_AROW(i, C-fragment row)
+          const int rbase = m0 + wm * 32 * NI + i * 32 + 4 * h;
           if (MODE == 0 && act == 1) {  // ReLU fast path (the reference default, train.py:37)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int rowc = rbase + DIB_AROW(i, (r & 3) + 8 * (r >> 2) + 4 * h);
+              const int rowc = rbase + (r & 3) + 8 * (r >> 2);
               if (rowc < M) Cg[(long long)rowc * g.ldc + colc] = fmaxf(acc[i][j][r] + bv, 0.f);
             }
           } else if (MODE == 1 && act == 1 && auxg != nullptr) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int rowc = rbase + DIB_AROW(i, (r & 3) + 8 * (r >> 2) + 4 * h);
+              const int rowc = rbase + (r & 3) + 8 * (r >> 2);
               if (rowc < M)
                 Cg[(long long)rowc * g.ldc + colc] =
                     auxg[(long long)rowc * g.ldaux + colc] > 0.f ? acc[i][j][r] : 0.f;
@@ -320,7 +296,7 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int rowc = rbase + DIB_AROW(i, (r & 3) + 8 * (r >> 2) + 4 * h);
+              const int rowc = rbase + (r & 3) + 8 * (r >> 2);
               if (rowc < M) {
                 float v = acc[i][j][r];
                 if (MODE == 0) v = dib_act(act, v + bv);
@@ -346,5 +322,3 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     }
   }
 }
-#undef DIB_AROW
-#undef DIB_BCOL

@@ -333,7 +333,8 @@ class HipEngine:
         ms = (ctypes.c_double * 15)()
         cnt = (c_int * 15)()
         check(self.lib.dib_profile_summary(ms, cnt), "dib_profile_summary")
-        names = [f"dib_gemm_kernel<{mode}, {ni}, {nj}, {64 if (ni, nj) == (2, 2) else 32}>"
+        bk = lambda mode, ni, nj: 64 if (ni, nj) == (2, 2) or (mode, ni, nj) == (2, 1, 2) else 32  # csrc/dib_api.hip launch_gemm_t
+        names = [f"dib_gemm_kernel<{mode}, {ni}, {nj}, {bk(mode, ni, nj)}>"
                  for mode in (0, 1, 2) for ni in (1, 2) for nj in (1, 2)]
         names += ["dib_fused_encoder_fwd_kernel", "dib_fused_encoder_bwd_kernel", "other"]
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names) if cnt[i]}
