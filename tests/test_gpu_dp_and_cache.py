@@ -20,6 +20,15 @@ def _env():
     return env
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
+
+
 @pytest.mark.timeout(900)
 def test_fit_under_rccl_one_rank_equals_single_process(tmp_path):
     """fit() launched by torch.distributed.run (nccl = RCCL backend, world size 1): the two-bucket async all-reduce
@@ -30,7 +39,7 @@ def test_fit_under_rccl_one_rank_equals_single_process(tmp_path):
     r = subprocess.run([sys.executable, worker, a], capture_output=True, text=True, timeout=400, env=_env())
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-                        "127.0.0.1", "--master-port", "29731", worker, b], capture_output=True, text=True, timeout=400,
+                        "127.0.0.1", "--master-port", _free_port(), worker, b], capture_output=True, text=True, timeout=400,
                        env=_env())
     assert r.returncode == 0, r.stderr[-3000:]
     s, d = np.load(a), np.load(b)
@@ -43,7 +52,7 @@ def test_fit_under_rccl_one_rank_equals_single_process(tmp_path):
 def test_bench_under_launcher_reports_joined_ranks():
     """bench.py under torch.distributed.run with one rank: RCCL path, `n_gpus` = ranks that joined the communicator."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-                        "127.0.0.1", "--master-port", "29732", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+                        "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
                         "--warmup", "1", "--blocks", "1", "--batch", "8192", "--no-cpu-baseline", "--no-extra"],
                        capture_output=True, text=True, timeout=600, env=_env(), cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
