@@ -126,7 +126,7 @@ def _cpu_baseline_worker(threads, budget_s):
     model.train_step(xt, yt, eps, 1e-3, "bce_logits")
     t0 = time.perf_counter()
     steps = 0
-    while steps < 8:
+    while steps < 64:  # about budget_s / 2 seconds of CPU work (>= 10 s at the default budget)
         model.train_step(xt, yt, eps, 1e-3, "bce_logits")
         steps += 1
         if time.perf_counter() - t0 > budget_s / 2:
