@@ -1268,7 +1268,7 @@ int dib_add_inplace(float* dst, const float* src, int64_t n, dib_stream_t stream
 int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,
                       float scale, float* o, float* lse, dib_stream_t stream) {
   if (!q || !k || !v || !o || !lse || B <= 0 || P <= 0 || H <= 0 || ld < (int64_t)H * key_dim || (ld & 3)) return DIB_E_ARG;
-  if (key_dim != kAttnD) return DIB_E_UNSUPPORTED;
+  if (key_dim != kAttnD || (int64_t)P * ld >= (1ll << 30)) return DIB_E_UNSUPPORTED;   // 32-bit row offsets inside one neighbourhood
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) != 0) return DIB_E_ARG;
   DibAttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.P = P; a.H = H; a.ld = ld; a.scale = scale;
@@ -1288,7 +1288,7 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
   if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !ws || B <= 0 || P <= 0 || H <= 0 ||
       ld < (int64_t)H * key_dim || (ld & 3))
     return DIB_E_ARG;
-  if (key_dim != kAttnD) return DIB_E_UNSUPPORTED;
+  if (key_dim != kAttnD || (int64_t)P * ld >= (1ll << 30)) return DIB_E_UNSUPPORTED;   // 32-bit row offsets inside one neighbourhood
   hipStream_t st = (hipStream_t)stream;
   float* delta = (float*)ws;
   float* part = delta + (((int64_t)B * H * P + 63) / 64) * 64;
@@ -1314,6 +1314,14 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
   }
   return rc;
 }
+
+#ifdef DIB_ATTN_TIMING
+// diagnostic build only (not declared in include/): copy the phase timers of the last dib_attention_bwd to the host
+extern "C" int dib_attn_debug_read(long long* out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dib_attn_dbg), 16 * sizeof(long long));
+}
+#endif
 
 int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* out, dib_stream_t stream) {
   if (!g || !y || !out || n <= 0 || !act_ok(act)) return DIB_E_ARG;

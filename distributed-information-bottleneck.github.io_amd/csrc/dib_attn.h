@@ -26,6 +26,14 @@
 #include "dib_common.h"
 #include "dib_gemm.h"
 
+// Order pins.  MFMAs are pure register instructions: neither __builtin_amdgcn_sched_barrier nor program order keeps the
+// instruction selector's list scheduler from floating them across a whole phase (it once sank all 64 S products of the
+// backward behind the 64 dP products, with 128 registers of operand fragments live).  Passing an accumulator through an
+// empty volatile asm makes it opaque there: its producers stay above, its consumers below, and volatile asms keep their
+// own order.  "a" = accumulator registers (the 512-register backward), "v" = the <= 168-register forward.
+#define DIB_PIN_ACC_A(x) asm volatile("" : "+a"(x))
+#define DIB_PIN_ACC_V(x) asm volatile("" : "+v"(x))
+
 constexpr int kAttnD = 128;          // key_dim (= value dim) of the notebook's MultiHeadAttention
 constexpr int kAttnPitch = kAttnD + 4;
 constexpr int kAttnTile = 32;        // keys (fwd, dq) / queries (dkv) per LDS tile
@@ -40,19 +48,28 @@ struct DibAttnArgs {
   int P, H; long long ld; float scale;
 };
 
-// 32 rows x 128 floats of a [T, ld] matrix (rows row0.. clamped to row_max) -> registers (4 float4 per thread, 256 threads)
-__device__ __forceinline__ void dib_attn_gload(float4 (&r)[4], const float* __restrict__ base, long long ld, int row0,
-                                               int row_max, int tid) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int row = min(row0 + (tid >> 5) + 8 * p, row_max);
-    r[p] = *reinterpret_cast<const float4*>(base + (long long)row * ld + (tid & 31) * 4);
-  }
+// 32 rows x 128 floats of a [T, ld] matrix (rows row0.. clamped to row_max) -> registers (4 float4 per thread, 256 threads).
+// Passed BY VALUE as a struct of four named float4: as `float4 (&)[4]` one of the two tiles of the backward ended up as a
+// 64-byte stack object - every global load was followed by `s_waitcnt vmcnt; scratch_store` a few instructions after issue.
+// Row offsets are 32-bit (the host entry checks P * ld < 2^30 elements): one v_mul_lo_u32 per row instead of a 64-bit multiply.
+struct DibAttnTile { float4 r0, r1, r2, r3; };
+__device__ __forceinline__ DibAttnTile dib_attn_gload(const float* __restrict__ base, long long ld, int row0, int row_max,
+                                                      int tid) {
+  const unsigned ldu = (unsigned)ld, col = (unsigned)(tid & 31) * 4u;
+  const int r = row0 + (tid >> 5);
+  DibAttnTile t;
+  t.r0 = *reinterpret_cast<const float4*>(base + ((unsigned)min(r, row_max) * ldu + col));
+  t.r1 = *reinterpret_cast<const float4*>(base + ((unsigned)min(r + 8, row_max) * ldu + col));
+  t.r2 = *reinterpret_cast<const float4*>(base + ((unsigned)min(r + 16, row_max) * ldu + col));
+  t.r3 = *reinterpret_cast<const float4*>(base + ((unsigned)min(r + 24, row_max) * ldu + col));
+  return t;
 }
-__device__ __forceinline__ void dib_attn_lstore(float* __restrict__ T, const float4 (&r)[4], int tid) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-    *reinterpret_cast<float4*>(T + ((tid >> 5) + 8 * p) * kAttnPitch + (tid & 31) * 4) = r[p];
+__device__ __forceinline__ void dib_attn_lstore(float* __restrict__ T, const DibAttnTile t, int tid, float mul = 1.0f) {
+  float* dst = T + (tid >> 5) * kAttnPitch + (tid & 31) * 4;
+  *reinterpret_cast<float4*>(dst) = make_float4(t.r0.x * mul, t.r0.y * mul, t.r0.z * mul, t.r0.w * mul);
+  *reinterpret_cast<float4*>(dst + 8 * kAttnPitch) = make_float4(t.r1.x * mul, t.r1.y * mul, t.r1.z * mul, t.r1.w * mul);
+  *reinterpret_cast<float4*>(dst + 16 * kAttnPitch) = make_float4(t.r2.x * mul, t.r2.y * mul, t.r2.z * mul, t.r2.w * mul);
+  *reinterpret_cast<float4*>(dst + 24 * kAttnPitch) = make_float4(t.r3.x * mul, t.r3.y * mul, t.r3.z * mul, t.r3.w * mul);
 }
 // KC fragment: 4 consecutive k of row (l31) for k-block q   |   MC fragment: rows 8q+4h+t (t = 0..3), column c
 __device__ __forceinline__ float4 dib_attn_kc(const float* __restrict__ T, int q, int l31, int h) {
@@ -116,16 +133,15 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
-  float4 rk[4], rv[4];
-  dib_attn_gload(rk, Kb, a.ld, 0, P - 1, tid);
-  dib_attn_gload(rv, Vb, a.ld, 0, P - 1, tid);
+  DibAttnTile rk = dib_attn_gload(Kb, a.ld, 0, P - 1, tid);
+  DibAttnTile rv = dib_attn_gload(Vb, a.ld, 0, P - 1, tid);
   for (int kt = 0; kt < n_tiles; ++kt) {
     dib_attn_lstore(Ks, rk, tid);
     dib_attn_lstore(Vs, rv, tid);
     __syncthreads();
     if (kt + 1 < n_tiles) {
-      dib_attn_gload(rk, Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
-      dib_attn_gload(rv, Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+      rk = dib_attn_gload(Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+      rv = dib_attn_gload(Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
     }
     if (wave_ok) {
       // S^T[key][query] = sum_d K[key][d] (scale Q[query][d]); the K fragment of step q + 1 is fetched before the MFMAs of
@@ -239,6 +255,15 @@ dib_attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o
 // writer and a fixed summation order (deterministic), S and dP are computed ONCE per tile pair: 5 tile products where the
 // separate dQ and dK/dV kernels of the first version needed 7.
 // ---------------------------------------------------------------------------------------------------------------------
+// Phase timing of the backward (a diagnostic build: -DDIB_ATTN_TIMING; tools/attn_phase_timing.py): wave 0 of workgroup
+// (1, 0, 0) accumulates s_memtime deltas per phase of the query-tile loop into dib_attn_dbg.
+#ifdef DIB_ATTN_TIMING
+__device__ long long dib_attn_dbg[16];
+#define DIB_T(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); tacc_[i] += now_ - tprev_; tprev_ = now_; \
+                      __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DIB_T(i) do { } while (0)
+#endif
 constexpr int kAttnPatch = 32 * 36;
 constexpr int DibAttnBwdLds = 2 * kAttnTile * kAttnPitch + 128 * kAttnPitch + 4 * kAttnPatch + 2 * kAttnTile;
 
@@ -292,38 +317,58 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
   const float dq_mul = (n_key_blocks > 1) ? 1.0f : a.scale;
 
   const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
-  float4 rq[4], rg[4];
   float rl_ = 0.f, rd_ = 0.f;
-  dib_attn_gload(rq, Qb, a.ld, 0, P - 1, tid);
-  dib_attn_gload(rg, dOb, a.ld, 0, P - 1, tid);
-  if (tid < kAttnTile) { rl_ = lse_b[min(tid, P - 1)]; rd_ = dlt_b[min(tid, P - 1)]; }
+  DibAttnTile rq = dib_attn_gload(Qb, a.ld, 0, P - 1, tid);
+  DibAttnTile rg = dib_attn_gload(dOb, a.ld, 0, P - 1, tid);
+  if (tid < kAttnTile) { rl_ = tid < P ? lse_b[tid] : INFINITY; rd_ = dlt_b[min(tid, P - 1)]; }
+  // a lane whose key lies beyond P contributes nothing: its probabilities are multiplied by 0 (lane-constant factor); a
+  // query beyond P carries lse = +inf in the LDS copy, so exp(s - lse) = 0 without a per-element test.  The loop body has no
+  // divergent control flow: the loop-carried dV / dK accumulators are only ever touched by MFMAs and stay in AGPRs (with
+  // an `if (wave has keys)` around the products the compiler kept them in VGPRs and copied all 128 registers into AGPRs
+  // and back on every query tile)
+  const float kmul = k_ok ? 1.0f : 0.0f;
+  // stage one query tile: registers (global) -> LDS.  The NEXT tile's global loads are issued after the second barrier of
+  // a tile and land during the dQ product; they go to LDS right after it (Qs / Gs are free by then).  Holding them in
+  // registers across the whole tile instead (the first version) cost 32 registers through the two big phases: the compiler
+  // parked them in AGPRs and spilled four float4 to scratch, each spill waiting for its load a few instructions after issue
+#define DIB_ATTN_STAGE_TILE()                                   \
+  do {                                                          \
+    dib_attn_lstore(Qs, rq, tid, a.scale);                      \
+    dib_attn_lstore(Gs, rg, tid);                               \
+    if (tid < kAttnTile) { Ls[tid] = rl_; Ds[tid] = rd_; }      \
+  } while (0)
+  DIB_ATTN_STAGE_TILE();
+#ifdef DIB_ATTN_TIMING
+  long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev_ = clock64();
+  const long long tstart_ = tprev_;
+#endif
   for (int qt = 0; qt < n_tiles; ++qt) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) { rq[p].x *= a.scale; rq[p].y *= a.scale; rq[p].z *= a.scale; rq[p].w *= a.scale; }
-    dib_attn_lstore(Qs, rq, tid);
-    dib_attn_lstore(Gs, rg, tid);
-    if (tid < kAttnTile) { Ls[tid] = rl_; Ds[tid] = rd_; }
     __syncthreads();
-    if (qt + 1 < n_tiles) {
-      dib_attn_gload(rq, Qb, a.ld, (qt + 1) * kAttnTile, P - 1, tid);
-      dib_attn_gload(rg, dOb, a.ld, (qt + 1) * kAttnTile, P - 1, tid);
-      if (tid < kAttnTile) {
-        rl_ = lse_b[min((qt + 1) * kAttnTile + tid, P - 1)];
-        rd_ = dlt_b[min((qt + 1) * kAttnTile + tid, P - 1)];
-      }
+    DIB_T(0);   // barrier A
+    // lse / delta of this lane's 16 queries (register r <-> query (r&3) + 8(r>>2) + 4h): 4 + 4 ds_read_b128, in flight
+    // during the S / dP products
+    float4 lq[4], dq4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      lq[g] = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * h);
+      dq4[g] = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * h);
     }
     dib_f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    if (wave_ok) {
+    {
       // S[query][key] and dP[query][key]: A = query-tile rows (KC), B = this lane's key row (K from the LDS block, V from
-      // registers); the three LDS fragments of step q + 1 are in flight during the 8 MFMAs of step q
+      // registers).  The three LDS fragments of step q + 1 are issued BEFORE the 8 MFMAs of step q (sched_barrier: left to
+      // itself the scheduler sinks them to just in front of their use and the wave - alone on its SIMD - eats one LDS
+      // latency per step)
       const float* Kw = Kblk + wave * 32 * kAttnPitch;
       float4 qq = dib_attn_kc(Qs, 0, l31, h), gg = dib_attn_kc(Gs, 0, l31, h), kk = dib_attn_kc(Kw, 0, l31, h);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int qn_ = q < 15 ? q + 1 : 15;
         const float4 qn = dib_attn_kc(Qs, qn_, l31, h), gn = dib_attn_kc(Gs, qn_, l31, h), kn = dib_attn_kc(Kw, qn_, l31, h);
+        __builtin_amdgcn_sched_barrier(0);
         s = DIB_MFMA(qq.x, kk.x, s);
         dp = DIB_MFMA(gg.x, vf[q].x, dp);
         s = DIB_MFMA(qq.y, kk.y, s);
@@ -332,69 +377,125 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
         dp = DIB_MFMA(gg.z, vf[q].z, dp);
         s = DIB_MFMA(qq.w, kk.w, s);
         dp = DIB_MFMA(gg.w, vf[q].w, dp);
+        DIB_PIN_ACC_A(s);
+        DIB_PIN_ACC_A(dp);
+        __builtin_amdgcn_sched_barrier(0);
         qq = qn; gg = gn; kk = kn;
       }
-      // register r <-> query qt*32 + (r&3) + 8(r>>2) + 4h ; lane <-> key
+    }
+    DIB_T(1);   // S / dP products issued
+    // first operand fragments of the dV / dK products: in flight during the exponentials
+    float4 gv[4], qv[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const bool ok = k_ok && (qt * kAttnTile + ql < P);
-        const float p = ok ? __expf(s[r] - Ls[ql]) : 0.f;
-        dp[r] = p * (dp[r] - Ds[ql]);                  // dS
+    for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Gs, 0, 32 * dt + l31, h);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) qv[dt] = dib_attn_mc(Qs, 0, 32 * dt + l31, h);
+    __builtin_amdgcn_sched_barrier(0);
+    // register r <-> query qt*32 + (r&3) + 8(r>>2) + 4h ; lane <-> key
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float lv[4] = {lq[g].x, lq[g].y, lq[g].z, lq[g].w};
+      const float dl[4] = {dq4[g].x, dq4[g].y, dq4[g].z, dq4[g].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 4 * g + t;
+        const float p = __expf(s[r] - lv[t]) * kmul;
+        dp[r] = p * (dp[r] - dl[t]);                   // dS
         s[r] = p;                                      // P
       }
     }
-    // dS^T into this wave's patch: patch[query][key] (zeros from a wave without keys)
+    // dS^T into this wave's patch: patch[query][key]
 #pragma unroll
     for (int r = 0; r < 16; ++r) my_patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = dp[r];
-    if (wave_ok) {
-      float4 gv[4], qv[4];
+    DIB_T(2);   // exponentials, dS, patch store
+    // dV^T += dO^T P, dK^T += Q^T dS.  Consecutive MFMAs go to DIFFERENT accumulators (dependent distance 4): a filler
+    // instruction between two MFMAs on the same accumulator costs ~43 cycles, between independent ones only its issue slot
+    // (MI355X_MICROARCH.md); the fragments of the next 8 queries are fetched under the current products
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Gs, 0, 32 * dt + l31, h);
+    for (int q = 0; q < 4; ++q) {
+      float4 gvn[4], qvn[4];
+      if (q < 3) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+        for (int dt = 0; dt < 4; ++dt) gvn[dt] = dib_attn_mc(Gs, q + 1, 32 * dt + l31, h);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) qv[dt] = dib_attn_mc(Qs, q, 32 * dt + l31, h);   // in flight during the dV MFMAs
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].x, s[4 * q + 0], dv[dt]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          dv[dt] = DIB_MFMA(gv[dt].x, s[4 * q + 0], dv[dt]);
-          dv[dt] = DIB_MFMA(gv[dt].y, s[4 * q + 1], dv[dt]);
-          dv[dt] = DIB_MFMA(gv[dt].z, s[4 * q + 2], dv[dt]);
-          dv[dt] = DIB_MFMA(gv[dt].w, s[4 * q + 3], dv[dt]);
-        }
-        if (q < 3) {
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].y, s[4 * q + 1], dv[dt]);
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) gv[dt] = dib_attn_mc(Gs, q + 1, 32 * dt + l31, h);   // in flight during the dK MFMAs
-        }
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].z, s[4 * q + 2], dv[dt]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          dk[dt] = DIB_MFMA(qv[dt].x, dp[4 * q + 0], dk[dt]);
-          dk[dt] = DIB_MFMA(qv[dt].y, dp[4 * q + 1], dk[dt]);
-          dk[dt] = DIB_MFMA(qv[dt].z, dp[4 * q + 2], dk[dt]);
-          dk[dt] = DIB_MFMA(qv[dt].w, dp[4 * q + 3], dk[dt]);
-        }
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].w, s[4 * q + 3], dv[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) DIB_PIN_ACC_A(dv[dt]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 3) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) qvn[dt] = dib_attn_mc(Qs, q + 1, 32 * dt + l31, h);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].x, dp[4 * q + 0], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].y, dp[4 * q + 1], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].z, dp[4 * q + 2], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].w, dp[4 * q + 3], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) DIB_PIN_ACC_A(dk[dt]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 3) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { gv[dt] = gvn[dt]; qv[dt] = qvn[dt]; }
       }
     }
-    __syncthreads();   // all four dS^T patches are in LDS; nobody reads Qs / Gs any more
+    DIB_T(3);   // dV / dK products issued
+    __syncthreads();   // all four dS^T patches are in LDS; nobody reads Qs / Gs / Ls / Ds any more
+    DIB_T(4);   // barrier B
     {
-      // dQ^T[d = 32*wave + .][query] over the workgroup's 128 keys: A = K block (MC), B = dS^T patches (b128 along keys)
-      dib_f32x16 dq;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-      float4 ds4 = *reinterpret_cast<const float4*>(patches + l31 * 36 + 4 * h);
-      float4 kk4 = dib_attn_mc(Kblk, 0, 32 * wave + l31, h);
-#pragma unroll
-      for (int st = 0; st < 16; ++st) {   // st = 4 * key wave + g
-        const int sn = st < 15 ? st + 1 : 15;
-        const float4 dsn = *reinterpret_cast<const float4*>(patches + (sn >> 2) * kAttnPatch + l31 * 36 + 8 * (sn & 3) + 4 * h);
-        const float4 kn4 = dib_attn_mc(Kblk + (sn >> 2) * 32 * kAttnPitch, sn & 3, 32 * wave + l31, h);
-        dq = DIB_MFMA(kk4.x, ds4.x, dq);
-        dq = DIB_MFMA(kk4.y, ds4.y, dq);
-        dq = DIB_MFMA(kk4.z, ds4.z, dq);
-        dq = DIB_MFMA(kk4.w, ds4.w, dq);
-        ds4 = dsn;
-        kk4 = kn4;
+      // next query tile (the last iteration re-loads its own tile: no branch in the loop body)
+      const int qnext = min(qt + 1, n_tiles - 1) * kAttnTile;
+      rq = dib_attn_gload(Qb, a.ld, qnext, P - 1, tid);
+      rg = dib_attn_gload(dOb, a.ld, qnext, P - 1, tid);
+      if (tid < kAttnTile) {
+        rl_ = qnext + tid < P ? lse_b[qnext + tid] : INFINITY;
+        rd_ = dlt_b[min(qnext + tid, P - 1)];
       }
+    }
+    {
+      // dQ^T[d = 32*wave + .][query] over the workgroup's 128 keys: A = K block (MC), B = dS^T patches (b128 along keys).
+      // Two accumulators (even / odd 8-key steps), MFMAs alternating between them: the LDS reads and waits between the
+      // MFMAs then never sit between two products on the same accumulator
+      dib_f32x16 dq, dq1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dq[r] = 0.f; dq1[r] = 0.f; }
+      auto ds_frag = [&](int st) {   // st = 4 * key wave + g
+        return *reinterpret_cast<const float4*>(patches + (st >> 2) * kAttnPatch + l31 * 36 + 8 * (st & 3) + 4 * h);
+      };
+      auto k_frag = [&](int st) { return dib_attn_mc(Kblk + (st >> 2) * 32 * kAttnPitch, st & 3, 32 * wave + l31, h); };
+      float4 dsa = ds_frag(0), dsb = ds_frag(1), ka = k_frag(0), kb = k_frag(1);
+#pragma unroll
+      for (int st = 0; st < 16; st += 2) {
+        const int sn = st < 14 ? st + 2 : 14;
+        const float4 dsan = ds_frag(sn), dsbn = ds_frag(sn + 1), kan = k_frag(sn), kbn = k_frag(sn + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        dq = DIB_MFMA(ka.x, dsa.x, dq);
+        dq1 = DIB_MFMA(kb.x, dsb.x, dq1);
+        dq = DIB_MFMA(ka.y, dsa.y, dq);
+        dq1 = DIB_MFMA(kb.y, dsb.y, dq1);
+        dq = DIB_MFMA(ka.z, dsa.z, dq);
+        dq1 = DIB_MFMA(kb.z, dsb.z, dq1);
+        dq = DIB_MFMA(ka.w, dsa.w, dq);
+        dq1 = DIB_MFMA(kb.w, dsb.w, dq1);
+        DIB_PIN_ACC_A(dq);
+        DIB_PIN_ACC_A(dq1);
+        __builtin_amdgcn_sched_barrier(0);
+        dsa = dsan; dsb = dsbn; ka = kan; kb = kbn;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] += dq1[r];
       // dq[r] = dQ^T[d = 32*wave + (r&3) + 8(r>>2) + 4h][query l31]
       const int qrow = qt * kAttnTile + l31;
       if (qrow < P) {
@@ -405,7 +506,18 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
               make_float4(dq[4 * g] * dq_mul, dq[4 * g + 1] * dq_mul, dq[4 * g + 2] * dq_mul, dq[4 * g + 3] * dq_mul);
       }
     }
+    DIB_T(5);   // next-tile loads issued, dQ product, dQ store
+    DIB_ATTN_STAGE_TILE();
+    DIB_T(6);   // next tile -> LDS
   }
+#ifdef DIB_ATTN_TIMING
+  if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+    for (int i = 0; i < 7; ++i) dib_attn_dbg[i] = tacc_[i];
+    dib_attn_dbg[7] = clock64() - tstart_;
+    dib_attn_dbg[8] = n_tiles;
+  }
+#endif
+#undef DIB_ATTN_STAGE_TILE
   dib_attn_store_rows(a.dv + tok0 * a.ld + head * kAttnD, a.ld, krow, k_ok && wave_ok, h, dv, 1.0f);
   dib_attn_store_rows(a.dk + tok0 * a.ld + head * kAttnD, a.ld, krow, k_ok && wave_ok, h, dk, 1.0f);  // Q tile was pre-scaled
 }
