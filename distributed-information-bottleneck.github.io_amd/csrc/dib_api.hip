@@ -92,7 +92,8 @@ struct dib_layout {
     const int E4 = (E + 3) / 4;
     const int rpb = std::max(1, 256 / E4);
     m.kl_blocks = cdiv(B, rpb);
-    m.kl_partial = take((int64_t)std::max(m.kl_blocks, 8 * 256) * F);  // fused fwd: <= 256 workgroups x 8 waves
+    m.kl_partial = take((int64_t)std::max(std::max(m.kl_blocks, 8 * 256), 8 * cdiv(B, 256)) * F);  // fused fwd: one row per 32-row
+                                                                                                      // sub-tile (dynamic tickets) or per wave
     m.loss_blocks = cdiv(B, 256);
     m.loss_partial = take((int64_t)std::max(m.loss_blocks, 512) * 2);  // also the fused output head's per-workgroup partials (<= 512)
     // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= DIB_SPLIT_ROWS rows per split
@@ -679,8 +680,14 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
     rc = fused_encoder_fwd(l, m, w, x, ldx, row_idx, row0, batch, params, seed, step, deterministic, st, &gx);
     if (rc) return rc;
     { ProfScope ps(kProfOther, (hipStream_t)stream);
+#if DIB_FUSED_DYNAMIC
+    (void)gx;
+    hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, 8 * cdiv(batch, 256), l->F,
+                       w + m.step_out); }
+#else
     hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, gx * 8, l->F,
                        w + m.step_out); }
+#endif
     return (int)hipGetLastError();
   }
   rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
@@ -1314,6 +1321,31 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
   }
   return rc;
 }
+
+#ifdef DIB_FUSED_TIMING
+// diagnostic build only (not declared in include/): phase timers of the last fused encoder forward
+extern "C" int dib_fused_debug_read(long long* out16) {
+  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dib_fused_dbg), 16 * sizeof(long long));
+}
+extern "C" int dib_fused_debug_reset() {
+  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
+  long long z[4] = {0, 0, 0, 0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dib_tl), z, sizeof(z));
+}
+extern "C" int dib_fused_debug_read_tl(long long* out4) {
+  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
+  return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(dib_tl), 4 * sizeof(long long));
+}
+extern "C" int dib_fused_debug_read_waves(long long* out8192) {
+  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
+  return (int)hipMemcpyFromSymbol(out8192, HIP_SYMBOL(dib_fused_wave_end), 8 * 1024 * sizeof(long long));
+}
+extern "C" int dib_fused_debug_read_wg(long long* out3072) {
+  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
+  return (int)hipMemcpyFromSymbol(out3072, HIP_SYMBOL(dib_fused_wg), 3 * 1024 * sizeof(long long));
+}
+#endif
 
 #ifdef DIB_ATTN_TIMING
 // diagnostic build only (not declared in include/): copy the phase timers of the last dib_attention_bwd to the host

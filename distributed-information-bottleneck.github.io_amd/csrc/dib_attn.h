@@ -342,6 +342,7 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
   long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev_ = clock64();
   const long long tstart_ = tprev_;
+  const long long wstart_ = wall_clock64();   // constant 100 MHz
 #endif
   for (int qt = 0; qt < n_tiles; ++qt) {
     __syncthreads();
@@ -515,6 +516,7 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
     for (int i = 0; i < 7; ++i) dib_attn_dbg[i] = tacc_[i];
     dib_attn_dbg[7] = clock64() - tstart_;
     dib_attn_dbg[8] = n_tiles;
+    dib_attn_dbg[9] = wall_clock64() - wstart_;
   }
 #endif
 #undef DIB_ATTN_STAGE_TILE

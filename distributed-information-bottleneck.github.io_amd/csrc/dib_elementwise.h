@@ -11,6 +11,13 @@
 // P is feature-major and ragged: P_f = P + poff*batch is a dense [batch, n_blocks*d_f] matrix and
 // P_f[b, j*d_f + c_local] = (j==0 ? x : sin(2^j * x)),  x = X[row(b), c]
 // ---------------------------------------------------------------------------------------------
+#ifdef DIB_FUSED_TIMING
+// timeline marks (s_memrealtime, 100 MHz) of the diagnostic build: [0] last posenc workgroup mark, [1] -(first fused-forward
+// entry), [2] last fused-forward workgroup done, [3] -(first entry of the kernel after it); reset by dib_fused_debug_reset
+__device__ long long dib_tl[4];
+#define DIB_TL_MAX(i, v) atomicMax((unsigned long long*)&dib_tl[i], (unsigned long long)(v))
+#define DIB_TL_MIN(i, v) atomicMax((unsigned long long*)&dib_tl[i], (unsigned long long)(0x7fffffffffffffffll - (v)))
+#endif
 template <int ROWS>   // batch rows per workgroup tile: 64, or 16 for mid-size batches (more workgroups: at B = 8192 the 64-row
                       // tiling is 128 workgroups of sinf-bound work on 256 CUs)
 __global__ void __launch_bounds__(256)
@@ -35,6 +42,9 @@ dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restr
   __syncthreads();
   const int r = threadIdx.x & (ROWS - 1), b = b0 + r;
   if (b >= batch) return;
+#ifdef DIB_FUSED_TIMING
+  if (threadIdx.x == 0) DIB_TL_MAX(0, wall_clock64());
+#endif
   for (int c = threadIdx.x / ROWS; c < 64 && c0 + c < ncols; c += 256 / ROWS) {
     const int4 cm = colmap[c0 + c];
     const float x = T[r][c];
@@ -105,6 +115,9 @@ __global__ void __launch_bounds__(256)
 dib_colsum_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, float* __restrict__ out) {
   __shared__ float red[4];
   const int f = blockIdx.x;
+#ifdef DIB_FUSED_TIMING
+  if (threadIdx.x == 0) DIB_TL_MIN(3, wall_clock64());
+#endif
   float s = 0.f;
   for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[(long long)i * stride + f];
   const float tot = dib_block_sum_256(s, red);

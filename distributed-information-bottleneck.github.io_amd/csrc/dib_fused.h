@@ -48,7 +48,7 @@ struct DibFusedCfg {
   static constexpr int W1_FLOATS = H1 * K1P, W2_FLOATS = H2 * P2, W3_FLOATS = N3 * P3;
   static constexpr int B_FLOATS = H1 + H2 + N3;
   static constexpr int PATCH = 32 * 36;               // per-wave 32x32 transpose patch (pitch 36)
-  static constexpr int LDS_FLOATS = W1_FLOATS + W2_FLOATS + W3_FLOATS + B_FLOATS + 8 * PATCH;
+  static constexpr int LDS_FLOATS = W1_FLOATS + W2_FLOATS + W3_FLOATS + B_FLOATS + 8 * PATCH + 4;   // + the sub-tile ticket counter
   static constexpr int T1 = H1 / 32, T2 = H2 / 32, T3 = N3 / 32;
 };
 
@@ -162,6 +162,51 @@ __device__ __forceinline__ void dib_stage_batched(int tid, LoadF load, StoreF st
   }
 }
 
+#ifndef DIB_FUSED_PAIR
+#define DIB_FUSED_PAIR 1
+#endif
+// The two waves that share a SIMD (waves w and w + 4 of the 512-thread workgroup) share its matrix pipe, and the hardware
+// arbitrates by priority, then AGE: with equal priorities waves 0-3 got every slot they asked for and waves 4-7 the
+// leftovers - measured (tools/fused_phase_timing.py): waves 0-3 finished their 64 tiles after 1.60 ms, waves 4-7 after 1.98 ms,
+// i.e. the last fifth of the kernel ran with ONE wave per SIMD.  No barrier in the tile loop keeps them together, so the
+// favoured role alternates instead: on even tile iterations waves 0-3 run at priority 1, on odd ones waves 4-7.
+#ifndef DIB_FUSED_PRIO
+#define DIB_FUSED_PRIO 0
+#endif
+#ifndef DIB_FUSED_PINGPONG
+#define DIB_FUSED_PINGPONG 0   // experiment (round 2): measured slower - the 'other' segment (8 back-to-back stash tiles) outlasts the
+#endif                        // matrix segment (35 k vs 29 k cycles per tile), 2.00 vs 1.94 ms
+// DYNAMIC sub-tile tickets (forward): the 32-row sub-tiles of the workgroup's 256-row tiles are handed out through an LDS
+// counter instead of 'wave w takes rows 32w..32w+31 of every tile'.  With the static map the four waves that the SIMD
+// arbiter favours (oldest first) finished their 64 sub-tiles after 1.53-1.60 ms, the other four after 1.90-1.98 ms
+// (tools/fused_phase_timing.py); with tickets the favoured waves simply take more sub-tiles and all eight finish within one
+// sub-tile of each other.  Results do not depend on who computed what: every output is per row, and the KL partial sums are
+// written PER SUB-TILE and added up in a fixed order by dib_colsum_partials_kernel.
+#ifndef DIB_FUSED_DYNAMIC
+#define DIB_FUSED_DYNAMIC 0   // measured (round 2): all eight waves then finish together (1.85 ms) but the kernel gains only 1 % (1.90 ->
+#endif                       // 1.89 ms; B = 8192: 0.265 -> 0.267 ms): the SIMD's aggregate tile rate is the limit, not the tail
+#if DIB_FUSED_PRIO == 1
+// (the condition must be PROVABLY wave-uniform - readfirstlane - or the compiler predicates both s_setprio with exec masks
+// and executes them unconditionally one after the other)
+#define DIB_FUSED_SET_PRIO(it) do { if (__builtin_amdgcn_readfirstlane(((it) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
+#elif DIB_FUSED_PRIO == 2   // experiment: the younger waves always favoured
+#define DIB_FUSED_SET_PRIO(it) do { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
+#elif DIB_FUSED_PRIO == 3   // experiment: alternate every 4 tiles
+#define DIB_FUSED_SET_PRIO(it) do { if (__builtin_amdgcn_readfirstlane((((it) >> 2) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
+#else
+#define DIB_FUSED_SET_PRIO(it) do { } while (0)
+#endif
+// Phase timing of the fused forward (diagnostic build -DDIB_FUSED_TIMING; tools/fused_phase_timing.py): wave 0 of workgroup
+// (0, 0) accumulates s_memtime deltas per phase of the tile loop into dib_fused_dbg.
+#ifdef DIB_FUSED_TIMING
+__device__ long long dib_fused_dbg[16];
+__device__ long long dib_fused_wave_end[8 * 1024];   // per (workgroup, wave): s_memrealtime at loop end
+__device__ long long dib_fused_wg[3 * 1024];   // per workgroup: s_memrealtime at kernel entry, after weight staging, at loop end
+#define DIB_FT(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); tacc_[i] += now_ - tprev_; tprev_ = now_; \
+                       __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DIB_FT(i) do { } while (0)
+#endif
 template <int H1, int H2, int E, bool RELU>
 __global__ void __launch_bounds__(512)
 dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
@@ -172,10 +217,16 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
   float* Wt3 = Wt2 + C::W2_FLOATS;        // [N3][H2+4]  rows >= 2E are zero
   float* Bs = Wt3 + C::W3_FLOATS;         // b1 | b2 | b3(padded)
   float* patch = Bs + C::B_FLOATS + (threadIdx.x >> 6) * C::PATCH;  // wave-private transpose patch
+  unsigned* ticket = reinterpret_cast<unsigned*>(Bs + C::B_FLOATS + 8 * C::PATCH);
+  if (threadIdx.x == 0) *ticket = 0u;   // visible after the barrier that ends the weight staging
 
   const int f = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, h = lane >> 5;
+#ifdef DIB_FUSED_TIMING
+  const long long wentry_ = wall_clock64();
+  if (tid == 0) DIB_TL_MIN(1, wentry_);
+#endif
   const int4 fm = a.featmap[f];
   const int in_dim = fm.y;
   const int F = a.F;
@@ -214,8 +265,8 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
   // lane (m,h) supplies p[k] for k = (r&3) + 8*(r>>2) + 4*h as the layer-1 B operand (reference models.py:22-23
   // values, produced by dib_posenc_kernel).  Loads are branch-free (clamped row / column, masked value) and the next
   // tile's values are fetched while the current tile computes.
-  auto load_p = [&](int tile, float (&dstp)[8]) {
-    const int bb = min(tile * 256 + wave * 32 + m, a.batch - 1);
+  auto load_p = [&](int tile, int slice, float (&dstp)[8]) {
+    const int bb = min(tile * 256 + slice * 32 + m, a.batch - 1);
     const float* src = Pf + (long long)bb * in_dim;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -225,16 +276,60 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     }
   };
   float p[8], pn[8];
-  if ((int)blockIdx.x < n_tiles) load_p(blockIdx.x, p);
+#if DIB_FUSED_DYNAMIC
+  const int n_sub = ((n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * 8;   // this workgroup's sub-tiles
+  auto take_ticket = [&]() -> int {
+    unsigned t = 0u;
+    if (lane == 0) t = atomicAdd(ticket, 1u);            // ds_add_rtn_u32
+    return __builtin_amdgcn_readfirstlane((int)t);
+  };
+  int sub = take_ticket();
+  if (sub < n_sub) load_p((int)blockIdx.x + (sub >> 3) * (int)gridDim.x, sub & 7, p);
+#else
+  if ((int)blockIdx.x < n_tiles) load_p(blockIdx.x, wave, p);
+#endif
 
+#ifdef DIB_FUSED_TIMING
+  long long tacc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev_ = clock64();
+  const long long tstart_ = tprev_;
+  const long long wstart_ = wall_clock64();   // constant 100 MHz
+  int ntl_ = 0;
+#endif
+#if DIB_FUSED_DYNAMIC
+  while (sub < n_sub) {
+    const int tile = (int)blockIdx.x + (sub >> 3) * (int)gridDim.x, slice = sub & 7;
+    const int sub_next = take_ticket();
+#else
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int b = tile * 256 + wave * 32 + m;   // local batch row of this lane
+    const int slice = wave;
+#endif
+    DIB_FUSED_SET_PRIO(tile / (int)gridDim.x);
+#ifdef DIB_FUSED_TIMING
+    ++ntl_;
+#endif
+    const int b = tile * 256 + slice * 32 + m;   // local batch row of this lane
     const bool valid = b < a.batch;
     const long long grow = a.row_idx ? (long long)a.row_idx[valid ? b : 0] : a.row0 + b;  // dataset row id
+#if DIB_FUSED_PINGPONG
+    // PING-PONG: the two waves of a SIMD (w, w + 4) alternate between a MATRIX segment (layers 1-3 back to back, the pipe to
+    // itself) and an OTHER segment (stashes, mask bits, noise, KL, stores, next tile's inputs), two s_barrier per tile;
+    // waves 4-7 run the same loop body rotated by one segment (leading instead of trailing barrier).  Without it the
+    // hardware's oldest-first arbitration let waves 0-3 finish 64 tiles in 1.60 ms while waves 4-7 needed 1.98 ms.
+    // Raw s_barrier: the two groups share no data (transpose patches are wave-private), so no fence / store drain.
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_barrier();   // readfirstlane: a provably uniform branch (a
+    // lane-dependent condition is predicated with exec masks, and s_barrier ignores exec: BOTH groups would execute it)
+#else
     {
+#if DIB_FUSED_DYNAMIC
+      const int sp = sub_next < n_sub ? sub_next : sub;   // harmless re-read after the last ticket
+      load_p((int)blockIdx.x + (sp >> 3) * (int)gridDim.x, sp & 7, pn);
+#else
       const int nt = tile + gridDim.x;
-      load_p(nt < n_tiles ? nt : tile, pn);  // prefetch (harmless re-read on the last tile)
+      load_p(nt < n_tiles ? nt : tile, slice, pn);  // prefetch (harmless re-read on the last tile)
+#endif
     }
+#endif
 
     // ---- layer 1: h1^T = act(W1^T p^T + b1) ----
     dib_f32x16 h1[C::T1];
@@ -256,17 +351,60 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       dib_act_tile<RELU>(slope, acc);
       h1[jo] = acc;
     }
+    DIB_FT(0);   // prefetch issue + layer 1
     // stash h1 (feature-major [F][B][H1]) for the backward pass (skipped for inference: DIB_FWD_INFERENCE)
+    auto stash_h1 = [&]() {
     if (a.h1 != nullptr) {
-      const int wrow0 = tile * 256 + wave * 32;
+      const int wrow0 = tile * 256 + slice * 32;
       const int rows_valid = min(32, a.batch - wrow0);
       float* dst = a.h1 + ((long long)f * a.batch + wrow0) * H1;
 #pragma unroll
       for (int jo = 0; jo < C::T1; ++jo) dib_store_tile(patch, h1[jo], dst + 32 * jo, H1, rows_valid, lane);
     }
 
+    };
+#if !DIB_FUSED_PINGPONG
+    stash_h1();
+#endif
+    DIB_FT(1);   // stash h1
     // ---- layer 2: h2^T = act(W2^T h1^T + b2) ----
     dib_f32x16 h2[C::T2];
+    if constexpr (DIB_FUSED_PAIR && C::T2 % 2 == 0) {
+    // two output tiles at a time, MFMAs alternating between their accumulators (a filler between two MFMAs on the SAME
+    // accumulator costs ~43 cycles, between independent ones only its issue slot), weight fragments of step s + 1 issued
+    // before the 8 MFMAs of step s
+#pragma unroll
+    for (int jo = 0; jo < C::T2; jo += 2) {
+      dib_f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = Bs[H1 + 32 * jo + dib_crow(r, h)]; acc1[r] = Bs[H1 + 32 * jo + 32 + dib_crow(r, h)]; }
+      const float* w0p = Wt2 + (32 * jo + m) * C::P2 + 4 * h;
+      const float* w1p = w0p + 32 * C::P2;
+      float4 wa = *reinterpret_cast<const float4*>(w0p), wb = *reinterpret_cast<const float4*>(w1p);
+#pragma unroll
+      for (int st = 0; st < 4 * C::T1; ++st) {
+        const int ji = st >> 2, g = st & 3, sn = st + 1 < 4 * C::T1 ? st + 1 : st;
+        const float4 wan = *reinterpret_cast<const float4*>(w0p + 8 * sn), wbn = *reinterpret_cast<const float4*>(w1p + 8 * sn);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = DIB_MFMA(wa.x, h1[ji][4 * g + 0], acc0);
+        acc1 = DIB_MFMA(wb.x, h1[ji][4 * g + 0], acc1);
+        acc0 = DIB_MFMA(wa.y, h1[ji][4 * g + 1], acc0);
+        acc1 = DIB_MFMA(wb.y, h1[ji][4 * g + 1], acc1);
+        acc0 = DIB_MFMA(wa.z, h1[ji][4 * g + 2], acc0);
+        acc1 = DIB_MFMA(wb.z, h1[ji][4 * g + 2], acc1);
+        acc0 = DIB_MFMA(wa.w, h1[ji][4 * g + 3], acc0);
+        acc1 = DIB_MFMA(wb.w, h1[ji][4 * g + 3], acc1);
+        asm volatile("" : "+v"(acc0));
+        asm volatile("" : "+v"(acc1));
+        __builtin_amdgcn_sched_barrier(0);
+        wa = wan; wb = wbn;
+      }
+      dib_act_tile<RELU>(slope, acc0);
+      dib_act_tile<RELU>(slope, acc1);
+      h2[jo] = acc0;
+      h2[jo + 1] = acc1;
+    }
+    } else {
 #pragma unroll
     for (int jo = 0; jo < C::T2; ++jo) {
       dib_f32x16 acc;
@@ -286,13 +424,17 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       dib_act_tile<RELU>(slope, acc);
       h2[jo] = acc;
     }
+    }
+    DIB_FT(2);   // layer 2 + activation
+    auto stash_h2_and_mask = [&]() {
     if (a.h2 != nullptr) {
-      const int wrow0 = tile * 256 + wave * 32;
+      const int wrow0 = tile * 256 + slice * 32;
       const int rows_valid = min(32, a.batch - wrow0);
       float* dst = a.h2 + ((long long)f * a.batch + wrow0) * H2;
 #pragma unroll
       for (int jo = 0; jo < C::T2; ++jo) dib_store_tile(patch, h2[jo], dst + 32 * jo, H2, rows_valid, lane);
     }
+    DIB_FT(11);   // stash h2 (inside the lambda)
     if (a.h2mask != nullptr && valid) {  // act'(h2) as one bit per unit: the fused backward needs nothing else of h2
       // h2 > 0  <=>  its bit pattern is a positive integer (+0 -> 0, negatives and -0 -> negative): v_med3_i32 clamps
       // it to {0,1} and v_lshl_or_b32 shifts it in - 2 VALU ops per unit, no compare / SGPR round trip.  (Inline asm:
@@ -311,8 +453,41 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       a.h2mask[((long long)f * a.batch + b) * 2 + h] = ((unsigned long long)word[1] << 32) | word[0];
     }
 
+    };
+#if !DIB_FUSED_PINGPONG
+    stash_h2_and_mask();
+#endif
+    DIB_FT(4);   // activation mask bits
     // ---- layer 3 (linear, reference models.py:78): out^T = W3^T h2^T + b3 ; rows [0,E) = mu, [E,2E) = logvar ----
     dib_f32x16 o[C::T3];
+    if constexpr (DIB_FUSED_PAIR && C::T3 == 2) {
+      dib_f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = Bs[H1 + H2 + dib_crow(r, h)]; acc1[r] = Bs[H1 + H2 + 32 + dib_crow(r, h)]; }
+      const float* w0p = Wt3 + m * C::P3 + 4 * h;
+      const float* w1p = w0p + 32 * C::P3;
+      float4 wa = *reinterpret_cast<const float4*>(w0p), wb = *reinterpret_cast<const float4*>(w1p);
+#pragma unroll
+      for (int st = 0; st < 4 * C::T2; ++st) {
+        const int ji = st >> 2, g = st & 3, sn = st + 1 < 4 * C::T2 ? st + 1 : st;
+        const float4 wan = *reinterpret_cast<const float4*>(w0p + 8 * sn), wbn = *reinterpret_cast<const float4*>(w1p + 8 * sn);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = DIB_MFMA(wa.x, h2[ji][4 * g + 0], acc0);
+        acc1 = DIB_MFMA(wb.x, h2[ji][4 * g + 0], acc1);
+        acc0 = DIB_MFMA(wa.y, h2[ji][4 * g + 1], acc0);
+        acc1 = DIB_MFMA(wb.y, h2[ji][4 * g + 1], acc1);
+        acc0 = DIB_MFMA(wa.z, h2[ji][4 * g + 2], acc0);
+        acc1 = DIB_MFMA(wb.z, h2[ji][4 * g + 2], acc1);
+        acc0 = DIB_MFMA(wa.w, h2[ji][4 * g + 3], acc0);
+        acc1 = DIB_MFMA(wb.w, h2[ji][4 * g + 3], acc1);
+        asm volatile("" : "+v"(acc0));
+        asm volatile("" : "+v"(acc1));
+        __builtin_amdgcn_sched_barrier(0);
+        wa = wan; wb = wbn;
+      }
+      o[0] = acc0;
+      o[1] = acc1;
+    } else {
 #pragma unroll
     for (int jo = 0; jo < C::T3; ++jo) {
       dib_f32x16 acc;
@@ -331,7 +506,27 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       }
       o[jo] = acc;
     }
+    }
 
+    DIB_FT(5);   // layer 3
+#if DIB_FUSED_PINGPONG
+    __builtin_amdgcn_s_barrier();   // end of the matrix segment: the partner wave takes the pipe
+    DIB_FT(9);    // barrier wait
+    {
+#if DIB_FUSED_DYNAMIC
+      const int sp = sub_next < n_sub ? sub_next : sub;
+      load_p((int)blockIdx.x + (sp >> 3) * (int)gridDim.x, sp & 7, pn);
+#else
+      const int nt = tile + gridDim.x;
+      load_p(nt < n_tiles ? nt : tile, slice, pn);  // next tile's inputs (harmless re-read on the last tile)
+#endif
+    }
+    DIB_FT(10);   // next tile's input loads issued
+    stash_h1();
+    DIB_FT(1);
+    stash_h2_and_mask();
+    DIB_FT(3);
+#endif
     // ---- epilogue: stash (mu|logvar), reparameterise (reference models.py:108), KL (models.py:111-112) ----
     // E % 32 == 0: mu tiles [0, E/32), logvar tiles [E/32, 2E/32), same register index.
     // E in {8,16}: one tile; mu in register groups g < E/8, logvar in groups g + E/8 (same lane).
@@ -368,8 +563,9 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
                        (mu.z * mu.z + sg.z * sg.z - lv.z - 1.f) + (mu.w * mu.w + sg.w * sg.w - lv.w - 1.f));
       }
     }
+    DIB_FT(6);   // eps, sigma, u, KL
     if (E >= 32) {  // full-line stores of (mu|logvar) [F][B][2E] and of u [B][F*E]
-      const int wrow0 = tile * 256 + wave * 32;
+      const int wrow0 = tile * 256 + slice * 32;
       const int rows_valid = min(32, a.batch - wrow0);
       float* eo_w = a.enc_out + ((long long)f * a.batch + wrow0) * C::E2;
 #pragma unroll
@@ -379,11 +575,49 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       for (int jo = 0; jo < ((E >= 32) ? (E / 32) : 1); ++jo)
         dib_store_tile(patch, ut[jo], u_w + 32 * jo, (long long)F * E, rows_valid, lane);
     }
+    DIB_FT(7);   // stash (mu|logvar), u
+#if DIB_FUSED_DYNAMIC
+    {
+      const float kls = dib_wave_sum(klp);
+      if (lane == 0) a.kl_partial[((long long)tile * 8 + slice) * F + f] = kls;   // one writer per (sub-tile, feature)
+    }
+#else
     kl_acc += dib_wave_sum(klp);
+#endif
 #pragma unroll
     for (int r = 0; r < 8; ++r) p[r] = pn[r];
+#if DIB_FUSED_PINGPONG
+    DIB_FT(12);   // KL wave sum
+    if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_barrier();
+#endif
+    DIB_FT(8);   // trailing barrier wait, loop end
+#if DIB_FUSED_DYNAMIC
+    sub = sub_next;
+#endif
   }
+#ifdef DIB_FUSED_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    for (int i = 0; i < 9; ++i) dib_fused_dbg[i] = tacc_[i];
+    dib_fused_dbg[9] = clock64() - tstart_;
+    dib_fused_dbg[10] = ntl_;
+    dib_fused_dbg[11] = wall_clock64() - wstart_;
+    for (int i = 9; i < 13; ++i) dib_fused_dbg[3 + i] = tacc_[i];   // [12..15]: barrier wait, input loads, stash h2, KL sum
+  }
+  if (lane == 0) {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 1024) dib_fused_wave_end[8 * wg + wave] = wall_clock64();
+  }
+  if (tid == 0) {
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 1024) { dib_fused_wg[3 * wg] = wentry_; dib_fused_wg[3 * wg + 1] = wstart_; dib_fused_wg[3 * wg + 2] = wall_clock64(); }
+    DIB_TL_MAX(2, wall_clock64());
+  }
+#endif
+#if !DIB_FUSED_DYNAMIC
   if (lane == 0) a.kl_partial[((long long)blockIdx.x * 8 + wave) * F + f] = kl_acc;
+#else
+  (void)kl_acc;
+#endif
 }
 
 // =====================================================================================================
@@ -517,6 +751,7 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
   };
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    DIB_FUSED_SET_PRIO(tile / (int)gridDim.x);
     const int wrow0 = tile * 256 + wave * 32;
     if (wrow0 >= a.batch) continue;  // wave-uniform; no barriers inside the loop
     const int rows_valid = min(32, a.batch - wrow0);

@@ -111,9 +111,9 @@ class SetTransformerDIB:
                  *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto"):
         """attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
         grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" (per batch shape, key_dim == 128):
-        flash for short sets (P <= 128: measured 3.4 vs 4.1 ms/step at the notebook's 32 x 50) and whenever the stashed
-        probabilities of all blocks would exceed `score_budget_bytes` (default 96 GB, a third of the MI355X's HBM: 32
-        neighbourhoods x 4096 particles would need 180 GB), else gemm (measured 20-35 % faster at P = 2048-4096 while it fits)."""
+        flash - since the round-2 rewrite of the attention kernels it is the faster path at every measured shape (ms/step flash
+        vs gemm: 32 x 50: 3.16 / 4.14, 4 x 512: 4.51 / 4.88, 2 x 2048: 15.6 / 15.7, 4 x 4096: 81.6 / 100.5;
+        profiles/r02final2_set_transformer_bench.txt) and it needs no [P, P] stash in HBM; key_dim != 128: gemm."""
         if not torch.cuda.is_available():
             raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.lib = _lib.load_library()
@@ -248,7 +248,8 @@ class SetTransformerDIB:
         ldS = _align4(P)
         if self.attention == "auto" and self.key_dim == 128:
             score_bytes = 4 * B * H * P * ldS * (self.number_attention_blocks + 1)
-            impl = "flash" if (P <= 128 or score_bytes > self.score_budget_bytes) else "gemm"
+            impl = "flash"   # (score_bytes = what the gemm path would stash; kept for the memory report)
+            del score_bytes
         else:
             impl = self.attention_impl
         F0 = self.particle_feature_dimensions

@@ -45,6 +45,8 @@ def main():
     for i, nm in enumerate(names):
         print(f"{nm:20s} {out[i] / n:9.0f} cycles/tile  {100.0 * out[i] / tot:5.1f} %")
     print(f"{'loop total':20s} {tot / n:9.0f} cycles/tile   (kernel body {out[7]} cycles, {n} tiles; MFMA floor 320 x 64 = 20480)")
+    if out[9] > 0:
+        print(f"shader clock during the loop: {out[7] / (out[9] / 100e6) / 1e9:.3f} GHz (s_memtime ticks / s_memrealtime at 100 MHz)")
 
 
 if __name__ == "__main__":
