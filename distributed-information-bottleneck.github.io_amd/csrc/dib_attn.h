@@ -106,6 +106,9 @@ __device__ __forceinline__ void dib_attn_store_rows(float* __restrict__ base, lo
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: grid (ceil(P / 128), H, B), 256 threads
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef DIB_ATTN_BWD_EXP_UNDER_MFMA
+#define DIB_ATTN_BWD_EXP_UNDER_MFMA 1
+#endif
 #ifndef DIB_ATTN_FWD_WAVES
 #define DIB_ATTN_FWD_WAVES 3   // measured (tools/attn_bench.py, 4 x 4096 x 12 heads): 3 waves/SIMD 4.26 ms = 97 TFLOP/s, 2 waves/SIMD 4.98 ms
 #endif
@@ -392,6 +395,76 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) qv[dt] = dib_attn_mc(Qs, 0, 32 * dt + l31, h);
     __builtin_amdgcn_sched_barrier(0);
+#if DIB_ATTN_BWD_EXP_UNDER_MFMA
+    // P and dS of query group g (register r = 4g + t <-> query qt*32 + t + 8g + 4h; lane <-> key).  Group 0 is computed here,
+    // group g + 1 inside the dV step of group g - VALU in the shadow of 16 MFMAs instead of 64 exposed exponentials per tile.
+    // The accumulators are made opaque at the top of every step (or the exponentials would be hoisted back up here) and the
+    // results pinned at its end (or they would sink to their first use).
+    float pv[16], dsv[16];
+    auto softmax_group = [&](int g) {
+      const float lv[4] = {lq[g].x, lq[g].y, lq[g].z, lq[g].w};
+      const float dl[4] = {dq4[g].x, dq4[g].y, dq4[g].z, dq4[g].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 4 * g + t;
+        const float p = __expf(s[r] - lv[t]) * kmul;
+        pv[r] = p;                                       // P
+        dsv[r] = p * (dp[r] - dl[t]);                    // dS
+      }
+    };
+    softmax_group(0);
+    DIB_T(2);   // exponentials of the first query group
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 gvn[4], qvn[4];
+      if (q < 3) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) gvn[dt] = dib_attn_mc(Gs, q + 1, 32 * dt + l31, h);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      DIB_PIN_ACC_A(s);
+      DIB_PIN_ACC_A(dp);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].x, pv[4 * q + 0], dv[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].y, pv[4 * q + 1], dv[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].z, pv[4 * q + 2], dv[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].w, pv[4 * q + 3], dv[dt]);
+      if (q < 3) softmax_group(q + 1);
+      // dS^T of this group into the wave's patch: patch[query][key]
+#pragma unroll
+      for (int t = 0; t < 4; ++t) my_patch[(t + 8 * q + 4 * h) * 36 + l31] = dsv[4 * q + t];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) DIB_PIN_ACC_A(dv[dt]);
+      if (q < 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { DIB_PIN_ACC_V(pv[4 * q + 4 + t]); DIB_PIN_ACC_V(dsv[4 * q + 4 + t]); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 3) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) qvn[dt] = dib_attn_mc(Qs, q + 1, 32 * dt + l31, h);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].x, dsv[4 * q + 0], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].y, dsv[4 * q + 1], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].z, dsv[4 * q + 2], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].w, dsv[4 * q + 3], dk[dt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) DIB_PIN_ACC_A(dk[dt]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < 3) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { gv[dt] = gvn[dt]; qv[dt] = qvn[dt]; }
+      }
+    }
+#else
     // register r <-> query qt*32 + (r&3) + 8(r>>2) + 4h ; lane <-> key
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -452,7 +525,10 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
         for (int dt = 0; dt < 4; ++dt) { gv[dt] = gvn[dt]; qv[dt] = qvn[dt]; }
       }
     }
+#endif
     DIB_T(3);   // dV / dK products issued
+    // first K fragments of the dQ product: the K block is static, so they can be in flight across the barrier
+    const float4 ka0 = dib_attn_mc(Kblk, 0, 32 * wave + l31, h), kb0 = dib_attn_mc(Kblk, 1, 32 * wave + l31, h);
     __syncthreads();   // all four dS^T patches are in LDS; nobody reads Qs / Gs / Ls / Ds any more
     DIB_T(4);   // barrier B
     {
@@ -476,7 +552,7 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
         return *reinterpret_cast<const float4*>(patches + (st >> 2) * kAttnPatch + l31 * 36 + 8 * (st & 3) + 4 * h);
       };
       auto k_frag = [&](int st) { return dib_attn_mc(Kblk + (st >> 2) * 32 * kAttnPitch, st & 3, 32 * wave + l31, h); };
-      float4 dsa = ds_frag(0), dsb = ds_frag(1), ka = k_frag(0), kb = k_frag(1);
+      float4 dsa = ds_frag(0), dsb = ds_frag(1), ka = ka0, kb = kb0;
 #pragma unroll
       for (int st = 0; st < 16; st += 2) {
         const int sn = st < 14 ? st + 2 : 14;

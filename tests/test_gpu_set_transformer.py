@@ -153,7 +153,12 @@ def test_large_token_count_uses_split_weight_gradients():
     """T = batch * particles >= 2048 tokens: weight gradients are accumulated in batch slabs + fixed-order reduce."""
     spec = sto.SetTransformerSpec(number_attention_blocks=1)
     B, P = 8, 300
-    m, p = _model(spec, seed=4)
+    # attention="gemm": with 307 200 ReLU units in the feed-forward block ONE unit whose pre-activation the float64 oracle and
+    # the fp32 device put on different sides of 0 shifts the ff0 / LayerNorm / attention / encoder gradients by ~1e-5 (the
+    # discontinuity the encoder-bank tests handle with device masks).  The flash forward's rounding happens to flip one at this
+    # seed (tools/st_grad_error_table.py: every block downstream of the flip is at 1e-9, every block upstream at 1e-6), the
+    # grouped-GEMM forward does not; this test is about the split weight-gradient slabs, flash has its own multi-tile cases.
+    m, p = _model(spec, seed=4, attention="gemm")
     rng = np.random.default_rng(2)
     feats = rng.standard_normal((B, P, 12)).astype(np.float32)
     y = (rng.random((B, 1)) > 0.5).astype(np.float32)
