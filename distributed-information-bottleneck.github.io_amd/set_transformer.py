@@ -112,8 +112,8 @@ class SetTransformerDIB:
         """attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
         grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" (per batch shape, key_dim == 128):
         flash - since the round-2 rewrite of the attention kernels it is the faster path at every measured shape (ms/step flash
-        vs gemm: 32 x 50: 3.16 / 4.14, 4 x 512: 4.51 / 4.88, 2 x 2048: 15.6 / 15.7, 4 x 4096: 81.6 / 100.5;
-        profiles/r02final2_set_transformer_bench.txt) and it needs no [P, P] stash in HBM; key_dim != 128: gemm."""
+        vs gemm: 32 x 50: 3.08 / 4.14, 4 x 512: 4.29 / 4.88, 2 x 2048: 15.0 / 15.7, 4 x 4096: 77.2 / 100.5;
+        profiles/r02am_set_transformer_bench.txt, r02final2_set_transformer_bench.txt) and it needs no [P, P] stash in HBM; key_dim != 128: gemm."""
         if not torch.cuda.is_available():
             raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.lib = _lib.load_library()
