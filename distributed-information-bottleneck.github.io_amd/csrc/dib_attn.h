@@ -12,7 +12,7 @@
 //             query j, so the row maximum / sum are register reductions plus one cross-half shuffle, and the probability
 //             tile P^T is - register for register - the B operand of O^T += V^T P^T (contraction index = key
 //             (r&3) + 8(r>>2) + 4h = the C-fragment row of register r): probabilities never touch LDS.
-//   backward  dib_attn_bwd_kernel (one wave = 32 keys, loops over query tiles; S = Q K^T evaluated UNtransposed so that
+//   backward  dib_attn_bwd_kernel (one wave = 32 keys, one wave per SIMD with the whole 512-register file, loops over query tiles; S = Q K^T evaluated UNtransposed so that
 //             P and dS are the B operands of dV^T += dO^T P and dK^T += Q^T dS, contraction index = query; the dQ
 //             contribution of the workgroup's 128 keys goes through an LDS transpose of dS into a per-key-block partial
 //             buffer) + dib_attn_dq_reduce_kernel: no atomics, one writer per element, fixed summation order.
@@ -30,7 +30,7 @@
 // instruction selector's list scheduler from floating them across a whole phase (it once sank all 64 S products of the
 // backward behind the 64 dP products, with 128 registers of operand fragments live).  Passing an accumulator through an
 // empty volatile asm makes it opaque there: its producers stay above, its consumers below, and volatile asms keep their
-// own order.  "a" = accumulator registers (the 512-register backward), "v" = the <= 168-register forward.
+// own order.  "a" = accumulator (AGPR) operands (the 512-register backward), "v" = values kept in VGPRs.
 #define DIB_PIN_ACC_A(x) asm volatile("" : "+a"(x))
 #define DIB_PIN_ACC_V(x) asm volatile("" : "+v"(x))
 

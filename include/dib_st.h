@@ -51,7 +51,8 @@ int dib_softmax_rows_bwd(const float* P_probs, float* dP, int64_t rows, int P, i
  * o[b, p, h, :] = sum_q softmax_q(scale * q[b, p, h, :] . k[b, q, h, :]) v[b, q, h, :].  q, k, v, o (and gradients) are
  * [B * P, ld] row-major, head h in columns [h * 128, (h + 1) * 128), 16-byte aligned.  The [P, P] scores never reach HBM
  * (online softmax forward, recomputation from lse [B, H, P] backward); deterministic (no atomics: the dQ contributions of
- * the 128-key blocks go through a partial buffer inside `ws` and a fixed-order reduce).  ws: dib_attention_bwd_workspace_bytes. */
+ * the 128-key blocks go through a partial buffer inside `ws` and a fixed-order reduce).  ws: dib_attention_bwd_workspace_bytes.
+ * DIB_E_UNSUPPORTED for key_dim != 128 or P * ld >= 2^30 elements (row offsets inside one neighbourhood are 32-bit). */
 int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,
                       float scale, float* o, float* lse, dib_stream_t stream);
 int64_t dib_attention_bwd_workspace_bytes(int B, int P, int H);
