@@ -1,0 +1,94 @@
+"""Resource audit of the generated gfx950 code (no GPU needed: hipcc cross-compiles to assembly).
+
+The performance of the hot kernels rests on properties the compiler decides and a harmless-looking source edit can lose
+(DESIGN.md 4.4 / 9 list how each was found): no stack objects or spills in the attention kernels (a `float4 (&)[4]` helper once
+left a prefetched tile in scratch: every global load was followed by a wait + scratch store), the attention backward's
+loop-carried accumulators resident in AGPRs (a divergent `if` around the MFMAs made the compiler copy all 128 of them into
+AGPRs and back on every query tile: 441 + 264 `v_accvgpr_*` per tile instead of the zero-initialisations only), register
+budgets that keep 2 waves per SIMD where the design assumes them, and the MFMA count of each tile body (= the algorithmic
+FLOPs; a changed count means the arithmetic changed).  The thresholds are the current values plus a little slack."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "distributed-information-bottleneck.github.io_amd", "csrc", "dib_api.hip")
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    hipcc = _hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not available")
+    out = str(tmp_path_factory.mktemp("isa") / "dib_api.s")
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", SRC, "-o", out],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = open(out).read()
+    info = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n", text, re.M):
+        end = text.find(".Lfunc_end", m.end())
+        if end < 0:
+            continue
+        body, tail = text[m.end():end], text[end:end + 4000]
+        meta = {k: int(v) for k, v in re.findall(r"; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize): (\d+)", tail)}
+        if "NumVgprs" not in meta:
+            continue
+        meta["mfma"] = len(re.findall(r"^\s*v_mfma", body, re.M))
+        meta["accvgpr_write"] = len(re.findall(r"v_accvgpr_write", body))
+        meta["accvgpr_read"] = len(re.findall(r"v_accvgpr_read", body))
+        info[m.group(1)] = meta
+    return info
+
+
+def _one(kernels, *needles):
+    hits = [k for k in kernels if all(n in k for n in needles)]
+    assert len(hits) == 1, (needles, hits)
+    return kernels[hits[0]]
+
+
+def test_attention_forward_two_waves_per_simd_no_scratch(kernels):
+    k = _one(kernels, "dib_attn_fwd_kernel")
+    assert k["ScratchSize"] == 0 and k["NumAgprs"] == 0
+    assert k["NumVgprs"] <= 256 and k["Occupancy"] == 2
+    assert k["mfma"] == 128               # 64 (S^T = K Q^T) + 64 (O^T += V^T P^T) per 32-key tile
+
+
+def test_attention_backward_accumulators_stay_in_agprs(kernels):
+    k = _one(kernels, "dib_attn_bwd_kernel")
+    assert k["ScratchSize"] == 0
+    assert k["mfma"] == 320               # S, dP (128) + dV, dK (128) + dQ (64) per 32-query tile
+    # zero-initialisations of the accumulators are the only v_accvgpr_write in the kernel (128 dV/dK once + 96 per tile + the
+    # zero-trip copy), the reads are the S / dP / dQ tiles leaving the matrix pipe: no per-tile shuffling of dV / dK
+    assert k["accvgpr_write"] <= 300, k
+    assert k["accvgpr_read"] <= 100, k
+    assert k["NumVgprs"] + k["NumAgprs"] <= 512
+
+
+def test_fused_encoder_kernels_keep_two_waves_per_simd(kernels):
+    fwd = _one(kernels, "dib_fused_encoder_fwd_kernelILi128ELi128ELi32ELb1")
+    bwd = _one(kernels, "dib_fused_encoder_bwd_kernelILi128ELi128ELi32ELb1")
+    assert fwd["NumVgprs"] <= 256 and fwd["Occupancy"] == 2 and fwd["ScratchSize"] == 0 and fwd["NumAgprs"] == 0
+    assert fwd["mfma"] == 416             # 32 (layer 1) + 256 (layer 2) + 128 (layer 3) per 32-sample tile
+    assert bwd["NumVgprs"] <= 256 and bwd["Occupancy"] == 2 and bwd["NumAgprs"] == 0
+    assert bwd["ScratchSize"] <= 32       # 2-3 spilled registers today
+    assert bwd["mfma"] == 480             # 128 + 256 (dgrads) + 32 (h1 recompute) + 64 (layer-1 weight gradient, 16x16x4)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_big_gemm_tiles_fit_two_workgroups_per_cu(kernels, mode):
+    k = _one(kernels, f"dib_gemm_kernelILi{mode}ELi2ELi2ELi64E")
+    assert k["ScratchSize"] == 0 and k["NumAgprs"] == 0
+    assert k["NumVgprs"] <= 256 and k["Occupancy"] >= 2
+    assert k["LDSByteSize"] <= 80 * 1024  # two workgroups per CU (160 KB of LDS)
+    assert k["mfma"] == 128               # one 64-deep K tile of the 128 x 128 output tile per wave
