@@ -48,9 +48,10 @@ def simulate_double_pendulum(data_path='./data/', simulation_params_dict=None, r
         th1 = rng.uniform() * 2 * np.pi
         h1 = l1 * (1.0 - np.cos(th1))
         arg = 1 - ((energy_over_g - m1 * h1) / m2 - h1) / l2  # second arm angle giving the prescribed potential energy
-        if not -1.0 <= arg <= 1.0:
+        sign = rng.integers(2) * 2 - 1   # drawn before the validity test, like the reference (simulate_pendulum.py:63-66 evaluates
+        if not -1.0 <= arg <= 1.0:       # arccos(...) * (randint(2)*2-1) and only then checks for NaN): same stream consumption
             continue
-        th2 = np.arccos(arg) * (rng.integers(2) * 2 - 1)
+        th2 = np.arccos(arg) * sign
         y0 = np.array([th1, 0.0, th2, 0.0])
         y = odeint(_rhs, y0, t, args=(l1, l2, m1, m2))
         e0 = total_energy(y0[None], l1, l2, m1, m2)[0]

@@ -213,3 +213,42 @@ def test_compression_matrix_figure_content_matches_reference_function(monkeypatc
     assert np.abs(m - g["b_matrix_literal"]).max() > 1e-3    # the reference literally draws the first 128 dataset rows
     assert np.array_equal(c[((1, 0), "plot")][0], g["b_left_x"]) and np.array_equal(c[((1, 0), "plot")][1], g["b_left_y"])
     assert np.array_equal(c[((0, 1), "plot")][0], g["b_top_x"]) and np.array_equal(c[((0, 1), "plot")][1], g["b_top_y"])
+
+
+def test_double_pendulum_data_path_matches_the_reference_executed(tmp_path):
+    """BASELINE config 2's data source.  tests/golden/pendulum.npz = the reference's simulate_pendulum.py executed with a
+    seeded global NumPy stream, then its data.fetch_double_pendulum on the file it wrote (make_golden_pendulum.py).
+    dib_amd.simulate_pendulum fed the same stream (a RandomState adapter: uniform() / randint(2), sign drawn before the validity
+    test like the reference) reproduces the trajectories; dib_amd.data.fetch_double_pendulum builds the same (x, y) pairs -
+    except that it holds out the FIRST tenth for validation where the reference's np.split trains on it."""
+    import dib_amd
+    from dib_amd import simulate_pendulum
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pendulum.npz"))
+
+    class LegacyStream:  # the reference draws from the global np.random stream (simulate_pendulum.py:58,63)
+        def __init__(self, seed):
+            self.r = np.random.RandomState(seed)
+
+        def uniform(self):
+            return self.r.uniform()
+
+        def integers(self, n):
+            return self.r.randint(n)
+
+    prm = {k[len("param_"):]: g[k].item() for k in g.files if k.startswith("param_")}
+    prm["number_trajectories"] = int(prm["number_trajectories"])
+    traj = simulate_pendulum.simulate_double_pendulum(str(tmp_path), prm, rng=LegacyStream(int(g["seed"])), save=True)
+    assert traj.shape == g["trajectories"].shape
+    # same stream, same initial conditions, same integrator: most trajectories agree to the last bit; where the right-hand side
+    # rounds one operation differently (`z**2` vs `z*z`) the chaotic dynamics amplify the last bit to ~3e-9 over these 3 s
+    assert np.abs(traj - g["trajectories"]).max() < 1e-6
+    assert np.array_equal(traj[:, 0, [1, 3]] == 0, g["trajectories"][:, 0, [1, 3]] == 0)
+    d = dib_amd.data.fetch_double_pendulum(data_path=str(tmp_path), pendulum_time_delta=float(g["time_delta"]))
+    assert d["feature_dimensionalities"] == list(g["feature_dimensionalities"]) and d["loss"] == "infonce"
+    # reference "train" = first tenth, "valid" = the rest; here the first tenth is the held-out set
+    for mine, theirs in (("x_valid", "x_train"), ("y_valid", "y_train"), ("x_train", "x_valid"), ("y_train", "y_valid")):
+        assert d[mine].shape == g[theirs].shape, (mine, d[mine].shape, g[theirs].shape)
+        assert np.abs(d[mine] - g[theirs].astype(np.float32)).max() < 1e-6, mine
+    # energy is conserved along every stored trajectory (the simulator's acceptance test)
+    e = simulate_pendulum.total_energy(traj.reshape(-1, 4)).reshape(traj.shape[:2])
+    assert np.abs(e / e[:, :1] - 1).max() < 1e-3
