@@ -27,6 +27,12 @@ class _Ax:
     def set_xticks(self, *a): pass
     def set_yticks(self, *a): pass
     def axis(self, *a): pass
+    # save_distributed_info_plane (visualization.py:83-113): a twin axis, z-order juggling
+    def twinx(self): return _Ax(self.rec, (self.key, "twin"))
+    def set_zorder(self, z): pass
+    def get_zorder(self): return 0
+    @property
+    def patch(self): return _Spine()
 
 
 class _GridSpec:
@@ -44,6 +50,9 @@ class _Fig:
     def add_subplot(self, key):
         return _Ax(self.rec, key)
 
+    def gca(self):
+        return _Ax(self.rec, "main")
+
     def savefig(self, fname, **kw):
         self.rec.saved.append(fname)
 
@@ -58,9 +67,14 @@ class Recorder:
         return _Fig(self)
 
     def axis(self, *a): pass
+    def gca(self): return _Ax(self, "main")
     def savefig(self, fname, **kw): self.saved.append(fname)
     def clf(self): pass
     def close(self, *a): pass
+
+    def plots(self, key):
+        """every (x, y) handed to ax.plot on the subplot `key`, in call order"""
+        return [(a[0], a[1]) for k, what, a, kw in self.calls if k == key and what == "plot"]
 
     def content(self):
         """{(subplot key, artist): [arrays]} with the first call per key kept."""

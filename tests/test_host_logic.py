@@ -252,3 +252,40 @@ def test_double_pendulum_data_path_matches_the_reference_executed(tmp_path):
     # energy is conserved along every stored trajectory (the simulator's acceptance test)
     e = simulate_pendulum.total_energy(traj.reshape(-1, 4)).reshape(traj.shape[:2])
     assert np.abs(e / e[:, :1] - 1).max() < 1e-3
+
+
+def test_info_plane_figure_content_matches_reference_function(monkeypatch, tmp_path):
+    """visualization.save_distributed_info_plane (History post-processing -> figure, reference visualization.py:83-113 executed
+    with the recording matplotlib stand-in, tests/golden/make_golden_misc.py): the sieve factor, the start index and every
+    array handed to ax.plot on the main and the twin axis."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from plt_recorder import Recorder
+    from make_golden_misc import info_plane_inputs
+    from dib_amd import visualization
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "misc.npz"))
+    kl, loss = info_plane_inputs()
+    for tag, (k, l, hy) in {"long": (kl, loss, 0.758), "short": (kl[:40, :1], loss[:40], None)}.items():
+        rec = Recorder()
+        monkeypatch.setattr(visualization, "_plt", lambda: rec)
+        saved = visualization.save_distributed_info_plane(k, l, str(tmp_path / tag), entropy_y=hy)
+        main_plots, twin_plots = rec.plots("main"), rec.plots(("main", "twin"))
+        assert len(main_plots) == int(g[f"ip_{tag}_n_main"]) and len(twin_plots) == int(g[f"ip_{tag}_n_twin"])
+        for i, (x, y) in enumerate(main_plots):
+            assert np.array_equal(x, g[f"ip_{tag}_main{i}_x"]) and np.array_equal(y, g[f"ip_{tag}_main{i}_y"]), (tag, "main", i)
+        for i, (x, y) in enumerate(twin_plots):
+            assert np.array_equal(x, g[f"ip_{tag}_twin{i}_x"]) and np.array_equal(y, g[f"ip_{tag}_twin{i}_y"]), (tag, "twin", i)
+        assert os.path.basename(saved) == os.path.basename(str(g[f"ip_{tag}_saved"][0])) == "distributed_info_plane.png"
+
+
+def test_chaos_maps_match_the_reference_executed():
+    """dib_amd.chaos_data.generate_data with seed=None draws its initial condition from NumPy's global stream like the
+    reference (chaos/chaos_data.py:3-55): under the same np.random.seed the trajectories are bit-identical to the reference's
+    (executed by tests/golden/make_golden_misc.py) - 1900 iterations of a chaotic map leave no room for a different rounding."""
+    from dib_amd import chaos_data
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "misc.npz"))
+    for name, prm in (("logistic", {}), ("henon", {}), ("ikeda", {}), ("logistic_r4", {"r": 4.0})):
+        np.random.seed(int(g["seed"]))
+        got = chaos_data.generate_data(name.split("_")[0], number_iterations=400, number_skip_iterations=1500, **prm)
+        assert got.shape == g[f"chaos_{name}"].shape
+        assert np.array_equal(got, g[f"chaos_{name}"]), (name, np.abs(got - g[f"chaos_{name}"]).max())
