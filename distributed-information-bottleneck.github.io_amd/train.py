@@ -59,6 +59,27 @@ def get_args(argv=None):
     return p.parse_args(argv)
 
 
+def postprocess_history(h, number_features, loss_is_info_based):
+    """reference train.py:168-178: per-epoch series from `history.history` - the task loss without its beta * sum KL term, KL
+    in bits, info-based losses in bits (same dtypes: float32 beta / loss series updated in place, float64 KL) - plus the
+    validation series the reference forgot to build."""
+    F = number_features
+    beta_series = np.float32(h['beta'])
+    kl_series = np.stack([h[f'KL{f}'] for f in range(F)], -1)
+    loss_series = np.float32(h['loss'])
+    loss_series_validation = np.float32(h['val_loss'])
+    loss_series -= beta_series * np.sum(kl_series, axis=-1)
+    kl_series /= np.log(2)
+    kl_series_validation = np.stack([h[f'val_KL{f}'] for f in range(F)], -1)
+    loss_series_validation -= np.float32(h['val_beta']) * np.sum(kl_series_validation, axis=-1)
+    kl_series_validation /= np.log(2)
+    if loss_is_info_based:
+        loss_series /= np.log(2)
+        loss_series_validation /= np.log(2)
+    return dict(beta=beta_series, kl_bits=kl_series, loss=loss_series, kl_bits_validation=kl_series_validation,
+                loss_validation=loss_series_validation)
+
+
 def main(argv=None):
     from . import data, models, optimizers, visualization
     args = get_args(argv)
@@ -128,19 +149,9 @@ def main(argv=None):
     history = model.fit(dataset_dict['x_train'], dataset_dict['y_train'], epochs=number_epochs, shuffle=True,
                         batch_size=args.batch_size, callbacks=callbacks, verbose=args.verbose,
                         validation_data=(dataset_dict['x_valid'], dataset_dict['y_valid']))
-    # ---- train.py:169-178 (and the kl_series_validation the reference forgot to build, App. A5) ----
-    F = dataset_dict['number_features']
-    h = history.history
-    beta_series = np.float32(h['beta'])
-    kl_series = np.stack([h[f'KL{f}'] for f in range(F)], -1)
-    kl_series_validation = np.stack([h[f'val_KL{f}'] for f in range(F)], -1)
-    loss_series = np.float32(h['loss']) - beta_series * np.sum(kl_series, axis=-1)
-    loss_series_validation = np.float32(h['val_loss']) - np.float32(h['val_beta']) * np.sum(kl_series_validation, -1)
-    kl_series /= np.log(2)
-    kl_series_validation /= np.log(2)
-    if dataset_dict['loss_is_info_based']:
-        loss_series /= np.log(2)
-        loss_series_validation /= np.log(2)
+    series = postprocess_history(history.history, dataset_dict['number_features'], dataset_dict['loss_is_info_based'])
+    beta_series, kl_series, loss_series = series['beta'], series['kl_bits'], series['loss']
+    kl_series_validation, loss_series_validation = series['kl_bits_validation'], series['loss_validation']
     if rank == 0:
         print('Finished training.')
         np.savez(os.path.join(args.artifact_outdir, 'history.npz'), beta=beta_series, kl_bits=kl_series,

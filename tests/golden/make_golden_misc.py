@@ -25,6 +25,18 @@ def info_plane_inputs():
     return kl, loss
 
 
+def history_inputs():
+    rng = np.random.default_rng(9)
+    n = 17
+    h = {"beta": np.float32(np.geomspace(1e-4, 3.0, n)).tolist(), "val_beta": np.float32(np.geomspace(1e-4, 3.0, n)).tolist()}
+    for f in range(3):
+        h[f"KL{f}"] = (np.abs(rng.standard_normal(n)) * 2).tolist()
+        h[f"val_KL{f}"] = (np.abs(rng.standard_normal(n)) * 2).tolist()
+    h["loss"] = (0.3 + rng.random(n) + np.float32(h["beta"]) * sum(np.array(h[f"KL{f}"]) for f in range(3))).tolist()
+    h["val_loss"] = (0.3 + rng.random(n) + np.float32(h["val_beta"]) * sum(np.array(h[f"val_KL{f}"]) for f in range(3))).tolist()
+    return h
+
+
 def main():
     out = {}
     kl, loss = info_plane_inputs()
@@ -46,6 +58,22 @@ def main():
     for name, prm in (("logistic", {}), ("henon", {}), ("ikeda", {}), ("logistic_r4", {"r": 4.0})):
         np.random.seed(SEED)
         out[f"chaos_{name}"] = ref.generate_data(name.split("_")[0], number_iterations=400, number_skip_iterations=1500, **prm)
+    # ---- train.py:168-178, the History post-processing statements themselves, executed on a synthetic history ----
+    h = history_inputs()
+    src = open(os.path.join(REF, "train.py")).read().split("\n")
+    first = next(i for i, l in enumerate(src) if "beta_series = np.float32(history.history['beta'])" in l)
+    last = next(i for i, l in enumerate(src) if "loss_series /= np.log(2)  ## convert the loss values to bits" in l)
+    block = [l for l in src[first:last + 1]]
+    indent = len(block[0]) - len(block[0].lstrip())
+    code = "\n".join(l[indent:] if l.strip() else "" for l in block)
+    import types
+    for info_based in (True, False):
+        g = {"np": np, "history": types.SimpleNamespace(history={k: list(v) for k, v in h.items()}),
+             "dataset_dict": {"number_features": 3, "loss_is_info_based": info_based}}
+        exec(compile(code, "train.py:%d-%d" % (first + 1, last + 1), "exec"), g)
+        tag = "info" if info_based else "plain"
+        out[f"hist_{tag}_loss"], out[f"hist_{tag}_kl_bits"], out[f"hist_{tag}_beta"] = g["loss_series"], g["kl_series"], g["beta_series"]
+        out[f"hist_{tag}_loss_validation_raw"] = g["loss_series_validation"]   # the reference leaves it as the raw val_loss
     np.savez_compressed(os.path.join(HERE, "misc.npz"), seed=SEED, **out)
     print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if not k.endswith(("_x", "_y"))})
 

@@ -289,3 +289,25 @@ def test_chaos_maps_match_the_reference_executed():
         got = chaos_data.generate_data(name.split("_")[0], number_iterations=400, number_skip_iterations=1500, **prm)
         assert got.shape == g[f"chaos_{name}"].shape
         assert np.array_equal(got, g[f"chaos_{name}"]), (name, np.abs(got - g[f"chaos_{name}"]).max())
+
+
+def test_history_postprocessing_matches_the_reference_statements():
+    """train.postprocess_history against reference train.py:168-178 - the statements themselves, cut out of the reference
+    script and executed on a synthetic `history.history` (tests/golden/make_golden_misc.py): loss without beta * sum KL, KL
+    and info-based losses in bits, float32 / float64 dtypes included.  The validation series are this project's addition
+    (the reference leaves val_loss raw and never builds kl_series_validation): checked by construction."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden_misc import history_inputs
+    from dib_amd import train
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "misc.npz"))
+    for tag, info_based in (("info", True), ("plain", False)):
+        out = train.postprocess_history(history_inputs(), 3, info_based)
+        assert out["loss"].dtype == g[f"hist_{tag}_loss"].dtype == np.float32
+        assert np.array_equal(out["loss"], g[f"hist_{tag}_loss"]) and np.array_equal(out["beta"], g[f"hist_{tag}_beta"])
+        assert np.array_equal(out["kl_bits"], g[f"hist_{tag}_kl_bits"])
+        h = history_inputs()
+        raw = g[f"hist_{tag}_loss_validation_raw"]
+        want = raw - np.float32(h["val_beta"]) * sum(np.array(h[f"val_KL{f}"]) for f in range(3))
+        want = want / np.log(2) if info_based else want
+        assert np.allclose(out["loss_validation"], want, rtol=1e-6, atol=1e-6)
