@@ -311,3 +311,30 @@ def test_history_postprocessing_matches_the_reference_statements():
         want = raw - np.float32(h["val_beta"]) * sum(np.array(h[f"val_KL{f}"]) for f in range(3))
         want = want / np.log(2) if info_based else want
         assert np.allclose(out["loss_validation"], want, rtol=1e-6, atol=1e-6)
+
+
+def test_train_script_end_to_end_on_the_checker_engine(monkeypatch, tmp_path):
+    """dib_amd.train.main (the reference's `python train.py --dataset boolean_circuit ...`, train.py:118-178) from argument
+    parsing to history.npz and the info-plane figure, with the TEST-ONLY oracle engine injected - the host logic of the script
+    path without a GPU (the same call runs on the device in tests/test_gpu_parity.py)."""
+    import dib_amd
+    from dib_amd import models, train
+    orig_init = models.DistributedIBNet.__init__
+
+    def init_with_checker_engine(self, *a, **k):
+        orig_init(self, *a, **k)
+        self._engine_factory = OracleEngine
+
+    monkeypatch.setattr(models.DistributedIBNet, "__init__", init_with_checker_engine)
+    hist = train.main(["--dataset", "boolean_circuit", "--number_pretraining_epochs", "1", "--number_annealing_epochs", "2",
+                       "--batch_size", "256", "--artifact_outdir", str(tmp_path), "--save_compression_matrices_frequency", "2",
+                       "--feature_encoder_architecture", "8", "8", "--integration_network_architecture", "16",
+                       "--feature_embedding_dimension", "4"])
+    h = hist.history
+    assert len(h["loss"]) == 3 and np.isfinite(h["loss"]).all() and np.isfinite(h["val_loss"]).all()
+    z = np.load(os.path.join(str(tmp_path), "history.npz"))
+    want = train.postprocess_history(h, 10, True)
+    assert z["kl_bits"].shape == (3, 10) and np.array_equal(z["loss"], want["loss"]) and np.array_equal(z["beta"], want["beta"])
+    assert np.allclose(z["beta"], np.float32(h["beta"])) and z["beta"][0] < z["beta"][-1]     # the annealing ramp ran
+    assert os.path.exists(os.path.join(str(tmp_path), "distributed_info_plane.png"))
+    assert any(f.startswith("feature_0_log10beta") for f in os.listdir(str(tmp_path)))
