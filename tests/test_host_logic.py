@@ -338,3 +338,12 @@ def test_train_script_end_to_end_on_the_checker_engine(monkeypatch, tmp_path):
     assert np.allclose(z["beta"], np.float32(h["beta"])) and z["beta"][0] < z["beta"][-1]     # the annealing ramp ran
     assert os.path.exists(os.path.join(str(tmp_path), "distributed_info_plane.png"))
     assert any(f.startswith("feature_0_log10beta") for f in os.listdir(str(tmp_path)))
+
+
+def test_per_particle_feature_set_matches_the_notebook_function_executed():
+    """dib_amd.set_transformer.convert_to_per_particle_feature_set (the PRODUCT's copy of notebook cell 6) against the notebook's
+    own function executed on the same raw positions / types (tests/golden/make_golden_set_transformer.py -> ref_feats)."""
+    from dib_amd.set_transformer import convert_to_per_particle_feature_set
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "set_transformer_forward.npz"))
+    got = convert_to_per_particle_feature_set(g["raw_pos"], g["raw_types"], number_particles_to_use=6)
+    assert got.shape == g["ref_feats"].shape and np.abs(got - g["ref_feats"]).max() < 1e-12
