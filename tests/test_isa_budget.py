@@ -92,3 +92,11 @@ def test_big_gemm_tiles_fit_two_workgroups_per_cu(kernels, mode):
     assert k["NumVgprs"] <= 256 and k["Occupancy"] >= 2
     assert k["LDSByteSize"] <= 80 * 1024  # two workgroups per CU (160 KB of LDS)
     assert k["mfma"] == 128               # one 64-deep K tile of the 128 x 128 output tile per wave
+
+
+def test_no_kernel_of_the_library_uses_scratch_except_the_fused_backward(kernels):
+    """83 kernels; the only private-segment use is the 128/128/32 fused backward's 2-3 spilled registers (<= 32 bytes).  A new
+    entry here is either a spill or - worse - an array that was not promoted to registers (see the module docstring)."""
+    assert len(kernels) >= 80
+    offenders = {k: v["ScratchSize"] for k, v in kernels.items() if v["ScratchSize"] > 0}
+    assert all("dib_fused_encoder_bwd_kernelILi128ELi128ELi32E" in k and v <= 32 for k, v in offenders.items()), offenders
