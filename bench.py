@@ -171,6 +171,66 @@ def _respawn_under_launcher(n):
     return subprocess.call(cmd, env=env)
 
 
+def config5_set_transformer(dev, nb=4, npart=4096, nfeat=16, steps=4, warmup=2):
+    """BASELINE config 5 on one GPU: per-particle set-transformer DIB (notebook ...set_transformer.ipynb:332-431), `nb`
+    neighbourhoods x 4096 particles, 3-D positions (16 derived per-particle features), the notebook's architecture; one step =
+    fwd + KL + BCE + bwd + Adam.  Second block of steps with HIP events around the attention kernels for the roofline of the
+    dominant kernel, dib_attn_bwd_kernel, priced on ALGORITHMIC FLOPs: the four backward products dV, dP, dQ, dK =
+    2 x the forward's two (the recomputed S = Q K^T the kernel also executes is not counted)."""
+    from dib_amd import SetTransformerDIB
+    from dib_amd.engine import profile_summary
+    torch.cuda.empty_cache()
+    st = SetTransformerDIB(particle_feature_dimensions=nfeat, device=dev)
+    rng = np.random.default_rng(5)
+    xs = torch.from_numpy(rng.standard_normal((nb, npart, nfeat)).astype(np.float32)).to(dev)
+    ys = torch.from_numpy((rng.random((nb, 1)) > 0.5).astype(np.float32)).to(dev)
+    st.beta_dev.fill_(1e-3)
+
+    def block(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            st.train_step(xs, ys)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    block(warmup)
+    dt5 = block(steps)
+    st.lib.dib_profile_enable(1)
+    dt5_prof = block(steps)
+    prof = profile_summary(st.lib)
+    st.lib.dib_profile_enable(0)
+    D, H, K, nblk = st.bottleneck_dimension, st.number_heads_per_mha, st.key_dim, st.number_attention_blocks
+    attn_fwd = 4 * H * K * npart * npart                        # S = Q K^T and O = P V per neighbourhood and block
+    per_blk = 3 * 2 * D * H * K * npart + attn_fwd + 2 * H * K * D * npart + 2 * (D * 128 + 128 * D) * npart
+    fwd = 2 * (nfeat * 5 * 128 + 128 * 128 + 128 * 64) * npart + nblk * per_blk
+    out = {"workload": f"BASELINE config 5: per-particle set-transformer DIB, {nb} neighbourhoods x {npart} particles x "
+                       f"{nfeat} features (3-D positions), {nblk} x [MHA {H} x {K}, Add+LN, FF, Add+LN], fp32",
+           "value": round(nb / dt5, 2), "unit": "neighbourhoods/s", "ms_per_step": round(1e3 * dt5, 2), "steps": steps,
+           "algorithmic_TFLOPs": round(3 * fwd * nb / dt5 / 1e12, 2),
+           "step_roofline_frac": round(3 * fwd * nb / dt5 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+           "attention": st.attention_impl, "params": st.n_params,
+           "ms_per_step_kernel_timing": round(1e3 * dt5_prof, 2)}
+    by = {}
+    for name, fl in (("dib_attn_fwd_kernel", attn_fwd * nb), ("dib_attn_bwd_kernel", 2 * attn_fwd * nb)):
+        if name in prof and prof[name][1]:
+            ms, cnt = prof[name]
+            tf = fl / (ms / cnt * 1e-3) / 1e12
+            by[name] = {"launches": cnt, "avg_launch_ms": round(ms / cnt, 4), "ms_per_step": round(ms / steps, 3),
+                        "flops_per_launch": fl, "achieved": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+    if by:
+        dom = max(by, key=lambda k: by[k]["ms_per_step"])
+        out["roofline"] = {"bound": "mfma", "achieved": by[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": by[dom]["frac"], "traffic": HBM_TRAFFIC.get(dom + "@config5"), "kernel": dom,
+                           "avg_launch_ms": by[dom]["avg_launch_ms"], "launches": by[dom]["launches"],
+                           "flops_per_launch": by[dom]["flops_per_launch"],
+                           "note": "algorithmic FLOPs (4 backward products = 2 x forward); the kernel also recomputes S"}
+        out["roofline_by_kernel"] = by
+    del st, xs, ys
+    torch.cuda.empty_cache()
+    return out
+
+
 class Workload:
     """One engine + resident dataset + the step of the benchmark for a (feature count, scaling mode)."""
 
@@ -267,6 +327,9 @@ def main():
     ap.add_argument("--dp-buckets", type=int, default=2, choices=[1, 2],
                     help="gradient all-reduce buckets: 2 = integration bucket overlapped with the encoder backward")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--config5-only", action="store_true",
+                    help="run only the BASELINE config-5 set-transformer step (the `extra.config5_set_transformer` object) and "
+                         "print it: the command the rocprofv3 passes of profiles/*_config5_* wrap")
     ap.add_argument("--dry-run-backend", default=None, help=argparse.SUPPRESS)  # CPU test of the launcher path (gloo)
     args = ap.parse_args()
 
@@ -308,6 +371,10 @@ def main():
         assert joined == args.gpus, f"{joined} RCCL ranks joined, expected {args.gpus}"
 
     import dib_amd  # noqa: F401
+    if args.config5_only:
+        assert world == 1
+        print(json.dumps(config5_set_transformer(dev, steps=max(2, min(args.steps, 6)))), flush=True)
+        return 0
     wl = Workload(64, dev, rank, world, dist, args.scaling, args.batch, args.dp_buckets)
     eng = wl.eng
     med, times = wl.measure(args.warmup, args.steps, args.blocks, dev)
@@ -391,32 +458,7 @@ def main():
             # BASELINE config 5: per-particle set-transformer DIB, 4096 particles per neighbourhood, 3-D positions
             # (16 derived per-particle features), the notebook's architecture; one step = fwd + KL + BCE + bwd + Adam
             try:
-                torch.cuda.empty_cache()
-                from dib_amd import SetTransformerDIB
-                nb, npart, nfeat = 4, 4096, 16
-                st = SetTransformerDIB(particle_feature_dimensions=nfeat)
-                rng = np.random.default_rng(5)
-                xs = torch.from_numpy(rng.standard_normal((nb, npart, nfeat)).astype(np.float32)).to(dev)
-                ys = torch.from_numpy((rng.random((nb, 1)) > 0.5).astype(np.float32)).to(dev)
-                st.beta_dev.fill_(1e-3)
-                for _ in range(2):
-                    st.train_step(xs, ys)
-                torch.cuda.synchronize()
-                t5 = time.perf_counter()
-                for _ in range(4):
-                    st.train_step(xs, ys)
-                torch.cuda.synchronize()
-                dt5 = (time.perf_counter() - t5) / 4
-                D, H, K = 32, 12, 128
-                per_blk = 3 * 2 * D * H * K * npart + 4 * H * K * npart * npart + 2 * H * K * D * npart + 2 * (D * 128 + 128 * D) * npart
-                fwd = 2 * (nfeat * 5 * 128 + 128 * 128 + 128 * 64) * npart + 6 * per_blk
-                extra["config5_set_transformer"] = {
-                    "workload": f"BASELINE config 5: per-particle set-transformer DIB, {nb} neighbourhoods x {npart} particles x "
-                                f"{nfeat} features (3-D positions), 6 x [MHA 12 x 128, Add+LN, FF, Add+LN], fp32",
-                    "value": round(nb / dt5, 2), "unit": "neighbourhoods/s", "ms_per_step": round(1e3 * dt5, 2),
-                    "algorithmic_TFLOPs": round(3 * fwd * nb / dt5 / 1e12, 2), "attention": st.attention_impl,
-                    "params": st.n_params}
-                del st, xs, ys
+                extra["config5_set_transformer"] = config5_set_transformer(dev)
             except Exception as e:  # noqa: BLE001 - the extra line must never take the headline down
                 extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_extra:

@@ -14,7 +14,10 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "libdib_hip.so")   # (tools/ab_bench.sh swaps experiment builds in under this name)
+LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
+# Kernel A/B experiments (tools/ab_bench.sh) point DIB_LIB_PATH at a variant build (exp/lib_TAG.so); the product artefact is
+# never overwritten.  A set-but-missing path is an error, not a silent return to the product library.
+LIB_OVERRIDE = os.environ.get("DIB_LIB_PATH") or None
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
 INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
 SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h", "dib_attn.h",
@@ -94,8 +97,7 @@ SIGNATURES = {
     "dib_output_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     "dib_integration_bwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
-                                     c_uint64, c_uint32, c_void_p, c_void_p]),
+    "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dib_grads_finalize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dib_grads_finalize_part": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dib_layout_part_range": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
@@ -148,8 +150,8 @@ SIGNATURES_ST = {
     "dib_token_kl_workspace_bytes": (c_int64, [c_int64, c_int]),
     "dib_token_reparam_kl_fwd": (c_int, [c_void_p, c_int64, c_int, c_float, c_uint64, c_uint32, c_int64, c_int, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
-    "dib_token_reparam_kl_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_float, c_uint64, c_uint32,
-                                         c_int64, c_void_p, c_void_p]),
+    "dib_token_reparam_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_float, c_void_p,
+                                         c_void_p]),
     "dib_mi_probe_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dib_mi_probe_bounds": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_uint64, c_uint32, c_uint32, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -164,6 +166,10 @@ def load_library(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    if LIB_OVERRIDE is not None:
+        if not os.path.exists(LIB_OVERRIDE):
+            raise RuntimeError(f"DIB_LIB_PATH={LIB_OVERRIDE} does not exist")
+        return _attach(ctypes.CDLL(os.path.abspath(LIB_OVERRIDE)))
     if build_if_missing and _stale():
         try:
             build_library()
@@ -172,7 +178,11 @@ def load_library(build_if_missing: bool = True):
                 raise
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    lib = ctypes.CDLL(LIB_PATH)
+    return _attach(ctypes.CDLL(LIB_PATH))
+
+
+def _attach(lib):
+    global _lib
     for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_ST.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

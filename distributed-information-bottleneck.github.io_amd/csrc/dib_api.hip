@@ -69,7 +69,7 @@ struct dib_layout {
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
-    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, skinny_partial, bf16_planes, total;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, h1mask, skinny_partial, bf16_planes, total;
     int skinny_chunks, skinny_rows;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
@@ -92,8 +92,7 @@ struct dib_layout {
     const int E4 = (E + 3) / 4;
     const int rpb = std::max(1, 256 / E4);
     m.kl_blocks = cdiv(B, rpb);
-    m.kl_partial = take((int64_t)std::max(std::max(m.kl_blocks, 8 * 256), 8 * cdiv(B, 256)) * F);  // fused fwd: one row per 32-row
-                                                                                                      // sub-tile (dynamic tickets) or per wave
+    m.kl_partial = take((int64_t)std::max(m.kl_blocks, 8 * 256) * F);  // fused fwd: one row per wave of the persistent grid
     m.loss_blocks = cdiv(B, 256);
     m.loss_partial = take((int64_t)std::max(m.loss_blocks, 512) * 2);  // also the fused output head's per-workgroup partials (<= 512)
     // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= DIB_SPLIT_ROWS rows per split
@@ -105,14 +104,16 @@ struct dib_layout {
     m.wgrad_partial = take(ns > 1 ? (int64_t)ns * align_up(n_params, 4) : 0);
     // fused backward: per-wave partials of d(W1|b1), [<= ceil(256/F) workgroups x 8 waves][F][16][H1]
     m.dw1_partial = take(fused_id >= 0 && n_enc == 2 ? (int64_t)cdiv(256, F) * 8 * F * 16 * enc_units[0] : 0);
+    // [F][B][2] x 64-bit act' masks (fused fwd -> fused bwd), one bit per hidden unit
     m.h2mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
+    m.h1mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
     // skinny output layer wgrad: row chunks of >= 64 rows, <= 512 chunks
     m.skinny_rows = std::max(64, cdiv(B, 512));
     m.skinny_chunks = cdiv(B, m.skinny_rows);
     {
       const int win = n_int == 0 ? F * E : int_units[n_int - 1];
       m.skinny_partial = take(out_dim <= 8 ? (int64_t)m.skinny_chunks * ((int64_t)win * out_dim + out_dim) : 0);
-    }  // [F][B][2] x 64-bit act'(h2) masks (fused fwd -> fused bwd)
+    }
     {  // DIB_GEMM_MODE=bf16x6: three bf16 planes [N][Kp] of the largest integration hidden-layer kernel
       int64_t need = 0;
       if (bf16x6)
@@ -131,9 +132,9 @@ namespace {
 
 // ---- optional live kernel timing (bench.py roofline): HIP events around every launch, on the launch stream ----
 // categories = kernel symbols: 0..11 dib_gemm_kernel<MODE,NI,NJ> at MODE*4 + (NI-1)*2 + (NJ-1); 12 fused encoder fwd;
-// 13 fused encoder bwd; 14 every other (HBM-bound) kernel
-constexpr int kProfCats = 15;
-constexpr int kProfFusedFwd = 12, kProfFusedBwd = 13, kProfOther = 14;
+// 13 fused encoder bwd; 14 every other (HBM-bound) kernel; 15 dib_attn_fwd_kernel; 16 dib_attn_bwd_kernel
+constexpr int kProfCats = 17;
+constexpr int kProfFusedFwd = 12, kProfFusedBwd = 13, kProfOther = 14, kProfAttnFwd = 15, kProfAttnBwd = 16;
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;                     // recycled events
@@ -183,6 +184,8 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
                   const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit,
                   int rows_per_split, long long split_stride, hipStream_t st) {
   const int tm = cdiv(M, 64 * NI), tn = cdiv(N, 64 * NJ);
+  // grid.y / grid.z are limited to 65535: a clean return code instead of a launch error
+  if (c.count > 65535 || (MODE == 2 && (long long)tm * tn > 65535)) return DIB_E_UNSUPPORTED;
   dim3 grid;
   if (MODE == 2) grid = dim3(nsplit, tm * tn, c.count);
   else grid = dim3(8 * cdiv(tm, 8) * tn, 1, c.count);  // XCD-aware 1-D tile order, see dib_gemm.h
@@ -296,6 +299,8 @@ static int launch_fused_fwd(const DibFusedFwdArgs& a, int gx, int F, hipStream_t
 // 6 x 50 = 300 workgroups on 256 CUs: a second, 17 %-full wave of workgroups doubled the kernel time.)
 static int fused_gx(const dib_layout* l, int batch) { return std::max(1, std::min(cdiv(batch, 256), std::max(1, 256 / l->F))); }
 
+static bool fused_bwd_ok(const dib_layout* l);
+
 static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w, const float* x, int64_t ldx,
                              const int32_t* row_idx, int64_t row0, int batch, const float* params, uint64_t seed,
                              uint32_t step, int deterministic, hipStream_t st, int* gx_out) {
@@ -307,7 +312,8 @@ static int fused_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.kl_partial = w + m.kl_partial; a.F = l->F; a.seed = seed; a.step = step;
   a.deterministic = deterministic & DIB_FWD_DETERMINISTIC;
   a.h2mask = (unsigned long long*)(w + m.h2mask);
-  if (deterministic & DIB_FWD_INFERENCE) { a.h1 = nullptr; a.h2 = nullptr; a.h2mask = nullptr; }  // no backward follows
+  a.h1mask = fused_bwd_ok(l) ? (unsigned long long*)(w + m.h1mask) : nullptr;
+  if (deterministic & DIB_FWD_INFERENCE) { a.h1 = nullptr; a.h2 = nullptr; a.h2mask = nullptr; a.h1mask = nullptr; }  // no backward follows
   a.step_dev = l->step_dev;
   const int gx = fused_gx(l, batch);
   *gx_out = gx;
@@ -349,14 +355,14 @@ static bool fused_bwd_ok(const dib_layout* l) {
 
 
 static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params,
-                             const float* beta_dev, float inv_bg, const int32_t* row_idx, int64_t row0, uint64_t seed,
-                             uint32_t step, hipStream_t st) {
+                             const float* beta_dev, float inv_bg, hipStream_t st) {
   DibFusedBwdArgs a;
-  a.P = w + m.P; a.row_idx = (const int*)row_idx; a.row0 = row0; a.batch = batch; a.params = params;
+  a.P = w + m.P; a.batch = batch; a.params = params;
   a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap; a.act = l->act;
-  a.h2mask = (const unsigned long long*)(w + m.h2mask); a.enc_out = w + m.enc_out; a.GU = w + m.g_u;
+  a.h2mask = (const unsigned long long*)(w + m.h2mask); a.h1mask = (const unsigned long long*)(w + m.h1mask);
+  a.enc_out = w + m.enc_out; a.U = w + m.U; a.GU = w + m.g_u;
   a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dw1_partial = w + m.dw1_partial;
-  a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F; a.seed = seed; a.step = step; a.step_dev = l->step_dev;
+  a.beta_dev = beta_dev; a.inv_bg = inv_bg; a.F = l->F;
   const int gx = fused_gx(l, batch);
   ProfScope ps(kProfFusedBwd, st);
   switch (l->fused_id) {
@@ -680,14 +686,8 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
     rc = fused_encoder_fwd(l, m, w, x, ldx, row_idx, row0, batch, params, seed, step, deterministic, st, &gx);
     if (rc) return rc;
     { ProfScope ps(kProfOther, (hipStream_t)stream);
-#if DIB_FUSED_DYNAMIC
-    (void)gx;
-    hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, 8 * cdiv(batch, 256), l->F,
-                       w + m.step_out); }
-#else
     hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, gx * 8, l->F,
                        w + m.step_out); }
-#endif
     return (int)hipGetLastError();
   }
   rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
@@ -868,8 +868,7 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
 }
 
 int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
-                         float inv_global_batch, const int32_t* row_idx, int64_t row0, uint64_t seed, uint32_t step,
-                         void* ws, dib_stream_t stream) {
+                         float inv_global_batch, void* ws, dib_stream_t stream) {
   if (!l || !params || !grads || !beta_dev || !ws || batch <= 0) return DIB_E_ARG;
   if (!l->dev_groups) return DIB_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -880,12 +879,11 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   int rc = DIB_OK;
   const bool fused = fused_bwd_ok(l);
   if (fused) {  // reparam/KL backward + both dgrads in one launch (dib_fused.h); wgrads below read its outputs
-    rc = fused_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, row_idx, row0, seed, step, st);
+    rc = fused_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, st);
   } else {
     { ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
-                       w + m.dout, beta_dev, inv_global_batch, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
-                       (unsigned long long)seed, (unsigned)step, l->step_dev); }
+                       w + m.U, w + m.dout, beta_dev, inv_global_batch, batch, l->F, l->E); }
     rc = (int)hipGetLastError();
   }
   if (rc) return rc;
@@ -1279,6 +1277,7 @@ int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) != 0) return DIB_E_ARG;
   DibAttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.P = P; a.H = H; a.ld = ld; a.scale = scale;
+  ProfScope ps(kProfAttnFwd, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -1296,6 +1295,9 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
       ld < (int64_t)H * key_dim || (ld & 3))
     return DIB_E_ARG;
   if (key_dim != kAttnD || (int64_t)P * ld >= (1ll << 30)) return DIB_E_UNSUPPORTED;   // 32-bit row offsets inside one neighbourhood
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv |
+        (uintptr_t)ws) & 15) != 0)
+    return DIB_E_ARG;   // every one of them is accessed with 16-byte loads / stores
   hipStream_t st = (hipStream_t)stream;
   float* delta = (float*)ws;
   float* part = delta + (((int64_t)B * H * P + 63) / 64) * 64;
@@ -1311,7 +1313,8 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
     hipError_t e = hipFuncSetAttribute((const void*)dib_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(dib_attn_bwd_kernel, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb);
+  { ProfScope ps(kProfAttnBwd, st);
+    hipLaunchKernelGGL(dib_attn_bwd_kernel, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   if (nkb > 1) {
@@ -1327,23 +1330,6 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
 extern "C" int dib_fused_debug_read(long long* out16) {
   if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
   return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dib_fused_dbg), 16 * sizeof(long long));
-}
-extern "C" int dib_fused_debug_reset() {
-  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
-  long long z[4] = {0, 0, 0, 0};
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(dib_tl), z, sizeof(z));
-}
-extern "C" int dib_fused_debug_read_tl(long long* out4) {
-  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
-  return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(dib_tl), 4 * sizeof(long long));
-}
-extern "C" int dib_fused_debug_read_waves(long long* out8192) {
-  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
-  return (int)hipMemcpyFromSymbol(out8192, HIP_SYMBOL(dib_fused_wave_end), 8 * 1024 * sizeof(long long));
-}
-extern "C" int dib_fused_debug_read_wg(long long* out3072) {
-  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
-  return (int)hipMemcpyFromSymbol(out3072, HIP_SYMBOL(dib_fused_wg), 3 * 1024 * sizeof(long long));
 }
 #endif
 
@@ -1362,7 +1348,7 @@ int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* 
 }
 
 int64_t dib_token_kl_workspace_bytes(int64_t T, int E) {
-  if (T <= 0 || E <= 0 || (E + 3) / 4 > 256) return DIB_E_ARG;
+  if (T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256) return DIB_E_ARG;   // same limit as the fwd / bwd entries
   return (int64_t)cdiv(T, std::max(1, 256 / ((E + 3) / 4))) * (int64_t)sizeof(float);
 }
 
@@ -1380,15 +1366,13 @@ int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logva
   return (int)hipGetLastError();
 }
 
-int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, int64_t T, int E, float logvar_offset,
-                             const float* beta_dev, float inv_batch, uint64_t seed, uint32_t step, int64_t row0,
-                             float* d_enc_out, dib_stream_t stream) {
-  if (!enc_out || !g_u || !beta_dev || !d_enc_out || T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256)
+int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, const float* u, int64_t T, int E, float logvar_offset,
+                             const float* beta_dev, float inv_batch, float* d_enc_out, dib_stream_t stream) {
+  if (!enc_out || !g_u || !u || !beta_dev || !d_enc_out || T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256)
     return DIB_E_ARG;
   const int blocks = cdiv(T, std::max(1, 256 / ((E + 3) / 4)));
-  hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, enc_out, g_u, d_enc_out,
-                     beta_dev, inv_batch, (const int*)nullptr, (long long)row0, (int)T, 1, E, (unsigned long long)seed,
-                     (unsigned)step, (const unsigned*)nullptr, logvar_offset);
+  hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, enc_out, g_u, u, d_enc_out,
+                     beta_dev, inv_batch, (int)T, 1, E, logvar_offset);
   return (int)hipGetLastError();
 }
 

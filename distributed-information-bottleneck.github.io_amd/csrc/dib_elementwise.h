@@ -11,13 +11,6 @@
 // P is feature-major and ragged: P_f = P + poff*batch is a dense [batch, n_blocks*d_f] matrix and
 // P_f[b, j*d_f + c_local] = (j==0 ? x : sin(2^j * x)),  x = X[row(b), c]
 // ---------------------------------------------------------------------------------------------
-#ifdef DIB_FUSED_TIMING
-// timeline marks (s_memrealtime, 100 MHz) of the diagnostic build: [0] last posenc workgroup mark, [1] -(first fused-forward
-// entry), [2] last fused-forward workgroup done, [3] -(first entry of the kernel after it); reset by dib_fused_debug_reset
-__device__ long long dib_tl[4];
-#define DIB_TL_MAX(i, v) atomicMax((unsigned long long*)&dib_tl[i], (unsigned long long)(v))
-#define DIB_TL_MIN(i, v) atomicMax((unsigned long long*)&dib_tl[i], (unsigned long long)(0x7fffffffffffffffll - (v)))
-#endif
 template <int ROWS>   // batch rows per workgroup tile: 64, or 16 for mid-size batches (more workgroups: at B = 8192 the 64-row
                       // tiling is 128 workgroups of sinf-bound work on 256 CUs)
 __global__ void __launch_bounds__(256)
@@ -42,9 +35,6 @@ dib_posenc_kernel(const float* __restrict__ X, long long ldx, const int* __restr
   __syncthreads();
   const int r = threadIdx.x & (ROWS - 1), b = b0 + r;
   if (b >= batch) return;
-#ifdef DIB_FUSED_TIMING
-  if (threadIdx.x == 0) DIB_TL_MAX(0, wall_clock64());
-#endif
   for (int c = threadIdx.x / ROWS; c < 64 && c0 + c < ncols; c += 256 / ROWS) {
     const int4 cm = colmap[c0 + c];
     const float x = T[r][c];
@@ -115,9 +105,6 @@ __global__ void __launch_bounds__(256)
 dib_colsum_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, float* __restrict__ out) {
   __shared__ float red[4];
   const int f = blockIdx.x;
-#ifdef DIB_FUSED_TIMING
-  if (threadIdx.x == 0) DIB_TL_MIN(3, wall_clock64());
-#endif
   float s = 0.f;
   for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[(long long)i * stride + f];
   const float tot = dib_block_sum_256(s, red);
@@ -125,14 +112,15 @@ dib_colsum_partials_kernel(const float* __restrict__ partial, int nblocks, int s
 }
 
 // Backward of reparam + KL (what tape.gradient derives from models.py:108,111-112,118):
-//   dmu = g_u + beta*mu/Bg ;  dlogvar = g_u*eps*0.5*exp(lv/2) + beta*0.5*(exp(lv)-1)/Bg
-// eps is regenerated from the counter (never stored).
+//   dmu = g_u + beta*mu/Bg ;  dlogvar = g_u*(eps*sigma)*0.5 + beta*0.5*(exp(lv)-1)/Bg
+// The noise term is recovered from the forward's own sample:  eps*sigma = u - mu  (u = fl(mu + fl(sigma*eps)), so the
+// difference carries at most one ulp of u; it is multiplied by 0.5*g_u).  Nothing is regenerated, and the gradient is by
+// construction the gradient of the forward that actually ran - library noise, caller-injected samples or the
+// deterministic forward (u = mu: the noise term vanishes).  U is sample-major [B][F*E] like GU.
 __global__ void __launch_bounds__(256)
-dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __restrict__ GU,
-                          float* __restrict__ dout, const float* __restrict__ beta_dev, float inv_bg,
-                          const int* __restrict__ row_idx, long long row0, int batch, int F, int E,
-                          unsigned long long seed, unsigned step, const unsigned* step_dev, float lv_off = 0.f) {
-  if (step_dev) step = step_dev[0];
+dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __restrict__ GU, const float* __restrict__ U,
+                          float* __restrict__ dout, const float* __restrict__ beta_dev, float inv_bg, int batch, int F, int E,
+                          float lv_off = 0.f) {
   const int E4 = (E + 3) >> 2;
   const int rows_per_block = 256 / E4;
   const int f = blockIdx.y;
@@ -140,22 +128,22 @@ dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __rest
   const int b = blockIdx.x * rows_per_block + r;
   if (r >= rows_per_block || b >= batch) return;
   const float kb = beta_dev[0] * inv_bg;
-  const long long grow = row_idx ? (long long)row_idx[b] : row0 + b;
   const long long o = ((long long)f * batch + b) * (2ll * E) + 4 * q;  // enc_out / dout are [F][B][2E]
-  const float* gu_p = GU + (long long)b * ((long long)F * E) + (long long)f * E + 4 * q;
-  float eps[4];
-  dib_eps4(seed, step, (uint32_t)grow, (uint32_t)f, (uint32_t)q, eps);
+  const long long so = (long long)b * ((long long)F * E) + (long long)f * E + 4 * q;
+  const float* gu_p = GU + so;
+  const float* u_p = U + so;
   if ((E & 3) == 0) {
     const float4 mu = *reinterpret_cast<const float4*>(enc_out + o);
     float4 lv = *reinterpret_cast<const float4*>(enc_out + o + E);
     lv.x += lv_off; lv.y += lv_off; lv.z += lv_off; lv.w += lv_off;
     const float4 gu = *reinterpret_cast<const float4*>(gu_p);
+    const float4 u = *reinterpret_cast<const float4*>(u_p);
     float4 dm, dl;
     dm.x = gu.x + kb * mu.x; dm.y = gu.y + kb * mu.y; dm.z = gu.z + kb * mu.z; dm.w = gu.w + kb * mu.w;
-    dl.x = gu.x * eps[0] * 0.5f * expf(0.5f * lv.x) + kb * 0.5f * (expf(lv.x) - 1.f);
-    dl.y = gu.y * eps[1] * 0.5f * expf(0.5f * lv.y) + kb * 0.5f * (expf(lv.y) - 1.f);
-    dl.z = gu.z * eps[2] * 0.5f * expf(0.5f * lv.z) + kb * 0.5f * (expf(lv.z) - 1.f);
-    dl.w = gu.w * eps[3] * 0.5f * expf(0.5f * lv.w) + kb * 0.5f * (expf(lv.w) - 1.f);
+    dl.x = gu.x * (u.x - mu.x) * 0.5f + kb * 0.5f * (expf(lv.x) - 1.f);
+    dl.y = gu.y * (u.y - mu.y) * 0.5f + kb * 0.5f * (expf(lv.y) - 1.f);
+    dl.z = gu.z * (u.z - mu.z) * 0.5f + kb * 0.5f * (expf(lv.z) - 1.f);
+    dl.w = gu.w * (u.w - mu.w) * 0.5f + kb * 0.5f * (expf(lv.w) - 1.f);
     *reinterpret_cast<float4*>(dout + o) = dm;
     *reinterpret_cast<float4*>(dout + o + E) = dl;
   } else {
@@ -163,7 +151,7 @@ dib_reparam_kl_bwd_kernel(const float* __restrict__ enc_out, const float* __rest
       if (4 * q + j < E) {
         const float mu = enc_out[o + j], lv = enc_out[o + E + j] + lv_off, gu = gu_p[j];
         dout[o + j] = gu + kb * mu;
-        dout[o + E + j] = gu * eps[j] * 0.5f * expf(0.5f * lv) + kb * 0.5f * (expf(lv) - 1.f);
+        dout[o + E + j] = gu * (u_p[j] - mu) * 0.5f + kb * 0.5f * (expf(lv) - 1.f);
       }
     }
   }

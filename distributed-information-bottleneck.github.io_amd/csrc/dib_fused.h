@@ -35,6 +35,7 @@ struct DibFusedFwdArgs {
   int act;
   float* h1; float* h2; float* enc_out; float* U; float* kl_partial;  // kl_partial[gridDim.x*8][F]
   unsigned long long* h2mask;  // [F][B][2] sign bits of h2 in fragment order (bit 16*tile + reg), for the fused backward
+  unsigned long long* h1mask;  // same for h1 (NULL: no fused backward follows)
   int F; unsigned long long seed; unsigned step; int deterministic;
   const unsigned* step_dev;  // if non-NULL the noise step is read from device memory (hipGraph replay)
 };
@@ -48,7 +49,7 @@ struct DibFusedCfg {
   static constexpr int W1_FLOATS = H1 * K1P, W2_FLOATS = H2 * P2, W3_FLOATS = N3 * P3;
   static constexpr int B_FLOATS = H1 + H2 + N3;
   static constexpr int PATCH = 32 * 36;               // per-wave 32x32 transpose patch (pitch 36)
-  static constexpr int LDS_FLOATS = W1_FLOATS + W2_FLOATS + W3_FLOATS + B_FLOATS + 8 * PATCH + 4;   // + the sub-tile ticket counter
+  static constexpr int LDS_FLOATS = W1_FLOATS + W2_FLOATS + W3_FLOATS + B_FLOATS + 8 * PATCH;
   static constexpr int T1 = H1 / 32, T2 = H2 / 32, T3 = N3 / 32;
 };
 
@@ -90,21 +91,11 @@ __device__ __forceinline__ int dib_patch_row(int lane, int pss) {
 __device__ __forceinline__ int dib_store_idx(int lane) {  // index 0..15 of the lane inside its ds_read_b128 service group
   return 4 * (((lane & 31) >> 2) >> 1) + (lane & 3);
 }
-__device__ __forceinline__ int dib_store_col(int lane) {
-#ifdef DIB_OLD_STORE_MAP
-  return (lane & 7) * 4;
-#else
-  return (dib_store_idx(lane) & 7) * 4;
-#endif
-}
+__device__ __forceinline__ int dib_store_col(int lane) { return (dib_store_idx(lane) & 7) * 4; }
 __device__ __forceinline__ int dib_store_row(int lane, int pss) {
-#ifdef DIB_OLD_STORE_MAP
-  return dib_patch_row(lane, pss);
-#else
   const int q = (lane & 31) >> 2;
   const int G = 2 * (lane >> 5) + ((0x96 >> q) & 1);
   return G + 4 * (pss & 1) + 16 * (pss >> 1) + 8 * (dib_store_idx(lane) >> 3);
-#endif
 }
 
 // Write one 32(samples) x 32(units) tile held as a transposed-product C fragment to row-major global memory
@@ -162,51 +153,48 @@ __device__ __forceinline__ void dib_stage_batched(int tid, LoadF load, StoreF st
   }
 }
 
-#ifndef DIB_FUSED_PAIR
-#define DIB_FUSED_PAIR 1
-#endif
-// The two waves that share a SIMD (waves w and w + 4 of the 512-thread workgroup) share its matrix pipe, and the hardware
-// arbitrates by priority, then AGE: with equal priorities waves 0-3 got every slot they asked for and waves 4-7 the
-// leftovers - measured (tools/fused_phase_timing.py): waves 0-3 finished their 64 tiles after 1.60 ms, waves 4-7 after 1.98 ms,
-// i.e. the last fifth of the kernel ran with ONE wave per SIMD.  No barrier in the tile loop keeps them together, so the
-// favoured role alternates instead: on even tile iterations waves 0-3 run at priority 1, on odd ones waves 4-7.
-#ifndef DIB_FUSED_PRIO
-#define DIB_FUSED_PRIO 0
-#endif
-#ifndef DIB_FUSED_PINGPONG
-#define DIB_FUSED_PINGPONG 0   // experiment (round 2): measured slower - the 'other' segment (8 back-to-back stash tiles) outlasts the
-#endif                        // matrix segment (35 k vs 29 k cycles per tile), 2.00 vs 1.94 ms
-// DYNAMIC sub-tile tickets (forward): the 32-row sub-tiles of the workgroup's 256-row tiles are handed out through an LDS
-// counter instead of 'wave w takes rows 32w..32w+31 of every tile'.  With the static map the four waves that the SIMD
-// arbiter favours (oldest first) finished their 64 sub-tiles after 1.53-1.60 ms, the other four after 1.90-1.98 ms
-// (tools/fused_phase_timing.py); with tickets the favoured waves simply take more sub-tiles and all eight finish within one
-// sub-tile of each other.  Results do not depend on who computed what: every output is per row, and the KL partial sums are
-// written PER SUB-TILE and added up in a fixed order by dib_colsum_partials_kernel.
-#ifndef DIB_FUSED_DYNAMIC
-#define DIB_FUSED_DYNAMIC 0   // measured (round 2): all eight waves then finish together (1.85 ms) but the kernel gains only 1 % (1.90 ->
-#endif                       // 1.89 ms; B = 8192: 0.265 -> 0.267 ms): the SIMD's aggregate tile rate is the limit, not the tail
-#if DIB_FUSED_PRIO == 1
-// (the condition must be PROVABLY wave-uniform - readfirstlane - or the compiler predicates both s_setprio with exec masks
-// and executes them unconditionally one after the other)
-#define DIB_FUSED_SET_PRIO(it) do { if (__builtin_amdgcn_readfirstlane(((it) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
-#elif DIB_FUSED_PRIO == 2   // experiment: the younger waves always favoured
-#define DIB_FUSED_SET_PRIO(it) do { if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
-#elif DIB_FUSED_PRIO == 3   // experiment: alternate every 4 tiles
-#define DIB_FUSED_SET_PRIO(it) do { if (__builtin_amdgcn_readfirstlane((((it) >> 2) ^ (wave >> 2)) & 1) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } while (0)
-#else
-#define DIB_FUSED_SET_PRIO(it) do { } while (0)
-#endif
 // Phase timing of the fused forward (diagnostic build -DDIB_FUSED_TIMING; tools/fused_phase_timing.py): wave 0 of workgroup
-// (0, 0) accumulates s_memtime deltas per phase of the tile loop into dib_fused_dbg.
+// (0, 0) accumulates s_memtime deltas per phase of the tile loop into dib_fused_dbg.  (The per-workgroup / per-wave timeline
+// marks of round 2 - profiles/r02w_*, r02ag_* - are in the git history.)
 #ifdef DIB_FUSED_TIMING
 __device__ long long dib_fused_dbg[16];
-__device__ long long dib_fused_wave_end[8 * 1024];   // per (workgroup, wave): s_memrealtime at loop end
-__device__ long long dib_fused_wg[3 * 1024];   // per workgroup: s_memrealtime at kernel entry, after weight staging, at loop end
 #define DIB_FT(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = clock64(); tacc_[i] += now_ - tprev_; tprev_ = now_; \
                        __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define DIB_FT(i) do { } while (0)
 #endif
+
+// act'(tile) as one bit per unit, fragment order (bit 16*tile + reg), for T tiles of a lane (T <= 4: one 64-bit word).
+// v > 0  <=>  its bit pattern is a positive integer (+0 -> 0, negatives and -0 -> negative): v_med3_i32 clamps it to {0,1} and
+// v_lshl_or_b32 shifts it in - 2 VALU ops per unit, no compare / SGPR round trip.  (Inline asm: the compiler otherwise
+// canonicalises the clamp back into v_cmp + v_cndmask + v_or3 with one live constant register per bit, which cost 22
+// spilled VGPRs and 0.1 ms.)
+template <int T>
+__device__ __forceinline__ unsigned long long dib_sign_bits(const dib_f32x16 (&t)[T]) {
+  static_assert(T <= 4, "one 64-bit mask word per lane");
+  unsigned int word[2] = {0u, 0u};
+#pragma unroll
+  for (int w = 0; w < (T + 1) / 2; ++w)
+#pragma unroll
+    for (int idx = (16 * T - 32 * w - 1 < 31 ? 16 * T - 32 * w - 1 : 31); idx >= 0; --idx) {  // high bit first: word = (word << 1) | on
+      const int e = 32 * w + idx;
+      int on;
+      asm("v_med3_i32 %0, %1, 0, 1" : "=v"(on) : "v"(t[e >> 4][e & 15]));
+      asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(word[w]) : "v"(word[w]), "v"(on));
+    }
+  return ((unsigned long long)word[1] << 32) | word[0];
+}
+// apply the stashed act' bits of tile jo to a gradient tile: keep = 0 or -1 via v_bfe_i32, then v_and (relu) / a select
+template <bool RELU>
+__device__ __forceinline__ void dib_mask_tile(dib_f32x16& acc, unsigned long long bits, int jo, float slope) {
+  const unsigned int word = (unsigned int)(bits >> (32 * ((16 * jo) >> 5)));
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int keep = __builtin_amdgcn_sbfe(word, (16 * jo + r) & 31, 1);
+    acc[r] = RELU ? __int_as_float(__float_as_int(acc[r]) & keep) : acc[r] * (keep ? 1.f : slope);
+  }
+}
+
 template <int H1, int H2, int E, bool RELU>
 __global__ void __launch_bounds__(512)
 dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
@@ -217,16 +205,10 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
   float* Wt3 = Wt2 + C::W2_FLOATS;        // [N3][H2+4]  rows >= 2E are zero
   float* Bs = Wt3 + C::W3_FLOATS;         // b1 | b2 | b3(padded)
   float* patch = Bs + C::B_FLOATS + (threadIdx.x >> 6) * C::PATCH;  // wave-private transpose patch
-  unsigned* ticket = reinterpret_cast<unsigned*>(Bs + C::B_FLOATS + 8 * C::PATCH);
-  if (threadIdx.x == 0) *ticket = 0u;   // visible after the barrier that ends the weight staging
 
   const int f = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, h = lane >> 5;
-#ifdef DIB_FUSED_TIMING
-  const long long wentry_ = wall_clock64();
-  if (tid == 0) DIB_TL_MIN(1, wentry_);
-#endif
   const int4 fm = a.featmap[f];
   const int in_dim = fm.y;
   const int F = a.F;
@@ -237,6 +219,9 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     const float* W1 = a.params + a.w_off[0 * F + f];
     const float* W2 = a.params + a.w_off[1 * F + f];
     const float* W3 = a.params + a.w_off[2 * F + f];
+    const float* b1 = a.params + a.b_off[0 * F + f];
+    const float* b2 = a.params + a.b_off[1 * F + f];
+    const float* b3 = a.params + a.b_off[2 * F + f];
     // Global loads are issued in batches of 8 before their LDS stores so that 8 L2 round trips overlap (the naive
     // load -> wait -> store loop serialised ~56 of them per thread: ~20-30 us of fixed cost per launch, 10 % of the kernel
     // at an 8192-row batch).
@@ -247,9 +232,6 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     dib_stage_batched<H2 * C::N3>(tid, [&](int i) { const int k = i / C::N3, n = i - k * C::N3;
                                                     return (n < C::E2) ? W3[(long long)k * C::E2 + n] : 0.f; },
                                   [&](int i, float v) { const int k = i / C::N3, n = i - k * C::N3; Wt3[n * C::P3 + k] = v; });
-    const float* b1 = a.params + a.b_off[0 * F + f];
-    const float* b2 = a.params + a.b_off[1 * F + f];
-    const float* b3 = a.params + a.b_off[2 * F + f];
     for (int i = tid; i < H1; i += 512) Bs[i] = b1[i];
     for (int i = tid; i < H2; i += 512) Bs[H1 + i] = b2[i];
     for (int i = tid; i < C::N3; i += 512) Bs[H1 + H2 + i] = (i < C::E2) ? b3[i] : 0.f;
@@ -265,8 +247,8 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
   // lane (m,h) supplies p[k] for k = (r&3) + 8*(r>>2) + 4*h as the layer-1 B operand (reference models.py:22-23
   // values, produced by dib_posenc_kernel).  Loads are branch-free (clamped row / column, masked value) and the next
   // tile's values are fetched while the current tile computes.
-  auto load_p = [&](int tile, int slice, float (&dstp)[8]) {
-    const int bb = min(tile * 256 + slice * 32 + m, a.batch - 1);
+  auto load_p = [&](int tile, float (&dstp)[8]) {
+    const int bb = min(tile * 256 + wave * 32 + m, a.batch - 1);
     const float* src = Pf + (long long)bb * in_dim;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -276,60 +258,28 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     }
   };
   float p[8], pn[8];
-#if DIB_FUSED_DYNAMIC
-  const int n_sub = ((n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) * 8;   // this workgroup's sub-tiles
-  auto take_ticket = [&]() -> int {
-    unsigned t = 0u;
-    if (lane == 0) t = atomicAdd(ticket, 1u);            // ds_add_rtn_u32
-    return __builtin_amdgcn_readfirstlane((int)t);
-  };
-  int sub = take_ticket();
-  if (sub < n_sub) load_p((int)blockIdx.x + (sub >> 3) * (int)gridDim.x, sub & 7, p);
-#else
-  if ((int)blockIdx.x < n_tiles) load_p(blockIdx.x, wave, p);
-#endif
+  if ((int)blockIdx.x < n_tiles) load_p(blockIdx.x, p);
 
 #ifdef DIB_FUSED_TIMING
-  long long tacc_[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tacc_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev_ = clock64();
   const long long tstart_ = tprev_;
   const long long wstart_ = wall_clock64();   // constant 100 MHz
   int ntl_ = 0;
 #endif
-#if DIB_FUSED_DYNAMIC
-  while (sub < n_sub) {
-    const int tile = (int)blockIdx.x + (sub >> 3) * (int)gridDim.x, slice = sub & 7;
-    const int sub_next = take_ticket();
-#else
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int slice = wave;
-#endif
-    DIB_FUSED_SET_PRIO(tile / (int)gridDim.x);
 #ifdef DIB_FUSED_TIMING
     ++ntl_;
 #endif
-    const int b = tile * 256 + slice * 32 + m;   // local batch row of this lane
+    const int wrow0 = tile * 256 + wave * 32;    // first local batch row of this wave
+    const int rows_valid = min(32, a.batch - wrow0);
+    const int b = wrow0 + m;                     // local batch row of this lane
     const bool valid = b < a.batch;
     const long long grow = a.row_idx ? (long long)a.row_idx[valid ? b : 0] : a.row0 + b;  // dataset row id
-#if DIB_FUSED_PINGPONG
-    // PING-PONG: the two waves of a SIMD (w, w + 4) alternate between a MATRIX segment (layers 1-3 back to back, the pipe to
-    // itself) and an OTHER segment (stashes, mask bits, noise, KL, stores, next tile's inputs), two s_barrier per tile;
-    // waves 4-7 run the same loop body rotated by one segment (leading instead of trailing barrier).  Without it the
-    // hardware's oldest-first arbitration let waves 0-3 finish 64 tiles in 1.60 ms while waves 4-7 needed 1.98 ms.
-    // Raw s_barrier: the two groups share no data (transpose patches are wave-private), so no fence / store drain.
-    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_barrier();   // readfirstlane: a provably uniform branch (a
-    // lane-dependent condition is predicated with exec masks, and s_barrier ignores exec: BOTH groups would execute it)
-#else
     {
-#if DIB_FUSED_DYNAMIC
-      const int sp = sub_next < n_sub ? sub_next : sub;   // harmless re-read after the last ticket
-      load_p((int)blockIdx.x + (sp >> 3) * (int)gridDim.x, sp & 7, pn);
-#else
       const int nt = tile + gridDim.x;
-      load_p(nt < n_tiles ? nt : tile, slice, pn);  // prefetch (harmless re-read on the last tile)
-#endif
+      load_p(nt < n_tiles ? nt : tile, pn);  // prefetch (harmless re-read on the last tile)
     }
-#endif
 
     // ---- layer 1: h1^T = act(W1^T p^T + b1) ----
     dib_f32x16 h1[C::T1];
@@ -352,27 +302,22 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       h1[jo] = acc;
     }
     DIB_FT(0);   // prefetch issue + layer 1
-    // stash h1 (feature-major [F][B][H1]) for the backward pass (skipped for inference: DIB_FWD_INFERENCE)
-    auto stash_h1 = [&]() {
+    // stash h1 (feature-major [F][B][H1]) for the layer-2 weight gradient (skipped for inference: DIB_FWD_INFERENCE) and
+    // act'(h1) as bits for the fused backward
     if (a.h1 != nullptr) {
-      const int wrow0 = tile * 256 + slice * 32;
-      const int rows_valid = min(32, a.batch - wrow0);
       float* dst = a.h1 + ((long long)f * a.batch + wrow0) * H1;
 #pragma unroll
       for (int jo = 0; jo < C::T1; ++jo) dib_store_tile(patch, h1[jo], dst + 32 * jo, H1, rows_valid, lane);
     }
-
-    };
-#if !DIB_FUSED_PINGPONG
-    stash_h1();
-#endif
+    if (a.h1mask != nullptr && valid) a.h1mask[((long long)f * a.batch + b) * 2 + h] = dib_sign_bits<C::T1>(h1);
     DIB_FT(1);   // stash h1
     // ---- layer 2: h2^T = act(W2^T h1^T + b2) ----
     dib_f32x16 h2[C::T2];
-    if constexpr (DIB_FUSED_PAIR && C::T2 % 2 == 0) {
+    if constexpr (C::T2 % 2 == 0) {
     // two output tiles at a time, MFMAs alternating between their accumulators (a filler between two MFMAs on the SAME
     // accumulator costs ~43 cycles, between independent ones only its issue slot), weight fragments of step s + 1 issued
-    // before the 8 MFMAs of step s
+    // before the 8 MFMAs of step s (sched_barrier + an empty asm pin: the instruction selector floats pure MFMAs across
+    // sched_barrier)
 #pragma unroll
     for (int jo = 0; jo < C::T2; jo += 2) {
       dib_f32x16 acc0, acc1;
@@ -426,41 +371,18 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     }
     }
     DIB_FT(2);   // layer 2 + activation
-    auto stash_h2_and_mask = [&]() {
     if (a.h2 != nullptr) {
-      const int wrow0 = tile * 256 + slice * 32;
-      const int rows_valid = min(32, a.batch - wrow0);
       float* dst = a.h2 + ((long long)f * a.batch + wrow0) * H2;
 #pragma unroll
       for (int jo = 0; jo < C::T2; ++jo) dib_store_tile(patch, h2[jo], dst + 32 * jo, H2, rows_valid, lane);
     }
-    DIB_FT(11);   // stash h2 (inside the lambda)
-    if (a.h2mask != nullptr && valid) {  // act'(h2) as one bit per unit: the fused backward needs nothing else of h2
-      // h2 > 0  <=>  its bit pattern is a positive integer (+0 -> 0, negatives and -0 -> negative): v_med3_i32 clamps
-      // it to {0,1} and v_lshl_or_b32 shifts it in - 2 VALU ops per unit, no compare / SGPR round trip.  (Inline asm:
-      // the compiler otherwise canonicalises the clamp back into v_cmp + v_cndmask + v_or3 with one live constant
-      // register per bit, which cost 22 spilled VGPRs and 0.1 ms.)
-      unsigned int word[2] = {0u, 0u};
-#pragma unroll
-      for (int w = 0; w < (C::T2 + 1) / 2; ++w)
-#pragma unroll
-        for (int idx = min(31, 16 * C::T2 - 32 * w - 1); idx >= 0; --idx) {  // high bit first: word = (word << 1) | on
-          const int e = 32 * w + idx;
-          int on;
-          asm("v_med3_i32 %0, %1, 0, 1" : "=v"(on) : "v"(h2[e >> 4][e & 15]));
-          asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(word[w]) : "v"(word[w]), "v"(on));
-        }
-      a.h2mask[((long long)f * a.batch + b) * 2 + h] = ((unsigned long long)word[1] << 32) | word[0];
-    }
-
-    };
-#if !DIB_FUSED_PINGPONG
-    stash_h2_and_mask();
-#endif
+    DIB_FT(3);   // stash h2
+    // act'(h2) as one bit per unit: the fused backward needs nothing else of h2
+    if (a.h2mask != nullptr && valid) a.h2mask[((long long)f * a.batch + b) * 2 + h] = dib_sign_bits<C::T2>(h2);
     DIB_FT(4);   // activation mask bits
     // ---- layer 3 (linear, reference models.py:78): out^T = W3^T h2^T + b3 ; rows [0,E) = mu, [E,2E) = logvar ----
     dib_f32x16 o[C::T3];
-    if constexpr (DIB_FUSED_PAIR && C::T3 == 2) {
+    if constexpr (C::T3 == 2) {
       dib_f32x16 acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] = Bs[H1 + H2 + dib_crow(r, h)]; acc1[r] = Bs[H1 + H2 + 32 + dib_crow(r, h)]; }
@@ -507,26 +429,7 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
       o[jo] = acc;
     }
     }
-
     DIB_FT(5);   // layer 3
-#if DIB_FUSED_PINGPONG
-    __builtin_amdgcn_s_barrier();   // end of the matrix segment: the partner wave takes the pipe
-    DIB_FT(9);    // barrier wait
-    {
-#if DIB_FUSED_DYNAMIC
-      const int sp = sub_next < n_sub ? sub_next : sub;
-      load_p((int)blockIdx.x + (sp >> 3) * (int)gridDim.x, sp & 7, pn);
-#else
-      const int nt = tile + gridDim.x;
-      load_p(nt < n_tiles ? nt : tile, slice, pn);  // next tile's inputs (harmless re-read on the last tile)
-#endif
-    }
-    DIB_FT(10);   // next tile's input loads issued
-    stash_h1();
-    DIB_FT(1);
-    stash_h2_and_mask();
-    DIB_FT(3);
-#endif
     // ---- epilogue: stash (mu|logvar), reparameterise (reference models.py:108), KL (models.py:111-112) ----
     // E % 32 == 0: mu tiles [0, E/32), logvar tiles [E/32, 2E/32), same register index.
     // E in {8,16}: one tile; mu in register groups g < E/8, logvar in groups g + E/8 (same lane).
@@ -565,8 +468,6 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     }
     DIB_FT(6);   // eps, sigma, u, KL
     if (E >= 32) {  // full-line stores of (mu|logvar) [F][B][2E] and of u [B][F*E]
-      const int wrow0 = tile * 256 + slice * 32;
-      const int rows_valid = min(32, a.batch - wrow0);
       float* eo_w = a.enc_out + ((long long)f * a.batch + wrow0) * C::E2;
 #pragma unroll
       for (int jo = 0; jo < C::T3; ++jo) dib_store_tile(patch, o[jo], eo_w + 32 * jo, C::E2, rows_valid, lane);
@@ -576,24 +477,10 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
         dib_store_tile(patch, ut[jo], u_w + 32 * jo, (long long)F * E, rows_valid, lane);
     }
     DIB_FT(7);   // stash (mu|logvar), u
-#if DIB_FUSED_DYNAMIC
-    {
-      const float kls = dib_wave_sum(klp);
-      if (lane == 0) a.kl_partial[((long long)tile * 8 + slice) * F + f] = kls;   // one writer per (sub-tile, feature)
-    }
-#else
     kl_acc += dib_wave_sum(klp);
-#endif
 #pragma unroll
     for (int r = 0; r < 8; ++r) p[r] = pn[r];
-#if DIB_FUSED_PINGPONG
-    DIB_FT(12);   // KL wave sum
-    if (__builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_barrier();
-#endif
-    DIB_FT(8);   // trailing barrier wait, loop end
-#if DIB_FUSED_DYNAMIC
-    sub = sub_next;
-#endif
+    DIB_FT(8);   // KL wave sum, loop end
   }
 #ifdef DIB_FUSED_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
@@ -601,65 +488,53 @@ dib_fused_encoder_fwd_kernel(DibFusedFwdArgs a) {
     dib_fused_dbg[9] = clock64() - tstart_;
     dib_fused_dbg[10] = ntl_;
     dib_fused_dbg[11] = wall_clock64() - wstart_;
-    for (int i = 9; i < 13; ++i) dib_fused_dbg[3 + i] = tacc_[i];   // [12..15]: barrier wait, input loads, stash h2, KL sum
-  }
-  if (lane == 0) {
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    if (wg < 1024) dib_fused_wave_end[8 * wg + wave] = wall_clock64();
-  }
-  if (tid == 0) {
-    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    if (wg < 1024) { dib_fused_wg[3 * wg] = wentry_; dib_fused_wg[3 * wg + 1] = wstart_; dib_fused_wg[3 * wg + 2] = wall_clock64(); }
-    DIB_TL_MAX(2, wall_clock64());
   }
 #endif
-#if !DIB_FUSED_DYNAMIC
   if (lane == 0) a.kl_partial[((long long)blockIdx.x * 8 + wave) * F + f] = kl_acc;
-#else
-  (void)kl_acc;
-#endif
 }
 
 // =====================================================================================================
 // BACKWARD "dgrad chain" (what tape.gradient derives for reference models.py:106-118, explicit at
 // train.py:203-219), ONE launch replacing the reparam/KL backward and both encoder dgrad GEMMs:
-//   dmu = g_u + beta*mu/Bg ; dlogvar = g_u*eps*0.5*exp(lv/2) + beta*0.5*(exp(lv)-1)/Bg       -> dout  [F][B][2E]
+//   dmu = g_u + beta*mu/Bg ; dlogvar = g_u*(u - mu)*0.5 + beta*0.5*(exp(lv)-1)/Bg           -> dout  [F][B][2E]
+//        (eps*sigma = u - mu: the forward's own sample is read back, 128 B per (sample, feature), instead of regenerating
+//        Philox + Box-Muller - ~100 VALU instructions per 4 values; it is also the gradient of whatever forward ran)
 //   dh2 = (dout @ W3^T) * act'(h2)   (act'(h2) from the 1-bit/unit mask the forward stashed)  -> dh2   [F][B][H2]
-//   dh1 = (dh2  @ W2^T) * act'(h1)     (h1 is RECOMPUTED from the encoded input: 4..8 MFMAs)   (never leaves the CU)
+//   dh1 = (dh2  @ W2^T) * act'(h1)   (act'(h1) from its bit mask too: round 2 recomputed the h1 tile - 32 MFMAs + W1 / b1
+//                                     fragments per 32 samples; the A/B is profiles/r03a_fused_diet_ab.txt)
+//                                                                                              (never leaves the CU)
 //   d(W1|b1) += [P | 1]^T @ dh1         (v_mfma_f32_16x16x4_f32 on the dh1 tile while it sits in the LDS patch;
 //                                        per-wave partials, reduced in fixed order by dib_dw1_reduce_kernel)
 // Same structure as the forward: one workgroup per feature, W2 / W3 resident in LDS in their natural
 // [in][out] orientation (they are the A operand of the transposed product dH_in^T = W * dH_out^T, fetched with
-// conflict-free ds_read_b128), gradients chained in MFMA accumulator registers, eps regenerated from the
-// Philox counter.  Row-major tiles (mu|logvar, g_u in; dout, dh2 out) cross between HBM and the
-// fragment layout through a wave-private LDS patch so every global access is a full 128-byte line.
-// The layer-2/3 weight gradients (contractions over the batch) then run as the grouped wgrad GEMMs on these buffers;
-// the layer-1 gradient (5 x H1 per feature: hopeless as a GEMM tile, and dh1 is 2.1 GB) is finished here.
+// conflict-free ds_read_b128), gradients chained in MFMA accumulator registers.  Row-major tiles (mu|logvar, u, g_u in;
+// dout, dh2 out) cross between HBM and the fragment layout through a wave-private LDS patch so every global access is a
+// full 128-byte line.  The layer-2/3 weight gradients (contractions over the batch) then run as the grouped wgrad GEMMs on
+// these buffers; the layer-1 gradient (5 x H1 per feature: hopeless as a GEMM tile, and dh1 is 2.1 GB) is finished here.
 // =====================================================================================================
 typedef float dib_f32x4 __attribute__((ext_vector_type(4)));
 #define DIB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 struct DibFusedBwdArgs {
-  const float* P; const int* row_idx; long long row0; int batch;
+  const float* P; int batch;
   const float* params; const long long* w_off; const long long* b_off; const int4* featmap;
   int act;
-  const unsigned long long* h2mask; const float* enc_out; const float* GU;   // stashes + dL/du [B][F*E]
+  const unsigned long long* h1mask; const unsigned long long* h2mask;   // act' bits stashed by the forward
+  const float* enc_out; const float* U; const float* GU;                // (mu|logvar) [F][B][2E]; u, dL/du [B][F*E]
   float* dout; float* dh2;
   float* dw1_partial;       // [gridDim.x*8 waves][F][16][H1]: per-wave partial of d(W1|b1) (row in_dim = bias gradient)
   const float* beta_dev; float inv_bg;
-  int F; unsigned long long seed; unsigned step;
-  const unsigned* step_dev;  // if non-NULL the noise step is read from device memory (hipGraph replay)
+  int F;
 };
 
 template <int H1, int H2, int E>
 struct DibFusedBwdCfg {
   static constexpr int E2 = 2 * E;
   static constexpr int N3 = (E2 + 31) / 32 * 32;
-  static constexpr int K1P = 20;                        // layer-1 transposed image pitch (inputs <= 16 wide)
   static constexpr int P2 = H2 + 4, P3 = N3 + 4;        // W2 image [H1][H2+4], W3 image [H2][N3+4]
-  static constexpr int W1_FLOATS = H1 * K1P, W2_FLOATS = H1 * P2, W3_FLOATS = H2 * P3;
+  static constexpr int W2_FLOATS = H1 * P2, W3_FLOATS = H2 * P3;
   static constexpr int PATCH = 32 * 36;
-  static constexpr int LDS_FLOATS = W1_FLOATS + W2_FLOATS + W3_FLOATS + H1 + 8 * PATCH;
+  static constexpr int LDS_FLOATS = W2_FLOATS + W3_FLOATS + 8 * PATCH;
   static constexpr int T1 = H1 / 32, T2 = H2 / 32, T3 = N3 / 32;
 };
 
@@ -693,17 +568,21 @@ __device__ __forceinline__ dib_f32x16 dib_tile_to_frag(float* __restrict__ patch
   return c;
 }
 
+// Sample row (of the wave's 32) that lane group lg (= lane >> 4) contracts in step s8 of the d(W1|b1) product: rows
+// s8 + 8*lg - the four lane groups of a step read rows 8 apart (288 floats = bank offset 32), 16 lanes x 8 bytes each (one
+// ds_read_b64 = hidden units 2j, 2j+1): the two groups of a 32-lane service half cover all 64 banks once.
+__device__ __forceinline__ int dib_dw1_row(int s8, int lg) { return s8 + 8 * lg; }
+
 template <int H1, int H2, int E, bool RELU>
 __global__ void __launch_bounds__(512)
 dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
   static_assert(E % 32 == 0, "fused backward: embedding dimension must be a multiple of 32");
+  static_assert(H1 / 32 <= 4 && H2 / 32 <= 4, "act' bit masks: one 64-bit word per (lane, layer)");
   using C = DibFusedBwdCfg<H1, H2, E>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Wt1 = lds;                      // [H1][K1P]  Wt1[n][k] = W1[k][n] (for the h1 recompute)
-  float* W2i = Wt1 + C::W1_FLOATS;       // [H1][H2+4] W2[k1][k2]
+  float* W2i = lds;                      // [H1][H2+4] W2[k1][k2]
   float* W3i = W2i + C::W2_FLOATS;       // [H2][N3+4] W3[k2][n], columns >= 2E zero
-  float* B1 = W3i + C::W3_FLOATS;        // b1
-  float* patch = B1 + H1 + (threadIdx.x >> 6) * C::PATCH;
+  float* patch = W3i + C::W3_FLOATS + (threadIdx.x >> 6) * C::PATCH;
 
   const int f = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -713,25 +592,18 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
   const int F = a.F;
   const float* Pf = a.P + (long long)fm.w * a.batch;
   {
-    const float* W1 = a.params + a.w_off[0 * F + f];
     const float* W2 = a.params + a.w_off[1 * F + f];
     const float* W3 = a.params + a.w_off[2 * F + f];
-    dib_stage_batched<H1 * 16>(tid, [&](int i) { const int k = i / H1; return (k < in_dim) ? W1[i] : 0.f; },
-                               [&](int i, float v) { const int k = i / H1, n = i - k * H1; Wt1[n * C::K1P + k] = v; });
     dib_stage_batched<H1 * H2>(tid, [&](int i) { return W2[i]; },
                                [&](int i, float v) { const int k1 = i / H2, k2 = i - k1 * H2; W2i[k1 * C::P2 + k2] = v; });
     dib_stage_batched<H2 * C::N3>(tid, [&](int i) { const int k2 = i / C::N3, n = i - k2 * C::N3;
                                                     return (n < C::E2) ? W3[(long long)k2 * C::E2 + n] : 0.f; },
                                   [&](int i, float v) { const int k2 = i / C::N3, n = i - k2 * C::N3; W3i[k2 * C::P3 + n] = v; });
-    const float* b1 = a.params + a.b_off[0 * F + f];
-    for (int i = tid; i < H1; i += 512) B1[i] = b1[i];
   }
   __syncthreads();
 
   const int n_tiles = (a.batch + 255) / 256;
-  const int ksteps1 = 4 * ((in_dim + 7) / 8);
   const float slope = dib_neg_slope(a.act);
-  const unsigned nstep = a.step_dev ? a.step_dev[0] : a.step;
   const float kb = a.beta_dev[0] * a.inv_bg;
   // d(W1|b1) accumulators: 16x16 tiles (rows = encoder-input index k, row in_dim = bias; cols = 16 hidden units)
   dib_f32x4 dw1[2 * C::T1];
@@ -739,50 +611,33 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
   for (int t = 0; t < 2 * C::T1; ++t) dw1[t] = dib_f32x4{0.f, 0.f, 0.f, 0.f};
   const int l15 = lane & 15, lg = lane >> 4;
 
-  auto load_p = [&](int tile, float (&dstp)[8]) {
-    const int bb = min(tile * 256 + wave * 32 + m, a.batch - 1);
-    const float* src = Pf + (long long)bb * in_dim;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int k = dib_crow(r, h);
-      const float v = src[min(k, in_dim - 1)];
-      dstp[r] = (k < in_dim) ? v : 0.f;
-    }
-  };
-
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    DIB_FUSED_SET_PRIO(tile / (int)gridDim.x);
     const int wrow0 = tile * 256 + wave * 32;
     if (wrow0 >= a.batch) continue;  // wave-uniform; no barriers inside the loop
     const int rows_valid = min(32, a.batch - wrow0);
     const int b = min(wrow0 + m, a.batch - 1);
-    const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
     const unsigned long long hbits = a.h2mask[((long long)f * a.batch + b) * 2 + h];  // act'(h2) bits, fragment order
+    const unsigned long long h1bits = a.h1mask[((long long)f * a.batch + b) * 2 + h];
     // ---- dout = d(loss + beta*KL)/d(mu|logvar), lane-local in fragment layout ----
     dib_f32x16 dout[C::T3];
     {
       const float* eo = a.enc_out + ((long long)f * a.batch + wrow0) * C::E2;
-      const float* gu = a.GU + (long long)wrow0 * ((long long)F * E) + (long long)f * E;
+      const long long so = (long long)wrow0 * ((long long)F * E) + (long long)f * E;
 #pragma unroll
       for (int t = 0; t < E / 32; ++t) {
         const DibTile4 vm = dib_tile_gload(eo + 32 * t, C::E2, rows_valid, lane);
         const DibTile4 vl = dib_tile_gload(eo + E + 32 * t, C::E2, rows_valid, lane);
-        const DibTile4 vg = dib_tile_gload(gu + 32 * t, (long long)F * E, rows_valid, lane);
+        const DibTile4 vg = dib_tile_gload(a.GU + so + 32 * t, (long long)F * E, rows_valid, lane);
+        const DibTile4 vu = dib_tile_gload(a.U + so + 32 * t, (long long)F * E, rows_valid, lane);
         const dib_f32x16 mu = dib_tile_to_frag(patch, vm, lane);
         const dib_f32x16 lv = dib_tile_to_frag(patch, vl, lane);
         const dib_f32x16 g = dib_tile_to_frag(patch, vg, lane);
+        const dib_f32x16 u = dib_tile_to_frag(patch, vu, lane);
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const int e0 = 32 * t + 8 * gq + 4 * h;
-          float eps[4] = {0.f, 0.f, 0.f, 0.f};
-          dib_eps4(a.seed, nstep, (uint32_t)grow, (uint32_t)f, (uint32_t)(e0 >> 2), eps);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * gq + j;
-            const float s = dib_sigma(lv[r]);
-            dout[t][r] = g[r] + kb * mu[r];
-            dout[t + E / 32][r] = g[r] * eps[j] * 0.5f * s + kb * 0.5f * (s * s - 1.f);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const float s = dib_sigma(lv[r]);
+          dout[t][r] = g[r] + kb * mu[r];
+          dout[t + E / 32][r] = g[r] * (u[r] - mu[r]) * 0.5f + kb * 0.5f * (s * s - 1.f);
         }
       }
       float* dd = a.dout + ((long long)f * a.batch + wrow0) * C::E2;
@@ -790,14 +645,12 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
       for (int t = 0; t < C::T3; ++t) dib_store_tile(patch, dout[t], dd + 32 * t, C::E2, rows_valid, lane);
     }
 
-    // encoded inputs for the h1 recompute (B operand) and for the layer-1 weight gradient (A operand: lane (i = lane&15,
-    // g = lane>>4) supplies [P | 1][row 4s+g][i]); issued here so they land during the dh2 MFMAs
-    float p[8];
-    load_p(tile, p);
+    // encoded inputs for the layer-1 weight gradient (A operand: lane (i = lane&15, g = lane>>4) supplies
+    // [P | 1][row dib_dw1_row(s, g)][i]); issued here so they land during the dh2 MFMAs
     float pa[8];
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) {
-      const int rl = 16 * (s8 >> 2) + (s8 & 3) + 4 * lg;            // row within the wave's 32 samples (see the dW1 MFMAs)
+      const int rl = dib_dw1_row(s8, lg);            // row within the wave's 32 samples (see the dW1 MFMAs)
       const float v = Pf[(long long)min(wrow0 + rl, a.batch - 1) * in_dim + min(l15, in_dim - 1)];
       pa[s8] = (rl < rows_valid) ? (l15 < in_dim ? v : (l15 == in_dim ? 1.f : 0.f)) : 0.f;
     }
@@ -821,18 +674,13 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
             acc = DIB_MFMA(w.z, dout[jt][4 * g + 2], acc);
             acc = DIB_MFMA(w.w, dout[jt][4 * g + 3], acc);
           }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned int word = (unsigned int)(hbits >> (32 * ((16 * jo) >> 5)));
-          const int keep = __builtin_amdgcn_sbfe(word, (16 * jo + r) & 31, 1);  // 0 or -1: v_bfe_i32 + v_and, no compare
-          acc[r] = RELU ? __int_as_float(__float_as_int(acc[r]) & keep) : acc[r] * (keep ? 1.f : slope);
-        }
+        dib_mask_tile<RELU>(acc, hbits, jo, slope);
         dh2[jo] = acc;
         dib_store_tile(patch, acc, dg + 32 * jo, H2, rows_valid, lane);
       }
     }
 
-    // ---- dh1^T = W2 dh2^T, masked by act'(h1); h1 tile recomputed from the encoded input ----
+    // ---- dh1^T = W2 dh2^T, masked by act'(h1) ----
     {
 #pragma unroll
       for (int jo = 0; jo < C::T1; ++jo) {
@@ -849,23 +697,9 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
             acc = DIB_MFMA(w.z, dh2[jt][4 * g + 2], acc);
             acc = DIB_MFMA(w.w, dh2[jt][4 * g + 3], acc);
           }
-        dib_f32x16 h1v;  // pre-activation of h1 tile jo: W1^T p + b1 (sign decides act')
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h1v[r] = B1[32 * jo + dib_crow(r, h)];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          if (4 * g < ksteps1) {
-            const float4 w = *reinterpret_cast<const float4*>(Wt1 + (32 * jo + m) * C::K1P + 8 * g + 4 * h);
-            h1v = DIB_MFMA(w.x, p[4 * g + 0], h1v);
-            h1v = DIB_MFMA(w.y, p[4 * g + 1], h1v);
-            h1v = DIB_MFMA(w.z, p[4 * g + 2], h1v);
-            h1v = DIB_MFMA(w.w, p[4 * g + 3], h1v);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = RELU ? (h1v[r] > 0.f ? acc[r] : 0.f) : acc[r] * (h1v[r] > 0.f ? 1.f : slope);
+        dib_mask_tile<RELU>(acc, h1bits, jo, slope);
         // dh1 tile -> LDS patch as row-major [m][n] (it never goes to HBM), then d(W1|b1) += [P|1]^T dh1 on 16x16x4 MFMAs:
-        // step s contracts 4 samples (rows rl(s, g) below); B operand: lane (j, g) reads dh1[rl][16*half + j] from the patch.
+        // step s contracts 4 samples (rows dib_dw1_row(s, g)); B operand: lane (j, g) reads dh1[row][.] from the patch.
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<float4*>(patch + m * 36 + 8 * g + 4 * h) =
@@ -873,12 +707,11 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
-          // the 4 lane groups read rows 4 apart (144 floats = 16 banks): 4 x 16 floats on disjoint banks
-          const int rl = 16 * (s8 >> 2) + (s8 & 3) + 4 * lg;
-          const float b0 = patch[rl * 36 + l15];
-          const float b1v = patch[rl * 36 + 16 + l15];
-          dw1[2 * jo] = DIB_MFMA16(pa[s8], b0, dw1[2 * jo]);
-          dw1[2 * jo + 1] = DIB_MFMA16(pa[s8], b1v, dw1[2 * jo + 1]);
+          const int rl = dib_dw1_row(s8, lg);
+          // accumulator 2*jo + c holds hidden units 32*jo + 2*j + c (j = lane & 15): the pair is one 8-byte read
+          const float2 bb = *reinterpret_cast<const float2*>(patch + rl * 36 + 2 * l15);
+          dw1[2 * jo] = DIB_MFMA16(pa[s8], bb.x, dw1[2 * jo]);
+          dw1[2 * jo + 1] = DIB_MFMA16(pa[s8], bb.y, dw1[2 * jo + 1]);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -890,7 +723,10 @@ dib_fused_encoder_bwd_kernel(DibFusedBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < 2 * C::T1; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(long long)(lg * 4 + r) * H1 + 16 * t + l15] = dw1[t][r];
+      for (int r = 0; r < 4; ++r) {
+        const int n = 32 * (t >> 1) + 2 * l15 + (t & 1);
+        dst[(long long)(lg * 4 + r) * H1 + n] = dw1[t][r];
+      }
   }
 }
 

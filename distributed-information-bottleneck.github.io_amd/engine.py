@@ -225,9 +225,9 @@ class HipEngine:
                   "dib_grads_finalize_part")
             off, cnt = self.part_range(1)
             on_integration_grads_ready(self.grads[off: off + cnt])
+        # (row_idx / row0 / seed / step are not needed by the device backward: eps * sigma = ws[U] - mu)
         check(self.lib.dib_encoder_bank_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads),
-                                            _ptr(self.beta_dev), float(inv_global_batch), _ptr(row_idx), int(row0),
-                                            int(seed), int(step) & 0xFFFFFFFF, _ptr(ws), st), "dib_encoder_bank_bwd")
+                                            _ptr(self.beta_dev), float(inv_global_batch), _ptr(ws), st), "dib_encoder_bank_bwd")
         check(self.lib.dib_grads_finalize_part(self.layout, batch, 0 if on_integration_grads_ready is not None else -1,
                                                _ptr(self.grads), _ptr(ws), st), "dib_grads_finalize_part")
 
@@ -330,14 +330,8 @@ class HipEngine:
 
     def profile_summary(self) -> dict:
         """{kernel symbol: (total ms, launches)} since profile_enable(True); synchronises."""
-        ms = (ctypes.c_double * 15)()
-        cnt = (c_int * 15)()
-        check(self.lib.dib_profile_summary(ms, cnt), "dib_profile_summary")
-        bk = lambda mode, ni, nj: 64 if (ni, nj) == (2, 2) or (mode, ni, nj) == (2, 1, 2) else 32  # csrc/dib_api.hip launch_gemm_t
-        names = [f"dib_gemm_kernel<{mode}, {ni}, {nj}, {bk(mode, ni, nj)}>"
-                 for mode in (0, 1, 2) for ni in (1, 2) for nj in (1, 2)]
-        names += ["dib_fused_encoder_fwd_kernel", "dib_fused_encoder_bwd_kernel", "other"]
-        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names) if cnt[i]}
+        return profile_summary(self.lib)
+
 
     # ---- views / helpers ---------------------------------------------------------------------
     def pred(self, batch: int) -> torch.Tensor:
@@ -424,3 +418,18 @@ class HipEngine:
         check(self.lib.dib_philox_normal_fill(_ptr(out), _ptr(row_idx), int(row0), batch, self.F, self.E, int(seed),
                                               int(step) & 0xFFFFFFFF, self._stream()), "dib_philox_normal_fill")
         return out
+
+
+PROFILE_CATEGORIES = 17  # include/dib_hip.h: DIB_PROFILE_CATEGORIES
+
+
+def profile_summary(lib) -> dict:
+    """{kernel symbol: (total ms, launches)} of the library's live HIP-event timing since dib_profile_enable(1)."""
+    ms = (ctypes.c_double * PROFILE_CATEGORIES)()
+    cnt = (c_int * PROFILE_CATEGORIES)()
+    check(lib.dib_profile_summary(ms, cnt), "dib_profile_summary")
+    bk = lambda mode, ni, nj: 64 if (ni, nj) == (2, 2) or (mode, ni, nj) == (2, 1, 2) else 32  # csrc/dib_api.hip launch_gemm_t
+    names = [f"dib_gemm_kernel<{mode}, {ni}, {nj}, {bk(mode, ni, nj)}>"
+             for mode in (0, 1, 2) for ni in (1, 2) for nj in (1, 2)]
+    names += ["dib_fused_encoder_fwd_kernel", "dib_fused_encoder_bwd_kernel", "other", "dib_attn_fwd_kernel", "dib_attn_bwd_kernel"]
+    return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names) if cnt[i]}

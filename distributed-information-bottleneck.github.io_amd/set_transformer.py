@@ -39,6 +39,9 @@ assert DESC.itemsize == 104  # include/dib_st.h: dib_gemm_desc
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, _lib.ACT_LEAKY_RELU_01
 LOSS_BCE_LOGITS = 0
+# Test switch: take train_step's collective branch even on a ONE-rank process group, so that the RCCL calls themselves run
+# on the single GPU the test box has (tests/_dp_gpu_st_worker.py).  A 1-rank sum all-reduce is the identity.
+_FORCE_DP_BRANCH = False
 
 
 def _ptr(t: Optional[torch.Tensor], off: int = 0):
@@ -108,16 +111,25 @@ class SetTransformerDIB:
                  number_heads_per_mha: int = 12, number_attention_blocks: int = 6,
                  ff_arch_per_block: Sequence[int] = (128, 32), final_processing_arch: Sequence[int] = (256,),
                  output_dimensionality: int = 1, logvar_initialization: float = -3.0, layer_norm_epsilon: float = 1e-3,
-                 *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto"):
-        """attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
+                 *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto",
+                 _checker_backend=None):
+        """_checker_backend: TEST SEAM (like DistributedIBNet._engine_factory): the CPU tests of the host logic - train_step's
+        data-parallel protocol, fit's schedules - inject an object that implements forward / loss_and_backward / _loss_only /
+        adam_step on the float64 CPU checker (tests/_oracle_set_transformer.py).  The product never sets it: without it the
+        constructor demands a GPU and the HIP library.
+        attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
         grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" (per batch shape, key_dim == 128):
         flash - since the round-2 rewrite of the attention kernels it is the faster path at every measured shape (ms/step flash
         vs gemm: 32 x 50: 3.08 / 4.14, 4 x 512: 4.29 / 4.88, 2 x 2048: 15.0 / 15.7, 4 x 4096: 77.2 / 100.5;
         profiles/r02am_set_transformer_bench.txt, r02final2_set_transformer_bench.txt) and it needs no [P, P] stash in HBM; key_dim != 128: gemm."""
-        if not torch.cuda.is_available():
-            raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
-        self.lib = _lib.load_library()
-        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self._checker = _checker_backend
+        if self._checker is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
+            self.lib = _lib.load_library()
+            self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        else:
+            self.lib, self.device = None, torch.device("cpu")
         self.particle_feature_dimensions = int(particle_feature_dimensions)
         self.number_positional_encoding_frequencies = int(number_positional_encoding_frequencies)
         self.particle_encoder_arch_spec = [int(u) for u in particle_encoder_arch_spec]
@@ -136,7 +148,6 @@ class SetTransformerDIB:
         if attention == "flash" and self.key_dim != 128:
             raise ValueError("attention='flash' needs key_dim == 128 (the notebook's value)")
         self.attention = attention
-        self.score_budget_bytes = 96 << 30
         self.attention_impl = "flash" if (attention == "flash" or (attention == "auto" and self.key_dim == 128)) else "gemm"
         assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
         # ---- flat parameter layout (Keras creation order) ----
@@ -148,13 +159,15 @@ class SetTransformerDIB:
             o = _align4(o + int(np.prod(shp)))
         self.n_alloc = o
         self.n_params = int(sum(int(np.prod(s)) for s in self.shapes.values()))
-        z = lambda n, dt=torch.float32: torch.zeros(n, dtype=dt, device=self.device)
+        fdt = torch.float32 if self._checker is None else torch.float64   # the CPU checker keeps its state in float64
+        z = lambda n, dt=fdt: torch.zeros(n, dtype=dt, device=self.device)
         self.params, self.grads, self.adam_m, self.adam_v = z(o), z(o), z(o), z(o)
-        self.beta_dev = torch.ones(1, dtype=torch.float32, device=self.device)
-        self.lr_dev = torch.full((1,), 1e-4, dtype=torch.float32, device=self.device)
+        self.beta_dev = torch.ones(1, dtype=fdt, device=self.device)
+        self.lr_dev = torch.full((1,), 1e-4, dtype=fdt, device=self.device)
         self.t_dev = z(1, torch.int64)
         self.set_params(self.init_params(init_seed))
         self._plans: Dict[Tuple[int, int], dict] = {}
+        self.max_step_plans = 4
         self._step = 0
         self.last = {}
 
@@ -212,7 +225,7 @@ class SetTransformerDIB:
             a = np.asarray(p[name], dtype=np.float32).reshape(-1)
             assert a.size == int(np.prod(shp)), name
             flat[self.offsets[name]: self.offsets[name] + a.size] = a
-        self.params.copy_(torch.from_numpy(flat))
+        self.params.copy_(torch.from_numpy(flat).to(self.params.dtype))
 
     def _unflatten(self, t: torch.Tensor) -> Dict[str, np.ndarray]:
         flat = t.detach().cpu().numpy()
@@ -242,16 +255,12 @@ class SetTransformerDIB:
     def _plan(self, B: int, P: int) -> dict:
         key = (B, P)
         if key in self._plans:
+            self._plans[key] = self._plans.pop(key)   # most recently used last
             return self._plans[key]
         D, H, K = self.bottleneck_dimension, self.number_heads_per_mha, self.key_dim
         HK, T = H * K, B * P
         ldS = _align4(P)
-        if self.attention == "auto" and self.key_dim == 128:
-            score_bytes = 4 * B * H * P * ldS * (self.number_attention_blocks + 1)
-            impl = "flash"   # (score_bytes = what the gemm path would stash; kept for the memory report)
-            del score_bytes
-        else:
-            impl = self.attention_impl
+        impl = self.attention_impl   # fixed by the constructor: flash for key_dim == 128 unless attention="gemm"
         F0 = self.particle_feature_dimensions
         pe_w = F0 * self.number_positional_encoding_frequencies
         enc_units = self.particle_encoder_arch_spec + [2 * D]
@@ -431,6 +440,11 @@ class SetTransformerDIB:
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
                     enc_units=enc_units)
+        # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
+        # (training batch, validation batch, a ragged tail), evict least recently used beyond that
+        step_keys = [k for k in self._plans if k[0] != "enc"]
+        if len(step_keys) >= self.max_step_plans:
+            self._plans.pop(step_keys[0])
         self._plans[key] = plan
         return plan
 
@@ -446,6 +460,8 @@ class SetTransformerDIB:
         embs_reparam [B, P, bottleneck] (optional): use these sampled embeddings instead of the library's counter-based
         noise (the notebook evaluates `set_transformer(tf.random.normal(...))` on its own samples; also how the golden
         fixture, which carries its own noise, is replayed)."""
+        if self._checker is not None:
+            return self._checker.forward(self, batch_inp, step, deterministic, row0, embs_reparam)
         x = batch_inp if isinstance(batch_inp, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(batch_inp, dtype=np.float32))
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         B, P, F0 = x.shape
@@ -507,6 +523,8 @@ class SetTransformerDIB:
     def loss_and_backward(self, is_loci, inv_global_batch: Optional[float] = None) -> None:
         """bce_losses = mean BCE(is_loci, logits); loss = bce_losses + beta_var * kl; tape.gradient(loss, variables).
         Gradients land in self.grads; self.last gets bce (device scalar)."""
+        if self._checker is not None:
+            return self._checker.loss_and_backward(self, is_loci, inv_global_batch)
         pl = self.last["plan"]
         B, P, T = self.last["B"], self.last["P"], pl["T"]
         lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
@@ -572,9 +590,10 @@ class SetTransformerDIB:
             self._view(pl, "g_x", T * D).copy_(self._view(pl, "g_s", T * D))
         # bottleneck: d(mu | raw logvar), beta * KL included
         ne = len(pl["enc_units"])
-        check(lib.dib_token_reparam_kl_bwd(_ptr(ws, off[f"enc_h{ne - 1}"]), _ptr(ws, off["g_x"]), T, D, self.logvar_initialization,
-                                           _ptr(self.beta_dev), inv, self.noise_seed, self.last["step"] & 0xFFFFFFFF,
-                                           self.last["row0"], _ptr(ws, off[f"g_enc_h{ne - 1}"]), st), "dib_token_reparam_kl_bwd")
+        # eps * sigma = x0 - mu: the gradient of the forward that ran (library noise, embs_reparam or deterministic)
+        check(lib.dib_token_reparam_kl_bwd(_ptr(ws, off[f"enc_h{ne - 1}"]), _ptr(ws, off["g_x"]), _ptr(ws, off["x0"]), T, D,
+                                           self.logvar_initialization, _ptr(self.beta_dev), inv,
+                                           _ptr(ws, off[f"g_enc_h{ne - 1}"]), st), "dib_token_reparam_kl_bwd")
         for l in range(ne - 1, -1, -1):
             g[f"enc{l}_wgrad"].run(lib, st)
             if l > 0:
@@ -587,6 +606,8 @@ class SetTransformerDIB:
         self.last["correct"] = out3[1:2]
 
     def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7) -> None:
+        if self._checker is not None:
+            return self._checker.adam_step(self, beta_1, beta_2, epsilon)
         check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v), self.n_alloc,
                                      _ptr(self.lr_dev), _ptr(self.t_dev), beta_1, beta_2, epsilon, 1.0, self._stream()),
               "dib_adam_step")
@@ -599,7 +620,7 @@ class SetTransformerDIB:
         [r*B/N, (r+1)*B/N), the noise is keyed by the global token index (results independent of N), the flat gradient
         buffer is all-reduced (RCCL over xGMI with the nccl backend), every rank applies the same Adam update."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DP_BRANCH):
             self.forward(batch_inp)
             self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
             if training:
@@ -609,7 +630,7 @@ class SetTransformerDIB:
         rank, world = dist.get_rank(), dist.get_world_size()
         B, P = int(batch_inp.shape[0]), int(batch_inp.shape[1])
         lo, hi = (B * rank) // world, (B * (rank + 1)) // world
-        stats = torch.zeros(2, dtype=torch.float32, device=self.device)   # [bce sum / B, kl sum / B] of the local rows
+        stats = torch.zeros(2, dtype=self.params.dtype, device=self.device)   # [bce sum / B, kl sum / B] of the local rows
         if hi > lo:
             self.forward(batch_inp[lo:hi], row0=lo * P)
             if training:
@@ -630,6 +651,8 @@ class SetTransformerDIB:
         return self.last["bce"]
 
     def _loss_only(self, is_loci, inv_global_batch: Optional[float] = None):
+        if self._checker is not None:
+            return self._checker.loss_only(self, is_loci, inv_global_batch)
         pl = self.last["plan"]
         B = self.last["B"]
         inv = 1.0 / B if inv_global_batch is None else float(inv_global_batch)

@@ -136,9 +136,12 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
                           dib_stream_t stream);
 int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, float* grads, void* ws,
                                dib_stream_t stream);
+/* dib_encoder_bank_bwd: tape.gradient through models.py:106-118 for the encoder bank (reparameterisation + beta*KL backward,
+ * dgrads, weight gradients).  The noise term of d(logvar) is recovered from the forward's own sample, eps*sigma = ws[U] -
+ * mu, so the backward needs neither the noise key nor the row ids, and it is the gradient of whatever forward wrote the
+ * workspace (library noise or DIB_FWD_DETERMINISTIC). */
 int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
-                         float inv_global_batch, const int32_t* row_idx, int64_t row0, uint64_t seed,
-                         uint32_t step, void* ws, dib_stream_t stream);
+                         float inv_global_batch, void* ws, dib_stream_t stream);
 /* reduce the split-batch wgrad partials into `grads` (fixed order => deterministic).
  * _part finalises one all-reduce bucket: 0 = encoder bank, 1 = integration network (its gradients are complete right
  * after dib_integration_bwd, so its RCCL all-reduce can overlap the encoder-bank backward), -1 = everything. */
@@ -189,10 +192,12 @@ int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int
 float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t feature, uint32_t e);
 
 /* ---- live kernel timing for bench.py's roofline: HIP events around every launch on the launch stream.
- * 15 categories = kernel symbols: 0..11 dib_gemm_kernel<MODE,NI,NJ> at MODE*4 + (NI-1)*2 + (NJ-1); 12 = fused
- * encoder forward; 13 = fused encoder backward; 14 = all other (HBM-bound) kernels.  summary() synchronises. */
+ * 17 categories = kernel symbols: 0..11 dib_gemm_kernel<MODE,NI,NJ> at MODE*4 + (NI-1)*2 + (NJ-1); 12 = fused
+ * encoder forward; 13 = fused encoder backward; 14 = all other (HBM-bound) kernels (not bracketed); 15 = dib_attn_fwd_kernel;
+ * 16 = dib_attn_bwd_kernel (include/dib_st.h).  summary() synchronises. */
+#define DIB_PROFILE_CATEGORIES 17
 int dib_profile_enable(int on);
-int dib_profile_summary(double* ms_by_category /*[15]*/, int* launches_by_category /*[15]*/);
+int dib_profile_summary(double* ms_by_category /*[17]*/, int* launches_by_category /*[17]*/);
 
 /* ---- EXPERIMENTAL: fp32 GEMM on the bf16 matrix pipe (csrc/dib_gemm_bf16x6.h) --------------------------------
  * C[M,N] = act(A[M,K] @ W[K,N] + bias) with every product formed from six bf16 piece products (three-way exact

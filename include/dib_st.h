@@ -80,13 +80,14 @@ int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* 
  *   logvar = raw + logvar_offset (-3); u = mu + exp(logvar/2) * eps; kl_sum = sum_{token, dim} 0.5 (mu^2 + e^logvar - logvar - 1)
  * (the caller divides by the number of neighbourhoods: "sum over dimension and particles, avg over batch").  eps is the
  * library's counter-based noise keyed by (seed, step, row0 + token, feature 0, dim).  Backward:
- *   d_enc_out = (g_u + k mu | g_u eps sigma / 2 + k (e^logvar - 1)/2), k = beta_dev[0] * inv_batch. */
+ *   d_enc_out = (g_u + k mu | g_u (u - mu) / 2 + k (e^logvar - 1)/2), k = beta_dev[0] * inv_batch, with u [T, E] the
+ * samples the forward pass actually used (eps sigma = u - mu): the library's, the caller's own (a caller may overwrite u
+ * before running the rest of the model) or mu itself (deterministic forward). */
 int64_t dib_token_kl_workspace_bytes(int64_t T, int E);
 int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logvar_offset, uint64_t seed, uint32_t step,
                              int64_t row0, int deterministic, float* u, float* kl_sum, void* ws, dib_stream_t stream);
-int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, int64_t T, int E, float logvar_offset,
-                             const float* beta_dev, float inv_batch, uint64_t seed, uint32_t step, int64_t row0,
-                             float* d_enc_out, dib_stream_t stream);
+int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, const float* u, int64_t T, int E, float logvar_offset,
+                             const float* beta_dev, float inv_batch, float* d_enc_out, dib_stream_t stream);
 
 /* Per-particle information map (notebook cell 8, "Now use probe points along with a bunch of real points to get the info
  * for points on a grid"): enc_probe [M, 2E] / enc_data [N, 2E] = particle_encoder outputs (mu | raw logvar), logvar_offset

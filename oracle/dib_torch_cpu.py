@@ -194,3 +194,36 @@ class TorchCpuDIB:
         task, kl, grads, _ = self.loss_and_grads(x, y, eps, beta, kind, chunk=chunk, batched=batched)
         self.apply_adam(grads, lr)
         return task, kl, grads
+
+
+# --------------------------------------------------------------------------------------------
+# InfoNCE loss + embedding gradients by float64 autograd (checker of dib_infonce_fwd_bwd at working batch sizes; the numpy
+# central-difference oracle dib_oracle.infonce_grads_numeric is O(B D) loss evaluations and only practical at B ~ 12).
+# reference: utils.py:75-175 (get_scaled_similarity), train.py:203-215 (eval_batch_infonce).  Pinned on the numpy restatement
+# dib_oracle.scaled_similarity / infonce_loss by tests/test_oracle_golden.py.
+# --------------------------------------------------------------------------------------------
+def scaled_similarity_torch(e1: torch.Tensor, e2: torch.Tensor, similarity_type: str, temperature: float) -> torch.Tensor:
+    eps = 1e-9
+    if similarity_type in ("l2sq", "l2"):
+        d2 = torch.clamp((e1 ** 2).sum(-1, keepdim=True) + (e2 ** 2).sum(-1)[None, :] - 2.0 * e1 @ e2.T, min=0.0)  # utils.py:85-90
+        sim = -d2 if similarity_type == "l2sq" else -torch.sqrt(d2 + eps)
+    elif similarity_type == "l1":
+        sim = -(e1[:, None, :] - e2[None, :, :]).abs().sum(-1)
+    elif similarity_type == "linf":
+        sim = -(e1[:, None, :] - e2[None, :, :]).abs().amax(-1)
+    elif similarity_type == "cosine":
+        sim = (e1 / e1.norm(dim=-1, keepdim=True)) @ (e2 / e2.norm(dim=-1, keepdim=True)).T
+    else:
+        raise ValueError("Similarity type not implemented: ", similarity_type)
+    return sim / temperature
+
+
+def infonce_loss_and_grads(e1, e2, similarity_type: str, temperature: float):
+    """(loss, dloss/de1, dloss/de2) of train.py:209-214: mean CE(arange(B), S) + mean CE(arange(B), S^T), float64."""
+    a = torch.tensor(np.asarray(e1), dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(np.asarray(e2), dtype=torch.float64, requires_grad=True)
+    S = scaled_similarity_torch(a, b, similarity_type, temperature)
+    d = torch.diagonal(S)
+    loss = (torch.logsumexp(S, 1) - d).mean() + (torch.logsumexp(S, 0) - d).mean()
+    ga, gb = torch.autograd.grad(loss, [a, b])
+    return float(loss.detach()), ga.numpy(), gb.numpy()

@@ -123,8 +123,34 @@ def init_params(spec: SetTransformerSpec, seed: int = 0) -> Dict[str, torch.Tens
     return p
 
 
-def _leaky(x, slope):
-    return torch.where(x > 0, x, slope * x)
+class _MaskedLeaky(torch.autograd.Function):
+    """leaky-relu / relu (slope 0) whose backward uses a GIVEN subgradient choice instead of its own `z > 0` (same idea as
+    oracle/dib_torch_cpu.py:_MaskedReLU): at 4096 particles a float32 device and this float64 restatement legitimately
+    disagree about the sign of a few pre-activations that sit within round-off of 0; the full-size parity test compares
+    gradients under the device's own choices and separately bounds how many choices differ and how close to 0 they sit."""
+
+    @staticmethod
+    def forward(ctx, z, mask, slope):
+        ctx.save_for_backward(mask)
+        ctx.slope = slope
+        return torch.where(z > 0, z, slope * z)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * torch.where(mask, 1.0, ctx.slope).to(g.dtype), None, None
+
+
+def _leaky(x, slope, masks=None, name=None, boundary=None):
+    """act(x); with masks[name] given, the backward follows that mask and `boundary[name]` records
+    (number of units where it differs from x > 0, largest |x| among them)."""
+    if masks is None or name not in masks:
+        return torch.where(x > 0, x, slope * x)
+    m = torch.as_tensor(masks[name]).reshape(x.shape)
+    if boundary is not None:
+        diff = m != (x > 0)
+        boundary[name] = (int(diff.sum()), float(x.detach().abs()[diff].max()) if bool(diff.any()) else 0.0)
+    return _MaskedLeaky.apply(x, m, slope)
 
 
 def _layer_norm(x, g, b, eps):
@@ -138,12 +164,12 @@ def positional_encoding(x, frequencies):
     return torch.cat([x] + [torch.sin(f * x) for f in frequencies], -1)
 
 
-def particle_encoder(spec, p, feats):
+def particle_encoder(spec, p, feats, masks=None, boundary=None):
     """[..., 12] -> [..., 2*bottleneck] (mu | raw logvar)."""
     h = positional_encoding(feats, spec.frequencies)
     n = len(spec.particle_encoder_arch_spec)
     for l in range(n):
-        h = _leaky(h @ p[f"enc{l}_w"] + p[f"enc{l}_b"], spec.leaky_slope)
+        h = _leaky(h @ p[f"enc{l}_w"] + p[f"enc{l}_b"], spec.leaky_slope, masks, f"enc{l}", boundary)
     return h @ p[f"enc{n}_w"] + p[f"enc{n}_b"]
 
 
@@ -152,13 +178,19 @@ def multi_head_attention(spec, p, b, x):
     q = torch.einsum("bpd,dhk->bphk", x, p[f"blk{b}_q_w"]) + p[f"blk{b}_q_b"]
     k = torch.einsum("bpd,dhk->bphk", x, p[f"blk{b}_k_w"]) + p[f"blk{b}_k_b"]
     v = torch.einsum("bpd,dhk->bphk", x, p[f"blk{b}_v_w"]) + p[f"blk{b}_v_b"]
-    scores = torch.einsum("bphk,bqhk->bhpq", q * (1.0 / math.sqrt(spec.key_dim)), k)
-    attn = torch.softmax(scores, dim=-1)
-    ctx = torch.einsum("bhpq,bqhk->bphk", attn, v)
+    scale = 1.0 / math.sqrt(spec.key_dim)
+    # one (neighbourhood, head) at a time: the [P, P] score matrix of 4096 particles is 134 MB in float64, all 12 heads of
+    # it with autograd's copies would be several GB; the arithmetic is the einsum("bphk,bqhk->bhpq") of the one-shot form
+    heads = []
+    for hh in range(q.shape[2]):
+        scores = torch.einsum("bpk,bqk->bpq", q[:, :, hh, :] * scale, k[:, :, hh, :])
+        attn = torch.softmax(scores, dim=-1)
+        heads.append(torch.einsum("bpq,bqk->bpk", attn, v[:, :, hh, :]))
+    ctx = torch.stack(heads, dim=2)
     return torch.einsum("bphk,hkd->bpd", ctx, p[f"blk{b}_o_w"]) + p[f"blk{b}_o_b"]
 
 
-def set_transformer(spec, p, u):
+def set_transformer(spec, p, u, masks=None, boundary=None):
     """[B, P, bottleneck] -> [B, out] (logits)."""
     x = u
     for b in range(spec.number_attention_blocks):
@@ -166,24 +198,25 @@ def set_transformer(spec, p, u):
                         spec.layer_norm_epsilon)
         ff = h
         for l in range(len(spec.ff_arch_per_block)):
-            ff = torch.relu(ff @ p[f"blk{b}_ff{l}_w"] + p[f"blk{b}_ff{l}_b"])
+            ff = _leaky(ff @ p[f"blk{b}_ff{l}_w"] + p[f"blk{b}_ff{l}_b"], 0.0, masks, f"b{b}_ff{l}", boundary)   # relu
         x = _layer_norm(h + ff, p[f"blk{b}_ln2_g"], p[f"blk{b}_ln2_b"], spec.layer_norm_epsilon)
     x = x.mean(dim=-2)                                        # nb:"x = tf.reduce_mean(x, axis=-2)"
     for l in range(len(spec.final_processing_arch)):
-        x = _leaky(x @ p[f"fin{l}_w"] + p[f"fin{l}_b"], spec.leaky_slope)
+        x = _leaky(x @ p[f"fin{l}_w"] + p[f"fin{l}_b"], spec.leaky_slope, masks, f"fin{l}", boundary)
     return x @ p["out_w"] + p["out_b"]
 
 
-def forward(spec, p, feats, eps, is_loci=None, beta=0.0):
-    """nb:"def train_step" forward part.  feats [B,P,12], eps [B,P,bottleneck] standard normal.  Returns dict."""
+def forward(spec, p, feats, eps, is_loci=None, beta=0.0, masks=None, boundary=None):
+    """nb:"def train_step" forward part.  feats [B,P,12], eps [B,P,bottleneck] standard normal.  Returns dict.
+    masks (optional): {"enc<l>", "b<b>_ff<l>", "fin<l>"} -> boolean act' choices for the backward (see _MaskedLeaky)."""
     feats = torch.as_tensor(feats, dtype=torch.float64)
     eps = torch.as_tensor(eps, dtype=torch.float64)
-    enc = particle_encoder(spec, p, feats)
+    enc = particle_encoder(spec, p, feats, masks, boundary)
     mu, logvar = enc[..., : spec.bottleneck_dimension], enc[..., spec.bottleneck_dimension:]
     logvar = logvar + spec.logvar_initialization
     u = mu + torch.exp(logvar / 2.0) * eps
     kl = (0.5 * (mu ** 2 + torch.exp(logvar) - logvar - 1.0)).sum(dim=(-1, -2)).mean()
-    pred = set_transformer(spec, p, u)
+    pred = set_transformer(spec, p, u, masks, boundary)
     out = dict(mu=mu, logvar=logvar, u=u, kl=kl, pred=pred)
     if is_loci is not None:
         y = torch.as_tensor(is_loci, dtype=torch.float64).reshape(pred.shape)
@@ -194,10 +227,10 @@ def forward(spec, p, feats, eps, is_loci=None, beta=0.0):
     return out
 
 
-def loss_and_grads(spec, p, feats, eps, is_loci, beta):
+def loss_and_grads(spec, p, feats, eps, is_loci, beta, masks=None, boundary=None):
     """d(bce + beta * KL)/d(params) by autograd (nb: tape.gradient(loss, all_trainable_variables))."""
     q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    out = forward(spec, q, feats, eps, is_loci, beta)
+    out = forward(spec, q, feats, eps, is_loci, beta, masks, boundary)
     grads = torch.autograd.grad(out["loss"], list(q.values()))
     return {k: float(v.detach()) for k, v in out.items() if v.dim() == 0}, dict(zip(q.keys(), grads))
 

@@ -126,3 +126,53 @@ def _run_infonce_dp(rank, world, port, out_dir):
 def test_infonce_data_parallel_gather_protocol(tmp_path):
     mp.spawn(_run_infonce_dp, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     mp.spawn(_run_infonce_dp, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+
+
+def _run_set_transformer_dp(rank, world, port, out_dir, batch):
+    """SetTransformerDIB.train_step (notebook `train_step`, DP over neighbourhoods - BASELINE config 5) on the CPU checker
+    backend: product host code, oracle arithmetic."""
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import set_transformer_oracle as sto
+    from _oracle_set_transformer import make_model
+    spec = sto.SetTransformerSpec(particle_encoder_arch_spec=[16], bottleneck_dimension=8, key_dim=4, number_heads_per_mha=2,
+                                  number_attention_blocks=2, ff_arch_per_block=[12, 8], final_processing_arch=[10])
+    m = make_model(spec, init_seed=4, noise_seed=9)
+    rng = np.random.default_rng(0)
+    P = 7
+    feats = rng.standard_normal((batch, P, 12)).astype(np.float32)
+    y = (rng.random((batch, 1)) > 0.5).astype(np.float32)
+    series = []
+    for step in range(4):
+        m.lr_dev.fill_(m.learning_rate_schedule(step + 1, 1e-2, 10))
+        m.beta_dev.fill_(m.beta_schedule(step, 1e-3, 1e-1, 4))
+        bce = m.train_step(feats, y)
+        series.append([float(bce.item()), float(m.last["kl"].item())])
+    val = m.train_step(feats[: max(1, batch - 1)], y[: max(1, batch - 1)], training=False)   # validation pass: no update
+    series.append([float(val.item()), float(m.last["kl"].item())])
+    np.savez(os.path.join(out_dir, f"st_b{batch}_w{world}_r{rank}.npz"), params=m.params.numpy(), series=np.array(series),
+             t=int(m.t_dev.item()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,batch", [(2, 6), (3, 2)])   # (3, 2): one rank has NO neighbourhood - same collectives on all
+def test_set_transformer_train_step_data_parallel_equals_single_process(tmp_path, world, batch):
+    out = str(tmp_path)
+    _run_set_transformer_dp(0, 1, _free_port(), out, batch)
+    mp.spawn(_run_set_transformer_dp, args=(world, _free_port(), out, batch), nprocs=world, join=True)
+    ref = np.load(os.path.join(out, f"st_b{batch}_w1_r0.npz"))
+    rs = [np.load(os.path.join(out, f"st_b{batch}_w{world}_r{r}.npz")) for r in range(world)]
+    assert int(ref["t"]) == 4
+    for r in rs:
+        assert np.array_equal(r["params"], rs[0]["params"]), "ranks diverged"
+        assert int(r["t"]) == 4
+        assert np.allclose(r["params"], ref["params"], rtol=1e-9, atol=1e-12)
+        assert np.allclose(r["series"], ref["series"], rtol=1e-9, atol=1e-12), (r["series"], ref["series"])

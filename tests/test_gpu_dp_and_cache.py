@@ -49,6 +49,26 @@ def test_fit_under_rccl_one_rank_equals_single_process(tmp_path):
 
 
 @pytest.mark.timeout(900)
+def test_set_transformer_train_step_under_rccl_one_rank_equals_single_process(tmp_path):
+    """SetTransformerDIB.train_step (BASELINE config 5's data-parallel step, notebook :419-431) launched by
+    torch.distributed.run on the nccl = RCCL backend with one rank, forced onto its collective branch: neighbourhood
+    sharding, global-token noise keys, gradient all-reduce and statistics all-reduce on the real communicator reproduce the
+    single-process run bit for bit."""
+    a, b = str(tmp_path / "single.npz"), str(tmp_path / "rccl.npz")
+    worker = os.path.join(HERE, "_dp_gpu_st_worker.py")
+    r = subprocess.run([sys.executable, worker, a], capture_output=True, text=True, timeout=400, env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                        "127.0.0.1", "--master-port", _free_port(), worker, b], capture_output=True, text=True, timeout=400,
+                       env=_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    s, d = np.load(a), np.load(b)
+    assert int(s["t"]) == 3 and int(d["t"]) == 3
+    for k in s.files:
+        assert np.array_equal(s[k], d[k]), (k, s[k], d[k])
+
+
+@pytest.mark.timeout(900)
 def test_bench_under_launcher_reports_joined_ranks():
     """bench.py under torch.distributed.run with one rank: RCCL path, `n_gpus` = ranks that joined the communicator."""
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",

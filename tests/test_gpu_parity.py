@@ -347,6 +347,48 @@ def test_infonce_loss_and_grads_match_oracle(kind):
     assert np.abs(gy.cpu().numpy() - g2).max() < 2e-4 * (1 + np.abs(g2).max())
 
 
+@pytest.mark.parametrize("D", [8, 64])
+@pytest.mark.parametrize("B", [12, 257, 2048])
+@pytest.mark.parametrize("kind", ["l2sq", "l2", "l1", "linf", "cosine"])
+def test_infonce_at_working_batch_sizes(kind, B, D):
+    """The sizes the path runs at: train.py:34 default batch 128, the chaos notebook 2048 (Chaos_experiments.ipynb:771-821),
+    shared space 64 (train.py:60).  The kernels launch dim3(batch, 2) x 256 threads: B > 256 is where their strided loops
+    over a similarity row iterate more than once, B = 257 the first ragged trip.  Checker: float64 autograd
+    (oracle/dib_torch_cpu.infonce_loss_and_grads, pinned on the numpy restatement on the CPU side).
+    Tolerances: loss 2e-5 relative; gradients 2e-4 of the largest gradient entry (fp32 similarity rows of up to 2048 terms;
+    the l2 form divides by sqrt(d2 + 1e-9), which amplifies fp32 cancellation in d2 for near-coincident pairs - none here)."""
+    import dib_torch_cpu as tc
+    eng, _ = _engine(SPECS["no_hidden"])
+    rng = np.random.default_rng(1000 * B + D)
+    a = rng.standard_normal((B, D)).astype(np.float32)
+    b = (a + 0.7 * rng.standard_normal((B, D))).astype(np.float32)
+    temp = 0.7 if kind != "l2sq" else 4.0     # l2sq distances grow with D: keep the softmax from saturating to one-hot
+    loss, gx, gy = eng.infonce(eng.to_device(a), eng.to_device(b), kind, temp)
+    ref, g1, g2 = tc.infonce_loss_and_grads(a, b, kind, temp)
+    assert abs(float(loss.item()) - ref) < 2e-5 * (1 + abs(ref)), (float(loss.item()), ref)
+    assert np.abs(gx.cpu().numpy() - g1).max() < 2e-4 * np.abs(g1).max() + 1e-9, ("d/dx", np.abs(gx.cpu().numpy() - g1).max(), np.abs(g1).max())
+    assert np.abs(gy.cpu().numpy() - g2).max() < 2e-4 * np.abs(g2).max() + 1e-9, ("d/dy", np.abs(gy.cpu().numpy() - g2).max(), np.abs(g2).max())
+
+
+def test_mi_sandwich_bounds_at_the_reference_evaluation_size():
+    """utils.py:10-11 evaluates the bounds on batches of 1024 (evaluation_batch_size); embedding dimension 32 (train.py:55).
+    Device float64 log-sum-exp kernel vs the literal restatement of utils.py:36-62 on the device's own samples."""
+    spec = orc.DIBSpec([1, 2], [16], [8], 1, feature_embedding_dimension=32)
+    eng, p = _engine(spec, 6)
+    rng = np.random.default_rng(7)
+    E, N = 32, 1024
+    for f, d in enumerate(spec.feature_dimensionalities):
+        xf = rng.standard_normal((N, d)).astype(np.float32)
+        enc = eng.encode_feature(f, xf)
+        lo, up = eng.mi_sandwich_bounds(enc, seed=3, step=5, feature=f)
+        e = enc.cpu().numpy().astype(np.float64)
+        u = orc.mi_sandwich_sample_u(e[:, :E], e[:, E:], 3, 5, f)
+        rlo, rup = orc.mi_sandwich_bounds_batch(e[:, :E], e[:, E:], u)
+        assert np.isfinite([rlo, rup]).all()
+        assert abs(lo - rlo) < 1e-4 * (1 + abs(rlo)) and abs(up - rup) < 1e-4 * (1 + abs(rup)), (lo, rlo, up, rup)
+        assert lo <= up + 1e-9 and lo <= np.log(N) + 1e-9
+
+
 def test_dense_stack_matches_numpy():
     """The Y-encoder MLP (DenseStack over dib_gemm): forward, backward and Keras-Adam vs numpy."""
     from dib_amd.dense import DenseStack

@@ -167,6 +167,20 @@ def test_infonce_oracle_similarity_properties(kind):
     assert l0 > 0 and abs(l0 - orc.infonce_loss(b, a, kind, 1.0)) < 1e-12  # symmetric in (X, Y)
 
 
+@pytest.mark.parametrize("kind", ["l2sq", "l2", "l1", "linf", "cosine"])
+def test_infonce_autograd_oracle_equals_numpy_restatement(kind):
+    """The float64 autograd checker used at working batch sizes (oracle/dib_torch_cpu.infonce_loss_and_grads) against the
+    numpy restatement of utils.py:131-175 / train.py:203-215 and its central-difference gradients."""
+    import dib_torch_cpu as tc
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((9, 6))
+    b = a + 0.7 * rng.standard_normal((9, 6))
+    loss, ga, gb = tc.infonce_loss_and_grads(a, b, kind, 0.7)
+    assert abs(loss - orc.infonce_loss(a, b, kind, 0.7)) < 1e-12
+    n1, n2 = orc.infonce_grads_numeric(a, b, kind, 0.7)
+    assert np.abs(ga - n1).max() < 1e-7 and np.abs(gb - n2).max() < 1e-7
+
+
 # ---- fixtures produced by executing the reference's own models.py source on a NumPy stand-in for TensorFlow
 #      (tests/golden/make_golden_models.py + tf_numpy_shim.py): pins the graph the reference builds ----
 _MODEL_CASES = [

@@ -6,8 +6,11 @@
 #   $1s      PMC SQ + GRBM counters           (MFMA-busy, wait breakdown, LDS bank conflicts, sustained clock)
 # usage: bash tools/collect_profiles.sh gpurun_out/r02x [bench args...]; then (CPU side)
 #        python tools/summarize_profiles.py gpurun_out/r02x r02x
+# CONFIG5=1: the passes wrap `bench.py --config5-only` (the BASELINE config-5 set-transformer step, 4 x 4096 particles);
+#        summarise with  python tools/summarize_profiles.py gpurun_out/r03x r03x_config5 @config5
 B=$1; shift
 ARGS="--steps 10 --warmup 2 --blocks 1 --no-cpu-baseline --no-extra --no-kernel-timing $*"
+if [ -n "$CONFIG5" ]; then ARGS="--config5-only --steps 3 $*"; fi
 R=$(pwd)
 export TMPDIR=/tmp
 cd /tmp

@@ -2,7 +2,9 @@
   <tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats summary, verbatim)
   <tag>_hbm_traffic_per_kernel.json + profiles/hbm_traffic_per_kernel.json (PMC FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE)
   <tag>_sq_summary.txt     (MFMA-busy fraction, sustained clock, wait breakdown per kernel)
-usage: python tools/summarize_profiles.py gpurun_out/prof6 r01g"""
+usage: python tools/summarize_profiles.py gpurun_out/prof6 r01g [@suffix]
+With a suffix (e.g. @config5: the set-transformer step) the kernels are merged into profiles/hbm_traffic_per_kernel.json
+under "<kernel><suffix>" instead of replacing the file (bench.py reads both workloads' dominant kernels from it)."""
 import collections
 import csv
 import json
@@ -22,7 +24,7 @@ def load(path, cname):
     return agg, cnt
 
 
-def main(base, tag):
+def main(base, tag, suffix=""):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
     shutil.copy(os.path.join(base, "kt_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
     fa, fc = load(base + "f/f_counter_collection.csv", "FETCH_SIZE")
@@ -35,8 +37,16 @@ def main(base, tag):
         traffic[name] = {"hbm_read_bytes_per_launch": round(2 * fa[k] / fc[k] * 1024),   # gfx950: FETCH_SIZE counts 1/2
                          "hbm_write_bytes_per_launch": round(wa.get(k, 0) / max(wc.get(k, 1), 1) * 1024),
                          "launches_sampled": fc[k]}
-    for fn in (f"{tag}_hbm_traffic_per_kernel.json", "hbm_traffic_per_kernel.json"):
-        json.dump(traffic, open(os.path.join(out, fn), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(out, f"{tag}_hbm_traffic_per_kernel.json"), "w"), indent=1)
+    cur = os.path.join(out, "hbm_traffic_per_kernel.json")
+    if suffix:
+        merged = json.load(open(cur)) if os.path.exists(cur) else {}
+        merged = {k: v for k, v in merged.items() if not k.endswith(suffix)}
+        merged.update({k + suffix: v for k, v in traffic.items()})
+        json.dump(merged, open(cur, "w"), indent=1)
+    else:
+        keep = {k: v for k, v in (json.load(open(cur)) if os.path.exists(cur) else {}).items() if "@" in k}
+        json.dump(dict(traffic, **keep), open(cur, "w"), indent=1)
     rows = list(csv.DictReader(open(base + "s/s_counter_collection.csv")))
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt, dur, seen = collections.Counter(), collections.defaultdict(float), set()
@@ -50,7 +60,7 @@ def main(base, tag):
     with open(os.path.join(out, f"{tag}_sq_summary.txt"), "w") as fh:
         fh.write("# MFMA_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs); clk = GRBM_GUI_ACTIVE/8/time\n")
         for k, v in agg.items():
-            if "gemm" not in k and "fused" not in k:
+            if "gemm" not in k and "fused" not in k and "attn" not in k:
                 continue
             n, wcyc = cnt[k], v["SQ_WAVE_CYCLES"]
             util = v["SQ_VALU_MFMA_BUSY_CYCLES"] / max(v["GRBM_GUI_ACTIVE"], 1) * 8 / 1024
@@ -63,4 +73,4 @@ def main(base, tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
