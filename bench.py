@@ -244,6 +244,7 @@ class Workload:
         self.eng.set_lr(3e-4)
         self.dp_buckets = dp_buckets
         self.enc_off, self.enc_cnt = self.eng.part_range(0)
+        self.tail_range = self.eng.part_range(3)
         self.set_scaling(scaling, global_batch)
 
     def set_scaling(self, scaling, global_batch):
@@ -272,12 +273,16 @@ class Workload:
             eng.train_step(self.xd, self.yd, None, self.row0(i), self.B, 0, i, "bce_logits", inv_global_batch=inv_gb)
             dist.all_reduce(eng.grads)
         else:
-            # two gradient buckets: the integration network's all-reduce (RCCL over xGMI) is issued as soon as its
-            # gradients are final and overlaps the encoder-bank backward; the encoder bucket follows the backward
+            # gradient buckets, each all-reduced (RCCL over xGMI, async) as soon as it is final: the integration
+            # network's under the whole encoder-bank backward; with 3 buckets the encoder front layers' under the last
+            # encoder layer's weight gradient, which alone trails the backward; with 2 the whole encoder bank trails it
             pending = []
+            issue = lambda g: pending.append(dist.all_reduce(g, async_op=True))
+            kw = dict(on_encoder_front_grads_ready=issue) if self.dp_buckets == 3 else {}
             eng.train_step(self.xd, self.yd, None, self.row0(i), self.B, 0, i, "bce_logits", inv_global_batch=inv_gb,
-                           on_integration_grads_ready=lambda g: pending.append(dist.all_reduce(g, async_op=True)))
-            pending.append(dist.all_reduce(eng.grads[self.enc_off: self.enc_off + self.enc_cnt], async_op=True))
+                           on_integration_grads_ready=issue, **kw)
+            off, cnt = self.tail_range if self.dp_buckets == 3 else (self.enc_off, self.enc_cnt)
+            issue(eng.grads[off: off + cnt])
             for w in pending:
                 w.wait()
         eng.adam_step()
@@ -324,8 +329,9 @@ def main():
     ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="global batch (strong) / per-GPU batch (weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` measurements (other scaling mode, config 4)")
-    ap.add_argument("--dp-buckets", type=int, default=2, choices=[1, 2],
-                    help="gradient all-reduce buckets: 2 = integration bucket overlapped with the encoder backward")
+    ap.add_argument("--dp-buckets", type=int, default=3, choices=[1, 2, 3],
+                    help="gradient all-reduce buckets: 3 (default) = integration / encoder front layers / last encoder layer, each "
+                         "issued as soon as it is final; 2 = integration overlapped, whole encoder bank after the backward; 1 = one")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--config5-only", action="store_true",
                     help="run only the BASELINE config-5 set-transformer step (the `extra.config5_set_transformer` object) and "

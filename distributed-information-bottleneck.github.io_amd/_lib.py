@@ -98,6 +98,7 @@ SIGNATURES = {
                                       c_void_p, c_void_p]),
     "dib_integration_bwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "dib_encoder_bank_bwd_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "dib_grads_finalize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dib_grads_finalize_part": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dib_layout_part_range": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
@@ -133,11 +134,12 @@ SIGNATURES_ST = {
     "dib_reduce_splits": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "dib_softmax_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "dib_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "dib_attention_stash_bytes": (c_int64, [c_int, c_int, c_int]),
     "dib_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_void_p,
-                                  c_void_p]),
+                                  c_void_p, c_void_p]),
     "dib_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
-    "dib_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
-                                  c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                       c_void_p, c_void_p]),
     "dib_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int64, c_int]),

@@ -867,9 +867,13 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
   return (int)hipGetLastError();
 }
 
-int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
-                         float inv_global_batch, void* ws, dib_stream_t stream) {
-  if (!l || !params || !grads || !beta_dev || !ws || batch <= 0) return DIB_E_ARG;
+// stages: bit 0 = the gradient chain (reparam/KL backward + dgrads) and every weight gradient except the last encoder
+// layer's; bit 1 = the last layer's weight gradient (independent of the others: it reads dout and the last hidden layer).
+// 3 = both, in the single-GPU order (last layer first).  The data-parallel caller runs stage 1, finalizes + all-reduces
+// part 2 (the front layers), then runs stage 2 under that all-reduce (dib_encoder_bank_bwd_stage).
+static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                                   float inv_global_batch, int stages, void* ws, dib_stream_t stream) {
+  if (!l || !params || !grads || !beta_dev || !ws || batch <= 0 || stages < 1 || stages > 3) return DIB_E_ARG;
   if (!l->dev_groups) return DIB_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
@@ -878,41 +882,47 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   const long long sstride = align_up(l->n_params, 4);
   int rc = DIB_OK;
   const bool fused = fused_bwd_ok(l);
-  if (fused) {  // reparam/KL backward + both dgrads in one launch (dib_fused.h); wgrads below read its outputs
-    rc = fused_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, st);
-  } else {
-    { ProfScope ps(kProfOther, (hipStream_t)stream);
-    hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
-                       w + m.U, w + m.dout, beta_dev, inv_global_batch, batch, l->F, l->E); }
-    rc = (int)hipGetLastError();
-  }
-  if (rc) return rc;
   const int LE = l->n_enc + 1;
+  if (stages & 1) {
+    if (fused) {  // reparam/KL backward + both dgrads in one launch (dib_fused.h); wgrads below read its outputs
+      rc = fused_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, st);
+    } else {
+      { ProfScope ps(kProfOther, (hipStream_t)stream);
+      hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
+                         w + m.U, w + m.dout, beta_dev, inv_global_batch, batch, l->F, l->E); }
+      rc = (int)hipGetLastError();
+    }
+    if (rc) return rc;
+  }
   // Optional fork / join (DIB_CONCURRENT_WGRAD=1, default off - measured slower, see Knobs): the last layer's weight gradient
   // (N = 2E <= 64 columns: HBM-bound, 4.5 TB/s with the matrix pipe 2/3 busy) is independent of the other layers' and can run
   // on the layout's side stream beside the MFMA-bound wide wgrad that follows it on the caller's stream; the caller's stream
   // waits for it before this entry returns its work.  Never while the per-kernel event timing of bench.py is on.
-  const bool fork = fused && knobs().concurrent_wgrad && l->side && !g_prof.on && LE >= 3 && l->enc_wgrad[LE - 1].max_n <= 64 &&
-                    batch >= 4096;
+  const bool fork = stages == 3 && fused && knobs().concurrent_wgrad && l->side && !g_prof.on && LE >= 3 &&
+                    l->enc_wgrad[LE - 1].max_n <= 64 && batch >= 4096;
   for (int ly = LE - 1; ly >= 0; --ly) {
-    if (fused && ly == 0) break;  // d(W1|b1) is produced inside the fused kernel and reduced in dib_grads_finalize
-    const float* gout = ly == LE - 1 ? w + m.dout : w + m.g_enc_h[ly];
+    const bool last = ly == LE - 1;
+    const float* gout = last ? w + m.dout : w + m.g_enc_h[ly];
     const float* hin = ly == 0 ? w + m.P : w + m.enc_h[ly - 1];
-    // narrow outputs (the 2E-wide last layer) run 128x64 tiles at 4 workgroups/CU: half as many, twice as long batch
-    // splits fill the chip in one wave (measured 0.88 -> 0.71 ms); the unused slabs of these blocks stay zero.
-    // (only from 32 splits = 16384 rows up: at B = 8192 the 16 -> 8 split halving measured 117 vs 103 us)
-    const bool halve = knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
-    hipStream_t lst = st;
-    if (fork && ly == LE - 1) {
-      if (hipEventRecord(l->ev_fork, st) != hipSuccess || hipStreamWaitEvent(l->side, l->ev_fork, 0) != hipSuccess)
-        return DIB_E_ARG;
-      lst = l->side;
+    const bool wgrad_here = (last ? (stages & 2) : (stages & 1)) && !(fused && ly == 0);  // fused: d(W1|b1) comes out of the
+                                                                                         // fused kernel, reduced at finalize
+    if (wgrad_here) {
+      // narrow outputs (the 2E-wide last layer) run 128x64 tiles at 4 workgroups/CU: half as many, twice as long batch
+      // splits fill the chip in one wave (measured 0.88 -> 0.71 ms); the unused slabs of these blocks stay zero.
+      // (only from 32 splits = 16384 rows up: at B = 8192 the 16 -> 8 split halving measured 117 vs 103 us)
+      const bool halve = knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
+      hipStream_t lst = st;
+      if (fork && last) {
+        if (hipEventRecord(l->ev_fork, st) != hipSuccess || hipStreamWaitEvent(l->side, l->ev_fork, 0) != hipSuccess)
+          return DIB_E_ARG;
+        lst = l->side;
+      }
+      rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0,
+                          halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, lst);
+      if (rc) return rc;
+      if (fork && last && hipEventRecord(l->ev_join, l->side) != hipSuccess) return DIB_E_ARG;
     }
-    rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0,
-                        halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, lst);
-    if (rc) return rc;
-    if (fork && ly == LE - 1 && hipEventRecord(l->ev_join, l->side) != hipSuccess) return DIB_E_ARG;
-    if (ly >= 1 && !fused) {
+    if ((stages & 1) && ly >= 1 && !fused) {
       rc = launch_gemm<1>(l, l->enc_dgrad[ly], gout, params, w + m.g_enc_h[ly - 1], nullptr, hin, nullptr, batch,
                           l->act, 1, 0, 0, st);
       if (rc) return rc;
@@ -922,32 +932,60 @@ int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* g
   return DIB_OK;
 }
 
+int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                         float inv_global_batch, void* ws, dib_stream_t stream) {
+  return encoder_bank_bwd_stages(l, batch, params, grads, beta_dev, inv_global_batch, 3, ws, stream);
+}
+
+int dib_encoder_bank_bwd_stage(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                               float inv_global_batch, int stage, void* ws, dib_stream_t stream) {
+  if (stage != 1 && stage != 2) return DIB_E_ARG;
+  return encoder_bank_bwd_stages(l, batch, params, grads, beta_dev, inv_global_batch, stage, ws, stream);
+}
+
+// [beg, end) of a gradient bucket in the flat buffers.  The layout is layer-major (all features' kernels of encoder layer 0,
+// their biases, layer 1, ..., then the integration network), every block boundary a multiple of 4 floats:
+//   0 = encoder bank, 1 = integration network, 2 = encoder layers before the last ("front"), 3 = last encoder layer ("tail"),
+//   -1 = everything
+static void part_bounds(const dib_layout* l, int part, long long* beg, long long* end) {
+  const long long split = l->int_w_off[0], tail = l->enc_w_off[l->n_enc][0], all = l->n_params;
+  switch (part) {
+    case 0: *beg = 0; *end = split; break;
+    case 1: *beg = split; *end = all; break;
+    case 2: *beg = 0; *end = tail; break;
+    case 3: *beg = tail; *end = split; break;
+    default: *beg = 0; *end = all; break;
+  }
+}
+
 int dib_layout_part_range(const dib_layout* l, int part, int64_t* offset, int64_t* count) {
-  if (!l || !offset || !count || part < 0 || part > 1) return DIB_E_ARG;
-  const int64_t split = l->int_w_off[0];  // encoder-bank parameters come first, then the integration network
-  *offset = part == 0 ? 0 : split;
-  *count = part == 0 ? split : l->n_params - split;
+  if (!l || !offset || !count || part < 0 || part > 3) return DIB_E_ARG;
+  long long beg, end;
+  part_bounds(l, part, &beg, &end);
+  *offset = beg;
+  *count = end - beg;
   return DIB_OK;
 }
 
-// part: 0 = encoder bank, 1 = integration network, -1 = everything
+// part: see part_bounds
 int dib_grads_finalize_part(dib_layout* l, int batch, int part, float* grads, void* ws, dib_stream_t stream) {
-  if (!l || !grads || !ws || batch <= 0 || part < -1 || part > 1) return DIB_E_ARG;
+  if (!l || !grads || !ws || batch <= 0 || part < -1 || part > 3) return DIB_E_ARG;
   const auto m = l->map(batch);
   hipStream_t st = (hipStream_t)stream;
   float* w = (float*)ws;
   if (m.nsplit > 1) {
     // partial slabs are spaced align_up(n_params,4) apart
     const long long stride = align_up(l->n_params, 4);
-    const long long split = l->int_w_off[0];  // multiple of 4 by construction of the layout
-    const long long beg = part == 1 ? split : 0, end = part == 0 ? split : stride;
+    long long beg, end;
+    part_bounds(l, part, &beg, &end);
+    if (part == -1 || part == 1) end = stride;   // the last bucket carries the alignment tail of the buffer
     { ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for((end - beg) / 4)), dim3(256), 0, st,
                        (const float*)(w + m.wgrad_partial + beg), end - beg, m.nsplit, stride, grads + beg); }
     int rc = (int)hipGetLastError();
     if (rc) return rc;
   }
-  if (part != 1 && fused_bwd_ok(l)) {  // layer-1 weight/bias gradients: fixed-order sum of the fused kernel's partials
+  if (part != 1 && part != 3 && fused_bwd_ok(l)) {  // layer-1 weight/bias gradients: fixed-order sum of the fused kernel's partials
     ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_dw1_reduce_kernel, dim3(l->F, 16), dim3(256), 0, st, (const float*)(w + m.dw1_partial),
                        fused_gx(l, batch) * 8, l->F, l->enc_units[0], l->dev_fused_offs, l->dev_fused_offs + 3 * l->F,
@@ -1270,13 +1308,19 @@ int dib_add_inplace(float* dst, const float* src, int64_t n, dib_stream_t stream
   return (int)hipGetLastError();
 }
 
+int64_t dib_attention_stash_bytes(int B, int P, int H) {
+  if (B <= 0 || P <= 0 || H <= 0) return DIB_E_ARG;
+  const int64_t nt = cdiv(P, kAttnTile);
+  return (int64_t)sizeof(float) * B * H * nt * nt * kAttnTile * kAttnTile;
+}
+
 int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,
-                      float scale, float* o, float* lse, dib_stream_t stream) {
+                      float scale, float* o, float* lse, float* s_stash, dib_stream_t stream) {
   if (!q || !k || !v || !o || !lse || B <= 0 || P <= 0 || H <= 0 || ld < (int64_t)H * key_dim || (ld & 3)) return DIB_E_ARG;
   if (key_dim != kAttnD || (int64_t)P * ld >= (1ll << 30)) return DIB_E_UNSUPPORTED;   // 32-bit row offsets inside one neighbourhood
-  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) != 0) return DIB_E_ARG;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)s_stash) & 15) != 0) return DIB_E_ARG;
   DibAttnArgs a{};
-  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.P = P; a.H = H; a.ld = ld; a.scale = scale;
+  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.s_stash = s_stash; a.P = P; a.H = H; a.ld = ld; a.scale = scale;
   ProfScope ps(kProfAttnFwd, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
@@ -1289,14 +1333,14 @@ int64_t dib_attention_bwd_workspace_bytes(int B, int P, int H) {
 }
 
 int dib_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
-                      int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk, float* dv,
-                      void* ws, dib_stream_t stream) {
+                      const float* s_stash, int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk,
+                      float* dv, void* ws, dib_stream_t stream) {
   if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !ws || B <= 0 || P <= 0 || H <= 0 ||
       ld < (int64_t)H * key_dim || (ld & 3))
     return DIB_E_ARG;
   if (key_dim != kAttnD || (int64_t)P * ld >= (1ll << 30)) return DIB_E_UNSUPPORTED;   // 32-bit row offsets inside one neighbourhood
   if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv |
-        (uintptr_t)ws) & 15) != 0)
+        (uintptr_t)ws | (uintptr_t)s_stash) & 15) != 0)
     return DIB_E_ARG;   // every one of them is accessed with 16-byte loads / stores
   hipStream_t st = (hipStream_t)stream;
   float* delta = (float*)ws;
@@ -1306,15 +1350,19 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
                      delta);
   DibAttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.s_stash = const_cast<float*>(s_stash);
   a.P = P; a.H = H; a.ld = ld; a.scale = scale;
   const size_t lds = (size_t)DibAttnBwdLds * sizeof(float);
   static bool attr_set[64] = {};
   if (dib_attr_needed(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)dib_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)dib_attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)dib_attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   { ProfScope ps(kProfAttnBwd, st);
-    hipLaunchKernelGGL(dib_attn_bwd_kernel, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb); }
+    if (s_stash) hipLaunchKernelGGL(dib_attn_bwd_kernel<true>, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb);
+    else hipLaunchKernelGGL(dib_attn_bwd_kernel<false>, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   if (nkb > 1) {

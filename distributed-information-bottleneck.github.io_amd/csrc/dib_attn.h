@@ -3,9 +3,16 @@
 // `tf.keras.layers.MultiHeadAttention(number_heads_per_mha, key_dim)(x, x, x)`, 12 heads x key_dim 128; BASELINE config 5
 // asks for 4096 particles per neighbourhood).  Exact fp32 on v_mfma_f32_32x32x2_f32.
 //
-// The [P, P] score matrix of a (neighbourhood, head) never exists in HBM (at P = 4096 it is 805 MB per block and
-// neighbourhood): keys / values stream through LDS in tiles of 32, softmax is computed online, the backward pass
-// recomputes the probabilities from the stashed per-query log-sum-exp.
+// Keys / values stream through LDS in tiles of 32, softmax is computed online; the [P, P] PROBABILITIES never exist in HBM.
+// The backward pass needs the scores again.  Two modes (the caller chooses by passing a stash buffer or NULL):
+//   recompute  S = (scale Q) K^T is evaluated a second time in the backward from q, k and the per-query log-sum-exp: no
+//              extra memory, 5 tile products per (key tile, query tile) pair for 4 algorithmic ones;
+//   stash      the forward writes the raw score tiles (before the softmax) to HBM, tile-major [b][h][key tile][query tile]
+//              [32 queries][32 keys], and the backward reads them back: 4 products.  At 4 x 4096 particles x 12 heads that is
+//              3.2 GB per attention block (19 GB for the notebook's six - MI355X has 288 GB), written once with
+//              non-temporal 16-byte stores and read once with fully coalesced dword loads, both in the shadow of the MFMAs;
+//              it takes 64 of the 320 MFMAs, the Q / K operand fetches of the S product (32 ds_read_b128) out of every
+//              backward tile.  Same-box A/B: profiles/r03c_attention_stash_ab.txt.
 //
 //   forward   dib_attn_fwd_kernel : one wave = 32 queries (workgroup = 128 queries of one (neighbourhood, head)).
 //             S^T = K Q^T is evaluated TRANSPOSED (rows = keys, columns = queries): lane (j, h) then holds 16 keys of ONE
@@ -34,6 +41,7 @@
 #define DIB_PIN_ACC_A(x) asm volatile("" : "+a"(x))
 #define DIB_PIN_ACC_V(x) asm volatile("" : "+v"(x))
 
+typedef float dib_nt4a __attribute__((ext_vector_type(4)));  // native vector type for non-temporal 16-byte stores
 constexpr int kAttnD = 128;          // key_dim (= value dim) of the notebook's MultiHeadAttention
 constexpr int kAttnPitch = kAttnD + 4;
 constexpr int kAttnTile = 32;        // keys (fwd, dq) / queries (dkv) per LDS tile
@@ -45,8 +53,14 @@ struct DibAttnArgs {
   const float* d_o;                                 // bwd: dL/do [T, ld]
   const float* delta;                               // bwd: [B][H][P]
   float* dq; float* dk; float* dv;                  // bwd out [T, ld]
+  float* s_stash;                                   // fwd out / bwd in (NULL: recompute), see dib_attn_stash_tile
   int P, H; long long ld; float scale;
 };
+
+// first element of the 32 x 32 score tile (key tile kt, query tile qt) of (neighbourhood b, head): row-major [query][key]
+__device__ __forceinline__ long long dib_attn_stash_tile(int b, int H, int head, int n_tiles, int kt, int qt) {
+  return ((((long long)b * H + head) * n_tiles + kt) * n_tiles + qt) * (long long)(kAttnTile * kAttnTile);
+}
 
 // 32 rows x 128 floats of a [T, ld] matrix (rows row0.. clamped to row_max) -> registers (4 float4 per thread, 256 threads).
 // Passed BY VALUE as a struct of four named float4: as `float4 (&)[4]` one of the two tiles of the backward ended up as a
@@ -164,6 +178,14 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
         s = DIB_MFMA(kk.w, qf[q].w, s);
         kk = kn;
       }
+      if (a.s_stash != nullptr) {
+        // raw scores for the backward (stash mode): lane (query j, h) owns keys 8g + 4h + {0..3} of its query - one 16-byte
+        // non-temporal store per register group; values of keys / queries beyond P are finite and multiplied by 0 there
+        float* sp = a.s_stash + dib_attn_stash_tile(b, a.H, head, n_tiles, kt, blockIdx.x * 4 + wave) + l31 * kAttnTile + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          __builtin_nontemporal_store(dib_nt4a{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]}, reinterpret_cast<dib_nt4a*>(sp + 8 * g));
+      }
       // online softmax over this tile's keys (register r <-> key kt*32 + (r&3) + 8(r>>2) + 4h)
       if (kt == n_tiles - 1) {   // only the last tile can hold keys beyond P
 #pragma unroll
@@ -272,6 +294,7 @@ __device__ long long dib_attn_dbg[16];
 constexpr int kAttnPatch = 32 * 36;
 constexpr int DibAttnBwdLds = 2 * kAttnTile * kAttnPitch + 128 * kAttnPitch + 4 * kAttnPatch + 2 * kAttnTile;
 
+template <bool STASH>   // STASH: scores read back from the forward's stash (4 tile products); else S recomputed (5)
 __global__ void __launch_bounds__(256, 1)
 dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -343,6 +366,12 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
     if (tid < kAttnTile) { Ls[tid] = rl_; Ds[tid] = rd_; }      \
   } while (0)
   DIB_ATTN_STAGE_TILE();
+  // stash mode: this wave's row of score tiles [key tile][query tile 0 ..] - lane (key l31, h) reads rows (queries) 4h + ...
+  const float* stash_w = nullptr;
+  if constexpr (STASH) {
+    const int ktw = min((int)blockIdx.x * 4 + wave, n_tiles - 1);   // a wave whose keys all lie beyond P re-reads a real tile (x 0)
+    stash_w = a.s_stash + dib_attn_stash_tile(b, a.H, head, n_tiles, ktw, 0) + 4 * h * kAttnTile + l31;
+  }
 #ifdef DIB_ATTN_TIMING
   long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev_ = clock64();
@@ -360,10 +389,45 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
       lq[g] = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * h);
       dq4[g] = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * h);
     }
-    dib_f32x16 s, dp;
+    float sv[16];   // S[query r][this lane's key]
+    dib_f32x16 dp;
+    if constexpr (STASH) {
+      // scores from the forward's stash: 16 dword loads, each 2 x 128 contiguous bytes per wave (rows = queries
+      // (r&3) + 8(r>>2) + 4h, column = this lane's key); they land during the dP product
+      // (fetching tile qt + 1 one tile ahead, during the dQ product, measured 1 % slower: profiles/r03c_attention_stash_ab.txt)
+      const float* sp = stash_w + (long long)qt * (kAttnTile * kAttnTile);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    {
+      for (int r = 0; r < 16; ++r) sv[r] = __builtin_nontemporal_load(sp + ((r & 3) + 8 * (r >> 2)) * kAttnTile);
+      // dP[query][key] = dO V^T: A = dO tile rows (KC), B = this lane's V row (registers).  Two accumulators (even / odd
+      // k-blocks) so that the LDS fetch of the next step never sits between two MFMAs on the same accumulator
+      dib_f32x16 dp1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dp[r] = 0.f; dp1[r] = 0.f; }
+      float4 ga = dib_attn_kc(Gs, 0, l31, h), gb = dib_attn_kc(Gs, 1, l31, h);
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) {
+        const int qn_ = q < 14 ? q + 2 : 14;
+        const float4 gan = dib_attn_kc(Gs, qn_, l31, h), gbn = dib_attn_kc(Gs, qn_ + 1, l31, h);
+        __builtin_amdgcn_sched_barrier(0);
+        dp = DIB_MFMA(ga.x, vf[q].x, dp);
+        dp1 = DIB_MFMA(gb.x, vf[q + 1].x, dp1);
+        dp = DIB_MFMA(ga.y, vf[q].y, dp);
+        dp1 = DIB_MFMA(gb.y, vf[q + 1].y, dp1);
+        dp = DIB_MFMA(ga.z, vf[q].z, dp);
+        dp1 = DIB_MFMA(gb.z, vf[q + 1].z, dp1);
+        dp = DIB_MFMA(ga.w, vf[q].w, dp);
+        dp1 = DIB_MFMA(gb.w, vf[q + 1].w, dp1);
+        DIB_PIN_ACC_A(dp);
+        DIB_PIN_ACC_A(dp1);
+        __builtin_amdgcn_sched_barrier(0);
+        ga = gan; gb = gbn;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] += dp1[r];
+    } else {
+      dib_f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
       // S[query][key] and dP[query][key]: A = query-tile rows (KC), B = this lane's key row (K from the LDS block, V from
       // registers).  The three LDS fragments of step q + 1 are issued BEFORE the 8 MFMAs of step q (sched_barrier: left to
       // itself the scheduler sinks them to just in front of their use and the wave - alone on its SIMD - eats one LDS
@@ -388,6 +452,8 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
         __builtin_amdgcn_sched_barrier(0);
         qq = qn; gg = gn; kk = kn;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = s[r];
     }
     DIB_T(1);   // S / dP products issued
     // first operand fragments of the dV / dK products: in flight during the exponentials
@@ -409,7 +475,7 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = 4 * g + t;
-        const float p = __expf(s[r] - lv[t]) * kmul;
+        const float p = __expf(sv[r] - lv[t]) * kmul;
         pv[r] = p;                                       // P
         dsv[r] = p * (dp[r] - dl[t]);                    // dS
       }
@@ -424,7 +490,8 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
         for (int dt = 0; dt < 4; ++dt) gvn[dt] = dib_attn_mc(Gs, q + 1, 32 * dt + l31, h);
       }
       __builtin_amdgcn_sched_barrier(0);
-      DIB_PIN_ACC_A(s);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) DIB_PIN_ACC_V(sv[r]);
       DIB_PIN_ACC_A(dp);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].x, pv[4 * q + 0], dv[dt]);
@@ -475,9 +542,9 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = 4 * g + t;
-        const float p = __expf(s[r] - lv[t]) * kmul;
+        const float p = __expf(sv[r] - lv[t]) * kmul;
         dp[r] = p * (dp[r] - dl[t]);                   // dS
-        s[r] = p;                                      // P
+        sv[r] = p;                                     // P
       }
     }
     // dS^T into this wave's patch: patch[query][key]
@@ -496,13 +563,13 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].x, s[4 * q + 0], dv[dt]);
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].x, sv[4 * q + 0], dv[dt]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].y, s[4 * q + 1], dv[dt]);
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].y, sv[4 * q + 1], dv[dt]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].z, s[4 * q + 2], dv[dt]);
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].z, sv[4 * q + 2], dv[dt]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].w, s[4 * q + 3], dv[dt]);
+      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].w, sv[4 * q + 3], dv[dt]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) DIB_PIN_ACC_A(dv[dt]);
       __builtin_amdgcn_sched_barrier(0);

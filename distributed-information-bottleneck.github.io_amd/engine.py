@@ -206,16 +206,20 @@ class HipEngine:
               "dib_loss_fwd_bwd")
 
     def part_range(self, part: int):
-        """(offset, count) of all-reduce bucket `part` (0 = encoder bank, 1 = integration network) in the flat buffers."""
+        """(offset, count) of gradient bucket `part` in the flat buffers (include/dib_hip.h): 0 = encoder bank,
+        1 = integration network, 2 = encoder layers before the last, 3 = last encoder layer (0 = 2 + 3)."""
         off, cnt = c_int64(), c_int64()
         check(self.lib.dib_layout_part_range(self.layout, part, byref(off), byref(cnt)), "dib_layout_part_range")
         return off.value, cnt.value
 
     def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float,
-                 on_integration_grads_ready=None, hidden_only: bool = False) -> None:
-        """Backward pass.  The integration-network gradients (bucket 1) are final right after dib_integration_bwd;
-        `on_integration_grads_ready(grads_slice)` is called at that point so a data-parallel caller can start their
-        all-reduce while the encoder-bank backward (the bulk of the step) is still running."""
+                 on_integration_grads_ready=None, hidden_only: bool = False, on_encoder_front_grads_ready=None) -> None:
+        """Backward pass, with the hooks of the data-parallel bucket protocol:
+        `on_integration_grads_ready(grads_slice)` is called as soon as the integration network's gradients (bucket 1) are
+        final - right after dib_integration_bwd - so their all-reduce runs under the whole encoder-bank backward;
+        `on_encoder_front_grads_ready(grads_slice)` (three-bucket protocol, needs the first hook too) is called when the
+        gradients of the encoder layers before the last (bucket 2) are final; the last layer's weight gradient (bucket 3)
+        is computed after it, under that all-reduce, and is the only part left for the caller to reduce afterwards."""
         ws = self.workspace(batch)
         st = self._stream()
         fn = self.lib.dib_integration_bwd_hidden if hidden_only else self.lib.dib_integration_bwd
@@ -226,6 +230,18 @@ class HipEngine:
             off, cnt = self.part_range(1)
             on_integration_grads_ready(self.grads[off: off + cnt])
         # (row_idx / row0 / seed / step are not needed by the device backward: eps * sigma = ws[U] - mu)
+        if on_encoder_front_grads_ready is not None:
+            assert on_integration_grads_ready is not None, "the three-bucket protocol needs both hooks"
+            for stage, part in ((1, 2), (2, 3)):
+                check(self.lib.dib_encoder_bank_bwd_stage(self.layout, batch, _ptr(self.params), _ptr(self.grads),
+                                                          _ptr(self.beta_dev), float(inv_global_batch), stage, _ptr(ws), st),
+                      "dib_encoder_bank_bwd_stage")
+                check(self.lib.dib_grads_finalize_part(self.layout, batch, part, _ptr(self.grads), _ptr(ws), st),
+                      "dib_grads_finalize_part")
+                if stage == 1:
+                    off, cnt = self.part_range(2)
+                    on_encoder_front_grads_ready(self.grads[off: off + cnt])
+            return
         check(self.lib.dib_encoder_bank_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads),
                                             _ptr(self.beta_dev), float(inv_global_batch), _ptr(ws), st), "dib_encoder_bank_bwd")
         check(self.lib.dib_grads_finalize_part(self.layout, batch, 0 if on_integration_grads_ready is not None else -1,
@@ -238,7 +254,7 @@ class HipEngine:
 
     def train_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
                    inv_global_batch: Optional[float] = None, accumulate: bool = True,
-                   on_integration_grads_ready=None) -> None:
+                   on_integration_grads_ready=None, on_encoder_front_grads_ready=None) -> None:
         """fwd + loss + bwd for the local rows; grads (partial sums over local rows / B_global) land in
         self.grads, ready for the data-parallel all-reduce(sum) and the optimizer step."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
@@ -253,7 +269,8 @@ class HipEngine:
                                                  self._stream()), "dib_output_head_fused")
         else:
             self.loss(loss_kind, y, row_idx, row0, batch, inv)
-        self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=fused_head)
+        self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=fused_head,
+                      on_encoder_front_grads_ready=on_encoder_front_grads_ready)
         if accumulate:
             self.accumulate_metrics(batch, inv)
 
@@ -288,15 +305,13 @@ class HipEngine:
         idx_stage = torch.zeros(batch, dtype=torch.int32, device=self.device)
         self.workspace(batch)
         self._ws_pinned.add(batch)  # the graph bakes this workspace's pointer in: never evict it
-        saved = (self.metrics_acc.clone(), self.grads.clone())
-        # eager warm-up: loads modules / sets kernel attributes outside the capture; state is restored afterwards
-        self.forward(x, idx_stage, 0, batch, seed, 0)
-        self.loss(loss_kind, y, idx_stage, 0, batch, inv_global_batch)
-        if train:
-            self.backward(idx_stage, 0, batch, seed, 0, inv_global_batch)
-        torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # Eager warm-up with EXACTLY the launch sequence that is captured below (the fused output head, the hidden-only
+        # integration passes, the optimizer and the counter bump included): every kernel's module load and every
+        # hipFuncSetAttribute happens outside the capture.  All state the warm-up touches is restored afterwards.
+        saved = [t.clone() for t in (self.metrics_acc, self.grads, self.params, self.adam_m, self.adam_v, self.t_dev,
+                                     self.step_dev)]
+
+        def body():
             if train:
                 self.train_step(x, y, idx_stage, 0, batch, seed, 0, loss_kind, inv_global_batch)
                 if optimizer == "adam":
@@ -306,9 +321,28 @@ class HipEngine:
             else:
                 self.eval_step(x, y, idx_stage, 0, batch, seed, 0, loss_kind, inv_global_batch)
             self.step_dev.add_(1)
-        self.metrics_acc.copy_(saved[0])
-        self.grads.copy_(saved[1])
+
+        def restore():
+            for t, v in zip((self.metrics_acc, self.grads, self.params, self.adam_m, self.adam_v, self.t_dev, self.step_dev),
+                            saved):
+                t.copy_(v)
+
+        body()
+        restore()
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        restore()   # (capture does not execute, but keep the contract obvious: the caller's state is untouched)
         return graph, idx_stage
+
+    def release_step_graph(self, batch: int) -> None:
+        """The caller has dropped every graph captured for `batch` rows: its workspace may be evicted again (it re-enters
+        the LRU as the most recent entry).  Without this, pinned workspaces accumulate for the lifetime of the engine."""
+        self._ws_pinned.discard(batch)
+        unpinned = [b for b in self._ws if b not in self._ws_pinned]
+        while len(unpinned) > self._WS_KEEP:
+            self._ws.pop(unpinned.pop(0))
 
     def adam_step(self, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0) -> None:
         check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),

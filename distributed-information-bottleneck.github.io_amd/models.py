@@ -146,6 +146,9 @@ class DistributedIBNet:
         self._device = device
         self._engine = None
         self._engine_factory = None  # tests inject a checker engine here; the product default is HipEngine
+        # data-parallel gradient all-reduce buckets (fit under torch.distributed): 3 = integration / encoder front layers /
+        # last encoder layer, each issued as soon as it is final (default); 2 = integration / encoder bank; 1 = one all-reduce
+        self.dp_buckets = int(os.environ.get("DIB_DP_BUCKETS", "3"))
         self.beta = _BetaVariable(self, 1.0)
         self.feature_encoders = [_FeatureEncoder(self, f) for f in range(self.number_features)]
         self.optimizer = None
@@ -418,22 +421,27 @@ class DistributedIBNet:
                 lo = (gb * rank) // world
                 hi = (gb * (rank + 1)) // world
                 # Every rank issues the SAME collectives every step, rows or no rows (a tail batch with fewer rows than
-                # ranks leaves some ranks empty: they contribute zeros): bucket 1 (integration network) is all-reduced
-                # while the encoder-bank backward still runs, bucket 0 (encoder bank) after it.
+                # ranks leaves some ranks empty: they contribute zeros).  Gradient buckets of the layer-major flat buffer
+                # (DESIGN 6), each all-reduced (RCCL, async) as soon as it is final:
+                #   1 integration network   - under the whole encoder-bank backward
+                #   2 encoder front layers  - under the last encoder layer's weight gradient      (dp_buckets == 3)
+                #   3 last encoder layer    - the only exposed one                                (dp_buckets == 3)
+                #   0 = 2 + 3 as one bucket after the backward                                    (dp_buckets == 2)
                 pending = []
-                two_buckets = dist is not None and hasattr(eng, "part_range")
+                nb = self.dp_buckets if (dist is not None and hasattr(eng, "part_range")) else 1
+                issue = lambda g: pending.append(dist.all_reduce(g, async_op=True))
                 if hi > lo:
-                    overlap = (lambda g: pending.append(dist.all_reduce(g, async_op=True))) if two_buckets else None
                     eng.train_step(xd, yd, order_dev[s0 + lo: s0 + hi], 0, hi - lo, self.noise_seed, self._step, kind,
-                                   inv_global_batch=1.0 / gb, on_integration_grads_ready=overlap)
+                                   inv_global_batch=1.0 / gb, on_integration_grads_ready=issue if nb >= 2 else None,
+                                   **(dict(on_encoder_front_grads_ready=issue) if nb == 3 else {}))
                 else:
                     eng.grads.zero_()
-                    if two_buckets:
-                        off, cnt = eng.part_range(1)
-                        pending.append(dist.all_reduce(eng.grads[off: off + cnt], async_op=True))
-                if two_buckets:
-                    off, cnt = eng.part_range(0)
-                    pending.append(dist.all_reduce(eng.grads[off: off + cnt], async_op=True))
+                    for part in ((1,) if nb == 2 else (1, 2) if nb == 3 else ()):
+                        off, cnt = eng.part_range(part)
+                        issue(eng.grads[off: off + cnt])
+                if nb >= 2:
+                    off, cnt = eng.part_range(3 if nb == 3 else 0)
+                    issue(eng.grads[off: off + cnt])
                     for w in pending:
                         w.wait()
                 elif dist is not None:

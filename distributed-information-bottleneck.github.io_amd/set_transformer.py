@@ -112,12 +112,15 @@ class SetTransformerDIB:
                  ff_arch_per_block: Sequence[int] = (128, 32), final_processing_arch: Sequence[int] = (256,),
                  output_dimensionality: int = 1, logvar_initialization: float = -3.0, layer_norm_epsilon: float = 1e-3,
                  *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto",
-                 _checker_backend=None):
+                 attention_score_stash_bytes: int = 64 << 30, _checker_backend=None):
         """_checker_backend: TEST SEAM (like DistributedIBNet._engine_factory): the CPU tests of the host logic - train_step's
         data-parallel protocol, fit's schedules - inject an object that implements forward / loss_and_backward / _loss_only /
         adam_step on the float64 CPU checker (tests/_oracle_set_transformer.py).  The product never sets it: without it the
         constructor demands a GPU and the HIP library.
-        attention: "flash" = dib_attention_fwd/bwd (scores never in HBM; key_dim must be 128), "gemm" = the products as
+        attention_score_stash_bytes: flash attention keeps the raw [P, P] score tiles of every block for the backward
+        (4 tile products per tile pair instead of 5, include/dib_st.h) when all blocks' tiles of a batch shape fit this budget
+        (4 x 4096 particles: 19.3 GB of the 288); above it - or with 0 - the backward recomputes them.
+        attention: "flash" = dib_attention_fwd/bwd (probabilities never in HBM; key_dim must be 128), "gemm" = the products as
         grouped GEMMs with the [P, P] probabilities stashed in HBM (any key_dim), "auto" (per batch shape, key_dim == 128):
         flash - since the round-2 rewrite of the attention kernels it is the faster path at every measured shape (ms/step flash
         vs gemm: 32 x 50: 3.08 / 4.14, 4 x 512: 4.29 / 4.88, 2 x 2048: 15.0 / 15.7, 4 x 4096: 77.2 / 100.5;
@@ -148,6 +151,7 @@ class SetTransformerDIB:
         if attention == "flash" and self.key_dim != 128:
             raise ValueError("attention='flash' needs key_dim == 128 (the notebook's value)")
         self.attention = attention
+        self.attention_score_stash_bytes = int(attention_score_stash_bytes)
         self.attention_impl = "flash" if (attention == "flash" or (attention == "auto" and self.key_dim == 128)) else "gemm"
         assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
         # ---- flat parameter layout (Keras creation order) ----
@@ -321,6 +325,14 @@ class SetTransformerDIB:
         take("kl_ws", int(self.lib.dib_token_kl_workspace_bytes(T, D)) // 4 + 4)
         take("loss_ws", int(self.lib.dib_loss_rows_workspace_bytes(B)) // 4 + 4)
         ws = torch.zeros(o, dtype=torch.float32, device=self.device)
+        # flash attention, stash mode: one score-tile buffer per block, outside the fp32-indexed workspace (its own allocation:
+        # 3.2 GB per block at 4 x 4096); None = recompute mode
+        stash = None
+        if impl == "flash":
+            per_block = int(self.lib.dib_attention_stash_bytes(B, P, H))
+            if 0 < per_block * self.number_attention_blocks <= self.attention_score_stash_bytes:
+                stash = [torch.empty(per_block // 4, dtype=torch.float32, device=self.device)
+                         for _ in range(self.number_attention_blocks)]
 
         # weight-gradient target: contraction over T tokens is split into slabs when T is large (fixed-order reduce)
         # (from 512 tokens up: with one slab the q/k/v and output-projection wgrads of the reference size, 1600 tokens, ran on
@@ -439,7 +451,7 @@ class SetTransformerDIB:
         for gg in g.values():
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
-                    enc_units=enc_units)
+                    enc_units=enc_units, stash=stash)
         # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
         # (training batch, validation batch, a ragged tail), evict least recently used beyond that
         step_keys = [k for k in self._plans if k[0] != "enc"]
@@ -495,8 +507,8 @@ class SetTransformerDIB:
             else:
                 HK = H * self.key_dim
                 check(lib.dib_attention_fwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]), B, P, H,
-                                            self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]), st),
-                      "dib_attention_fwd")
+                                            self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
+                                            _ptr(pl["stash"][b]) if pl["stash"] else c_void_p(0), st), "dib_attention_fwd")
             g[f"b{b}_o_fwd"].run(lib, st)
             check(lib.dib_add_layernorm_fwd(_ptr(ws, off[xin]), _ptr(ws, off[f"b{b}_mha"]), T, D,
                                             _ptr(self.params, self.offsets[pre + "ln1_g"]), _ptr(self.params, self.offsets[pre + "ln1_b"]),
@@ -578,8 +590,8 @@ class SetTransformerDIB:
             else:
                 HK = H * self.key_dim
                 check(lib.dib_attention_bwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
-                                            _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]), B, P, H,
-                                            self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
+                                            _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
+                                            _ptr(pl["stash"][b]) if pl["stash"] else c_void_p(0), B, P, H, self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
                                             _ptr(ws, off["attn_delta"]), st), "dib_attention_bwd")
             g[f"b{b}_qkv_wgrad"].run(lib, st)
             g[f"b{b}_qkv_dgrad"].run(lib, st)

@@ -142,9 +142,17 @@ int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, fl
  * workspace (library noise or DIB_FWD_DETERMINISTIC). */
 int dib_encoder_bank_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
                          float inv_global_batch, void* ws, dib_stream_t stream);
+/* The same work in two stages, for the data-parallel caller that wants the encoder bank's gradients in two all-reduce
+ * buckets: stage 1 = the gradient chain and every weight gradient except the last encoder layer's (then
+ * dib_grads_finalize_part(2) and the all-reduce of part 2), stage 2 = the last layer's weight gradient, which needs nothing
+ * of stage 1's weight gradients and runs under that all-reduce (then part 3).  Stage 1 then stage 2 == dib_encoder_bank_bwd. */
+int dib_encoder_bank_bwd_stage(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                               float inv_global_batch, int stage, void* ws, dib_stream_t stream);
 /* reduce the split-batch wgrad partials into `grads` (fixed order => deterministic).
- * _part finalises one all-reduce bucket: 0 = encoder bank, 1 = integration network (its gradients are complete right
- * after dib_integration_bwd, so its RCCL all-reduce can overlap the encoder-bank backward), -1 = everything. */
+ * _part finalises one all-reduce bucket of the layer-major flat buffer: 0 = encoder bank, 1 = integration network (its
+ * gradients are complete right after dib_integration_bwd, so its RCCL all-reduce can overlap the encoder-bank backward),
+ * 2 = encoder layers before the last, 3 = last encoder layer (0 = 2 + 3, contiguous), -1 = everything.
+ * dib_layout_part_range: (offset, count) of a part in floats. */
 int dib_grads_finalize(dib_layout* l, int batch, float* grads, void* ws, dib_stream_t stream);
 int dib_grads_finalize_part(dib_layout* l, int batch, int part, float* grads, void* ws, dib_stream_t stream);
 int dib_layout_part_range(const dib_layout* l, int part, int64_t* offset, int64_t* count);

@@ -74,11 +74,14 @@ class OracleEngine:
         acc[self.F + 2] += batch
 
     def part_range(self, part):
+        """same bucket numbering as include/dib_hip.h: 0 encoder bank, 1 integration, 2 encoder front layers, 3 last layer"""
         split = min(b["offset"] for b in self.blocks if b["net"] == 1)
-        return (0, split) if part == 0 else (split, self.n_params - split)
+        last = max(b["layer"] for b in self.blocks if b["net"] == 0)
+        tail = min(b["offset"] for b in self.blocks if b["net"] == 0 and b["layer"] == last)
+        return {0: (0, split), 1: (split, self.n_params - split), 2: (0, tail), 3: (tail, split - tail)}[part]
 
     def train_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None, accumulate=True,
-                   on_integration_grads_ready=None):
+                   on_integration_grads_ready=None, on_encoder_front_grads_ready=None):
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         rows, xb, c = self._fwd(x, row_idx, row0, batch, seed, step)
         yb = y.numpy()[rows]
@@ -86,9 +89,12 @@ class OracleEngine:
                                   loss_scale_rows=int(round(1.0 / inv)))
         self.grads.copy_(torch.from_numpy(params_to_flat(self.blocks, g, self.n_params, np.float64)))
         self._gstruct = g
-        if on_integration_grads_ready is not None:  # two-bucket data-parallel protocol of the product engine
+        if on_integration_grads_ready is not None:  # bucket protocol of the product engine: same hooks, same order
             off, cnt = self.part_range(1)
             on_integration_grads_ready(self.grads[off: off + cnt])
+        if on_encoder_front_grads_ready is not None:
+            off, cnt = self.part_range(2)
+            on_encoder_front_grads_ready(self.grads[off: off + cnt])
         if accumulate:
             self._account(c, task, yb, loss_kind, batch, inv)
 

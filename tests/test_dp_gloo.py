@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _run(rank, world, port, out_dir, n_rows=80):
+def _run(rank, world, port, out_dir, n_rows=80, buckets=3):
     for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,12 +41,13 @@ def _run(rank, world, port, out_dir, n_rows=80):
     x, y = x[:n_rows], y[:n_rows]
     model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=1, shuffle_seed=2, init_seed=3)
     model._engine_factory = OracleEngine
+    model.dp_buckets = buckets
     opt = dib_amd.optimizers.get("adam")
     opt.learning_rate = 5e-3
     model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
     cb = dib_amd.InfoBottleneckAnnealingCallback(1e-3, 0.5, 1, 2)
     hist = model.fit(x, y, epochs=3, batch_size=32, callbacks=[cb], verbose=False, validation_data=(x[:30], y[:30]))
-    np.savez(os.path.join(out_dir, f"n{n_rows}_w{world}_r{rank}.npz"), params=model._engine.get_flat_params(),
+    np.savez(os.path.join(out_dir, f"n{n_rows}_w{world}_r{rank}_b{buckets}.npz"), params=model._engine.get_flat_params(),
              **{k: np.array(v) for k, v in hist.history.items()})
     if world > 1:
         dist.barrier()
@@ -54,13 +55,16 @@ def _run(rank, world, port, out_dir, n_rows=80):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_fit_equals_single_process(tmp_path):
+@pytest.mark.parametrize("buckets", [1, 2, 3])
+def test_two_rank_fit_equals_single_process(tmp_path, buckets):
+    """buckets: the gradient all-reduce protocol of fit() - 1 = one all-reduce after the backward, 2 = integration bucket
+    issued early + encoder bank, 3 = integration / encoder front layers / last encoder layer (the default)."""
     out = str(tmp_path)
     _run(0, 1, _free_port(), out)
-    mp.spawn(_run, args=(2, _free_port(), out), nprocs=2, join=True)
-    ref = np.load(os.path.join(out, "n80_w1_r0.npz"))
-    r0 = np.load(os.path.join(out, "n80_w2_r0.npz"))
-    r1 = np.load(os.path.join(out, "n80_w2_r1.npz"))
+    mp.spawn(_run, args=(2, _free_port(), out, 80, buckets), nprocs=2, join=True)
+    ref = np.load(os.path.join(out, "n80_w1_r0_b3.npz"))
+    r0 = np.load(os.path.join(out, f"n80_w2_r0_b{buckets}.npz"))
+    r1 = np.load(os.path.join(out, f"n80_w2_r1_b{buckets}.npz"))
     assert np.allclose(r0["params"], r1["params"], rtol=0, atol=0), "ranks diverged"
     assert np.allclose(r0["params"], ref["params"], rtol=1e-9, atol=1e-12)
     for k in ref.files:
@@ -71,15 +75,16 @@ def test_two_rank_fit_equals_single_process(tmp_path):
 
 
 @pytest.mark.timeout(300)
-def test_three_rank_fit_with_tail_batch_smaller_than_world(tmp_path):
+@pytest.mark.parametrize("buckets", [2, 3])
+def test_three_rank_fit_with_tail_batch_smaller_than_world(tmp_path, buckets):
     """n % batch_size = 1 on 3 ranks: two ranks have NO rows in the tail batch.  Every rank must still issue the same
-    collectives (both gradient buckets) - a mismatch hangs RCCL (round-1 advisor finding) - and the result must equal
-    the single-process run."""
+    collectives (every gradient bucket, in the same order) - a mismatch hangs RCCL (round-1 advisor finding) - and the
+    result must equal the single-process run."""
     out = str(tmp_path)
     _run(0, 1, _free_port(), out, 65)
-    mp.spawn(_run, args=(3, _free_port(), out, 65), nprocs=3, join=True)
-    ref = np.load(os.path.join(out, "n65_w1_r0.npz"))
-    rs = [np.load(os.path.join(out, f"n65_w3_r{r}.npz")) for r in range(3)]
+    mp.spawn(_run, args=(3, _free_port(), out, 65, buckets), nprocs=3, join=True)
+    ref = np.load(os.path.join(out, "n65_w1_r0_b3.npz"))
+    rs = [np.load(os.path.join(out, f"n65_w3_r{r}_b{buckets}.npz")) for r in range(3)]
     for r in rs:
         assert np.array_equal(r["params"], rs[0]["params"]), "ranks diverged"
         for k in ref.files:

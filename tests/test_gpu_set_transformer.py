@@ -21,12 +21,16 @@ GOLD = os.path.join(ROOT, "tests", "golden", "set_transformer_forward.npz")
 
 
 def _model(spec: sto.SetTransformerSpec, seed=0, noise_seed=5, bias_scale=0.05, attention="auto"):
+    """attention: "auto" | "gemm" | "flash" (score tiles stashed for the backward) | "flash_recompute" (no stash)."""
     import dib_amd
+    kw = {}
+    if attention == "flash_recompute":
+        attention, kw = "flash", dict(attention_score_stash_bytes=0)
     m = dib_amd.SetTransformerDIB(spec.particle_feature_dimensions, spec.number_positional_encoding_frequencies,
                                   spec.particle_encoder_arch_spec, spec.bottleneck_dimension, spec.key_dim,
                                   spec.number_heads_per_mha, spec.number_attention_blocks, spec.ff_arch_per_block,
                                   spec.final_processing_arch, spec.output_dimensionality, spec.logvar_initialization,
-                                  spec.layer_norm_epsilon, init_seed=seed, noise_seed=noise_seed, attention=attention)
+                                  spec.layer_norm_epsilon, init_seed=seed, noise_seed=noise_seed, attention=attention, **kw)
     p = m.get_params()
     rng = np.random.default_rng(seed + 100)
     for k in p:  # non-trivial biases / LayerNorm parameters (Keras initialises them to 0 / 1, which hides mistakes)
@@ -82,6 +86,9 @@ SPECS = {
     "flash_multi_tile": (sto.SetTransformerSpec(number_attention_blocks=1, number_heads_per_mha=3), 2, 300, "flash"),
     "gemm_multi_tile": (sto.SetTransformerSpec(number_attention_blocks=1, number_heads_per_mha=3), 2, 300, "gemm"),
     "flash_33": (sto.SetTransformerSpec(number_attention_blocks=1, number_heads_per_mha=2), 3, 33, "flash"),
+    # the backward without the score stash (S recomputed from q, k, lse)
+    "flash_recompute_multi_tile": (sto.SetTransformerSpec(number_attention_blocks=1, number_heads_per_mha=3), 2, 300, "flash_recompute"),
+    "flash_recompute_33": (sto.SetTransformerSpec(number_attention_blocks=2, number_heads_per_mha=2), 3, 33, "flash_recompute"),
 }
 
 
@@ -89,7 +96,7 @@ SPECS = {
 def test_forward_backward_parity(name):
     spec, B, P, attention = SPECS[name]
     m, p = _model(spec, seed=sum(map(ord, name)) % 97, attention=attention)
-    assert m.attention_impl == attention
+    assert m.attention_impl == attention.split("_")[0]
     rng = np.random.default_rng(B * 100 + P)
     feats = rng.standard_normal((B, P, spec.particle_feature_dimensions)).astype(np.float32)
     y = (rng.random((B, 1)) > 0.5).astype(np.float32)
@@ -98,6 +105,8 @@ def test_forward_backward_parity(name):
     pred = m.forward(feats, step=step).cpu().numpy()
     m.loss_and_backward(y)
     torch.cuda.synchronize()
+    if m.attention_impl == "flash":
+        assert (m.last["plan"]["stash"] is None) == (attention == "flash_recompute")
     E = spec.bottleneck_dimension
     eps = _eps(5, step, B * P, E).reshape(B, P, E)
     vals, grads = sto.loss_and_grads(spec, p, feats.astype(np.float64), eps, y.astype(np.float64), beta)
@@ -183,7 +192,48 @@ def test_config5_size_4096_particles_flash_all_gradients():
     Reference: ...set_transformer.ipynb:332-389 (model), :419-431 (bottleneck + loss)."""
     spec = sto.SetTransformerSpec(number_attention_blocks=2)
     m = _masked_parity(spec, 2, 4096, seed=12, attention="flash")
-    assert m.attention_impl == "flash" and m.last["plan"]["nsplit"] == 32
+    assert m.attention_impl == "flash" and m.last["plan"]["nsplit"] == 32 and m.last["plan"]["stash"] is not None
+
+
+@pytest.mark.parametrize("B,P,H", [(2, 300, 3), (1, 33, 2), (1, 1100, 1)])
+def test_attention_backward_score_stash_equals_recompute(B, P, H):
+    """dib_attention_fwd/bwd in both modes on the same inputs (include/dib_st.h): the stashed score tiles are the numbers the
+    backward would recompute (same products, same k order), so o, lse and dq / dk / dv agree to fp32 round-off; partial last
+    key / query tiles and key blocks whose last waves have no keys included."""
+    import ctypes
+    from dib_amd._lib import check, load_library
+    lib = load_library()
+    D, dev = 128, torch.device("cuda:0")
+    T, ld = B * P, H * D
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + P)
+    mk = lambda: (torch.randn((T, ld), generator=g) * 0.5).to(dev)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale = 1.0 / D ** 0.5
+    res = {}
+    for mode in ("stash", "recompute"):
+        o, dq, dk, dv = (torch.zeros_like(q) for _ in range(4))
+        lse = torch.zeros(B * H * P, device=dev)
+        ws = torch.zeros(int(lib.dib_attention_bwd_workspace_bytes(B, P, H)) // 4, device=dev)
+        stash = torch.full((int(lib.dib_attention_stash_bytes(B, P, H)) // 4,), float("nan"), device=dev) if mode == "stash" else None
+        sp = p(stash) if stash is not None else ctypes.c_void_p(0)
+        check(lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, ld, scale, p(o), p(lse), sp, st), "fwd")
+        check(lib.dib_attention_bwd(p(q), p(k), p(v), p(o), p(do), p(lse), sp, B, P, H, D, ld, scale, p(dq), p(dk), p(dv), p(ws),
+                                    st), "bwd")
+        torch.cuda.synchronize()
+        res[mode] = (o, lse, dq, dk, dv)
+    for name, a, b in zip(("o", "lse", "dq", "dk", "dv"), res["stash"], res["recompute"]):
+        assert torch.isfinite(a).all(), name
+        assert (a - b).abs().max() <= 1e-6 * b.abs().max(), (name, float((a - b).abs().max()), float(b.abs().max()))
+    # and against plain float64 attention
+    qd, kd, vd, dod = (t.double().cpu().view(B, P, H, D).requires_grad_(True) for t in (q, k, v, do))
+    att = torch.softmax(torch.einsum("bphd,bqhd->bhpq", qd, kd) * scale, -1)
+    od = torch.einsum("bhpq,bqhd->bphd", att, vd)
+    gq, gk, gv = torch.autograd.grad((od * dod.detach()).sum(), [qd, kd, vd])
+    for name, a, b in (("o", res["stash"][0], od), ("dq", res["stash"][2], gq), ("dk", res["stash"][3], gk), ("dv", res["stash"][4], gv)):
+        b = b.detach().reshape(T, ld)
+        assert (a.double().cpu() - b).abs().max() <= 2e-5 * b.abs().max(), name
 
 
 def test_train_steps_match_oracle_adam():

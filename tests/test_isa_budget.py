@@ -65,7 +65,10 @@ def test_attention_forward_two_waves_per_simd_no_scratch(kernels):
 
 
 def test_attention_backward_accumulators_stay_in_agprs(kernels):
-    k = _one(kernels, "dib_attn_bwd_kernel")
+    ks = _one(kernels, "dib_attn_bwd_kernelILb1E")   # stash mode: scores read back from the forward's stash
+    assert ks["ScratchSize"] == 0 and ks["mfma"] == 256             # dP (64) + dV, dK (128) + dQ (64): the algorithmic four
+    assert ks["accvgpr_write"] <= 320 and ks["accvgpr_read"] <= 120 and ks["NumVgprs"] + ks["NumAgprs"] <= 512
+    k = _one(kernels, "dib_attn_bwd_kernelILb0E")    # recompute mode
     assert k["ScratchSize"] == 0
     assert k["mfma"] == 320               # S, dP (128) + dV, dK (128) + dQ (64) per 32-query tile
     # zero-initialisations of the accumulators are the only v_accvgpr_write in the kernel (128 dV/dK once + 96 per tile + the

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--particles", type=int, default=4096)
     ap.add_argument("--heads", type=int, default=12)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--stash", type=int, default=1, help="1: forward stashes the score tiles, backward reads them; 0: recompute")
     a = ap.parse_args()
     import dib_amd  # noqa: F401
     from dib_amd._lib import check, load_library
@@ -35,10 +36,12 @@ def main():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     scale = 1.0 / D ** 0.5
-    fwd = lambda: check(lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, ld, scale, p(o), p(lse), st), "fwd")
-    bwd = lambda: check(lib.dib_attention_bwd(p(q), p(k), p(v), p(o), p(do), p(lse), B, P, H, D, ld, scale, p(dq), p(dk), p(dv),
+    stash = torch.empty(int(lib.dib_attention_stash_bytes(B, P, H)) // 4, device=dev) if a.stash else None
+    sp = p(stash) if a.stash else ctypes.c_void_p(0)
+    fwd = lambda: check(lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, ld, scale, p(o), p(lse), sp, st), "fwd")
+    bwd = lambda: check(lib.dib_attention_bwd(p(q), p(k), p(v), p(o), p(do), p(lse), sp, B, P, H, D, ld, scale, p(dq), p(dk), p(dv),
                                               p(ws), st), "bwd")
-    out = {"B": B, "P": P, "H": H}
+    out = {"B": B, "P": P, "H": H, "score_stash": bool(a.stash)}
     for name, fn, units in (("fwd", fwd, 2), ("bwd", bwd, 4)):
         fn(); fn()
         torch.cuda.synchronize()

@@ -33,9 +33,9 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     i64, f32 = ctypes.c_int64, ctypes.c_float
     scale = 1.0 / D ** 0.5
-    assert lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, i64(ld), f32(scale), p(o), p(lse), st) == 0
+    assert lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, i64(ld), f32(scale), p(o), p(lse), ctypes.c_void_p(0), st) == 0
     for _ in range(3):
-        assert lib.dib_attention_bwd(p(q), p(k), p(v), p(o), p(do), p(lse), B, P, H, D, i64(ld), f32(scale), p(dq), p(dk), p(dv),
+        assert lib.dib_attention_bwd(p(q), p(k), p(v), p(o), p(do), p(lse), ctypes.c_void_p(0), B, P, H, D, i64(ld), f32(scale), p(dq), p(dk), p(dv),
                                      p(ws), st) == 0
     out = (ctypes.c_longlong * 16)()
     assert lib.dib_attn_debug_read(out) == 0
