@@ -224,10 +224,39 @@ def config5_set_transformer(dev, nb=4, npart=4096, nfeat=16, steps=4, warmup=2):
                            "frac": by[dom]["frac"], "traffic": HBM_TRAFFIC.get(dom + "@config5"), "kernel": dom,
                            "avg_launch_ms": by[dom]["avg_launch_ms"], "launches": by[dom]["launches"],
                            "flops_per_launch": by[dom]["flops_per_launch"],
-                           "note": "algorithmic FLOPs (4 backward products = 2 x forward); the kernel also recomputes S"}
+                           "note": "algorithmic FLOPs: the 4 backward tile products = 2 x forward; " +
+                                   ("score-stash mode: exactly these 4 are executed (the forward left the raw score tiles in HBM)"
+                                    if st.last["plan"]["stash"] is not None else
+                                    "recompute mode: the kernel executes a 5th product, S = q k^T")}
+        out["attention_score_stash"] = st.last["plan"]["stash"] is not None
         out["roofline_by_kernel"] = by
     del st, xs, ys
     torch.cuda.empty_cache()
+    return out
+
+
+def reference_size_set_transformer(dev, steps=30, warmup=5):
+    """The notebook's own configuration (...set_transformer.ipynb:304-307, 419-431): 32 neighbourhoods x 50 particles x 12
+    features, 6 attention blocks - ~190 launches of <= 40 us per step, bound by launch / dependency latency.  Eager launches
+    vs one hipGraph replay per step (SetTransformerDIB(use_graphs=True), the DIB_ENABLE_GRAPHS opt-in)."""
+    from dib_amd import SetTransformerDIB
+    rng = np.random.default_rng(6)
+    xs = torch.from_numpy(rng.standard_normal((32, 50, 12)).astype(np.float32)).to(dev)
+    ys = torch.from_numpy((rng.random((32, 1)) > 0.5).astype(np.float32)).to(dev)
+    out = {"workload": "set-transformer DIB at the notebook's size: 32 neighbourhoods x 50 particles x 12 features, fp32"}
+    for key, graphs in (("eager", False), ("graph_replay", True)):
+        st = SetTransformerDIB(device=dev, use_graphs=graphs)
+        st.beta_dev.fill_(1e-3)
+        for _ in range(warmup):
+            st.train_step(xs, ys)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st.train_step(xs, ys)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[key] = {"ms_per_step": round(1e3 * dt, 3), "neighbourhoods_per_s": round(32 / dt, 1)}
+        del st
     return out
 
 
@@ -403,6 +432,15 @@ def main():
                                      "global_batch": wl.gb}
         wl.set_scaling(args.scaling, args.batch)
 
+    if not args.no_extra and world > 1:
+        # BASELINE config 5 under data parallelism (neighbourhoods sharded over the ranks, gradient all-reduce over RCCL inside
+        # SetTransformerDIB.train_step): one neighbourhood of 4096 particles per GPU, i.e. never fewer neighbourhoods than ranks
+        try:
+            extra["config5_set_transformer"] = dict(config5_set_transformer(dev, nb=max(4, world), steps=3),
+                                                    parallelism=f"dp{world} over neighbourhoods")
+        except Exception as e:  # noqa: BLE001
+            extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         gb, B = wl.gb, wl.B
         sps = args.steps * gb / med
@@ -467,6 +505,10 @@ def main():
                 extra["config5_set_transformer"] = config5_set_transformer(dev)
             except Exception as e:  # noqa: BLE001 - the extra line must never take the headline down
                 extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                extra["set_transformer_notebook_size"] = reference_size_set_transformer(dev)
+            except Exception as e:  # noqa: BLE001
+                extra["set_transformer_notebook_size"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_extra:
             # opt-in mode, separately labelled (never the headline): the integration network's two hidden-layer FORWARD
             # products evaluated as six bf16 piece products per fp32 product on the bf16 matrix pipe (fp32-accurate, see

@@ -150,7 +150,7 @@ SIGNATURES_ST = {
     "dib_add_inplace": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "dib_act_grad_mul": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "dib_token_kl_workspace_bytes": (c_int64, [c_int64, c_int]),
-    "dib_token_reparam_kl_fwd": (c_int, [c_void_p, c_int64, c_int, c_float, c_uint64, c_uint32, c_int64, c_int, c_void_p,
+    "dib_token_reparam_kl_fwd": (c_int, [c_void_p, c_int64, c_int, c_float, c_uint64, c_uint32, c_void_p, c_int64, c_int, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
     "dib_token_reparam_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_float, c_void_p,
                                          c_void_p]),

@@ -1401,13 +1401,14 @@ int64_t dib_token_kl_workspace_bytes(int64_t T, int E) {
 }
 
 int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logvar_offset, uint64_t seed, uint32_t step,
-                             int64_t row0, int deterministic, float* u, float* kl_sum, void* ws, dib_stream_t stream) {
+                             const uint32_t* step_dev, int64_t row0, int deterministic, float* u, float* kl_sum, void* ws,
+                             dib_stream_t stream) {
   if (!enc_out || !u || !kl_sum || !ws || T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256) return DIB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = cdiv(T, std::max(1, 256 / ((E + 3) / 4)));
   hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(blocks, 1), dim3(256), 0, st, enc_out, u, (float*)ws, (const int*)nullptr,
                      (long long)row0, (int)T, 1, E, (unsigned long long)seed, (unsigned)step, deterministic ? 1 : 0,
-                     (const unsigned*)nullptr, logvar_offset);
+                     (const unsigned*)step_dev, logvar_offset);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, 1, kl_sum);

@@ -98,6 +98,26 @@ class _Gemm:
                                    self.rps, self.stride, stream), "dib_gemm_grouped")
 
 
+class _SplitKGemm:
+    """A skinny product C[M, N] = A[M, K] @ W (N = the model width, 32; K = heads * key_dim = 1536) with FEW row tiles: the
+    output has ceil(M / 64) workgroups' worth of tiles and each would walk all of K with one tile of prefetch - at the
+    notebook's size (1600 tokens) 25 workgroups x 48 dependent k-tiles = 84 us for 0.16 GFLOP, the two slowest launches of
+    the whole step.  Here the contraction is cut into `ksplit` chunks that run as extra GROUPS of the same grouped launch
+    (one partial slab each), summed in a fixed order by dib_reduce_splits: deterministic, no new kernel."""
+
+    def __init__(self, gemm: "_Gemm", partial, partial_off, n, nslabs, out, out_off):
+        self.gemm, self.partial, self.partial_off, self.n, self.nslabs, self.out, self.out_off = \
+            gemm, partial, partial_off, n, nslabs, out, out_off
+
+    def upload(self, device):
+        self.gemm.upload(device)
+
+    def run(self, lib, stream):
+        self.gemm.run(lib, stream)
+        check(lib.dib_reduce_splits(_ptr(self.partial, self.partial_off), self.n, self.nslabs, self.n,
+                                    _ptr(self.out, self.out_off), stream), "dib_reduce_splits")
+
+
 def _d(a_off, lda, b_off, ldb, c_off, ldc, M, N, K, bias_off=-1, aux_off=0, ldaux=0):
     return dict(a_off=a_off, b_off=b_off, c_off=c_off, bias_off=bias_off, aux_off=aux_off, M=M, N=N, K=K, lda=lda, ldb=ldb,
                 ldc=ldc, ldaux=ldaux)
@@ -112,11 +132,15 @@ class SetTransformerDIB:
                  ff_arch_per_block: Sequence[int] = (128, 32), final_processing_arch: Sequence[int] = (256,),
                  output_dimensionality: int = 1, logvar_initialization: float = -3.0, layer_norm_epsilon: float = 1e-3,
                  *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto",
-                 attention_score_stash_bytes: int = 64 << 30, _checker_backend=None):
+                 attention_score_stash_bytes: int = 64 << 30, use_graphs: Optional[bool] = None, _checker_backend=None):
         """_checker_backend: TEST SEAM (like DistributedIBNet._engine_factory): the CPU tests of the host logic - train_step's
         data-parallel protocol, fit's schedules - inject an object that implements forward / loss_and_backward / _loss_only /
         adam_step on the float64 CPU checker (tests/_oracle_set_transformer.py).  The product never sets it: without it the
         constructor demands a GPU and the HIP library.
+        use_graphs: replay the whole training step (copy-in, ~190 launches, Adam, noise-step bump) as one captured hipGraph
+        per (batch, particles) shape - the notebook's own configuration, 32 neighbourhoods x 50 particles, is bound by launch
+        and dependency latency, not by arithmetic.  Default: the DIB_ENABLE_GRAPHS=1 opt-in shared with DistributedIBNet.fit.
+        Single-process only (the data-parallel step has collectives between its launches).
         attention_score_stash_bytes: flash attention keeps the raw [P, P] score tiles of every block for the backward
         (4 tile products per tile pair instead of 5, include/dib_st.h) when all blocks' tiles of a batch shape fit this budget
         (4 x 4096 particles: 19.3 GB of the 288); above it - or with 0 - the backward recomputes them.
@@ -172,6 +196,10 @@ class SetTransformerDIB:
         self.set_params(self.init_params(init_seed))
         self._plans: Dict[Tuple[int, int], dict] = {}
         self.max_step_plans = 4
+        import os
+        self.use_graphs = (os.environ.get("DIB_ENABLE_GRAPHS", "0") == "1") if use_graphs is None else bool(use_graphs)
+        self._graphs: Dict[Tuple[int, int], dict] = {}
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # noise step of graph replays (uint32 bits)
         self._step = 0
         self.last = {}
 
@@ -318,6 +346,15 @@ class SetTransformerDIB:
             take("attn_delta", int(self.lib.dib_attention_bwd_workspace_bytes(B, P, H)) // 4)   # delta + dQ key-block partials
         for nm in ("q", "k", "v"):
             take(f"g_x{nm}", T * D)
+        # split-K of the two skinny [T, heads*key_dim] x [heads*key_dim, D] products when there are few row tiles (_SplitKGemm)
+        ksplit, mt = 1, (T + 63) // 64
+        if mt < 128:
+            for cand in (8, 4, 2):
+                if HK % (cand * 32) == 0 and HK // cand >= 64:
+                    ksplit = cand
+                    break
+        if ksplit > 1:
+            take("ksplit_ws", 3 * ksplit * T * D)
         for l, u in enumerate(enc_units):
             take(f"g_enc_h{l}", T * u)
         ln_ws = int(self.lib.dib_add_layernorm_bwd_workspace_bytes(T, D)) // 4
@@ -337,7 +374,9 @@ class SetTransformerDIB:
         # weight-gradient target: contraction over T tokens is split into slabs when T is large (fixed-order reduce)
         # (from 512 tokens up: with one slab the q/k/v and output-projection wgrads of the reference size, 1600 tokens, ran on
         # 12-36 workgroups looping over all rows - 110-137 us each, the top entries of the first profile)
-        nsplit = max(1, min(32, T // 256))
+        # (64-row slabs up to 2048 tokens: at 1600 tokens the 6 slabs of the T // 256 rule left the feed-forward wgrads on 6
+        # workgroups walking 9 dependent k-tiles each - 24 us per launch, 28 such launches per step)
+        nsplit = max(1, min(32, T // 64))
         rps = ((T + nsplit - 1) // nsplit + 31) // 32 * 32
         nsplit = (T + rps - 1) // rps
         slabs = torch.zeros(nsplit * self.n_alloc, dtype=torch.float32, device=self.device) if nsplit > 1 else None
@@ -386,7 +425,15 @@ class SetTransformerDIB:
             if gemm_attn:
                 g[f"b{b}_pv"] = _Gemm(0, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
                                            off[f"b{b}_ctx"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
-            g[f"b{b}_o_fwd"] = dense_fwd(f"b{b}_ctx", HK, pre + "o_w", pre + "o_b", f"b{b}_mha", D, ACT_NONE, T)
+            if ksplit > 1:
+                ck = HK // ksplit
+                g[f"b{b}_o_fwd"] = _SplitKGemm(
+                    _Gemm(0, [_d(off[f"b{b}_ctx"] + s_ * ck, HK, po[pre + "o_w"] + s_ * ck * D, D, off["ksplit_ws"] + s_ * T * D, D,
+                                 T, D, ck, bias_off=po[pre + "o_b"] if s_ == 0 else -1) for s_ in range(ksplit)],
+                          ws, self.params, ws, bias=self.params),
+                    ws, off["ksplit_ws"], T * D, ksplit, ws, off[f"b{b}_mha"])
+            else:
+                g[f"b{b}_o_fwd"] = dense_fwd(f"b{b}_ctx", HK, pre + "o_w", pre + "o_b", f"b{b}_mha", D, ACT_NONE, T)
             d, src = D, f"b{b}_h"
             for l, u in enumerate(ff):
                 g[f"b{b}_ff{l}_fwd"] = dense_fwd(src, d, pre + f"ff{l}_w", pre + f"ff{l}_b", f"b{b}_ff{l}", u, ACT_RELU, T)
@@ -424,8 +471,16 @@ class SetTransformerDIB:
             g[f"b{b}_qkv_wgrad"] = _Gemm(2, [_d(off[xin], D, off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, D, HK, T,
                                                 bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, ws, gt, bias_out=gt,
                                          nsplit=nsplit, rows_per_split=rps, split_stride=self.n_alloc)
-            g[f"b{b}_qkv_dgrad"] = _Gemm(1, [_d(off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, off[f"g_x{nm}"], D, T, D, HK)
-                                             for nm in "qkv"], ws, self.params, ws)
+            if ksplit > 1:   # 3 projections x ksplit chunks -> 3 * ksplit slabs, summed straight into g_xq (= g_xq + g_xk + g_xv)
+                ck = HK // ksplit
+                g[f"b{b}_qkv_dgrad"] = _SplitKGemm(
+                    _Gemm(1, [_d(off[f"g_{nm}"] + s_ * ck, HK, po[pre + nm + "_w"] + s_ * ck, HK,
+                                 off["ksplit_ws"] + (i_ * ksplit + s_) * T * D, D, T, D, ck)
+                              for i_, nm in enumerate("qkv") for s_ in range(ksplit)], ws, self.params, ws),
+                    ws, off["ksplit_ws"], T * D, 3 * ksplit, ws, off["g_xq"])
+            else:
+                g[f"b{b}_qkv_dgrad"] = _Gemm(1, [_d(off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, off[f"g_x{nm}"], D, T, D, HK)
+                                                 for nm in "qkv"], ws, self.params, ws)
         # head: pooled [B, D] -> Dense(256, LeakyReLU(0.1)) -> Dense(out)
         d, src = D, "pool"
         for l, u in enumerate(self.final_processing_arch):
@@ -451,10 +506,10 @@ class SetTransformerDIB:
         for gg in g.values():
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
-                    enc_units=enc_units, stash=stash)
+                    enc_units=enc_units, stash=stash, ksplit=ksplit)
         # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
         # (training batch, validation batch, a ragged tail), evict least recently used beyond that
-        step_keys = [k for k in self._plans if k[0] != "enc"]
+        step_keys = [k for k in self._plans if k[0] != "enc" and k not in self._graphs]   # a captured graph pins its plan
         if len(step_keys) >= self.max_step_plans:
             self._plans.pop(step_keys[0])
         self._plans[key] = plan
@@ -466,7 +521,7 @@ class SetTransformerDIB:
 
     # ---- forward (notebook train_step, forward part) -------------------------------------------------------------------
     def forward(self, batch_inp, step: Optional[int] = None, deterministic: bool = False, row0: int = 0,
-                embs_reparam=None) -> torch.Tensor:
+                embs_reparam=None, _step_from_device: bool = False) -> torch.Tensor:
         """embs = particle_encoder(batch_inp); logvar - 3; reparameterised sample; kl; loci_prediction = set_transformer(u).
         batch_inp [B, P, particle_feature_dimensions].  Returns the logits [B, out]; self.last holds kl (device scalar).
         embs_reparam [B, P, bottleneck] (optional): use these sampled embeddings instead of the library's counter-based
@@ -489,7 +544,8 @@ class SetTransformerDIB:
         for l in range(ne):
             g[f"enc{l}_fwd"].run(lib, st)
         check(lib.dib_token_reparam_kl_fwd(_ptr(ws, off[f"enc_h{ne - 1}"]), T, D, self.logvar_initialization, self.noise_seed,
-                                           step & 0xFFFFFFFF, int(row0), 1 if deterministic else 0, _ptr(ws, off["x0"]),
+                                           step & 0xFFFFFFFF, _ptr(self.step_dev) if _step_from_device else c_void_p(0),
+                                           int(row0), 1 if deterministic else 0, _ptr(ws, off["x0"]),
                                            _ptr(ws, off["kl_sum"]), _ptr(ws, off["kl_ws"]), st), "dib_token_reparam_kl_fwd")
         if embs_reparam is not None:
             er = embs_reparam if isinstance(embs_reparam, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(embs_reparam, dtype=np.float32))
@@ -597,8 +653,9 @@ class SetTransformerDIB:
             g[f"b{b}_qkv_dgrad"].run(lib, st)
             # g_x (input of the block) = residual + the three projection inputs
             check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xq"]), T * D, st), "dib_add_inplace")
-            check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xk"]), T * D, st), "dib_add_inplace")
-            check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xv"]), T * D, st), "dib_add_inplace")
+            if pl["ksplit"] == 1:   # (split-K: the slab reduce already summed the three projections' gradients into g_xq)
+                check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xk"]), T * D, st), "dib_add_inplace")
+                check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xv"]), T * D, st), "dib_add_inplace")
             self._view(pl, "g_x", T * D).copy_(self._view(pl, "g_s", T * D))
         # bottleneck: d(mu | raw logvar), beta * KL included
         ne = len(pl["enc_units"])
@@ -633,6 +690,8 @@ class SetTransformerDIB:
         buffer is all-reduced (RCCL over xGMI with the nccl backend), every rank applies the same Adam update."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DP_BRANCH):
+            if training and self.use_graphs and self._checker is None:
+                return self._train_step_graph(batch_inp, is_loci)
             self.forward(batch_inp)
             self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
             if training:
@@ -660,6 +719,52 @@ class SetTransformerDIB:
             self.adam_step()
         self._step += 1
         self.last["bce"], self.last["kl"] = stats[0:1], stats[1:2]
+        return self.last["bce"]
+
+    def _set_step_dev(self, value: int) -> None:
+        v = int(value) & 0xFFFFFFFF
+        self.step_dev.fill_(v - (1 << 32) if v >= (1 << 31) else v)   # uint32 bit pattern in an int32 tensor
+
+    def _train_step_graph(self, batch_inp, is_loci):
+        """train_step as one hipGraph replay: inputs are copied into fixed staging buffers, everything else the step reads
+        that changes between replays (beta, learning rate, Adam t, the noise step) already lives in device memory.  The
+        eager warm-up runs exactly the captured sequence (module loads / hipFuncSetAttribute outside the capture) and every
+        piece of state it touches is restored.  Same launches in the same order as the eager step: bit-identical results."""
+        x = batch_inp if isinstance(batch_inp, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(batch_inp, dtype=np.float32))
+        y = is_loci if isinstance(is_loci, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(is_loci, dtype=np.float32))
+        B, P = int(x.shape[0]), int(x.shape[1])
+        g = self._graphs.get((B, P))
+        if g is None:
+            xs = torch.zeros((B, P, self.particle_feature_dimensions), dtype=torch.float32, device=self.device)
+            ys = torch.zeros((B, self.output_dimensionality), dtype=torch.float32, device=self.device)
+            xs.copy_(x.to(self.device).reshape(xs.shape))
+            ys.copy_(y.to(self.device).reshape(ys.shape))
+            self._graphs[(B, P)] = {}          # pins the plan against LRU eviction from here on
+            self._plan(B, P)
+            state = (self.params, self.adam_m, self.adam_v, self.t_dev, self.step_dev, self.grads)
+            saved = [t.clone() for t in state]
+
+            def body():
+                self.forward(xs, step=0, _step_from_device=True)
+                self.loss_and_backward(ys)
+                self.adam_step()
+
+            self._set_step_dev(self._step)
+            body()
+            for t, v in zip(state, saved):
+                t.copy_(v)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                body()
+            g = self._graphs[(B, P)] = dict(graph=graph, xs=xs, ys=ys, last=dict(self.last))
+        else:
+            g["xs"].copy_(x.to(self.device).reshape(g["xs"].shape))
+            g["ys"].copy_(y.to(self.device).reshape(g["ys"].shape))
+        self._set_step_dev(self._step)
+        g["graph"].replay()
+        self._step += 1
+        self.last = dict(g["last"], step=self._step - 1)   # kl / bce / correct: tensors of the graph's pool, rewritten by every replay
         return self.last["bce"]
 
     def _loss_only(self, is_loci, inv_global_batch: Optional[float] = None):

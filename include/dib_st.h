@@ -90,6 +90,7 @@ int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* 
  * before running the rest of the model) or mu itself (deterministic forward). */
 int64_t dib_token_kl_workspace_bytes(int64_t T, int E);
 int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logvar_offset, uint64_t seed, uint32_t step,
+                             const uint32_t* step_dev /* non-NULL: the noise step is read from device memory (hipGraph replay) */,
                              int64_t row0, int deterministic, float* u, float* kl_sum, void* ws, dib_stream_t stream);
 int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, const float* u, int64_t T, int E, float logvar_offset,
                              const float* beta_dev, float inv_batch, float* d_enc_out, dib_stream_t stream);

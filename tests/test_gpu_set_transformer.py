@@ -347,3 +347,32 @@ def test_fit_loop_runs_the_notebook_schedule():
     assert len(hist["bce_series_val"]) == 3 and np.isfinite(hist["bce_series_val"]).all()
     assert all(0.0 <= a <= 1.0 for a in hist["acc_series_val"])
     assert abs(float(m.lr_dev.item()) - 1e-3) < 1e-9 and int(m.t_dev.item()) == 12
+
+
+def test_graph_replay_of_the_train_step_is_bit_identical_to_eager():
+    """use_graphs=True (DIB_ENABLE_GRAPHS=1 opt-in): the notebook's configuration - 32 neighbourhoods x 50 particles - as one
+    hipGraph replay per step; same launches in the same order, device-resident noise step: parameters, Adam state, KL and BCE
+    equal the eager run bit for bit, across a change of batch contents, beta and learning rate between replays."""
+    import dib_amd
+    rng = np.random.default_rng(0)
+    xs = rng.standard_normal((3, 32, 50, 12)).astype(np.float32)
+    ys = (rng.random((3, 32, 1)) > 0.5).astype(np.float32)
+    out = {}
+    for mode in (False, True):
+        m = dib_amd.SetTransformerDIB(number_attention_blocks=2, init_seed=1, noise_seed=2, use_graphs=mode)
+        series = []
+        for step in range(5):
+            m.lr_dev.fill_(m.learning_rate_schedule(step + 1, 1e-3, 20))
+            m.beta_dev.fill_(m.beta_schedule(step, 1e-3, 1e-1, 5))
+            bce = m.train_step(xs[step % 3], ys[step % 3])
+            series.append((float(bce.item()), float(m.last["kl"].item())))
+        val = float(m.train_step(xs[0], ys[0], training=False).item())   # eager evaluation pass between replays
+        bce = m.train_step(xs[1], ys[1])
+        series.append((float(bce.item()), float(m.last["kl"].item()), val))
+        torch.cuda.synchronize()
+        out[mode] = (m.params.clone(), m.adam_m.clone(), m.adam_v.clone(), int(m.t_dev.item()), series)
+        assert (len(m._graphs) == 1) == mode
+    assert out[True][3] == out[False][3] == 6
+    assert out[True][4] == out[False][4], (out[True][4], out[False][4])
+    for a, b in zip(out[True][:3], out[False][:3]):
+        assert torch.equal(a, b)

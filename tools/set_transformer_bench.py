@@ -36,9 +36,11 @@ def main():
     ap.add_argument("--features", type=int, default=12)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--graphs", type=int, default=0, help="1: one hipGraph replay per step (SetTransformerDIB(use_graphs=True))")
     a = ap.parse_args()
     import dib_amd
-    m = dib_amd.SetTransformerDIB(particle_feature_dimensions=a.features, attention=os.environ.get("DIB_ST_ATTENTION", "auto"))
+    m = dib_amd.SetTransformerDIB(particle_feature_dimensions=a.features, attention=os.environ.get("DIB_ST_ATTENTION", "auto"),
+                                  use_graphs=bool(a.graphs))
     rng = np.random.default_rng(0)
     x = torch.from_numpy(rng.standard_normal((a.batch, a.particles, a.features)).astype(np.float32)).to(m.device)
     y = torch.from_numpy((rng.random((a.batch, 1)) > 0.5).astype(np.float32)).to(m.device)
@@ -56,7 +58,7 @@ def main():
     print(json.dumps({"workload": f"set-transformer DIB, {a.batch} neighbourhoods x {a.particles} particles x {a.features} features",
                       "ms_per_step": round(1e3 * dt, 3), "neighbourhoods_per_s": round(a.batch / dt, 1),
                       "algorithmic_TFLOPs": round(fl / dt / 1e12, 2), "params": m.n_params,
-                      "attention": m.attention_impl}))
+                      "attention": m.attention_impl, "graph_replay": bool(a.graphs)}))
 
 
 if __name__ == "__main__":
