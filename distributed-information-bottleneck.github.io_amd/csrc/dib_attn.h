@@ -123,9 +123,6 @@ __device__ __forceinline__ void dib_attn_store_rows(float* __restrict__ base, lo
 #ifndef DIB_ATTN_BWD_EXP_UNDER_MFMA
 #define DIB_ATTN_BWD_EXP_UNDER_MFMA 1
 #endif
-#ifndef DIB_ATTN_BWD_EARLY_PREFETCH   // 1: the next query tile's global loads are issued at the TOP of a tile (32 registers live
-#define DIB_ATTN_BWD_EARLY_PREFETCH 0 // through the dP / dV / dK phases) and go to LDS right after barrier B, in front of the dQ
-#endif                                // product; 0: issued after barrier B, stored after the dQ product (waits for them there)
 #ifndef DIB_ATTN_FWD_WAVES
 #define DIB_ATTN_FWD_WAVES 2   // measured (tools/attn_bench.py, 4 x 4096 x 12 heads, same box): 2 waves/SIMD (206 registers, no spills)
 #endif                         // 3.16-3.19 ms = 130 TFLOP/s = 0.83 of peak; 3 waves/SIMD (168 registers, 36 spilled) 3.78-3.80 ms.
@@ -384,17 +381,6 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
   for (int qt = 0; qt < n_tiles; ++qt) {
     __syncthreads();
     DIB_T(0);   // barrier A
-#if DIB_ATTN_BWD_EARLY_PREFETCH
-    {
-      const int qnext = min(qt + 1, n_tiles - 1) * kAttnTile;
-      rq = dib_attn_gload(Qb, a.ld, qnext, P - 1, tid);
-      rg = dib_attn_gload(dOb, a.ld, qnext, P - 1, tid);
-      if (tid < kAttnTile) {
-        rl_ = qnext + tid < P ? lse_b[qnext + tid] : INFINITY;
-        rd_ = dlt_b[min(qnext + tid, P - 1)];
-      }
-    }
-#endif
     // lse / delta of this lane's 16 queries (register r <-> query (r&3) + 8(r>>2) + 4h): 4 + 4 ds_read_b128, in flight
     // during the S / dP products
     float4 lq[4], dq4[4];
@@ -614,11 +600,10 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
     const float4 ka0 = dib_attn_mc(Kblk, 0, 32 * wave + l31, h), kb0 = dib_attn_mc(Kblk, 1, 32 * wave + l31, h);
     __syncthreads();   // all four dS^T patches are in LDS; nobody reads Qs / Gs / Ls / Ds any more
     DIB_T(4);   // barrier B
-#if DIB_ATTN_BWD_EARLY_PREFETCH
-    DIB_ATTN_STAGE_TILE();   // Qs / Gs / Ls / Ds are free, the loads landed two phases ago
-#else
     {
-      // next query tile (the last iteration re-loads its own tile: no branch in the loop body)
+      // next query tile (the last iteration re-loads its own tile: no branch in the loop body).  Issuing these loads at the
+      // TOP of the tile and storing them to LDS here, in front of the dQ product (32 registers live through the dP / dV / dK
+      // phases), measured slower: 7.75 -> 8.12 ms in stash mode (profiles/r03f_attention_early_prefetch_ab.txt)
       const int qnext = min(qt + 1, n_tiles - 1) * kAttnTile;
       rq = dib_attn_gload(Qb, a.ld, qnext, P - 1, tid);
       rg = dib_attn_gload(dOb, a.ld, qnext, P - 1, tid);
@@ -627,7 +612,6 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
         rd_ = dlt_b[min(qnext + tid, P - 1)];
       }
     }
-#endif
     {
       // dQ^T[d = 32*wave + .][query] over the workgroup's 128 keys: A = K block (MC), B = dS^T patches (b128 along keys).
       // Two accumulators (even / odd 8-key steps), MFMAs alternating between them: the LDS reads and waits between the
@@ -671,9 +655,7 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
       }
     }
     DIB_T(5);   // next-tile loads issued, dQ product, dQ store
-#if !DIB_ATTN_BWD_EARLY_PREFETCH
     DIB_ATTN_STAGE_TILE();
-#endif
     DIB_T(6);   // next tile -> LDS
   }
 #ifdef DIB_ATTN_TIMING
