@@ -10,7 +10,7 @@
 //   stash      the forward writes the raw score tiles (before the softmax) to HBM, tile-major [b][h][key tile][query tile]
 //              [32 queries][32 keys], and the backward reads them back: 4 products.  At 4 x 4096 particles x 12 heads that is
 //              3.2 GB per attention block (19 GB for the notebook's six - MI355X has 288 GB), written once with
-//              non-temporal 16-byte stores and read once with fully coalesced dword loads, both in the shadow of the MFMAs;
+//              16-byte stores and read once with fully coalesced (non-temporal) dword loads, both in the shadow of the MFMAs;
 //              it takes 64 of the 320 MFMAs, the Q / K operand fetches of the S product (32 ds_read_b128) out of every
 //              backward tile.  Same-box A/B: profiles/r03c_attention_stash_ab.txt.
 //
@@ -180,11 +180,13 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
       }
       if (a.s_stash != nullptr) {
         // raw scores for the backward (stash mode): lane (query j, h) owns keys 8g + 4h + {0..3} of its query - one 16-byte
-        // non-temporal store per register group; values of keys / queries beyond P are finite and multiplied by 0 there
+        // store per register group (plain: the two 16-byte halves of a 32-byte sector come from two lanes and merge in L2;
+        // non-temporal stores measured 1.7 % slower, profiles/r03g_attention_stash_cache_policy_ab.txt); values of keys /
+        // queries beyond P are finite and multiplied by 0 there
         float* sp = a.s_stash + dib_attn_stash_tile(b, a.H, head, n_tiles, kt, blockIdx.x * 4 + wave) + l31 * kAttnTile + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          __builtin_nontemporal_store(dib_nt4a{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]}, reinterpret_cast<dib_nt4a*>(sp + 8 * g));
+          *reinterpret_cast<dib_nt4a*>(sp + 8 * g) = dib_nt4a{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
       }
       // online softmax over this tile's keys (register r <-> key kt*32 + (r&3) + 8(r>>2) + 4h)
       if (kt == n_tiles - 1) {   // only the last tile can hold keys beyond P
