@@ -684,19 +684,11 @@ dib_attn_dq_reduce_kernel(const float* __restrict__ part, int B, int P, int H, i
     const int qy = (int)(row % P);
     const long long bh = row / P;
     const float4* src = reinterpret_cast<const float4*>(part + ((bh * n_key_blocks) * P + qy) * kAttnD) + c4;
-    // eight partial loads in flight per thread, added in key-block order (the summation order is fixed: deterministic)
-    const long long kstride = (long long)P * (kAttnD / 4);
+    // (a version with eight non-temporal partial loads in flight per thread measured SLOWER: 726 vs 601 us at 4 x 4096 x 12,
+    // profiles/r03h_config5_kernel_stats.csv vs r03b - the plain loop already streams at 5.5 TB/s)
     float4 sacc = src[0];
-    int kb = 1;
-    for (; kb + 8 <= n_key_blocks; kb += 8) {
-      dib_nt4a v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const dib_nt4a*>(src + (kb + u) * kstride));
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { sacc.x += v[u].x; sacc.y += v[u].y; sacc.z += v[u].z; sacc.w += v[u].w; }
-    }
-    for (; kb < n_key_blocks; ++kb) {
-      const float4 v = src[kb * kstride];
+    for (int kb = 1; kb < n_key_blocks; ++kb) {
+      const float4 v = src[(long long)kb * P * (kAttnD / 4)];
       sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
     }
     const long long b = bh / H;

@@ -106,6 +106,57 @@ def test_workspace_cache_is_lru_and_never_evicts_a_graph_workspace():
     assert 77 not in eng._ws
 
 
+@pytest.mark.parametrize("arch", ["fused_128_128_32", "general_ragged"])
+def test_three_bucket_backward_hooks_equal_the_plain_backward(arch):
+    """The staged encoder backward of the data-parallel protocol (dib_encoder_bank_bwd_stage 1 -> finalize part 2 -> hook ->
+    stage 2 -> finalize part 3) on the fused and on the general (ragged, odd widths) path: the hooks see final
+    gradient slices at the time they are called, the buckets tile the flat buffer, and the result equals the one-call backward
+    bit for bit - at a batch that uses split weight-gradient slabs and at one that does not."""
+    from dib_amd.engine import HipEngine
+    if arch == "fused_128_128_32":
+        eng = HipEngine([1] * 6, [128, 128], [64, 32], 1, feature_embedding_dimension=32, init_seed=2)
+    else:
+        eng = HipEngine([2, 1, 3], [24, 40], [20], 1, feature_embedding_dimension=6, init_seed=2)
+    ranges = [eng.part_range(p) for p in range(4)]
+    (o0, c0), (o1, c1), (o2, c2), (o3, c3) = ranges
+    assert o2 == 0 and o3 == c2 and c2 + c3 == c0 and o1 == c0 and o1 + c1 == eng.n_params
+    rng = np.random.default_rng(0)
+    for B in (96, 4096):
+        x = eng.to_device(rng.standard_normal((B, eng.sum_d)).astype(np.float32))
+        y = eng.to_device((rng.random((B, 1)) > 0.5).astype(np.float32))
+        eng.set_beta(0.05)
+        eng.train_step(x, y, None, 0, B, 1, 3, "bce_logits")
+        torch.cuda.synchronize()
+        ref = eng.grads.clone()
+        seen = {}
+        eng.grads.zero_()
+        eng.train_step(x, y, None, 0, B, 1, 3, "bce_logits", accumulate=False,
+                       on_integration_grads_ready=lambda g: seen.__setitem__("integration", g.clone()),
+                       on_encoder_front_grads_ready=lambda g: seen.__setitem__("front", g.clone()))
+        torch.cuda.synchronize()
+        assert torch.equal(eng.grads, ref), (arch, B)
+        assert torch.equal(seen["integration"], ref[o1: o1 + c1]) and torch.equal(seen["front"], ref[o2: o2 + c2])
+
+
+def test_released_step_graph_unpins_its_workspace():
+    from dib_amd.engine import HipEngine
+    eng = HipEngine([1, 1], [32, 32], [16], 1, feature_embedding_dimension=32)
+    x = torch.randn(64, 2, device=eng.device)
+    y = (x[:, :1] > 0).float()
+    eng.enable_step_counter(0)
+    before = (eng.params.clone(), eng.t_dev.clone(), eng.step_dev.clone())
+    graph, stage = eng.capture_step_graph(x, y, 48, "bce_logits", 1.0 / 48, 0, True)
+    # the warm-up ran the captured sequence (fused head, Adam, counter bump) eagerly and restored every piece of state
+    assert torch.equal(eng.params, before[0]) and torch.equal(eng.t_dev, before[1]) and torch.equal(eng.step_dev, before[2])
+    assert 48 in eng._ws_pinned
+    del graph
+    eng.release_step_graph(48)
+    assert 48 not in eng._ws_pinned
+    for b in (50, 51, 52, 53, 54):
+        eng.workspace(b)
+    assert 48 not in eng._ws   # evictable again
+
+
 def test_autograd_bridge_refuses_clobbered_workspace():
     import dib_amd
     model = dib_amd.DistributedIBNet([1, 1, 1], [32, 32], [16], 1, feature_embedding_dimension=32)

@@ -376,3 +376,18 @@ def test_graph_replay_of_the_train_step_is_bit_identical_to_eager():
     assert out[True][4] == out[False][4], (out[True][4], out[False][4])
     for a, b in zip(out[True][:3], out[False][:3]):
         assert torch.equal(a, b)
+
+
+def test_step_plans_are_lru_capped_and_graph_plans_pinned():
+    """A (batch, particles) plan holds the whole step workspace, the gradient slabs and the score stash: at most
+    `max_step_plans` unpinned ones are kept (round-2 advisor finding: unbounded growth); a captured graph pins its plan."""
+    import dib_amd
+    m = dib_amd.SetTransformerDIB(number_attention_blocks=1, init_seed=0, use_graphs=True)
+    rng = np.random.default_rng(0)
+    m.train_step(rng.standard_normal((2, 9, 12)).astype(np.float32), np.ones((2, 1), np.float32))   # captured: pinned
+    for P in (5, 6, 7, 8, 10, 11):
+        m.forward(rng.standard_normal((2, P, 12)).astype(np.float32))
+    keys = [k for k in m._plans if k[0] != "enc"]
+    assert (2, 9) in keys and len(keys) <= m.max_step_plans + 1 and (2, 5) not in keys and (2, 11) in keys
+    bce = m.train_step(rng.standard_normal((2, 9, 12)).astype(np.float32), np.ones((2, 1), np.float32))
+    assert np.isfinite(float(bce.item()))

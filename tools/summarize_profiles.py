@@ -33,7 +33,7 @@ def main(base, tag, suffix=""):
     for k in fa:
         if "dib_" not in k:
             continue
-        name = k.split("<128")[0] if "fused" in k else k
+        name = k.split("<128")[0] if "fused" in k else (k.split("<")[0] if "attn" in k else k)
         traffic[name] = {"hbm_read_bytes_per_launch": round(2 * fa[k] / fc[k] * 1024),   # gfx950: FETCH_SIZE counts 1/2
                          "hbm_write_bytes_per_launch": round(wa.get(k, 0) / max(wc.get(k, 1), 1) * 1024),
                          "launches_sampled": fc[k]}
