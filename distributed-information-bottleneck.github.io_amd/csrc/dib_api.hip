@@ -1065,7 +1065,8 @@ int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu
 
 int64_t dib_infonce_workspace_bytes(int batch) {
   if (batch <= 0) return DIB_E_ARG;
-  return (int64_t)sizeof(float) * ((int64_t)batch * batch + 2ll * batch + 64);
+  // S [B^2] | lse [2B] | norms [2B] | W = dL/dS [B^2] | Linf arg-max coordinate [B^2] (int32)
+  return (int64_t)sizeof(float) * (3ll * batch * batch + 4ll * batch + 64);
 }
 
 int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int dim, int similarity, float temperature,
@@ -1073,18 +1074,35 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
   if (!emb_x || !emb_y || !loss_out || !ws || batch <= 0 || dim <= 0 || temperature <= 0.f) return DIB_E_ARG;
   if (similarity < 0 || similarity > 4 || dim > 256) return DIB_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  const int64_t bb = (int64_t)batch * batch;
   float* S = (float*)ws;
-  float* lse = S + (int64_t)batch * batch;
+  float* lse = S + bb;
+  float* norms = lse + 2ll * batch;
+  float* W = norms + 2ll * batch;
+  int* amax = (int*)(W + bb);
   const float inv_t = 1.0f / temperature;
+  const int tiles = cdiv(batch, 32);
+  static bool attr_set[64] = {};
+  if (dib_attr_needed(attr_set)) {   // two 32-row tiles of up to 256 (+1) floats: 65 792 bytes at the widest
+    hipError_t e = hipFuncSetAttribute((const void*)dib_infonce_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * 32 * 257 * (int)sizeof(float));
+    if (e != hipSuccess) return (int)e;
+  }
   ProfScope ps(kProfOther, st);
-  hipLaunchKernelGGL(dib_infonce_sim_kernel, dim3(grid_for((int64_t)batch * batch)), dim3(256), 0, st, emb_x, emb_y, batch,
-                     dim, similarity, inv_t, S);
+  if (similarity == 0 || similarity == 1 || similarity == 4)
+    hipLaunchKernelGGL(dib_infonce_norms_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, emb_x, emb_y, batch, dim, norms);
+  hipLaunchKernelGGL(dib_infonce_sim_kernel, dim3(tiles, tiles), dim3(256), (size_t)2 * 32 * (dim + 1) * sizeof(float), st, emb_x,
+                     emb_y, batch, dim, similarity, inv_t, (const float*)norms, S, amax);
   hipLaunchKernelGGL(dib_infonce_lse_kernel, dim3(batch, 2), dim3(256), 0, st, (const float*)S, batch, lse);
   hipLaunchKernelGGL(dib_infonce_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)S, (const float*)lse, batch,
                      loss_out);
-  if (g_x && g_y)
+  if (g_x && g_y) {
+    hipLaunchKernelGGL(dib_infonce_w_kernel, dim3(grid_for(bb)), dim3(256), 0, st, (const float*)S, (const float*)lse, batch, inv_t,
+                       W);
     hipLaunchKernelGGL(dib_infonce_grad_kernel, dim3(batch, 2), dim3(256), 256 * sizeof(float), st, emb_x, emb_y,
-                       (const float*)S, (const float*)lse, batch, dim, similarity, inv_t, g_x, g_y);
+                       (const float*)S, (const float*)W, (const float*)norms, (const int*)amax, batch, dim, similarity, temperature,
+                       g_x, g_y);
+  }
   return (int)hipGetLastError();
 }
 

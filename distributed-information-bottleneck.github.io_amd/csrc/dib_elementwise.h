@@ -526,39 +526,72 @@ dib_mi_probe_rows_kernel(const float* __restrict__ enc_probe, const double* __re
 // ---------------------------------------------------------------------------------------------
 // InfoNCE path (reference train.py:201-220 eval_batch_infonce; utils.py:75-175 get_scaled_similarity):
 //   S = similarity(emb_x, emb_y) / T  [B,B] ;  loss = mean_i CE(i, S[i,:]) + mean_j CE(j, S[:,j])  (NOT halved)
-// similarity ids: 0 l2sq, 1 l2, 2 l1, 3 linf, 4 cosine.  B is the batch (<= a few thousand), D the shared
-// embedding width: B^2*D work - tiny next to the encoder bank, so plain (deterministic) VALU kernels.
+// similarity ids: 0 l2sq, 1 l2, 2 l1, 3 linf, 4 cosine.  B is the batch (128 by default, 2048 in the chaos notebook), D the
+// shared embedding width (64 by default).  Deterministic VALU kernels, O(B^2 D) each:
+//   norms   |x_i|^2, |y_j|^2 once per row (l2sq / l2 / cosine)
+//   sim     32 x 32 pairs per workgroup, both 32-row embedding tiles in LDS (odd pitch: conflict-free), one dot product /
+//           L1 / Linf reduction per pair; Linf also records its arg-max coordinate
+//   lse     row and column log-sum-exp;   loss
+//   w       dL/dS_ij = (softmax_row_i(S)_ij + softmax_col_j(S)_ij - 2 delta_ij) / (B T): two exponentials per PAIR
+//   grad    g_x[i][e] = sum_j w_ij dsim_ij/dx_ie (and g_y): thread = (coordinate e, partner group), O(1) per (pair, e) from
+//           S, the norms and the arg-max table.
+// (Round 3: the first version recomputed the norms and the dot product inside the gradient loop - O(B^2 D^2), 9.0 ms per
+// call at B = 2048, D = 64 against 0.35 ms for the whole encoder step; tools/infonce_bench.py, profiles/r03i_*, r03j_*.)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dib_similarity(int kind, const float* __restrict__ a, const float* __restrict__ b, int D,
-                                                float inv_t) {
+__global__ void __launch_bounds__(256)
+dib_infonce_norms_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, float* __restrict__ norms) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * B) return;
+  const float* r = idx < B ? X + (long long)idx * D : Y + (long long)(idx - B) * D;
   float s = 0.f;
-  if (kind == 0 || kind == 1) {  // utils.py:85-90: max(|a|^2 + |b|^2 - 2 a.b, 0)
-    float na = 0.f, nb = 0.f, ab = 0.f;
-    for (int e = 0; e < D; ++e) { na += a[e] * a[e]; nb += b[e] * b[e]; ab += a[e] * b[e]; }
-    const float d2 = fmaxf(na + nb - 2.0f * ab, 0.f);
-    s = (kind == 0) ? -d2 : -sqrtf(d2 + 1e-9f);
-  } else if (kind == 2) {
-    for (int e = 0; e < D; ++e) s -= fabsf(a[e] - b[e]);
-  } else if (kind == 3) {
-    float mx = 0.f;
-    for (int e = 0; e < D; ++e) mx = fmaxf(mx, fabsf(a[e] - b[e]));
-    s = -mx;
-  } else {
-    float na = 0.f, nb = 0.f, ab = 0.f;
-    for (int e = 0; e < D; ++e) { na += a[e] * a[e]; nb += b[e] * b[e]; ab += a[e] * b[e]; }
-    s = ab / (sqrtf(na) * sqrtf(nb));
-  }
-  return s * inv_t;
+  for (int e = 0; e < D; ++e) s += r[e] * r[e];
+  norms[idx] = s;
 }
 
+// grid (ceil(B/32) column tiles, ceil(B/32) row tiles), 256 threads, dynamic LDS 2 * 32 * (D + 1) floats
 __global__ void __launch_bounds__(256)
 dib_infonce_sim_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, int kind, float inv_t,
-                       float* __restrict__ S) {
-  const long long total = (long long)B * B;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(idx / B), j = (int)(idx - (long long)i * B);
-    S[idx] = dib_similarity(kind, X + (long long)i * D, Y + (long long)j * D, D, inv_t);
+                       const float* __restrict__ norms, float* __restrict__ S, int* __restrict__ amax) {
+  extern __shared__ float sm[];
+  const int P = D + 1;
+  float* Xs = sm;
+  float* Ys = sm + 32 * P;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  for (int idx = threadIdx.x; idx < 32 * D; idx += 256) {
+    const int r = idx / D, e = idx - r * D;
+    Xs[r * P + e] = (i0 + r < B) ? X[(long long)(i0 + r) * D + e] : 0.f;
+    Ys[r * P + e] = (j0 + r < B) ? Y[(long long)(j0 + r) * D + e] : 0.f;
+  }
+  __syncthreads();
+  const int tj = threadIdx.x & 31, ti = threadIdx.x >> 5;
+  const int j = j0 + tj;
+  const float* b = Ys + tj * P;
+  for (int k = 0; k < 4; ++k) {
+    const int i = i0 + ti + 8 * k;
+    if (i >= B || j >= B) continue;
+    const float* a = Xs + (ti + 8 * k) * P;
+    float s;
+    if (kind == 0 || kind == 1 || kind == 4) {
+      float ab = 0.f;
+      for (int e = 0; e < D; ++e) ab += a[e] * b[e];
+      const float na = norms[i], nb = norms[B + j];
+      if (kind == 4) {
+        s = ab / (sqrtf(na) * sqrtf(nb));
+      } else {  // utils.py:85-90: max(|a|^2 + |b|^2 - 2 a.b, 0)
+        const float d2 = fmaxf(na + nb - 2.0f * ab, 0.f);
+        s = (kind == 0) ? -d2 : -sqrtf(d2 + 1e-9f);
+      }
+    } else if (kind == 2) {
+      s = 0.f;
+      for (int e = 0; e < D; ++e) s -= fabsf(a[e] - b[e]);
+    } else {
+      float mx = -1.f;
+      int am = 0;
+      for (int e = 0; e < D; ++e) { const float v = fabsf(a[e] - b[e]); if (v > mx) { mx = v; am = e; } }  // first maximum
+      s = -mx;
+      amax[(long long)i * B + j] = am;
+    }
+    S[(long long)i * B + j] = s * inv_t;
   }
 }
 
@@ -592,51 +625,56 @@ dib_infonce_loss_kernel(const float* __restrict__ S, const float* __restrict__ l
   if (threadIdx.x == 0) loss_out[0] = tot / (float)B;
 }
 
-// gradient wrt the embeddings.  dL/dS_ij = (softmax_row_i(S)_ij + softmax_col_j(S)_ij - 2 delta_ij) / B.
-// which = 0: block i accumulates g_x[i] = sum_j dL/dS_ij * dS_ij/dx_i ; which = 1: block j accumulates g_y[j].
+// W_ij = dL/d(unscaled similarity)_ij = (softmax_row_i(S)_ij + softmax_col_j(S)_ij - 2 delta_ij) / (B T)
+__global__ void __launch_bounds__(256)
+dib_infonce_w_kernel(const float* __restrict__ S, const float* __restrict__ lse, int B, float inv_t, float* __restrict__ W) {
+  const long long total = (long long)B * B;
+  const float sc = inv_t / (float)B;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int i = (int)(idx / B), j = (int)(idx - (long long)i * B);
+    const float sij = S[idx];
+    W[idx] = (expf(sij - lse[i]) + expf(sij - lse[B + j]) - (i == j ? 2.0f : 0.f)) * sc;
+  }
+}
+
+// gradient wrt the embeddings.  which = 0: block i accumulates g_x[i] = sum_j W_ij dsim_ij/dx_i ; which = 1: block j
+// accumulates g_y[j] = sum_i W_ij dsim_ij/dy_j.  Thread t owns coordinate e = t % D of partner group t / D (D <= 256);
+// the partner's coordinate is one coalesced load, everything else about the pair comes from S / the norms / the arg-max
+// table.  Fixed-order sum over the partner groups (deterministic).
 __global__ void __launch_bounds__(256)
 dib_infonce_grad_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ S,
-                        const float* __restrict__ lse, int B, int D, int kind, float inv_t, float* __restrict__ GX,
-                        float* __restrict__ GY) {
-  extern __shared__ float acc[];  // [256][D] partial gradients would be too big: use [4 waves][D] via atomics-free tree
+                        const float* __restrict__ W, const float* __restrict__ norms, const int* __restrict__ amax, int B,
+                        int D, int kind, float temperature, float* __restrict__ GX, float* __restrict__ GY) {
+  extern __shared__ float acc[];
   const int which = blockIdx.y, me = blockIdx.x;
   const float* self = (which == 0 ? X : Y) + (long long)me * D;
   const float* others = which == 0 ? Y : X;
   float* out = (which == 0 ? GX : GY) + (long long)me * D;
-  // each thread handles a strided subset of partners and a strided subset of dims is impossible at once, so:
-  // thread t owns dimension e = t % D for partner group t / D (requires 256 % D == 0 or D <= 256)
   const int groups = max(1, 256 / D);
   const int e = threadIdx.x % D, grp = threadIdx.x / D;
   float g = 0.f;
   if (grp < groups) {
-    const float invB = 1.0f / (float)B;
+    const float se = self[e];
+    const float ra = (kind == 4) ? rsqrtf(norms[which == 0 ? me : B + me]) : 0.f;
     for (int o = grp; o < B; o += groups) {
-      const int i = which == 0 ? me : o, j = which == 0 ? o : me;
-      const float sij = S[(long long)i * B + j];
-      float w = (expf(sij - lse[i]) + expf(sij - lse[B + j]) - (i == j ? 2.0f : 0.f)) * invB * inv_t;
-      const float* a = self;                       // the embedding being differentiated
-      const float* b = others + (long long)o * D;  // its partner
-      float d = 0.f;                                // d(sim)/d(self_e) before the 1/T factor
-      if (kind == 0 || kind == 1) {
-        float na = 0.f, nb = 0.f, ab = 0.f;
-        for (int q = 0; q < D; ++q) { na += a[q] * a[q]; nb += b[q] * b[q]; ab += a[q] * b[q]; }
-        const float d2 = na + nb - 2.0f * ab;
-        if (d2 > 0.f) {
-          d = -2.0f * (a[e] - b[e]);
-          if (kind == 1) d *= 0.5f / sqrtf(d2 + 1e-9f);
-        }
+      const long long idx = which == 0 ? (long long)me * B + o : (long long)o * B + me;
+      const float w = W[idx];
+      const float oe = others[(long long)o * D + e];
+      float d;  // d(unscaled similarity) / d(self_e)
+      if (kind == 0) {          // -d2, d2 = max(.,0): S = -d2/T < 0  <=>  d2 > 0
+        d = S[idx] < 0.f ? -2.0f * (se - oe) : 0.f;
+      } else if (kind == 1) {   // -sqrt(d2 + 1e-9): r = sqrt(d2 + 1e-9) = -S T; d2 > 0  <=>  r^2 > 1e-9
+        const float r = -S[idx] * temperature;
+        d = (r * r > 1.0000005e-9f) ? -(se - oe) / r : 0.f;
       } else if (kind == 2) {
-        const float df = a[e] - b[e];
+        const float df = se - oe;
         d = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f);
       } else if (kind == 3) {
-        float mx = -1.f; int am = 0;
-        for (int q = 0; q < D; ++q) { const float v = fabsf(a[q] - b[q]); if (v > mx) { mx = v; am = q; } }
-        if (am == e) { const float df = a[e] - b[e]; d = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f); }
-      } else {
-        float na = 0.f, nb = 0.f, ab = 0.f;
-        for (int q = 0; q < D; ++q) { na += a[q] * a[q]; nb += b[q] * b[q]; ab += a[q] * b[q]; }
-        const float ra = rsqrtf(na), rb = rsqrtf(nb);
-        d = (b[e] * rb - (ab * ra * rb) * a[e] * ra) * ra;
+        d = 0.f;
+        if (amax[idx] == e) { const float df = se - oe; d = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f); }
+      } else {                  // a.b / (|a||b|): (b_e/|b| - sim a_e/|a|) / |a|
+        const float rb = rsqrtf(norms[which == 0 ? B + o : o]);
+        d = (oe * rb - (S[idx] * temperature) * se * ra) * ra;
       }
       g += w * d;
     }

@@ -381,6 +381,24 @@ def test_infonce_at_working_batch_sizes(kind, B, D):
     assert ey < tol * np.abs(g2).max() + 1e-9, ("d/dy", ey, np.abs(g2).max(), temp)
 
 
+@pytest.mark.parametrize("B,D", [(33, 256), (70, 5), (1, 7)])
+@pytest.mark.parametrize("kind", ["l2sq", "l2", "l1", "linf", "cosine"])
+def test_infonce_edge_shapes(kind, B, D):
+    """ragged 32 x 32 pair tiles, the widest supported embedding (256: the similarity kernel's LDS tiles need the raised
+    dynamic-LDS limit), a width that does not divide 256, a single-row batch (loss 0, gradients 0)."""
+    import dib_torch_cpu as tc
+    eng, _ = _engine(SPECS["no_hidden"])
+    rng = np.random.default_rng(B + D)
+    a = (rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)
+    b = (a + 0.5 * rng.standard_normal((B, D)) / np.sqrt(D)).astype(np.float32)
+    loss, gx, gy = eng.infonce(eng.to_device(a), eng.to_device(b), kind, 0.5)
+    ref, g1, g2 = tc.infonce_loss_and_grads(a, b, kind, 0.5)
+    tol = 1e-3 if kind == "linf" else 2e-4
+    assert abs(float(loss.item()) - ref) < 2e-5 * (1 + abs(ref)), (float(loss.item()), ref)
+    assert np.abs(gx.cpu().numpy() - g1).max() < tol * np.abs(g1).max() + 1e-7
+    assert np.abs(gy.cpu().numpy() - g2).max() < tol * np.abs(g2).max() + 1e-7
+
+
 def test_mi_sandwich_bounds_at_the_reference_evaluation_size():
     """utils.py:10-11 evaluates the bounds on batches of 1024 (evaluation_batch_size); embedding dimension 32 (train.py:55).
     Device float64 log-sum-exp kernel vs the literal restatement of utils.py:36-62 on the device's own samples."""
