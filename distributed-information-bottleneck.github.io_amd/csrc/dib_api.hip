@@ -205,6 +205,8 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 // are the measured choices.
 struct Knobs {
   int fwd_small_wgs = 512;   // forward/dgrad: below this many 128-row workgroups use 64-row tiles
+  int fwd_narrow_wgs = 1024; // forward: below this many 64x128 workgroups use 64x64 tiles (round 3: 512 -> 1024, the set
+                             // transformer's q/k/v projection at 1600 tokens: step 1.99 -> 1.87 ms; profiles/r03l_forward_tile_rule.txt)
   int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
   int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
   int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
@@ -212,6 +214,7 @@ struct Knobs {
                              // the two kernels together ask for 5.8 TB/s of HBM and evict each other's L2 lines
   Knobs() {
     if (const char* e = std::getenv("DIB_FWD_SMALL_WGS")) fwd_small_wgs = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FWD_NARROW_WGS")) fwd_narrow_wgs = std::atoi(e);
     if (const char* e = std::getenv("DIB_L3_HALVE")) l3_halve = std::atoi(e);
     if (const char* e = std::getenv("DIB_FORCE_TILE0")) force_tile[0] = std::atoi(e);
     if (const char* e = std::getenv("DIB_FORCE_TILE1")) force_tile[1] = std::atoi(e);
@@ -233,10 +236,10 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
     // few 128-row tiles (small batches): 64-row tiles double the workgroup count (2 fit per CU at 128x128, 4 at 64x128)
     const long long wgs = (long long)cdiv(M, 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
     if (wgs < knobs().fwd_small_wgs) ni1 = true;
-    // still under two workgroups per CU: halve the per-wave work once more.  Forward GEMMs switch below 512 workgroups
+    // still under two workgroups per CU: halve the per-wave work once more.  Forward GEMMs switch below 1024 workgroups
     // (measured at B = 8192: the integration forward on 512 64x64 tiles instead of 256 64x128 tiles, step -30 us); the
     // dgrads measured no different and keep the round-1 threshold.
-    if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * c.count < (MODE == 0 ? 512 : 128)) nj1 = true;
+    if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * c.count < (MODE == 0 ? knobs().fwd_narrow_wgs : 128)) nj1 = true;
   }
   if (MODE == 2 && !ni1 && !nj1) {
     // small weight gradients (e.g. a 256x256 layer): 128x128 tiles x splits do not fill 256 CUs -> 64-row tiles

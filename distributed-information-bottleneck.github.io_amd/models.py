@@ -149,6 +149,8 @@ class DistributedIBNet:
         # data-parallel gradient all-reduce buckets (fit under torch.distributed): 3 = integration / encoder front layers /
         # last encoder layer, each issued as soon as it is final (default); 2 = integration / encoder bank; 1 = one all-reduce
         self.dp_buckets = int(os.environ.get("DIB_DP_BUCKETS", "3"))
+        if self.dp_buckets not in (1, 2, 3):
+            raise ValueError(f"DIB_DP_BUCKETS={self.dp_buckets}: 1, 2 or 3")
         self.beta = _BetaVariable(self, 1.0)
         self.feature_encoders = [_FeatureEncoder(self, f) for f in range(self.number_features)]
         self.optimizer = None

@@ -526,7 +526,12 @@ class SetTransformerDIB:
         batch_inp [B, P, particle_feature_dimensions].  Returns the logits [B, out]; self.last holds kl (device scalar).
         embs_reparam [B, P, bottleneck] (optional): use these sampled embeddings instead of the library's counter-based
         noise (the notebook evaluates `set_transformer(tf.random.normal(...))` on its own samples; also how the golden
-        fixture, which carries its own noise, is replayed)."""
+        fixture, which carries its own noise, is replayed).
+        Backward after any of the three forwards is consistent with it: the bottleneck's noise term is recovered as
+        eps * sigma = x0 - mu from the sample that was actually used (dib_token_reparam_kl_bwd) - library noise, an injected
+        sample (treated as mu + sigma * eps with its implied eps held fixed: the reparameterised gradient of that sample), or
+        the deterministic forward (x0 = mu: the term vanishes).  (Round 2 regenerated the library's eps in the backward, which
+        was silently wrong for the last two - advisor finding.)"""
         if self._checker is not None:
             return self._checker.forward(self, batch_inp, step, deterministic, row0, embs_reparam)
         x = batch_inp if isinstance(batch_inp, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(batch_inp, dtype=np.float32))
@@ -740,23 +745,27 @@ class SetTransformerDIB:
             xs.copy_(x.to(self.device).reshape(xs.shape))
             ys.copy_(y.to(self.device).reshape(ys.shape))
             self._graphs[(B, P)] = {}          # pins the plan against LRU eviction from here on
-            self._plan(B, P)
-            state = (self.params, self.adam_m, self.adam_v, self.t_dev, self.step_dev, self.grads)
-            saved = [t.clone() for t in state]
+            try:
+                self._plan(B, P)
+                state = (self.params, self.adam_m, self.adam_v, self.t_dev, self.step_dev, self.grads)
+                saved = [t.clone() for t in state]
 
-            def body():
-                self.forward(xs, step=0, _step_from_device=True)
-                self.loss_and_backward(ys)
-                self.adam_step()
+                def body():
+                    self.forward(xs, step=0, _step_from_device=True)
+                    self.loss_and_backward(ys)
+                    self.adam_step()
 
-            self._set_step_dev(self._step)
-            body()
-            for t, v in zip(state, saved):
-                t.copy_(v)
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+                self._set_step_dev(self._step)
                 body()
+                for t, v in zip(state, saved):
+                    t.copy_(v)
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body()
+            except Exception:
+                self._graphs.pop((B, P), None)   # no half-built entry: the next call starts over (or the caller goes eager)
+                raise
             g = self._graphs[(B, P)] = dict(graph=graph, xs=xs, ys=ys, last=dict(self.last))
         else:
             g["xs"].copy_(x.to(self.device).reshape(g["xs"].shape))

@@ -391,3 +391,34 @@ def test_step_plans_are_lru_capped_and_graph_plans_pinned():
     assert (2, 9) in keys and len(keys) <= m.max_step_plans + 1 and (2, 5) not in keys and (2, 11) in keys
     bce = m.train_step(rng.standard_normal((2, 9, 12)).astype(np.float32), np.ones((2, 1), np.float32))
     assert np.isfinite(float(bce.item()))
+
+
+@pytest.mark.parametrize("mode", ["injected_sample", "deterministic"])
+def test_backward_follows_the_forward_that_ran(mode):
+    """Round-2 advisor finding: forward(embs_reparam=...) / forward(deterministic=True) followed by loss_and_backward used
+    the LIBRARY's noise in the d(logvar) term.  The backward now recovers eps * sigma = x0 - mu from the sample that was
+    used: gradients equal the oracle's with the caller's own eps / with eps = 0."""
+    spec = sto.SetTransformerSpec(number_attention_blocks=1)
+    B, P, E = 3, 21, 32
+    m, p = _model(spec, seed=9)
+    rng = np.random.default_rng(4)
+    feats = rng.standard_normal((B, P, 12)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32)
+    beta = 0.3
+    m.beta_dev.fill_(beta)
+    if mode == "injected_sample":
+        eps = rng.standard_normal((B, P, E))
+        enc = m.particle_encoder(feats).cpu().numpy().astype(np.float64)
+        u = enc[..., :E] + np.exp((enc[..., E:] + spec.logvar_initialization) / 2.0) * eps
+        m.forward(feats, embs_reparam=u.astype(np.float32), step=123)
+    else:
+        eps = np.zeros((B, P, E))
+        m.forward(feats, deterministic=True, step=123)
+    m.loss_and_backward(y)
+    torch.cuda.synchronize()
+    vals, grads = sto.loss_and_grads(spec, p, feats.astype(np.float64), eps, y.astype(np.float64), beta)
+    got = m.get_grads()
+    gmax = max(float(r.abs().max()) for r in grads.values())
+    for k, r in grads.items():
+        r = r.numpy()
+        assert np.abs(got[k] - r).max() <= 1e-3 * max(np.abs(r).max(), 1e-3 * gmax), (mode, k)
