@@ -1068,8 +1068,8 @@ int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu
 
 int64_t dib_infonce_workspace_bytes(int batch) {
   if (batch <= 0) return DIB_E_ARG;
-  // S [B^2] | lse [2B] | norms [2B] | W = dL/dS [B^2] | Linf arg-max coordinate [B^2] (int32)
-  return (int64_t)sizeof(float) * (3ll * batch * batch + 4ll * batch + 64);
+  // S, ST, C, CT, C2, C2T [B^2 floats each] | arg-max, its transpose [B^2 int32 each] | lse [2B] | norms [2B]
+  return (int64_t)sizeof(float) * (8ll * batch * batch + 4ll * batch + 64);
 }
 
 int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int dim, int similarity, float temperature,
@@ -1079,10 +1079,15 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
   hipStream_t st = (hipStream_t)stream;
   const int64_t bb = (int64_t)batch * batch;
   float* S = (float*)ws;
-  float* lse = S + bb;
+  float* ST = S + bb;
+  float* C = ST + bb;
+  float* CT = C + bb;
+  float* C2 = CT + bb;
+  float* C2T = C2 + bb;
+  int* amax = (int*)(C2T + bb);
+  int* amaxT = amax + bb;
+  float* lse = (float*)(amaxT + bb);
   float* norms = lse + 2ll * batch;
-  float* W = norms + 2ll * batch;
-  int* amax = (int*)(W + bb);
   const float inv_t = 1.0f / temperature;
   const int tiles = cdiv(batch, 32);
   static bool attr_set[64] = {};
@@ -1095,16 +1100,17 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
   if (similarity == 0 || similarity == 1 || similarity == 4)
     hipLaunchKernelGGL(dib_infonce_norms_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, emb_x, emb_y, batch, dim, norms);
   hipLaunchKernelGGL(dib_infonce_sim_kernel, dim3(tiles, tiles), dim3(256), (size_t)2 * 32 * (dim + 1) * sizeof(float), st, emb_x,
-                     emb_y, batch, dim, similarity, inv_t, (const float*)norms, S, amax);
-  hipLaunchKernelGGL(dib_infonce_lse_kernel, dim3(batch, 2), dim3(256), 0, st, (const float*)S, batch, lse);
+                     emb_y, batch, dim, similarity, inv_t, (const float*)norms, S, ST, amax, amaxT);
+  hipLaunchKernelGGL(dib_infonce_lse_kernel, dim3(batch, 2), dim3(256), 0, st, (const float*)S, (const float*)ST, batch, lse);
   hipLaunchKernelGGL(dib_infonce_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)S, (const float*)lse, batch,
                      loss_out);
   if (g_x && g_y) {
-    hipLaunchKernelGGL(dib_infonce_w_kernel, dim3(grid_for(bb)), dim3(256), 0, st, (const float*)S, (const float*)lse, batch, inv_t,
-                       W);
+    hipLaunchKernelGGL(dib_infonce_coef_kernel, dim3(grid_for(bb, 256, 2048), 2), dim3(256), 0, st, (const float*)S,
+                       (const float*)ST, (const float*)lse, (const float*)norms, batch, similarity, inv_t, temperature, C, CT, C2,
+                       C2T);
     hipLaunchKernelGGL(dib_infonce_grad_kernel, dim3(batch, 2), dim3(256), 256 * sizeof(float), st, emb_x, emb_y,
-                       (const float*)S, (const float*)W, (const float*)norms, (const int*)amax, batch, dim, similarity, temperature,
-                       g_x, g_y);
+                       (const float*)C, (const float*)CT, (const float*)C2, (const float*)C2T, (const int*)amax,
+                       (const int*)amaxT, batch, dim, similarity, g_x, g_y);
   }
   return (int)hipGetLastError();
 }
@@ -1119,7 +1125,7 @@ int dib_positional_encoding(const float* x, int64_t ldx, int n, int d, int n_fre
 
 int64_t dib_mi_workspace_bytes(int n, int E) {
   if (n <= 0 || E <= 0) return DIB_E_ARG;
-  return (int64_t)sizeof(double) * (2ll * n * E + n);
+  return (int64_t)sizeof(double) * (4ll * n * E + n);   // 1/sigma, u [N][E]; c [N]; mu, 1/sigma dimension-major [E][N]
 }
 
 int dib_mi_sandwich_rows(const float* enc_out, int n, int E, uint64_t seed, uint32_t step, uint32_t feature,
@@ -1129,12 +1135,14 @@ int dib_mi_sandwich_rows(const float* enc_out, int n, int E, uint64_t seed, uint
   double* inv_sigma = (double*)ws;
   double* u = inv_sigma + (int64_t)n * E;
   double* cj = u + (int64_t)n * E;
+  double* mu_t = cj + n;
+  double* is_t = mu_t + (int64_t)n * E;
   hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, enc_out, n, E, (unsigned long long)seed,
-                     (unsigned)step, (unsigned)feature, inv_sigma, u, cj);
+                     (unsigned)step, (unsigned)feature, inv_sigma, u, cj, mu_t, is_t);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL(dib_mi_rows_kernel, dim3(n), dim3(256), 0, st, enc_out, n, E, (const double*)inv_sigma,
-                     (const double*)u, (const double*)cj, lower_rows, upper_rows);
+                     (const double*)u, (const double*)cj, (const double*)mu_t, (const double*)is_t, lower_rows, upper_rows);
   return (int)hipGetLastError();
 }
 
@@ -1448,7 +1456,7 @@ int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, const float
 
 int64_t dib_mi_probe_workspace_bytes(int n_probes, int n_data, int E) {
   if (n_probes <= 0 || n_data <= 0 || E <= 0) return DIB_E_ARG;
-  return (int64_t)sizeof(double) * ((2ll * E + 1) * ((int64_t)n_probes + n_data));
+  return (int64_t)sizeof(double) * ((4ll * E + 1) * ((int64_t)n_probes + n_data));   // per point set as dib_mi_workspace_bytes
 }
 
 int dib_mi_probe_bounds(const float* enc_probe, int n_probes, const float* enc_data, int n_data, int E, float logvar_offset,
@@ -1459,18 +1467,22 @@ int dib_mi_probe_bounds(const float* enc_probe, int n_probes, const float* enc_d
   double* is_p = (double*)ws;
   double* u_p = is_p + (int64_t)n_probes * E;
   double* c_p = u_p + (int64_t)n_probes * E;
-  double* is_d = c_p + n_probes;
+  double* mut_p = c_p + n_probes;
+  double* ist_p = mut_p + (int64_t)n_probes * E;
+  double* is_d = ist_p + (int64_t)n_probes * E;
   double* u_d = is_d + (int64_t)n_data * E;
   double* c_d = u_d + (int64_t)n_data * E;
+  double* mut_d = c_d + n_data;
+  double* ist_d = mut_d + (int64_t)n_data * E;
   hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n_probes, 256)), dim3(256), 0, st, enc_probe, n_probes, E,
-                     (unsigned long long)seed, (unsigned)step, (unsigned)feature, is_p, u_p, c_p, logvar_offset);
+                     (unsigned long long)seed, (unsigned)step, (unsigned)feature, is_p, u_p, c_p, mut_p, ist_p, logvar_offset);
   hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n_data, 256)), dim3(256), 0, st, enc_data, n_data, E,
-                     (unsigned long long)seed, (unsigned)step, (unsigned)feature + 1u, is_d, u_d, c_d, logvar_offset);
+                     (unsigned long long)seed, (unsigned)step, (unsigned)feature + 1u, is_d, u_d, c_d, mut_d, ist_d, logvar_offset);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL(dib_mi_probe_rows_kernel, dim3(n_probes), dim3(256), 0, st, enc_probe, (const double*)u_p,
-                     (const double*)is_p, (const double*)c_p, enc_data, (const double*)is_d, (const double*)c_d, n_data, E,
-                     lower_rows, upper_rows);
+                     (const double*)is_p, (const double*)c_p, (const double*)mut_d, (const double*)ist_d, (const double*)c_d,
+                     n_data, E, lower_rows, upper_rows);
   rc = (int)hipGetLastError();
   if (rc) return rc;
   if (u_probe_out)

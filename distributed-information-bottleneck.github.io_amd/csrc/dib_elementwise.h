@@ -390,7 +390,8 @@ dib_bhattacharyya_kernel(const float* __restrict__ mu1, const float* __restrict_
 __global__ void __launch_bounds__(256)
 dib_mi_prep_kernel(const float* __restrict__ enc_out /*[N][2E]*/, int n, int E, unsigned long long seed, unsigned step,
                    unsigned feature, double* __restrict__ inv_sigma /*[N][E]*/, double* __restrict__ u /*[N][E]*/,
-                   double* __restrict__ cj /*[N]*/, float lv_off = 0.f /* set transformer: logvar - 3 */) {
+                   double* __restrict__ cj /*[N]*/, double* __restrict__ mu_t /*[E][N]*/, double* __restrict__ is_t /*[E][N]*/,
+                   float lv_off = 0.f /* set transformer: logvar - 3 */) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const float* mu = enc_out + (long long)j * 2 * E;
@@ -405,6 +406,11 @@ dib_mi_prep_kernel(const float* __restrict__ enc_out /*[N][2E]*/, int n, int E, 
       const double sd = exp(0.5 * l);
       inv_sigma[(long long)j * E + e] = 1.0 / sd;
       u[(long long)j * E + e] = (double)mu[e] + sd * (double)eps[t];
+      // dimension-major copies for the row kernels: thread j of a row's workgroup reads [e][j] - consecutive threads,
+      // consecutive addresses (the point-major arrays made every load of the N^2 E inner loop touch 64 cache lines per
+      // wave: 218 us per 1024 x 1024 x 32 evaluation; round 3)
+      mu_t[(long long)e * n + j] = (double)mu[e];
+      is_t[(long long)e * n + j] = 1.0 / sd;
       slv += l;
     }
   }
@@ -418,19 +424,17 @@ __device__ __forceinline__ void dib_lse_add(double& mx, double& sm, double v) {
 
 __global__ void __launch_bounds__(256)
 dib_mi_rows_kernel(const float* __restrict__ enc_out, int n, int E, const double* __restrict__ inv_sigma,
-                   const double* __restrict__ u, const double* __restrict__ cj, double* __restrict__ lower_rows,
-                   double* __restrict__ upper_rows) {
+                   const double* __restrict__ u, const double* __restrict__ cj, const double* __restrict__ mu_t,
+                   const double* __restrict__ is_t, double* __restrict__ lower_rows, double* __restrict__ upper_rows) {
   __shared__ double smx[256], ssm[256];
   const int i = blockIdx.x;
   const double* ui = u + (long long)i * E;
   double mx = -1.0e300, sm = 0.0;  // log-sum-exp over j != i
   for (int j = threadIdx.x; j < n; j += 256) {
     if (j == i) continue;
-    const float* mu = enc_out + (long long)j * 2 * E;
-    const double* is = inv_sigma + (long long)j * E;
     double q = 0.0;
     for (int e = 0; e < E; ++e) {
-      const double d = (ui[e] - (double)mu[e]) * is[e];
+      const double d = (ui[e] - mu_t[(long long)e * n + j]) * is_t[(long long)e * n + j];
       q = fma(d, d, q);
     }
     dib_lse_add(mx, sm, cj[j] - 0.5 * q);
@@ -476,7 +480,7 @@ dib_mi_rows_kernel(const float* __restrict__ enc_out, int n, int E, const double
 __global__ void __launch_bounds__(256)
 dib_mi_probe_rows_kernel(const float* __restrict__ enc_probe, const double* __restrict__ u_probe,
                          const double* __restrict__ is_probe, const double* __restrict__ c_probe,
-                         const float* __restrict__ enc_data, const double* __restrict__ is_data,
+                         const double* __restrict__ mu_t_data /*[E][n_data]*/, const double* __restrict__ is_t_data,
                          const double* __restrict__ c_data, int n_data, int E, double* __restrict__ lower_rows,
                          double* __restrict__ upper_rows) {
   __shared__ double smx[256], ssm[256];
@@ -484,11 +488,9 @@ dib_mi_probe_rows_kernel(const float* __restrict__ enc_probe, const double* __re
   const double* ui = u_probe + (long long)i * E;
   double mx = -1.0e300, sm = 0.0;
   for (int j = threadIdx.x; j < n_data; j += 256) {
-    const float* mu = enc_data + (long long)j * 2 * E;
-    const double* is = is_data + (long long)j * E;
     double q = 0.0;
     for (int e = 0; e < E; ++e) {
-      const double d = (ui[e] - (double)mu[e]) * is[e];
+      const double d = (ui[e] - mu_t_data[(long long)e * n_data + j]) * is_t_data[(long long)e * n_data + j];
       q = fma(d, d, q);
     }
     dib_lse_add(mx, sm, c_data[j] - 0.5 * q);
@@ -530,11 +532,11 @@ dib_mi_probe_rows_kernel(const float* __restrict__ enc_probe, const double* __re
 // shared embedding width (64 by default).  Deterministic VALU kernels, O(B^2 D) each:
 //   norms   |x_i|^2, |y_j|^2 once per row (l2sq / l2 / cosine)
 //   sim     32 x 32 pairs per workgroup, both 32-row embedding tiles in LDS (odd pitch: conflict-free), one dot product /
-//           L1 / Linf reduction per pair; Linf also records its arg-max coordinate
-//   lse     row and column log-sum-exp;   loss
-//   w       dL/dS_ij = (softmax_row_i(S)_ij + softmax_col_j(S)_ij - 2 delta_ij) / (B T): two exponentials per PAIR
-//   grad    g_x[i][e] = sum_j w_ij dsim_ij/dx_ie (and g_y): thread = (coordinate e, partner group), O(1) per (pair, e) from
-//           S, the norms and the arg-max table.
+//           L1 / Linf reduction per pair; Linf also records its arg-max coordinate; S and its transpose are both written
+//   lse     row log-sum-exp of S and of ST (= column log-sum-exp);   loss
+//   coef    per-pair gradient coefficient(s) from dL/dS_ij = (softmax_row + softmax_col - 2 delta) / (B T), both orientations
+//   grad    g_x[i][e] = sum_j coef_ij (x_ie - y_je)-type sums (and g_y over the transposed copies): thread = (coordinate e,
+//           partner group), coefficients of 256 partners at a time through LDS.
 // (Round 3: the first version recomputed the norms and the dot product inside the gradient loop - O(B^2 D^2), 9.0 ms per
 // call at B = 2048, D = 64 against 0.35 ms for the whole encoder step; tools/infonce_bench.py, profiles/r03i_*, r03j_*.)
 // ---------------------------------------------------------------------------------------------
@@ -548,11 +550,16 @@ dib_infonce_norms_kernel(const float* __restrict__ X, const float* __restrict__ 
   norms[idx] = s;
 }
 
-// grid (ceil(B/32) column tiles, ceil(B/32) row tiles), 256 threads, dynamic LDS 2 * 32 * (D + 1) floats
+// grid (ceil(B/32) column tiles, ceil(B/32) row tiles), 256 threads, dynamic LDS 2 * 32 * (D + 1) floats.
+// Writes S AND its transpose ST (and the arg-max table and its transpose): every later pass over columns - column
+// log-sum-exp, g_y - then reads rows of the transposed copy, coalesced (the first version walked S with stride B).
 __global__ void __launch_bounds__(256)
 dib_infonce_sim_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, int kind, float inv_t,
-                       const float* __restrict__ norms, float* __restrict__ S, int* __restrict__ amax) {
+                       const float* __restrict__ norms, float* __restrict__ S, float* __restrict__ ST,
+                       int* __restrict__ amax, int* __restrict__ amaxT) {
   extern __shared__ float sm[];
+  __shared__ float tile[32][33];
+  __shared__ int atile[32][33];
   const int P = D + 1;
   float* Xs = sm;
   float* Ys = sm + 32 * P;
@@ -567,14 +574,14 @@ dib_infonce_sim_kernel(const float* __restrict__ X, const float* __restrict__ Y,
   const int j = j0 + tj;
   const float* b = Ys + tj * P;
   for (int k = 0; k < 4; ++k) {
-    const int i = i0 + ti + 8 * k;
-    if (i >= B || j >= B) continue;
-    const float* a = Xs + (ti + 8 * k) * P;
-    float s;
+    const int il = ti + 8 * k, i = i0 + il;
+    const float* a = Xs + il * P;
+    float s = 0.f;
+    int am = 0;
     if (kind == 0 || kind == 1 || kind == 4) {
       float ab = 0.f;
       for (int e = 0; e < D; ++e) ab += a[e] * b[e];
-      const float na = norms[i], nb = norms[B + j];
+      const float na = norms[min(i, B - 1)], nb = norms[B + min(j, B - 1)];
       if (kind == 4) {
         s = ab / (sqrtf(na) * sqrtf(nb));
       } else {  // utils.py:85-90: max(|a|^2 + |b|^2 - 2 a.b, 0)
@@ -582,27 +589,38 @@ dib_infonce_sim_kernel(const float* __restrict__ X, const float* __restrict__ Y,
         s = (kind == 0) ? -d2 : -sqrtf(d2 + 1e-9f);
       }
     } else if (kind == 2) {
-      s = 0.f;
       for (int e = 0; e < D; ++e) s -= fabsf(a[e] - b[e]);
     } else {
       float mx = -1.f;
-      int am = 0;
       for (int e = 0; e < D; ++e) { const float v = fabsf(a[e] - b[e]); if (v > mx) { mx = v; am = e; } }  // first maximum
       s = -mx;
-      amax[(long long)i * B + j] = am;
     }
-    S[(long long)i * B + j] = s * inv_t;
+    s *= inv_t;
+    tile[il][tj] = s;
+    atile[il][tj] = am;
+    if (i < B && j < B) {
+      S[(long long)i * B + j] = s;
+      if (kind == 3) amax[(long long)i * B + j] = am;
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < 4; ++k) {   // transposed tile: row = column index j0 + .., consecutive lanes = consecutive i
+    const int jl = ti + 8 * k, jj = j0 + jl, ii = i0 + tj;
+    if (jj < B && ii < B) {
+      ST[(long long)jj * B + ii] = tile[tj][jl];
+      if (kind == 3) amaxT[(long long)jj * B + ii] = atile[tj][jl];
+    }
   }
 }
 
-// lse[0][i] = LSE_j S[i][j] (rows), lse[1][j] = LSE_i S[i][j] (columns); one block per row / column
+// lse[0][i] = LSE_j S[i][j] (rows of S), lse[1][j] = LSE_i S[i][j] (rows of ST); one block per row
 __global__ void __launch_bounds__(256)
-dib_infonce_lse_kernel(const float* __restrict__ S, int B, float* __restrict__ lse) {
+dib_infonce_lse_kernel(const float* __restrict__ S, const float* __restrict__ ST, int B, float* __restrict__ lse) {
   __shared__ float red[4];
   const int which = blockIdx.y, idx = blockIdx.x;
-  const long long stride = which == 0 ? 1 : B, base = which == 0 ? (long long)idx * B : idx;
+  const float* row = (which == 0 ? S : ST) + (long long)idx * B;
   float mx = -INFINITY;
-  for (int t = threadIdx.x; t < B; t += 256) mx = fmaxf(mx, S[base + t * stride]);
+  for (int t = threadIdx.x; t < B; t += 256) mx = fmaxf(mx, row[t]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   __syncthreads();
@@ -610,7 +628,7 @@ dib_infonce_lse_kernel(const float* __restrict__ S, int B, float* __restrict__ l
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sm = 0.f;
-  for (int t = threadIdx.x; t < B; t += 256) sm += expf(S[base + t * stride] - mx);
+  for (int t = threadIdx.x; t < B; t += 256) sm += expf(row[t] - mx);
   const float tot = dib_block_sum_256(sm, red);
   if (threadIdx.x == 0) lse[(long long)which * B + idx] = mx + logf(tot);
 }
@@ -625,61 +643,97 @@ dib_infonce_loss_kernel(const float* __restrict__ S, const float* __restrict__ l
   if (threadIdx.x == 0) loss_out[0] = tot / (float)B;
 }
 
-// W_ij = dL/d(unscaled similarity)_ij = (softmax_row_i(S)_ij + softmax_col_j(S)_ij - 2 delta_ij) / (B T)
+// Per-pair gradient coefficient, for BOTH orientations (blockIdx.y = 0: C[i][j] from S; 1: CT[j][i] from ST - the same
+// numbers, each written along its own rows).  With w_ij = dL/d(unscaled similarity)_ij = (softmax_row_i(S)_ij +
+// softmax_col_j(S)_ij - 2 delta_ij) / (B T), the derivative of the similarity w.r.t. coordinate e of the row's own embedding
+// a (partner b) factors as
+//   l2sq  -2 (a_e - b_e)            if d2 > 0  (S = -d2/T < 0)                 c = -2 w
+//   l2    -(a_e - b_e) / r          r = sqrt(d2 + 1e-9) = -S T, if r^2 > 1e-9   c = -w / r
+//   l1    -sign(a_e - b_e)                                                      c = -w
+//   linf  -sign(a_e - b_e) [e == argmax]                                        c = -w
+//   cos   (b_e/|b| - sim a_e/|a|) / |a|    c = w / (|a| |b|),  c2 = w sim / |a|^2  (second output plane)
+// so the gradient kernel spends 2-4 instructions per (pair, coordinate) instead of re-deriving this per coordinate.
 __global__ void __launch_bounds__(256)
-dib_infonce_w_kernel(const float* __restrict__ S, const float* __restrict__ lse, int B, float inv_t, float* __restrict__ W) {
+dib_infonce_coef_kernel(const float* __restrict__ S, const float* __restrict__ ST, const float* __restrict__ lse,
+                        const float* __restrict__ norms, int B, int kind, float inv_t, float temperature,
+                        float* __restrict__ C, float* __restrict__ CT, float* __restrict__ C2, float* __restrict__ C2T) {
   const long long total = (long long)B * B;
+  const int tr = blockIdx.y;                    // 0: rows = x index i; 1: rows = y index j
+  const float* Sm = tr == 0 ? S : ST;
+  float* Cm = tr == 0 ? C : CT;
+  float* C2m = tr == 0 ? C2 : C2T;
   const float sc = inv_t / (float)B;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int i = (int)(idx / B), j = (int)(idx - (long long)i * B);
-    const float sij = S[idx];
-    W[idx] = (expf(sij - lse[i]) + expf(sij - lse[B + j]) - (i == j ? 2.0f : 0.f)) * sc;
+    const int r = (int)(idx / B), c = (int)(idx - (long long)r * B);
+    const int i = tr == 0 ? r : c, j = tr == 0 ? c : r;
+    const float sij = Sm[idx];
+    const float w = (expf(sij - lse[i]) + expf(sij - lse[B + j]) - (i == j ? 2.0f : 0.f)) * sc;
+    float cf;
+    if (kind == 0) cf = sij < 0.f ? -2.0f * w : 0.f;
+    else if (kind == 1) { const float rr = -sij * temperature; cf = (rr * rr > 1.0000005e-9f) ? -w / rr : 0.f; }
+    else if (kind == 2 || kind == 3) cf = -w;
+    else {
+      const float nself = norms[tr == 0 ? i : B + j], noth = norms[tr == 0 ? B + j : i];
+      const float ra = rsqrtf(nself), rb = rsqrtf(noth);
+      cf = w * ra * rb;
+      C2m[idx] = w * (sij * temperature) * ra * ra;
+    }
+    Cm[idx] = cf;
   }
 }
 
-// gradient wrt the embeddings.  which = 0: block i accumulates g_x[i] = sum_j W_ij dsim_ij/dx_i ; which = 1: block j
-// accumulates g_y[j] = sum_i W_ij dsim_ij/dy_j.  Thread t owns coordinate e = t % D of partner group t / D (D <= 256);
-// the partner's coordinate is one coalesced load, everything else about the pair comes from S / the norms / the arg-max
-// table.  Fixed-order sum over the partner groups (deterministic).
+// gradient wrt the embeddings.  which = 0: block i accumulates g_x[i] over its row of C; which = 1: block j accumulates
+// g_y[j] over its row of CT.  Thread t owns coordinate e = t % D of partner group t / D (D <= 256).  Partners are taken in
+// chunks of 256: the chunk's coefficients (and arg-max coordinates) go through LDS once, then every (pair, coordinate) costs a
+// broadcast LDS read, one coalesced load of the partner's coordinate and 2-4 VALU instructions.  Fixed-order sums
+// (deterministic).
 __global__ void __launch_bounds__(256)
-dib_infonce_grad_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ S,
-                        const float* __restrict__ W, const float* __restrict__ norms, const int* __restrict__ amax, int B,
-                        int D, int kind, float temperature, float* __restrict__ GX, float* __restrict__ GY) {
-  extern __shared__ float acc[];
+dib_infonce_grad_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ C,
+                        const float* __restrict__ CT, const float* __restrict__ C2, const float* __restrict__ C2T,
+                        const int* __restrict__ amax, const int* __restrict__ amaxT, int B, int D, int kind,
+                        float* __restrict__ GX, float* __restrict__ GY) {
+  extern __shared__ float acc[];        // [256] partial gradients
+  __shared__ float cs[256], cs2[256];
+  __shared__ int ams[256];
   const int which = blockIdx.y, me = blockIdx.x;
   const float* self = (which == 0 ? X : Y) + (long long)me * D;
   const float* others = which == 0 ? Y : X;
+  const float* crow = (which == 0 ? C : CT) + (long long)me * B;
+  const float* c2row = (which == 0 ? C2 : C2T) + (long long)me * B;
+  const int* arow = (which == 0 ? amax : amaxT) + (long long)me * B;
   float* out = (which == 0 ? GX : GY) + (long long)me * D;
   const int groups = max(1, 256 / D);
   const int e = threadIdx.x % D, grp = threadIdx.x / D;
+  const bool live = grp < groups;
+  const float se = live ? self[e] : 0.f;
   float g = 0.f;
-  if (grp < groups) {
-    const float se = self[e];
-    const float ra = (kind == 4) ? rsqrtf(norms[which == 0 ? me : B + me]) : 0.f;
-    for (int o = grp; o < B; o += groups) {
-      const long long idx = which == 0 ? (long long)me * B + o : (long long)o * B + me;
-      const float w = W[idx];
-      const float oe = others[(long long)o * D + e];
-      float d;  // d(unscaled similarity) / d(self_e)
-      if (kind == 0) {          // -d2, d2 = max(.,0): S = -d2/T < 0  <=>  d2 > 0
-        d = S[idx] < 0.f ? -2.0f * (se - oe) : 0.f;
-      } else if (kind == 1) {   // -sqrt(d2 + 1e-9): r = sqrt(d2 + 1e-9) = -S T; d2 > 0  <=>  r^2 > 1e-9
-        const float r = -S[idx] * temperature;
-        d = (r * r > 1.0000005e-9f) ? -(se - oe) / r : 0.f;
-      } else if (kind == 2) {
-        const float df = se - oe;
-        d = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f);
-      } else if (kind == 3) {
-        d = 0.f;
-        if (amax[idx] == e) { const float df = se - oe; d = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f); }
-      } else {                  // a.b / (|a||b|): (b_e/|b| - sim a_e/|a|) / |a|
-        const float rb = rsqrtf(norms[which == 0 ? B + o : o]);
-        d = (oe * rb - (S[idx] * temperature) * se * ra) * ra;
+  for (int o0 = 0; o0 < B; o0 += 256) {
+    const int n = min(256, B - o0);
+    __syncthreads();
+    if ((int)threadIdx.x < n) {
+      cs[threadIdx.x] = crow[o0 + threadIdx.x];
+      if (kind == 4) cs2[threadIdx.x] = c2row[o0 + threadIdx.x];
+      if (kind == 3) ams[threadIdx.x] = arow[o0 + threadIdx.x];
+    }
+    __syncthreads();
+    if (live) {
+      for (int ol = grp; ol < n; ol += groups) {
+        const float oe = others[(long long)(o0 + ol) * D + e];
+        const float c = cs[ol];
+        if (kind == 0 || kind == 1) {
+          g += c * (se - oe);
+        } else if (kind == 2) {
+          const float df = se - oe;
+          g += df > 0.f ? c : (df < 0.f ? -c : 0.f);
+        } else if (kind == 3) {
+          if (ams[ol] == e) { const float df = se - oe; g += df > 0.f ? c : (df < 0.f ? -c : 0.f); }
+        } else {
+          g += c * oe - cs2[ol] * se;
+        }
       }
-      g += w * d;
     }
   }
-  acc[threadIdx.x] = (grp < groups) ? g : 0.f;
+  acc[threadIdx.x] = live ? g : 0.f;
   __syncthreads();
   if (threadIdx.x < D) {  // fixed-order sum over the partner groups
     float s = 0.f;

@@ -1,20 +1,22 @@
 """DenseStack: a plain MLP ([PositionalEncoding] -> Dense(units, act)* -> Dense(out)) on the same hand-written
-gfx950 GEMM kernels (dib_gemm through the C ABI), used for the InfoNCE path's output encoder
-(reference train.py:184-192: `output_encoder`).  Forward, backward and Keras-Adam all run on the device."""
+gfx950 GEMM kernels, used for the InfoNCE path's output encoder (reference train.py:184-192: `output_encoder`).
+Forward, backward and Keras-Adam all run on the device.
+
+Per batch size a plan holds the activations, the gradient buffers and the descriptor tables of `dib_gemm_grouped`
+(include/dib_st.h), built and uploaded once: a step is 3 launches per layer with no per-call descriptor traffic.  Weight
+gradients contract over the batch in <= 32 row slabs (one partial parameter buffer each) summed in a fixed order by
+`dib_reduce_splits` - the first version ran every weight gradient as ONE workgroup per 128 x 128 output tile walking the
+whole batch: 265 us per layer at the chaos notebook's batch of 2048 (profiles/r03m_*)."""
 from __future__ import annotations
 
 import math
-from ctypes import c_void_p
-from typing import List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
 
+from ._gemm_plan import _Gemm, _d, _ptr
 from ._lib import ACTIVATIONS, check
-
-
-def _ptr(t):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
 class DenseStack:
@@ -41,8 +43,8 @@ class DenseStack:
         self.grads, self.adam_m, self.adam_v = z(), z(), z()
         self.t_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.lr_dev = torch.full((1,), 1e-3, dtype=torch.float32, device=self.device)
-        self._desc = torch.zeros(256, dtype=torch.uint8, device=self.device)
-        self._acts: List[torch.Tensor] = []
+        self._plans: Dict[int, dict] = {}
+        self._last: Optional[dict] = None
 
     # views
     def kernel(self, l):
@@ -52,43 +54,85 @@ class DenseStack:
     def bias(self, l):
         return self.params[self.b_off[l]: self.b_off[l] + self.dims[l][1]]
 
-    def _gemm(self, mode, M, N, K, A, lda, B, ldb, C, ldc, bias, aux, ldaux, act):
-        check(self.lib.dib_gemm(mode, M, N, K, _ptr(A), lda, _ptr(B), ldb, _ptr(C), ldc, _ptr(bias), _ptr(aux), ldaux, act,
-                                _ptr(self._desc), self.eng._stream()), "dib_gemm")
+    def _plan(self, n: int) -> dict:
+        pl = self._plans.get(n)
+        if pl is not None:
+            return pl
+        L = len(self.dims)
+        off, o = {}, 0
+
+        def take(name, cnt):
+            nonlocal o
+            off[name] = o
+            o = (o + int(cnt) + 3) // 4 * 4
+
+        take("y", n * self.input_dim)
+        take("a0", n * self.dims[0][0])                      # (positionally encoded) input
+        for l, (_, wo) in enumerate(self.dims):
+            take(f"a{l + 1}", n * wo)                        # post-activation output of layer l
+            take(f"g{l + 1}", n * wo)                        # dL/d(pre-activation of layer l) (= dL/d output for the last)
+        ws = torch.zeros(o, dtype=torch.float32, device=self.device)
+        # weight gradients: batch slabs of >= 64 rows (multiple of 32), <= 32 of them, fixed-order reduce
+        nsplit = max(1, min(32, n // 64))
+        rps = ((n + nsplit - 1) // nsplit + 31) // 32 * 32
+        nsplit = (n + rps - 1) // rps
+        slabs = torch.zeros(nsplit * self.n_params, dtype=torch.float32, device=self.device) if nsplit > 1 else None
+        gt = slabs if nsplit > 1 else self.grads
+        g = {}
+        for l, (wi, wo) in enumerate(self.dims):
+            act = self.act if l < L - 1 else 0
+            g[f"fwd{l}"] = _Gemm(0, [_d(off[f"a{l}"], wi, self.w_off[l], wo, off[f"a{l + 1}"], wo, n, wo, wi,
+                                        bias_off=self.b_off[l])], ws, self.params, ws, bias=self.params, act=act)
+            g[f"wgrad{l}"] = _Gemm(2, [_d(off[f"a{l}"], wi, off[f"g{l + 1}"], wo, self.w_off[l], wo, wi, wo, n,
+                                          bias_off=self.b_off[l])], ws, ws, gt, bias_out=gt, nsplit=nsplit,
+                                   rows_per_split=rps, split_stride=self.n_params)
+            if l > 0:   # dL/d(pre-activation of layer l-1) = (g_l @ W_l^T) * act'(a_l)
+                g[f"dgrad{l}"] = _Gemm(1, [_d(off[f"g{l + 1}"], wo, self.w_off[l], wo, off[f"g{l}"], wi, n, wi, wo,
+                                              aux_off=off[f"a{l}"], ldaux=wi)], ws, self.params, ws, aux=ws, act=self.act)
+        for gg in g.values():
+            gg.upload(self.device)
+        if len(self._plans) >= 4:                             # train batch, validation batch, their tails
+            self._plans.pop(next(iter(self._plans)))
+        pl = self._plans[n] = dict(n=n, ws=ws, off=off, g=g, nsplit=nsplit, slabs=slabs)
+        return pl
+
+    def _view(self, pl, name, rows, cols):
+        o = pl["off"][name]
+        return pl["ws"][o: o + rows * cols].view(rows, cols)
 
     def forward(self, y: torch.Tensor) -> torch.Tensor:
-        y = y.to(device=self.device, dtype=torch.float32).contiguous()
+        """[n, input_dim] -> [n, output_dim].  The result is a view into the plan's workspace: valid until the next forward
+        with the same batch size."""
+        y = y.to(device=self.device, dtype=torch.float32)
         n = y.shape[0]
+        pl = self._plan(n)
+        st = self.eng._stream()
         if self.n_freq > 1:
-            h = torch.empty((n, self.input_dim * self.n_freq), dtype=torch.float32, device=self.device)
-            check(self.lib.dib_positional_encoding(_ptr(y), y.stride(0), n, self.input_dim, self.n_freq, _ptr(h),
-                                                   self.eng._stream()), "dib_positional_encoding")
+            self._view(pl, "y", n, self.input_dim).copy_(y)
+            check(self.lib.dib_positional_encoding(_ptr(pl["ws"], pl["off"]["y"]), self.input_dim, n, self.input_dim, self.n_freq,
+                                                   _ptr(pl["ws"], pl["off"]["a0"]), st), "dib_positional_encoding")
         else:
-            h = y
-        self._acts = [h]
-        L = len(self.dims)
-        for l, (i, o) in enumerate(self.dims):
-            out = torch.empty((n, o), dtype=torch.float32, device=self.device)
-            self._gemm(0, n, o, i, h, i, self.kernel(l), o, out, o, self.bias(l), None, 0, self.act if l < L - 1 else 0)
-            self._acts.append(out)
-            h = out
-        return h
+            self._view(pl, "a0", n, self.input_dim).copy_(y)
+        for l in range(len(self.dims)):
+            pl["g"][f"fwd{l}"].run(self.lib, st)
+        self._last = pl
+        return self._view(pl, f"a{len(self.dims)}", n, self.dims[-1][1])
 
     def backward(self, g_out: torch.Tensor) -> None:
-        """grads <- d loss / d params given d loss / d output (overwrites self.grads)."""
-        g = g_out.contiguous()
-        n = g.shape[0]
-        for l in reversed(range(len(self.dims))):
-            i, o = self.dims[l]
-            h_in = self._acts[l]
-            gw = self.grads[self.w_off[l]: self.w_off[l] + i * o]
-            gb = self.grads[self.b_off[l]: self.b_off[l] + o]
-            # wgrad: dW[i,o] = h_in[n,i]^T @ g[n,o], bias gradient = column sums of g
-            self._gemm(2, i, o, n, h_in, i, g, o, gw, o, gb, None, 0, 0)
+        """grads <- d loss / d params given d loss / d output of the last forward (overwrites self.grads)."""
+        pl = self._last
+        assert pl is not None and g_out.shape[0] == pl["n"], "backward follows a forward with the same batch"
+        n, L, st = pl["n"], len(self.dims), self.eng._stream()
+        self._view(pl, f"g{L}", n, self.dims[-1][1]).copy_(g_out)
+        if pl["nsplit"] == 1:
+            self.grads.zero_()
+        for l in reversed(range(L)):
+            pl["g"][f"wgrad{l}"].run(self.lib, st)   # dW[i,o] = a_l^T @ g_{l+1}; bias gradient = column sums of g_{l+1}
             if l > 0:
-                gi = torch.empty((n, i), dtype=torch.float32, device=self.device)
-                self._gemm(1, n, i, o, g, o, self.kernel(l), o, gi, i, None, h_in, i, self.act)
-                g = gi
+                pl["g"][f"dgrad{l}"].run(self.lib, st)
+        if pl["nsplit"] > 1:
+            check(self.lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_params, pl["nsplit"], self.n_params, _ptr(self.grads), st),
+                  "dib_reduce_splits")
 
     def adam_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-7) -> None:
         self.lr_dev.fill_(float(lr))

@@ -29,27 +29,14 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._gemm_plan import DESC, _Gemm, _d, _ptr, _ptr8
 from ._lib import check
-
-DESC = np.dtype([("a_off", "<i8"), ("b_off", "<i8"), ("c_off", "<i8"), ("bias_off", "<i8"), ("aux_off", "<i8"),
-                 ("a_boff", "<i8"), ("b_boff", "<i8"), ("c_boff", "<i8"), ("aux_boff", "<i8"),
-                 ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"), ("ldaux", "<i4"),
-                 ("flags", "<i4")])
-assert DESC.itemsize == 104  # include/dib_st.h: dib_gemm_desc
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, _lib.ACT_LEAKY_RELU_01
 LOSS_BCE_LOGITS = 0
 # Test switch: take train_step's collective branch even on a ONE-rank process group, so that the RCCL calls themselves run
 # on the single GPU the test box has (tests/_dp_gpu_st_worker.py).  A 1-rank sum all-reduce is the identity.
 _FORCE_DP_BRANCH = False
-
-
-def _ptr(t: Optional[torch.Tensor], off: int = 0):
-    return c_void_p(t.data_ptr() + 4 * off) if t is not None else c_void_p(0)
-
-
-def _ptr8(t: Optional[torch.Tensor]):
-    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
 def _align4(n: int) -> int:
@@ -72,32 +59,6 @@ def convert_to_per_particle_feature_set(particle_positions, types, number_partic
     return feats
 
 
-class _Gemm:
-    """One grouped-GEMM launch: a device descriptor table + base tensors."""
-
-    def __init__(self, mode, descs, A, B, C, bias=None, aux=None, bias_out=None, act=0, nsplit=1, rows_per_split=0,
-                 split_stride=0):
-        self.mode, self.n = mode, len(descs)
-        self.max_m = int(max(d["M"] for d in descs))
-        self.max_n = int(max(d["N"] for d in descs))
-        arr = np.zeros(len(descs), dtype=DESC)
-        for i, d in enumerate(descs):
-            for k, v in d.items():
-                arr[i][k] = v
-        self.host = arr
-        self.dev = None
-        self.A, self.B, self.C, self.bias, self.aux, self.bias_out = A, B, C, bias, aux, bias_out
-        self.act, self.nsplit, self.rps, self.stride = act, nsplit, rows_per_split, split_stride
-
-    def upload(self, device):
-        self.dev = torch.from_numpy(self.host.view(np.uint8).copy()).to(device)
-
-    def run(self, lib, stream):
-        check(lib.dib_gemm_grouped(self.mode, self.n, _ptr(self.dev), self.max_m, self.max_n, _ptr(self.A), _ptr(self.B),
-                                   _ptr(self.C), _ptr(self.bias), _ptr(self.aux), _ptr(self.bias_out), self.act, self.nsplit,
-                                   self.rps, self.stride, stream), "dib_gemm_grouped")
-
-
 class _SplitKGemm:
     """A skinny product C[M, N] = A[M, K] @ W (N = the model width, 32; K = heads * key_dim = 1536) with FEW row tiles: the
     output has ceil(M / 64) workgroups' worth of tiles and each would walk all of K with one tile of prefetch - at the
@@ -116,11 +77,6 @@ class _SplitKGemm:
         self.gemm.run(lib, stream)
         check(lib.dib_reduce_splits(_ptr(self.partial, self.partial_off), self.n, self.nslabs, self.n,
                                     _ptr(self.out, self.out_off), stream), "dib_reduce_splits")
-
-
-def _d(a_off, lda, b_off, ldb, c_off, ldc, M, N, K, bias_off=-1, aux_off=0, ldaux=0):
-    return dict(a_off=a_off, b_off=b_off, c_off=c_off, bias_off=bias_off, aux_off=aux_off, M=M, N=N, K=K, lda=lda, ldb=ldb,
-                ldc=ldc, ldaux=ldaux)
 
 
 class SetTransformerDIB:

@@ -418,13 +418,15 @@ def test_mi_sandwich_bounds_at_the_reference_evaluation_size():
         assert lo <= up + 1e-9 and lo <= np.log(N) + 1e-9
 
 
-def test_dense_stack_matches_numpy():
-    """The Y-encoder MLP (DenseStack over dib_gemm): forward, backward and Keras-Adam vs numpy."""
+@pytest.mark.parametrize("n", [37, 2048])
+def test_dense_stack_matches_numpy(n):
+    """The Y-encoder MLP (DenseStack over dib_gemm_grouped): forward, backward and Keras-Adam vs numpy; n = 2048 (the chaos
+    notebook's batch) runs the weight gradients in 32 batch slabs + fixed-order reduce."""
     from dib_amd.dense import DenseStack
     eng, _ = _engine(SPECS["no_hidden"])
     ds = DenseStack(eng, 6, [20, 12], 5, "relu", True, 3, seed=4)
     rng = np.random.default_rng(0)
-    y = rng.standard_normal((37, 6)).astype(np.float32)
+    y = rng.standard_normal((n, 6)).astype(np.float32)
     out = ds.forward(eng.to_device(y)).cpu().numpy()
     Ws = [ds.kernel(l).cpu().numpy().astype(np.float64) for l in range(3)]
     bs = [rng.standard_normal(ds.dims[l][1]) * 0.1 for l in range(3)]
