@@ -235,6 +235,30 @@ def config5_set_transformer(dev, nb=4, npart=4096, nfeat=16, steps=4, warmup=2):
     return out
 
 
+def config2_infonce_loop(dev, batch):
+    """BASELINE config 2's training path: the custom InfoNCE loop (reference train.py:180-289) on the double-pendulum layout -
+    feature dimensionalities [2, 1, 2, 1] (angles as unit vectors, velocities), positional encoding, encoder [128, 128], E = 32,
+    integration [256, 256] -> 64-d shared space, Y encoder [128, 128] (a DenseStack), similarity l2, Adam.  Synthetic data of
+    that shape; one step = X forward + Y forward + [B, B] InfoNCE loss and gradients + both backwards + both Adam updates."""
+    import dib_amd
+    from dib_amd import infonce
+    rng = np.random.default_rng(7)
+    n = batch * 16
+    x = rng.standard_normal((n, 6)).astype(np.float32)
+    y = (x + 0.3 * rng.standard_normal((n, 6))).astype(np.float32)
+    model = dib_amd.DistributedIBNet([2, 1, 2, 1], ENC, INTEG, 64, feature_embedding_dimension=E, device=dev)
+    kw = dict(batch_size=batch, number_pretraining_epochs=1, number_annealing_epochs=1, beta_start=1e-4, beta_end=1.0,
+              learning_rate=3e-4, shared_dimensionality=64, similarity="l2")
+    infonce.fit_infonce(model, x, y, x[:batch], y[:batch], **kw)                  # warm-up: 16 train + 4 validation steps
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kw.update(number_pretraining_epochs=2, number_annealing_epochs=3)
+    infonce.fit_infonce(model, x, y, x[:batch], y[:batch], **kw)                  # 4 x 16 train steps + 5 x 2 validation steps
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (4 * 16 + 5 * 2)
+    return {"batch": batch, "ms_per_step": round(1e3 * dt, 3), "samples_per_s": round(batch / dt, 1)}
+
+
 def reference_size_set_transformer(dev, steps=30, warmup=5):
     """The notebook's own configuration (...set_transformer.ipynb:304-307, 419-431): 32 neighbourhoods x 50 particles x 12
     features, 6 attention blocks - ~190 launches of <= 40 us per step, bound by launch / dependency latency.  Eager launches
@@ -509,6 +533,12 @@ def main():
                 extra["set_transformer_notebook_size"] = reference_size_set_transformer(dev)
             except Exception as e:  # noqa: BLE001
                 extra["set_transformer_notebook_size"] = {"error": f"{type(e).__name__}: {e}"}
+            try:   # the reference's default batch (train.py:34) and the chaos notebook's (Chaos_experiments.ipynb:771-821)
+                extra["config2_infonce_loop"] = {
+                    "workload": "BASELINE config 2 path: custom InfoNCE loop, pendulum layout [2,1,2,1], shared space 64, l2, fp32",
+                    "runs": [config2_infonce_loop(dev, 128), config2_infonce_loop(dev, 2048)]}
+            except Exception as e:  # noqa: BLE001
+                extra["config2_infonce_loop"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_extra:
             # opt-in mode, separately labelled (never the headline): the integration network's two hidden-layer FORWARD
             # products evaluated as six bf16 piece products per fp32 product on the bf16 matrix pipe (fp32-accurate, see

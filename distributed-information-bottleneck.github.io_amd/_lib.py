@@ -145,6 +145,8 @@ SIGNATURES_ST = {
     "dib_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int64, c_int]),
     "dib_add_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
+    "dib_add_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                            c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_mean_pool_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_mean_pool_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_add_inplace": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

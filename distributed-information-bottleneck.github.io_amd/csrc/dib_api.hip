@@ -1297,25 +1297,32 @@ int64_t dib_add_layernorm_bwd_workspace_bytes(int64_t T, int D) {
   return (int64_t)ln_grid(T, D) * 4 * (D <= 32 ? 2 : 1) * 2 * D * (int64_t)sizeof(float);
 }
 
-int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t T, int D,
-                          float* ds, float* dgamma_dbeta, void* ws, dib_stream_t stream) {
+int dib_add_layernorm_bwd_fused(const float* dy, const float* dy2, const float* xhat, const float* rstd, const float* gamma,
+                                int64_t T, int D, float* ds, const float* act_src, int act, float* dz, float* dgamma_dbeta,
+                                void* ws, dib_stream_t stream) {
   if (!dy || !xhat || !rstd || !gamma || !ds || !dgamma_dbeta || !ws || T <= 0 || D <= 0) return DIB_E_ARG;
+  if ((dz != nullptr) != (act_src != nullptr) || (dz && !act_ok(act))) return DIB_E_ARG;
   if (D > 256) return DIB_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int grid = ln_grid(T, D);
   float* partial = (float*)ws;
   if (D <= 32)
-    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<32>, dim3(grid), dim3(256), 0, st, dy, xhat, rstd, gamma, (long long)T, D,
-                       ds, partial);
+    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<32>, dim3(grid), dim3(256), 0, st, dy, dy2, xhat, rstd, gamma, (long long)T, D,
+                       ds, act_src, act, dz, partial);
   else
-    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, dy, xhat, rstd, gamma, (long long)T, D,
-                       ds, partial);
+    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, dy, dy2, xhat, rstd, gamma, (long long)T, D,
+                       ds, act_src, act, dz, partial);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   // [gamma gradient (D) | beta gradient (D)] = fixed-order column sums of the per-slot partials
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2 * D), dim3(256), 0, st, (const float*)partial,
                      grid * 4 * (D <= 32 ? 2 : 1), 2 * D, dgamma_dbeta);
   return (int)hipGetLastError();
+}
+
+int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t T, int D,
+                          float* ds, float* dgamma_dbeta, void* ws, dib_stream_t stream) {
+  return dib_add_layernorm_bwd_fused(dy, nullptr, xhat, rstd, gamma, T, D, ds, nullptr, 0, nullptr, dgamma_dbeta, ws, stream);
 }
 
 int dib_mean_pool_fwd(const float* x, int B, int P, int D, float* out, dib_stream_t stream) {

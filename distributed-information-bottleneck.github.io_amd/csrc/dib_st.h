@@ -156,10 +156,15 @@ dib_add_layernorm_fwd_kernel(const float* __restrict__ A, const float* __restric
 // backward: dxhat = dy * gamma; ds = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) (flows to BOTH addends);
 // per-slot partial sums of dgamma = sum_rows dy * xhat and dbeta = sum_rows dy: partial[slot][2][D], slot = row group of
 // the launch (fixed geometry => fixed order), reduced by dib_colsum_partials_kernel.
+// Optional fusions (round 3: the set transformer at 1600 tokens is a chain of ~5 us launches):
+//   dY2      second gradient addend: dY := dY + dY2 (the residual branch's gradient arriving at LN1 - was dib_add_inplace)
+//   act_src  post-activation tensor of the branch that fed the Add: dZ = dS * act'(act_src) (the feed-forward block's last
+//            relu in front of LN2 - was dib_act_grad_mul)
 template <int W>
 __global__ void __launch_bounds__(256)
-dib_add_layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ xhat, const float* __restrict__ rstd,
-                             const float* __restrict__ gamma, long long T, int D, float* __restrict__ dS,
+dib_add_layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ dY2, const float* __restrict__ xhat,
+                             const float* __restrict__ rstd, const float* __restrict__ gamma, long long T, int D,
+                             float* __restrict__ dS, const float* __restrict__ act_src, int act, float* __restrict__ dZ,
                              float* __restrict__ partial) {
   constexpr int RPW = 64 / W;
   const int lane = threadIdx.x & 63, sub = lane / W, l = lane % W;
@@ -176,7 +181,7 @@ dib_add_layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restri
     for (int c = 0; c < 256 / W; ++c) {
       const int j = l + c * W;
       const bool in = ok && j < D;
-      const float dy = in ? dY[row * D + j] : 0.f;
+      const float dy = in ? (dY2 ? dY[row * D + j] + dY2[row * D + j] : dY[row * D + j]) : 0.f;
       xh[c] = in ? xhat[row * D + j] : 0.f;
       dxh[c] = in ? dy * gamma[j] : 0.f;
       pg[c] += dy * xh[c];
@@ -190,7 +195,11 @@ dib_add_layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restri
 #pragma unroll
       for (int c = 0; c < 256 / W; ++c) {
         const int j = l + c * W;
-        if (j < D) dS[row * D + j] = rs * (dxh[c] - m1 - xh[c] * m2);
+        if (j < D) {
+          const float v = rs * (dxh[c] - m1 - xh[c] * m2);
+          dS[row * D + j] = v;
+          if (dZ) dZ[row * D + j] = v * dib_act_grad(act, act_src[row * D + j]);
+        }
       }
     }
   }

@@ -291,7 +291,9 @@ class SetTransformerDIB:
         for l, u in enumerate(self.final_processing_arch):
             take(f"g_fin{l}", B * u)
         take("g_pool", B * D)
-        take("g_x", T * D); take("g_s", T * D); take("g_z", T * D); take("g_h", T * D)
+        # g_x / g_s: gradient w.r.t. a block's output / input, ping-ponging from block to block (no copy); g_a: both addends
+        # of LN2; g_z: feed-forward pre-activation; g_h: the feed-forward branch's gradient w.r.t. h
+        take("g_x", T * D); take("g_s", T * D); take("g_a", T * D); take("g_z", T * D); take("g_h", T * D)
         for l, u in enumerate(ff[:-1]):
             take(f"g_ff{l}", T * u)
         for nm in ("q", "k", "v", "ctx"):
@@ -408,8 +410,9 @@ class SetTransformerDIB:
                 else:
                     g[f"b{b}_ff0_dgrad"] = dense_dgrad(gy, ky, pre + "ff0_w", "g_h", D, T)
             # attention output projection
-            g[f"b{b}_o_wgrad"] = dense_wgrad(f"b{b}_ctx", HK, "g_s", D, pre + "o_w", pre + "o_b", T)
-            g[f"b{b}_o_dgrad"] = dense_dgrad("g_s", D, pre + "o_w", "g_ctx", HK, T)
+            gout = self._block_grad_names(b)[1]   # gradient w.r.t. the block's input x (= gradient of LN1's two addends)
+            g[f"b{b}_o_wgrad"] = dense_wgrad(f"b{b}_ctx", HK, gout, D, pre + "o_w", pre + "o_b", T)
+            g[f"b{b}_o_dgrad"] = dense_dgrad(gout, D, pre + "o_w", "g_ctx", HK, T)
             if gemm_attn:
                 g[f"b{b}_dv"] = _Gemm(2, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off["g_ctx"] + bi * P * HK + hi * K, HK,
                                            off["g_v"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
@@ -470,6 +473,12 @@ class SetTransformerDIB:
             self._plans.pop(step_keys[0])
         self._plans[key] = plan
         return plan
+
+    def _block_grad_names(self, b: int):
+        """(buffer holding dL/d(output of block b), buffer receiving dL/d(input of block b)): "g_x" and "g_s" alternate from
+        block to block in backward order, so a block's result is the next block's input without a copy."""
+        k = self.number_attention_blocks - 1 - b
+        return ("g_x", "g_s") if k % 2 == 0 else ("g_s", "g_x")
 
     def _view(self, plan, name, *shape):
         o = plan["off"][name]
@@ -577,23 +586,23 @@ class SetTransformerDIB:
         nff = len(self.ff_arch_per_block)
         for b in range(self.number_attention_blocks - 1, -1, -1):
             pre = f"blk{b}_"
-            # x_out = LN2(h + ff): g_x -> g_s (gradient of both addends), d(gamma2, beta2)
-            check(lib.dib_add_layernorm_bwd(_ptr(ws, off["g_x"]), _ptr(ws, off[f"b{b}_xhat2"]), _ptr(ws, off[f"b{b}_rstd2"]),
-                                            _ptr(self.params, self.offsets[pre + "ln2_g"]), T, D, _ptr(ws, off["g_s"]),
-                                            _ptr(gt, self.offsets[pre + "ln2_g"]), _ptr(ws, off["ln_ws"]), st),
-                  "dib_add_layernorm_bwd")
-            # feed-forward branch: mask of its last relu, then the Dense chain backwards
-            check(lib.dib_act_grad_mul(_ptr(ws, off["g_s"]), _ptr(ws, off[f"b{b}_ff{nff - 1}"]), ACT_RELU, T * D,
-                                       _ptr(ws, off["g_z"]), st), "dib_act_grad_mul")
+            gin, gout = self._block_grad_names(b)
+            # x_out = LN2(h + ff): gin -> g_a (gradient of both addends) and, in the same pass, g_z = g_a * relu'(ff output)
+            # (the feed-forward branch's pre-activation gradient), d(gamma2, beta2)
+            check(lib.dib_add_layernorm_bwd_fused(_ptr(ws, off[gin]), c_void_p(0), _ptr(ws, off[f"b{b}_xhat2"]),
+                                                  _ptr(ws, off[f"b{b}_rstd2"]), _ptr(self.params, self.offsets[pre + "ln2_g"]), T, D,
+                                                  _ptr(ws, off["g_a"]), _ptr(ws, off[f"b{b}_ff{nff - 1}"]), ACT_RELU,
+                                                  _ptr(ws, off["g_z"]), _ptr(gt, self.offsets[pre + "ln2_g"]), _ptr(ws, off["ln_ws"]),
+                                                  st), "dib_add_layernorm_bwd_fused")
             for l in range(nff - 1, -1, -1):
                 g[f"b{b}_ff{l}_wgrad"].run(lib, st)
                 g[f"b{b}_ff{l}_dgrad"].run(lib, st)
-            check(lib.dib_add_inplace(_ptr(ws, off["g_h"]), _ptr(ws, off["g_s"]), T * D, st), "dib_add_inplace")  # + residual
-            # h = LN1(x + mha): g_h -> g_s, d(gamma1, beta1)
-            check(lib.dib_add_layernorm_bwd(_ptr(ws, off["g_h"]), _ptr(ws, off[f"b{b}_xhat1"]), _ptr(ws, off[f"b{b}_rstd1"]),
-                                            _ptr(self.params, self.offsets[pre + "ln1_g"]), T, D, _ptr(ws, off["g_s"]),
-                                            _ptr(gt, self.offsets[pre + "ln1_g"]), _ptr(ws, off["ln_ws"]), st),
-                  "dib_add_layernorm_bwd")
+            # h = LN1(x + mha): (g_h + g_a, the residual) -> gout, d(gamma1, beta1)
+            check(lib.dib_add_layernorm_bwd_fused(_ptr(ws, off["g_h"]), _ptr(ws, off["g_a"]), _ptr(ws, off[f"b{b}_xhat1"]),
+                                                  _ptr(ws, off[f"b{b}_rstd1"]), _ptr(self.params, self.offsets[pre + "ln1_g"]), T, D,
+                                                  _ptr(ws, off[gout]), c_void_p(0), 0, c_void_p(0),
+                                                  _ptr(gt, self.offsets[pre + "ln1_g"]), _ptr(ws, off["ln_ws"]), st),
+                  "dib_add_layernorm_bwd_fused")
             # multi-head attention
             g[f"b{b}_o_wgrad"].run(lib, st)
             g[f"b{b}_o_dgrad"].run(lib, st)
@@ -612,16 +621,16 @@ class SetTransformerDIB:
                                             _ptr(ws, off["attn_delta"]), st), "dib_attention_bwd")
             g[f"b{b}_qkv_wgrad"].run(lib, st)
             g[f"b{b}_qkv_dgrad"].run(lib, st)
-            # g_x (input of the block) = residual + the three projection inputs
-            check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xq"]), T * D, st), "dib_add_inplace")
+            # gradient w.r.t. the block's input = residual (already in gout) + the three projection inputs
+            check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off["g_xq"]), T * D, st), "dib_add_inplace")
             if pl["ksplit"] == 1:   # (split-K: the slab reduce already summed the three projections' gradients into g_xq)
-                check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xk"]), T * D, st), "dib_add_inplace")
-                check(lib.dib_add_inplace(_ptr(ws, off["g_s"]), _ptr(ws, off["g_xv"]), T * D, st), "dib_add_inplace")
-            self._view(pl, "g_x", T * D).copy_(self._view(pl, "g_s", T * D))
+                check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off["g_xk"]), T * D, st), "dib_add_inplace")
+                check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off["g_xv"]), T * D, st), "dib_add_inplace")
         # bottleneck: d(mu | raw logvar), beta * KL included
         ne = len(pl["enc_units"])
         # eps * sigma = x0 - mu: the gradient of the forward that ran (library noise, embs_reparam or deterministic)
-        check(lib.dib_token_reparam_kl_bwd(_ptr(ws, off[f"enc_h{ne - 1}"]), _ptr(ws, off["g_x"]), _ptr(ws, off["x0"]), T, D,
+        g_u = "g_x" if self.number_attention_blocks % 2 == 0 else "g_s"   # where the last processed block left dL/d(x0)
+        check(lib.dib_token_reparam_kl_bwd(_ptr(ws, off[f"enc_h{ne - 1}"]), _ptr(ws, off[g_u]), _ptr(ws, off["x0"]), T, D,
                                            self.logvar_initialization, _ptr(self.beta_dev), inv,
                                            _ptr(ws, off[f"g_enc_h{ne - 1}"]), st), "dib_token_reparam_kl_bwd")
         for l in range(ne - 1, -1, -1):

@@ -73,6 +73,12 @@ int dib_add_layernorm_fwd(const float* a, const float* b, int64_t T, int D, cons
 int64_t dib_add_layernorm_bwd_workspace_bytes(int64_t T, int D);
 int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t T, int D,
                           float* ds, float* dgamma_dbeta, void* ws, dib_stream_t stream);
+/* The same with two optional fusions: dy2 (a second gradient addend: dY = dy + dy2 - the residual branch's gradient) and
+ * (act_src, act, dz): dz = ds * act'(act_src) for the branch that fed the Add through activation `act` (act_src = its
+ * post-activation output).  NULL / NULL: dib_add_layernorm_bwd. */
+int dib_add_layernorm_bwd_fused(const float* dy, const float* dy2, const float* xhat, const float* rstd, const float* gamma,
+                                int64_t T, int D, float* ds, const float* act_src, int act, float* dz, float* dgamma_dbeta,
+                                void* ws, dib_stream_t stream);
 
 /* tf.reduce_mean(x, axis=-2): x [B, P, D] -> out [B, D]; backward dx = g / P broadcast over the particle axis */
 int dib_mean_pool_fwd(const float* x, int B, int P, int D, float* out, dib_stream_t stream);
