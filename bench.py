@@ -253,9 +253,9 @@ def config2_infonce_loop(dev, batch):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kw.update(number_pretraining_epochs=2, number_annealing_epochs=3)
-    infonce.fit_infonce(model, x, y, x[:batch], y[:batch], **kw)                  # 4 x 16 train steps + 5 x 2 validation steps
+    infonce.fit_infonce(model, x, y, x[:batch], y[:batch], **kw)                  # 4 x 16 train steps + 4 x 2 validation steps
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / (4 * 16 + 5 * 2)
+    dt = (time.perf_counter() - t0) / (4 * 16 + 4 * 2)
     return {"batch": batch, "ms_per_step": round(1e3 * dt, 3), "samples_per_s": round(batch / dt, 1)}
 
 
