@@ -158,8 +158,8 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
     dib_attn_lstore(Ks, rk, tid);
     dib_attn_lstore(Vs, rv, tid);
     __syncthreads();
-    if (kt + 1 < n_tiles) {
-      rk = dib_attn_gload(Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+    if (kt + 1 < n_tiles) {   // (issuing the V tile's loads after the S product instead - the GEMM's prefetch-piece trick - measured
+      rk = dib_attn_gload(Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);   // no different here: profiles/r03s_*)
       rv = dib_attn_gload(Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
     }
     if (wave_ok) {

@@ -60,6 +60,8 @@ struct DibStage {
   }
   static __device__ __forceinline__ int col(int tid) { return KC ? ((tid % (BK / 4)) * 4) : ((tid % (EXT / 4)) * 4); }
 
+  // loads float4 p in [P0, P1) of the tile (the whole tile by default; the weight gradients issue it in pieces)
+  template <int P0 = 0, int P1 = NP>
   static __device__ __forceinline__ void gload(float4 (&r)[NP], const float* __restrict__ base, long long ld,
                                                int mn0, int mn_max, int k0, int k_max, bool vec, int tid) {
     const int r0 = KC ? mn0 : k0, c0 = KC ? k0 : mn0;
@@ -67,11 +69,11 @@ struct DibStage {
     const int rext = KC ? EXT : BK, cext = KC ? BK : EXT;
     if (vec && r0 + rext <= Rmax && c0 + cext <= Cmax) {  // interior tile: unconditional 16 B loads
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
+      for (int p = P0; p < P1; ++p)
         r[p] = *reinterpret_cast<const float4*>(base + (long long)(r0 + row(tid, p)) * ld + c0 + col(tid));
     } else {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
+      for (int p = P0; p < P1; ++p) {
         const int R = r0 + row(tid, p), Cc = c0 + col(tid);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (R < Rmax) {
@@ -175,10 +177,37 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     SA::lstore(As, ra, tid);
     SB::lstore(Bs, rb, tid);
     __syncthreads();
-    if (k0 + BK < kend) {  // next tile's global loads fly during this tile's MFMAs
-      SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
-      SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
-    }
+#ifndef DIB_GEMM_SPLIT_PREFETCH
+#define DIB_GEMM_SPLIT_PREFETCH 1   // 0 (A/B baseline, rounds 1-2): the whole prefetch issued at the top of the MFMA phase
+#endif
+    // The next K-tile's global loads are issued in PIECES spread over this tile's MFMA phase instead of one burst after the
+    // barrier: a workgroup's HBM request stream becomes even, and the tiled kernels' read rate moves from 4.45 TB/s towards
+    // what the streaming kernels reach.  Measured per shape (same-box A/B of 2 / 4 pieces, weight gradients only / every mode,
+    // profiles/r03r_gemm_prefetch_pieces_ab.txt): 64-deep forward / dgrad tiles want 4 pieces (dgrad 0.79 -> 0.73 ms), the
+    // weight gradients and the 32-deep tiles 2 (layer-3 wgrad 0.70 -> 0.65 ms; 4 pieces there: 0.71).
+    constexpr int kPieces = DIB_GEMM_SPLIT_PREFETCH == 0 ? 1 : ((MODE != 2 && BK == 64) ? 4 : 2);
+    constexpr int QN = BK / 8;   // MFMA sub-phases of a K-tile
+    const bool have_next = k0 + BK < kend;
+    // piece i of the next tile's global loads (kPieces == 2: A | B; 4: A lo | A hi | B lo | B hi) is issued at sub-phase
+    // i * QN / kPieces of this tile's MFMAs
+    auto prefetch_piece = [&](auto piece_c) {
+      constexpr int piece = decltype(piece_c)::value;
+      if (!have_next) return;
+      if constexpr (kPieces == 1) {
+        SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
+        SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
+      } else if constexpr (kPieces == 2) {
+        if constexpr (piece == 0) SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
+        else SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
+      } else {
+        constexpr int HA = (SA::NP + 1) / 2, HB = (SB::NP + 1) / 2;
+        if constexpr (piece == 0) SA::template gload<0, HA>(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
+        else if constexpr (piece == 1) SA::template gload<HA, SA::NP>(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
+        else if constexpr (piece == 2) SB::template gload<0, HB>(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
+        else SB::template gload<HB, SB::NP>(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
+      }
+    };
+    prefetch_piece(std::integral_constant<int, 0>{});
     if (do_bias) {
       constexpr int PARTS = 256 / BN, RPP = BK / PARTS;
       const int colb = tid % BN, part = tid / BN;
@@ -188,6 +217,16 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     if (active) {  // rows/cols/k beyond the matrix edge are zero-filled in LDS, so all BK/2 k-steps always run
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
+        if constexpr (kPieces > 1) {
+          if (q > 0 && (q * kPieces) % QN == 0) {   // q = i * QN / kPieces, i = 1 .. kPieces - 1 (compile-time after unrolling)
+            __builtin_amdgcn_sched_barrier(0);
+            const int piece = q * kPieces / QN;
+            if (piece == 1) prefetch_piece(std::integral_constant<int, 1>{});
+            else if (piece == 2) prefetch_piece(std::integral_constant<int, 2>{});
+            else if (piece == 3) prefetch_piece(std::integral_constant<int, 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         float4 a[NI], b[NJ];
 #pragma unroll
         for (int i = 0; i < NI; ++i) a[i] = SA::frag(As, wm * 32 * NI + i * 32, q, l31, h);
@@ -202,6 +241,12 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
             acc[i][j] = DIB_MFMA(a[i].z, b[j].z, acc[i][j]);
             acc[i][j] = DIB_MFMA(a[i].w, b[j].w, acc[i][j]);
           }
+      }
+    } else if constexpr (kPieces > 1) {   // a wave without output still stages its share of the next tile
+      prefetch_piece(std::integral_constant<int, 1>{});
+      if constexpr (kPieces == 4) {
+        prefetch_piece(std::integral_constant<int, 2>{});
+        prefetch_piece(std::integral_constant<int, 3>{});
       }
     }
     __syncthreads();
