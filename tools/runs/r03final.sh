@@ -1,7 +1,7 @@
 #!/bin/bash
 # r03final: validation + measurement of the final round-3 library: the whole `-m gpu` suite, smoke(), the default bench line,
 # rocprofv3 stats + PMC passes of the config-3 step and of the config-5 step (stash mode), step tables of the secondary paths
-O=gpurun_out/r03final; mkdir -p $O
+O=gpurun_out/${RUN_TAG:-r03final}; mkdir -p $O
 (timeout 1700 python -m pytest tests -m gpu -q > $O/pytest_all.log 2>&1; echo "rc=$?" >> $O/pytest_all.log); tail -5 $O/pytest_all.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1200 $O/bench.json
