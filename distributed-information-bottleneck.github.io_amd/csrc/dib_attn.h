@@ -651,9 +651,10 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
       if (qrow < P) {
         float* dst = dq_out + (long long)qrow * dq_ld + 32 * wave + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(dst + 8 * g) =
-              make_float4(dq[4 * g] * dq_mul, dq[4 * g + 1] * dq_mul, dq[4 * g + 2] * dq_mul, dq[4 * g + 3] * dq_mul);
+        for (int g = 0; g < 4; ++g)   // non-temporal: the 3.4 GB of partials are read once, by the reduce kernel, after the whole
+                                      // launch (same-box A/B: backward 7.73 -> 7.66 ms, profiles/r03u_attention_dq_partial_nt_ab.txt)
+          __builtin_nontemporal_store(dib_nt4a{dq[4 * g] * dq_mul, dq[4 * g + 1] * dq_mul, dq[4 * g + 2] * dq_mul, dq[4 * g + 3] * dq_mul},
+                                      reinterpret_cast<dib_nt4a*>(dst + 8 * g));
       }
     }
     DIB_T(5);   // next-tile loads issued, dQ product, dQ store
