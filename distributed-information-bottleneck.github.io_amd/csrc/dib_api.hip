@@ -179,6 +179,31 @@ DibGemmGroup make_group(Off a, int lda, Off b, int ldb, Off c, int ldc, int64_t 
   return g;
 }
 
+// Tile-rule knobs, overridable from the environment for A/B measurements on the GPU (tools/ab_bench.sh); the defaults
+// are the measured choices.
+struct Knobs {
+  int fwd_small_wgs = 512;   // forward/dgrad: below this many 128-row workgroups use 64-row tiles
+  int fwd_narrow_wgs = 1024; // forward: below this many 64x128 workgroups use 64x64 tiles (round 3: 512 -> 1024, the set
+                             // transformer's q/k/v projection at 1600 tokens: step 1.99 -> 1.87 ms; profiles/r03l_forward_tile_rule.txt)
+  int stream_rows = 8192;    // GEMMs with at least this many streamed rows load / store them non-temporally (1 << 30: never)
+  int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
+  int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
+  int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
+                             // OFF: measured slower (same box, B = 65536: 8.44-8.50 vs 8.37 ms; B = 8192: 1.345 vs 1.313 ms) -
+                             // the two kernels together ask for 5.8 TB/s of HBM and evict each other's L2 lines
+  Knobs() {
+    if (const char* e = std::getenv("DIB_FWD_SMALL_WGS")) fwd_small_wgs = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FWD_NARROW_WGS")) fwd_narrow_wgs = std::atoi(e);
+    if (const char* e = std::getenv("DIB_GEMM_STREAM_ROWS")) stream_rows = std::atoi(e);
+    if (const char* e = std::getenv("DIB_L3_HALVE")) l3_halve = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FORCE_TILE0")) force_tile[0] = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FORCE_TILE1")) force_tile[1] = std::atoi(e);
+    if (const char* e = std::getenv("DIB_FORCE_TILE2")) force_tile[2] = std::atoi(e);
+    if (const char* e = std::getenv("DIB_CONCURRENT_WGRAD")) concurrent_wgrad = std::atoi(e);
+  }
+};
+inline const Knobs& knobs() { static Knobs k; return k; }
+
 template <int MODE, int NI, int NJ>
 int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int N, const float* A, const float* B, float* C,
                   const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit,
@@ -196,33 +221,15 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 #define DIB_BK212 64   // 64x128 wgrad tile (the 256x256 integration layer): 0.136 -> 0.124 ms with 64-deep K-tiles (same-box A/B)
 #endif
   constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
+  // cache policy of the streamed operands / outputs (dib_gemm.h: stream_flags): non-temporal from 8192 streamed rows up
+  // (DIB_GEMM_STREAM_ROWS; M for forward / dgrad, the contracted rows for a weight gradient)
+  const long long streamed_rows = MODE == 2 ? (long long)nsplit * rows_per_split : (long long)M;
+  const int stream_flags = streamed_rows >= knobs().stream_rows ? 3 : 0;
   hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
-                     bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride);
+                     bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride, stream_flags);
   return (int)hipGetLastError();
 }
 
-// Tile-rule knobs, overridable from the environment for A/B measurements on the GPU (tools/ab_bench.sh); the defaults
-// are the measured choices.
-struct Knobs {
-  int fwd_small_wgs = 512;   // forward/dgrad: below this many 128-row workgroups use 64-row tiles
-  int fwd_narrow_wgs = 1024; // forward: below this many 64x128 workgroups use 64x64 tiles (round 3: 512 -> 1024, the set
-                             // transformer's q/k/v projection at 1600 tokens: step 1.99 -> 1.87 ms; profiles/r03l_forward_tile_rule.txt)
-  int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
-  int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
-  int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
-                             // OFF: measured slower (same box, B = 65536: 8.44-8.50 vs 8.37 ms; B = 8192: 1.345 vs 1.313 ms) -
-                             // the two kernels together ask for 5.8 TB/s of HBM and evict each other's L2 lines
-  Knobs() {
-    if (const char* e = std::getenv("DIB_FWD_SMALL_WGS")) fwd_small_wgs = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FWD_NARROW_WGS")) fwd_narrow_wgs = std::atoi(e);
-    if (const char* e = std::getenv("DIB_L3_HALVE")) l3_halve = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FORCE_TILE0")) force_tile[0] = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FORCE_TILE1")) force_tile[1] = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FORCE_TILE2")) force_tile[2] = std::atoi(e);
-    if (const char* e = std::getenv("DIB_CONCURRENT_WGRAD")) concurrent_wgrad = std::atoi(e);
-  }
-};
-inline const Knobs& knobs() { static Knobs k; return k; }
 
 template <int MODE>
 int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* A, const float* B, float* C,

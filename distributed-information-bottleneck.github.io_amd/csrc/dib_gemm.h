@@ -61,16 +61,26 @@ struct DibStage {
   static __device__ __forceinline__ int col(int tid) { return KC ? ((tid % (BK / 4)) * 4) : ((tid % (EXT / 4)) * 4); }
 
   // loads float4 p in [P0, P1) of the tile (the whole tile by default; the weight gradients issue it in pieces)
+  // nt: non-temporal loads (a streamed operand that nobody re-reads soon: keeps it out of the way of what IS re-read)
   template <int P0 = 0, int P1 = NP>
   static __device__ __forceinline__ void gload(float4 (&r)[NP], const float* __restrict__ base, long long ld,
-                                               int mn0, int mn_max, int k0, int k_max, bool vec, int tid) {
+                                               int mn0, int mn_max, int k0, int k_max, bool vec, int tid, bool nt = false) {
     const int r0 = KC ? mn0 : k0, c0 = KC ? k0 : mn0;
     const int Rmax = KC ? mn_max : k_max, Cmax = KC ? k_max : mn_max;
     const int rext = KC ? EXT : BK, cext = KC ? BK : EXT;
     if (vec && r0 + rext <= Rmax && c0 + cext <= Cmax) {  // interior tile: unconditional 16 B loads
+      if (nt) {   // block-uniform
+        typedef float f4nt __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int p = P0; p < P1; ++p)
-        r[p] = *reinterpret_cast<const float4*>(base + (long long)(r0 + row(tid, p)) * ld + c0 + col(tid));
+        for (int p = P0; p < P1; ++p) {
+          const f4nt v = __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(base + (long long)(r0 + row(tid, p)) * ld + c0 + col(tid)));
+          r[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+      } else {
+#pragma unroll
+        for (int p = P0; p < P1; ++p)
+          r[p] = *reinterpret_cast<const float4*>(base + (long long)(r0 + row(tid, p)) * ld + c0 + col(tid));
+      }
     } else {
 #pragma unroll
       for (int p = P0; p < P1; ++p) {
@@ -114,7 +124,7 @@ __global__ void __launch_bounds__(256, 2)  // >= 2 workgroups per CU: keep VGPR+
 dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict__ Abase,
                 const float* __restrict__ Bbase, float* __restrict__ Cbase, const float* __restrict__ bias,
                 const float* __restrict__ aux, float* __restrict__ bias_out, int batch, int act, int tiles_m,
-                int tiles_n, int rows_per_split, long long split_stride) {
+                int tiles_n, int rows_per_split, long long split_stride, int stream_flags = 0) {
   constexpr bool A_KC = (MODE != 2);
   constexpr bool B_KC = (MODE == 1);
   constexpr int BM = 64 * NI, BN = 64 * NJ;
@@ -186,6 +196,12 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     // profiles/r03r_gemm_prefetch_pieces_ab.txt): 64-deep forward / dgrad tiles want 4 pieces (dgrad 0.79 -> 0.73 ms), the
     // weight gradients and the 32-deep tiles 2 (layer-3 wgrad 0.70 -> 0.65 ms; 4 pieces there: 0.71).
     constexpr int kPieces = DIB_GEMM_SPLIT_PREFETCH == 0 ? 1 : ((MODE != 2 && BK == 64) ? 4 : 2);
+    // stream_flags bit 0 (set by the host for LARGE streamed operands, launch_gemm_t): the streamed operands - both of a
+    // weight gradient, the activation matrix of a forward / dgrad - are loaded non-temporally; bit 1: the forward / dgrad
+    // output is stored non-temporally.  Same-box A/Bs at B = 65536 (profiles/r03v_gemm_cache_policy_ab.txt): between -3 % and
+    // nothing on the step depending on the box, never slower; small shapes re-read their operands from L2 and lose 1-2 % with
+    // it, so the host leaves the flags off below 8192 streamed rows.
+    const bool kNtA = (stream_flags & 1) != 0, kNtB = (stream_flags & 1) != 0 && MODE == 2;
     constexpr int QN = BK / 8;   // MFMA sub-phases of a K-tile
     const bool have_next = k0 + BK < kend;
     // piece i of the next tile's global loads (kPieces == 2: A | B; 4: A lo | A hi | B lo | B hi) is issued at sub-phase
@@ -194,17 +210,17 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
       constexpr int piece = decltype(piece_c)::value;
       if (!have_next) return;
       if constexpr (kPieces == 1) {
-        SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
-        SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
+        SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid, kNtA);
+        SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid, kNtB);
       } else if constexpr (kPieces == 2) {
-        if constexpr (piece == 0) SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
-        else SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
+        if constexpr (piece == 0) SA::gload(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid, kNtA);
+        else SB::gload(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid, kNtB);
       } else {
         constexpr int HA = (SA::NP + 1) / 2, HB = (SB::NP + 1) / 2;
-        if constexpr (piece == 0) SA::template gload<0, HA>(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
-        else if constexpr (piece == 1) SA::template gload<HA, SA::NP>(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid);
-        else if constexpr (piece == 2) SB::template gload<0, HB>(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
-        else SB::template gload<HB, SB::NP>(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid);
+        if constexpr (piece == 0) SA::template gload<0, HA>(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid, kNtA);
+        else if constexpr (piece == 1) SA::template gload<HA, SA::NP>(ra, Ag, g.lda, m0, M, k0 + BK, kend, vecA, tid, kNtA);
+        else if constexpr (piece == 2) SB::template gload<0, HB>(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid, kNtB);
+        else SB::template gload<HB, SB::NP>(rb, Bg, g.ldb, n0, N, k0 + BK, kend, vecB, tid, kNtB);
       }
     };
     prefetch_piece(std::integral_constant<int, 0>{});
@@ -303,7 +319,14 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
         v.x *= dib_act_grad(act, x.x); v.y *= dib_act_grad(act, x.y); v.z *= dib_act_grad(act, x.z); v.w *= dib_act_grad(act, x.w);
       }
       float* cp = Cg + (long long)rowc * g.ldc + colc;
-      if (vecC) *reinterpret_cast<float4*>(cp) = v;
+      if (vecC) {
+        if (stream_flags & 2) {
+          typedef float f4nt __attribute__((ext_vector_type(4)));
+          __builtin_nontemporal_store(f4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f4nt*>(cp));
+        } else {
+          *reinterpret_cast<float4*>(cp) = v;
+        }
+      }
       else {
         cp[0] = v.x;
         if (colc + 1 < N) cp[1] = v.y;
