@@ -224,7 +224,10 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
   // cache policy of the streamed operands / outputs (dib_gemm.h: stream_flags): non-temporal from 8192 streamed rows up
   // (DIB_GEMM_STREAM_ROWS; M for forward / dgrad, the contracted rows for a weight gradient)
   const long long streamed_rows = MODE == 2 ? (long long)nsplit * rows_per_split : (long long)M;
-  const int stream_flags = streamed_rows >= knobs().stream_rows ? 3 : 0;
+  // ... and the output non-temporally only when it cannot stay in the 256 MB infinity cache for its consumer anyway (the 67 MB
+  // hidden activation of the integration network, stored non-temporally, cost the fused head that reads it next 19 us)
+  const bool big_out = MODE != 2 && (long long)M * N * (long long)sizeof(float) * c.count >= (256ll << 20);
+  const int stream_flags = streamed_rows >= knobs().stream_rows ? (big_out ? 3 : 1) : 0;
   hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
                      bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride, stream_flags);
   return (int)hipGetLastError();
