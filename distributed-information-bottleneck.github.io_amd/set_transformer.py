@@ -486,12 +486,14 @@ class SetTransformerDIB:
 
     # ---- forward (notebook train_step, forward part) -------------------------------------------------------------------
     def forward(self, batch_inp, step: Optional[int] = None, deterministic: bool = False, row0: int = 0,
-                embs_reparam=None, _step_from_device: bool = False) -> torch.Tensor:
+                embs_reparam=None, _step_from_device: bool = False, for_backward: bool = True) -> torch.Tensor:
         """embs = particle_encoder(batch_inp); logvar - 3; reparameterised sample; kl; loci_prediction = set_transformer(u).
         batch_inp [B, P, particle_feature_dimensions].  Returns the logits [B, out]; self.last holds kl (device scalar).
         embs_reparam [B, P, bottleneck] (optional): use these sampled embeddings instead of the library's counter-based
         noise (the notebook evaluates `set_transformer(tf.random.normal(...))` on its own samples; also how the golden
         fixture, which carries its own noise, is replayed).
+        for_backward=False (evaluation passes): the flash attention does not write its score stash (3.2 GB per block at
+        4 x 4096 particles); a loss_and_backward after such a forward recomputes the scores instead.
         Backward after any of the three forwards is consistent with it: the bottleneck's noise term is recovered as
         eps * sigma = x0 - mu from the sample that was actually used (dib_token_reparam_kl_bwd) - library noise, an injected
         sample (treated as mu + sigma * eps with its implied eps held fixed: the reparameterised gradient of that sample), or
@@ -504,6 +506,7 @@ class SetTransformerDIB:
         B, P, F0 = x.shape
         assert F0 == self.particle_feature_dimensions
         pl = self._plan(B, P)
+        use_stash = bool(for_backward) and pl["stash"] is not None
         lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
         T, D = pl["T"], self.bottleneck_dimension
         step = self._step if step is None else int(step)
@@ -534,7 +537,7 @@ class SetTransformerDIB:
                 HK = H * self.key_dim
                 check(lib.dib_attention_fwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]), B, P, H,
                                             self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
-                                            _ptr(pl["stash"][b]) if pl["stash"] else c_void_p(0), st), "dib_attention_fwd")
+                                            _ptr(pl["stash"][b]) if use_stash else c_void_p(0), st), "dib_attention_fwd")
             g[f"b{b}_o_fwd"].run(lib, st)
             check(lib.dib_add_layernorm_fwd(_ptr(ws, off[xin]), _ptr(ws, off[f"b{b}_mha"]), T, D,
                                             _ptr(self.params, self.offsets[pre + "ln1_g"]), _ptr(self.params, self.offsets[pre + "ln1_b"]),
@@ -553,7 +556,7 @@ class SetTransformerDIB:
             g[f"fin{l}_fwd"].run(lib, st)
         g["out_fwd"].run(lib, st)
         self.attention_impl = pl["impl"]   # what this batch shape ran on (reporting)
-        self.last = dict(plan=pl, step=step, row0=int(row0), B=B, P=P,
+        self.last = dict(plan=pl, step=step, row0=int(row0), B=B, P=P, stash=use_stash,
                          kl=self._view(pl, "kl_sum", 1) / B)   # "sum over dimension and particles, avg over batch"
         return self._view(pl, "pred", B, self.output_dimensionality)
 
@@ -617,7 +620,8 @@ class SetTransformerDIB:
                 HK = H * self.key_dim
                 check(lib.dib_attention_bwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
                                             _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
-                                            _ptr(pl["stash"][b]) if pl["stash"] else c_void_p(0), B, P, H, self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
+                                            _ptr(pl["stash"][b]) if self.last.get("stash") else c_void_p(0),   # as the forward ran
+                                            B, P, H, self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
                                             _ptr(ws, off["attn_delta"]), st), "dib_attention_bwd")
             g[f"b{b}_qkv_wgrad"].run(lib, st)
             g[f"b{b}_qkv_dgrad"].run(lib, st)
@@ -662,7 +666,7 @@ class SetTransformerDIB:
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DP_BRANCH):
             if training and self.use_graphs and self._checker is None:
                 return self._train_step_graph(batch_inp, is_loci)
-            self.forward(batch_inp)
+            self.forward(batch_inp, for_backward=training)
             self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
             if training:
                 self.adam_step()
@@ -673,7 +677,7 @@ class SetTransformerDIB:
         lo, hi = (B * rank) // world, (B * (rank + 1)) // world
         stats = torch.zeros(2, dtype=self.params.dtype, device=self.device)   # [bce sum / B, kl sum / B] of the local rows
         if hi > lo:
-            self.forward(batch_inp[lo:hi], row0=lo * P)
+            self.forward(batch_inp[lo:hi], row0=lo * P, for_backward=training)
             if training:
                 self.loss_and_backward(is_loci[lo:hi], inv_global_batch=1.0 / B)
             else:
@@ -877,7 +881,7 @@ class SetTransformerDIB:
                     for s0 in range(0, xv.shape[0], batch_size):
                         xb, yb = xv[s0: s0 + batch_size], yv[s0: s0 + batch_size]
                         bces.append(float(self.train_step(xb, yb, training=False).item()))
-                        pred = self.forward(xb).cpu().numpy()   # a second sampled pass, as in the notebook
+                        pred = self.forward(xb, for_backward=False).cpu().numpy()   # a second sampled pass, as in the notebook
                         right += float((np.sign(pred) == (yb * 2 - 1)).sum())
                         n += len(xb)
                     hist["bce_series_val"].append(float(np.mean(bces)))

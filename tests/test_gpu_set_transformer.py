@@ -422,3 +422,35 @@ def test_backward_follows_the_forward_that_ran(mode):
     for k, r in grads.items():
         r = r.numpy()
         assert np.abs(got[k] - r).max() <= 1e-3 * max(np.abs(r).max(), 1e-3 * gmax), (mode, k)
+
+
+def test_evaluation_forward_skips_the_score_stash_and_backward_still_agrees():
+    """forward(for_backward=False) does not write the attention score stash (3.2 GB per block at 4 x 4096 particles);
+    a backward after it must recompute the scores rather than read a stash the forward never wrote."""
+    spec = sto.SetTransformerSpec(number_attention_blocks=2)
+    B, P = 2, 200
+    m, _ = _model(spec, seed=21, attention="flash")
+    rng = np.random.default_rng(8)
+    feats = rng.standard_normal((B, P, spec.particle_feature_dimensions)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32)
+    m.beta_dev.fill_(0.05)
+    p1 = m.forward(feats, step=3).clone()
+    assert m.last["stash"] is True
+    m.loss_and_backward(y)
+    torch.cuda.synchronize()
+    ref = m.get_grads()
+    for s in m.last["plan"]["stash"]:
+        s.fill_(float("nan"))            # whatever is in the stash now must not be read
+    p2 = m.forward(feats, step=3, for_backward=False)
+    assert m.last["stash"] is False and torch.equal(p1, p2)
+    assert all(bool(torch.isnan(s).all()) for s in m.last["plan"]["stash"]), "evaluation forward wrote the stash"
+    m.loss_and_backward(y)
+    torch.cuda.synchronize()
+    got = m.get_grads()
+    gmax = max(float(np.abs(r).max()) for r in ref.values())
+    for k, r in ref.items():
+        assert np.isfinite(got[k]).all(), k
+        assert np.abs(got[k] - r).max() <= 2e-5 * max(np.abs(r).max(), 1e-3 * gmax), k
+    # the evaluation train_step takes the no-stash path
+    m.train_step(feats, y, training=False)
+    assert m.last["stash"] is False
