@@ -35,6 +35,7 @@ import socket
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -368,6 +369,31 @@ class Workload:
         return med, times
 
 
+class _ExtrasDeadline:
+    """The multi-GPU `extra` measurements run AFTER the headline line has been assembled and under this deadline: a
+    collective that never completes in one of them (ranks out of step after an error on one rank) must not take the measured
+    headline down with it.  On expiry rank 0 prints the line with what it has and EVERY rank leaves with status 0 (each rank
+    arms its own timer; they start within a barrier's skew of each other)."""
+
+    def __init__(self, seconds: float, rank: int, out, extra: dict):
+        self.seconds, self.rank, self.out, self.extra = float(seconds), rank, out, extra
+        self.timer = threading.Timer(self.seconds, self._expire)
+        self.timer.daemon = True
+
+    def _expire(self):
+        if self.rank == 0:
+            self.out["extra"] = dict(self.extra, error=f"the multi-GPU extras did not finish within {self.seconds:.0f} s; the "
+                                                       "headline measurement was complete before they started")
+            print(json.dumps(self.out), flush=True)
+        os._exit(0)
+
+    def start(self):
+        self.timer.start()
+
+    def cancel(self):
+        self.timer.cancel()
+
+
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-baseline-worker":
         _cpu_baseline_worker(int(sys.argv[2]), float(sys.argv[3]))
@@ -386,6 +412,8 @@ def main():
                     help="gradient all-reduce buckets: 3 (default) = integration / encoder front layers / last encoder layer, each "
                          "issued as soon as it is final; 2 = integration overlapped, whole encoder bank after the backward; 1 = one")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--extra-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the `extra` measurements may take before the headline line is printed without them")
     ap.add_argument("--config5-only", action="store_true",
                     help="run only the BASELINE config-5 set-transformer step (the `extra.config5_set_transformer` object) and "
                          "print it: the command the rocprofv3 passes of profiles/*_config5_* wrap")
@@ -446,26 +474,8 @@ def main():
         prof = eng.profile_summary()
         eng.profile_enable(False)
 
-    extra = {}
-    if not args.no_extra and world > 1:  # the other scaling mode, same engine
-        other = "weak" if args.scaling == "strong" else "strong"
-        wl.set_scaling(other, args.batch)
-        m2, t2 = wl.measure(2, args.steps, 1, dev)
-        extra[f"{other}_scaling"] = {"value": round(args.steps * wl.gb / m2, 1), "unit": "samples/s",
-                                     "ms_per_step": round(1e3 * m2 / args.steps, 4), "per_gpu_batch": wl.B,
-                                     "global_batch": wl.gb}
-        wl.set_scaling(args.scaling, args.batch)
-
-    if not args.no_extra and world > 1:
-        # BASELINE config 5 under data parallelism (neighbourhoods sharded over the ranks, gradient all-reduce over RCCL inside
-        # SetTransformerDIB.train_step): one neighbourhood of 4096 particles per GPU, i.e. never fewer neighbourhoods than ranks
-        try:
-            extra["config5_set_transformer"] = dict(config5_set_transformer(dev, nb=max(4, world), steps=3),
-                                                    parallelism=f"dp{world} over neighbourhoods")
-        except Exception as e:  # noqa: BLE001
-            extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
-
-    if rank == 0:
+    out = None
+    if rank == 0:  # the headline line, assembled before any extra touches the workload object
         gb, B = wl.gb, wl.B
         sps = args.steps * gb / med
         per_gpu_tf = sps * FLOPS_PER_SAMPLE / 1e12 / world
@@ -508,6 +518,30 @@ def main():
                 out["other_timed_kernels_ms_per_step"] = rest
         if "roofline" not in out:
             out["roofline"] = dict(out["step_roofline"], traffic=None)
+    extra = {}
+    if not args.no_extra and world > 1:
+        deadline = _ExtrasDeadline(args.extra_timeout, rank, out, extra)
+        deadline.start()
+        try:  # the other scaling mode, same engine
+            other = "weak" if args.scaling == "strong" else "strong"
+            wl.set_scaling(other, args.batch)
+            m2, t2 = wl.measure(2, args.steps, 1, dev)
+            extra[f"{other}_scaling"] = {"value": round(args.steps * wl.gb / m2, 1), "unit": "samples/s",
+                                         "ms_per_step": round(1e3 * m2 / args.steps, 4), "per_gpu_batch": wl.B,
+                                         "global_batch": wl.gb}
+            wl.set_scaling(args.scaling, args.batch)
+        except Exception as e:  # noqa: BLE001
+            extra["other_scaling"] = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE config 5 under data parallelism (neighbourhoods sharded over the ranks, gradient all-reduce over RCCL inside
+        # SetTransformerDIB.train_step): one neighbourhood of 4096 particles per GPU, i.e. never fewer neighbourhoods than ranks
+        try:
+            extra["config5_set_transformer"] = dict(config5_set_transformer(dev, nb=max(4, world), steps=3),
+                                                    parallelism=f"dp{world} over neighbourhoods")
+        except Exception as e:  # noqa: BLE001
+            extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
+        deadline.cancel()
+
+    if rank == 0:
         if world == 1 and not args.no_extra:
             # BASELINE config 4 (amorphous-plasticity radial density, 50 shell features; the notebook and its data are a
             # missing blob in the reference, so x ~ N(0,1) [N, 50] per SURVEY 8d), same step, same batch

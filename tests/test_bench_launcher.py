@@ -35,3 +35,35 @@ def test_flop_model_matches_survey():
     assert bench.gemm_flops_per_sample(64) == 13141504   # SURVEY 8(a) totals, config 3
     assert bench.gemm_flops_per_sample(50) == 10353152   # config 4
     assert sum(bench.flops_by_kernel().values()) == 13141504
+
+
+@pytest.mark.parametrize("rank", [0, 1])
+def test_multi_gpu_extras_deadline_prints_the_headline_and_every_rank_leaves(rank):
+    """A collective that never completes inside a multi-GPU `extra` must not take the measured headline down: on expiry
+    rank 0 prints the line assembled BEFORE the extras, every rank exits with status 0."""
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "out = {'metric': 'm', 'value': 1.0}; extra = {'weak_scaling': {'value': 2.0}}\n"
+            "d = bench._ExtrasDeadline(0.3, %d, out, extra); d.start()\n"
+            "time.sleep(30)\n"          # the hung collective
+            "print('not reached'); sys.exit(3)\n") % (ROOT, rank)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    if rank == 0:
+        out = json.loads(lines[-1])
+        assert out["metric"] == "m" and out["value"] == 1.0
+        assert out["extra"]["weak_scaling"] == {"value": 2.0} and "did not finish" in out["extra"]["error"]
+    else:
+        assert lines == [] and "not reached" not in res.stdout
+
+
+def test_multi_gpu_extras_deadline_cancelled_in_time_is_silent():
+    sys.path.insert(0, ROOT)
+    import bench
+    import time
+    out, extra = {"metric": "m"}, {}
+    d = bench._ExtrasDeadline(0.5, 0, out, extra)
+    d.start()
+    d.cancel()
+    time.sleep(0.8)
+    assert "extra" not in out
