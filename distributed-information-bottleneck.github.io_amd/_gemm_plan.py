@@ -56,6 +56,22 @@ class _Gemm:
 
 
 
+class _SkinnyKGemm(_Gemm):
+    """The same launch record for `dib_gemm_skinny_k` (include/dib_st.h): mode 0 / 1 products whose contraction is at most
+    32 wide and whose output is large - a streaming kernel bound by its output stores.  All groups share M, N, K."""
+
+    @staticmethod
+    def fits(mode, descs, act=0, aux=None) -> bool:
+        d0 = descs[0]
+        return (mode in (0, 1) and act == 0 and aux is None and 0 < d0["K"] <= 32 and d0["K"] % 4 == 0 and d0["N"] % 32 == 0
+                and all((d["M"], d["N"], d["K"]) == (d0["M"], d0["N"], d0["K"]) for d in descs))
+
+    def run(self, lib, stream):
+        d0 = self.host[0]
+        check(lib.dib_gemm_skinny_k(self.mode, self.n, _ptr(self.dev), int(d0["M"]), int(d0["N"]), int(d0["K"]), _ptr(self.A),
+                                    _ptr(self.B), _ptr(self.C), _ptr(self.bias), stream), "dib_gemm_skinny_k")
+
+
 def _d(a_off, lda, b_off, ldb, c_off, ldc, M, N, K, bias_off=-1, aux_off=0, ldaux=0):
     return dict(a_off=a_off, b_off=b_off, c_off=c_off, bias_off=bias_off, aux_off=aux_off, M=M, N=N, K=K, lda=lda, ldb=ldb,
                 ldc=ldc, ldaux=ldaux)

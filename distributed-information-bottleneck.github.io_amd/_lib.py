@@ -132,6 +132,7 @@ SIGNATURES_ST = {
     "dib_gemm_grouped": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "dib_reduce_splits": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "dib_gemm_skinny_k": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_softmax_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "dib_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "dib_attention_stash_bytes": (c_int64, [c_int, c_int, c_int]),

@@ -1267,6 +1267,27 @@ int dib_gemm_grouped(int mode, int n_groups, const dib_gemm_desc* dev_desc, int 
   }
 }
 
+int dib_gemm_skinny_k(int mode, int n_groups, const dib_gemm_desc* dev_desc, int M, int N, int K, const float* A,
+                      const float* B, float* C, const float* bias, dib_stream_t stream) {
+  if (!dev_desc || !A || !B || !C || n_groups <= 0 || M <= 0 || N <= 0 || K <= 0 || mode < 0 || mode > 1) return DIB_E_ARG;
+  if (K > 32 || (K & 3) || (N & 31) || n_groups > 65535 || cdiv(N, 128) > 65535) return DIB_E_UNSUPPORTED;
+  const DibGemmGroup* g = reinterpret_cast<const DibGemmGroup*>(dev_desc);
+  // >= ~4096 workgroups of 4 independent waves (16 wave slots per CU), at most 8 row tiles of 64 per workgroup
+  const int total_tiles = cdiv(M, 64), cn = cdiv(N, 128);
+  int chunks = std::max(1, std::min(total_tiles, cdiv(4096, cn * n_groups)));
+  int tiles = std::min(8, cdiv(total_tiles, chunks));
+  chunks = cdiv(total_tiles, tiles);
+  const int nt_store = (long long)M * N * (long long)sizeof(float) * n_groups >= (256ll << 20) ? 1 : 0;
+  const dim3 grid(chunks, cn, n_groups);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0)
+    hipLaunchKernelGGL(dib_gemm_skinnyk_kernel<0>, grid, dim3(256), 0, st, g, A, B, C, bias, M, N, K, tiles, nt_store);
+  else
+    hipLaunchKernelGGL(dib_gemm_skinnyk_kernel<1>, grid, dim3(256), 0, st, g, A, B, C, (const float*)nullptr, M, N, K, tiles,
+                       nt_store);
+  return (int)hipGetLastError();
+}
+
 int dib_softmax_rows_fwd(float* S, int64_t rows, int P, int ld, float scale, dib_stream_t stream) {
   if (!S || rows <= 0 || P <= 0 || ld < P) return DIB_E_ARG;
   const dim3 grid(grid_for(rows, 4, 8192));

@@ -390,3 +390,120 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny-K streaming GEMM (K <= 32): C[M,N] = A[M,K] @ B (+ bias) for the projections of the set transformer whose
+// contraction is the 32-wide residual stream and whose output is hundreds of MB (q / k / v at 16 384 tokens: 302 MB; the
+// gradient of the attention context: 100 MB).  Such a launch is bound by its output stores; in the tiled kernel above a
+// workgroup is a load -> 32-deep product -> 64 KB store sequence with two workgroups per CU to overlap them (1.9 TB/s).
+// Here a WAVE is the unit: its 32 columns of B live in registers for the whole launch, A rows are fetched straight into
+// MFMA operand layout (4 consecutive k per lane: one 16-byte load), a 64 x 32 output block is 32 MFMAs and 32 store
+// instructions of two full 128-byte lines each; no LDS, no barrier, 16 waves per CU in flight.
+//   MODE 0: B = [K, N] (Keras kernel, Dense forward), bias added;   MODE 1: B = [N, K] (Dense dgrad: C = A @ B^T).
+// grid (row chunks, ceil(N / 128), groups); wave w of a workgroup owns columns n0 + 32w ..; a chunk is `tiles` 64-row tiles.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256)
+dib_gemm_skinnyk_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict__ Abase,
+                        const float* __restrict__ Bbase, float* __restrict__ Cbase, const float* __restrict__ bias,
+                        int M, int N, int K, int tiles, int nt_store) {
+  const DibGemmGroup g = groups[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * 128 + wave * 32;
+  if (n0 >= N) return;   // whole wave (N is a multiple of 32)
+  const float* A = Abase + g.a_off;
+  const float* B = Bbase + g.b_off;
+  float* C = Cbase + g.c_off;
+  const int col = n0 + l31;
+  // 16-byte accesses along k need aligned rows (block-uniform; the set transformer's buffers are)
+  const bool vec_a = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool vec_b = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  // this lane's column of B: bf[q] = B[k = 8q + 4h + t][col], t = x..w (zero beyond K)
+  float4 bf[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = 8 * q + 4 * h;
+    bf[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) {   // K % 4 == 0
+      if (MODE == 1) {
+        const float* p = B + (long long)col * g.ldb + k;
+        bf[q] = vec_b ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
+      } else {
+        const float* p = B + (long long)k * g.ldb + col;
+        bf[q] = make_float4(p[0], p[g.ldb], p[2 * (long long)g.ldb], p[3 * (long long)g.ldb]);
+      }
+    }
+  }
+  const float bv = (MODE == 0 && bias != nullptr && g.bias_off >= 0) ? bias[g.bias_off + col] : 0.f;
+  const int row_first = blockIdx.x * tiles * 64;
+  const unsigned lda = (unsigned)g.lda;
+  // A rows of one 64-row tile in operand layout: af[s][q] = A[row0 + 32s + l31][8q + 4h ..+3] (rows clamped, k >= K -> 0)
+  auto load_tile = [&](float4 (&af)[2][4], int row0) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float* src = A + (long long)min(row0 + 32 * s + l31, M - 1) * lda + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        af[s][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (8 * q + 4 * h < K) {
+          const float* p = src + 8 * q;
+          af[s][q] = vec_a ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
+        }
+      }
+    }
+  };
+  float4 cur[2][4], nxt[2][4];
+  load_tile(cur, row_first);
+  for (int t = 0; t < tiles; ++t) {
+    const int row0 = row_first + t * 64;
+    if (row0 >= M) break;
+    if (t + 1 < tiles) load_tile(nxt, min(row0 + 64, M - 1));   // in flight during this tile's products and stores
+    dib_f32x16 acc[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][r] = bv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // the two row sub-tiles alternate: neighbouring MFMAs are independent
+      acc[0] = DIB_MFMA(cur[0][q].x, bf[q].x, acc[0]);
+      acc[1] = DIB_MFMA(cur[1][q].x, bf[q].x, acc[1]);
+      acc[0] = DIB_MFMA(cur[0][q].y, bf[q].y, acc[0]);
+      acc[1] = DIB_MFMA(cur[1][q].y, bf[q].y, acc[1]);
+      acc[0] = DIB_MFMA(cur[0][q].z, bf[q].z, acc[0]);
+      acc[1] = DIB_MFMA(cur[1][q].z, bf[q].z, acc[1]);
+      acc[0] = DIB_MFMA(cur[0][q].w, bf[q].w, acc[0]);
+      acc[1] = DIB_MFMA(cur[1][q].w, bf[q].w, acc[1]);
+    }
+    // acc[s][r] = C[row0 + 32s + (r&3) + 8(r>>2) + 4h][col]: per store instruction two rows x 32 consecutive columns.
+    // Interior tiles (workgroup-uniform test) store unconditionally; nt_store (uniform): an output too large to stay in the
+    // infinity cache for its consumer.
+    auto store_tile = [&](auto interior_c, auto nt_c) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float* dst = C + (long long)(row0 + 32 * s + 4 * h) * g.ldc + col;
+        const int rlim = M - (row0 + 32 * s + 4 * h);   // rows of this lane's group that exist
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (decltype(interior_c)::value || dr < rlim) {
+            if (decltype(nt_c)::value) __builtin_nontemporal_store(acc[s][r], dst + (long long)dr * g.ldc);
+            else dst[(long long)dr * g.ldc] = acc[s][r];
+          }
+        }
+      }
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    if (row0 + 64 <= M) {
+      if (nt_store) store_tile(T_{}, T_{}); else store_tile(T_{}, F_{});
+    } else {
+      if (nt_store) store_tile(F_{}, T_{}); else store_tile(F_{}, F_{});
+    }
+    if (t + 1 < tiles) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[s][q] = nxt[s][q];
+    }
+  }
+}

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from ctypes import c_void_p
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -29,7 +30,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._gemm_plan import DESC, _Gemm, _d, _ptr, _ptr8
+from ._gemm_plan import DESC, _Gemm, _SkinnyKGemm, _d, _ptr, _ptr8
 from ._lib import check
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, _lib.ACT_LEAKY_RELU_01
@@ -132,6 +133,8 @@ class SetTransformerDIB:
             raise ValueError("attention='flash' needs key_dim == 128 (the notebook's value)")
         self.attention = attention
         self.attention_score_stash_bytes = int(attention_score_stash_bytes)
+        # token count from which the q / k / v projections and the context gradient run as streaming skinny-K launches
+        self.skinny_k_min_tokens = int(os.environ.get("DIB_SKINNY_K_MIN_TOKENS", "2048"))
         self.attention_impl = "flash" if (attention == "flash" or (attention == "auto" and self.key_dim == 128)) else "gemm"
         assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
         # ---- flat parameter layout (Keras creation order) ----
@@ -152,7 +155,6 @@ class SetTransformerDIB:
         self.set_params(self.init_params(init_seed))
         self._plans: Dict[Tuple[int, int], dict] = {}
         self.max_step_plans = 4
-        import os
         self.use_graphs = (os.environ.get("DIB_ENABLE_GRAPHS", "0") == "1") if use_graphs is None else bool(use_graphs)
         self._graphs: Dict[Tuple[int, int], dict] = {}
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # noise step of graph replays (uint32 bits)
@@ -371,9 +373,13 @@ class SetTransformerDIB:
             xin = "x0" if b == 0 else f"b{b - 1}_x"
             pre = f"blk{b}_"
             # q, k, v projections: 3 groups
-            g[f"b{b}_qkv_fwd"] = _Gemm(0, [_d(off[xin], D, po[pre + nm + "_w"], HK, off[f"b{b}_{nm}"], HK, T, HK, D,
-                                              bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, self.params, ws,
-                                       bias=self.params)
+            qkv_descs = [_d(off[xin], D, po[pre + nm + "_w"], HK, off[f"b{b}_{nm}"], HK, T, HK, D, bias_off=po[pre + nm + "_b"])
+                         for nm in "qkv"]
+            # from skinny_k_min_tokens tokens up the projections out of the D-wide residual stream are store-bound streaming
+            # launches (dib_gemm_skinny_k); below, the tiled grouped GEMM
+            skinny = T >= self.skinny_k_min_tokens
+            mk = _SkinnyKGemm if skinny and _SkinnyKGemm.fits(0, qkv_descs) else _Gemm
+            g[f"b{b}_qkv_fwd"] = mk(0, qkv_descs, ws, self.params, ws, bias=self.params)
             gemm_attn = impl == "gemm"
             # scores S_bh = Q_bh K_bh^T (scale folded into the softmax)
             if gemm_attn:
@@ -412,7 +418,9 @@ class SetTransformerDIB:
             # attention output projection
             gout = self._block_grad_names(b)[1]   # gradient w.r.t. the block's input x (= gradient of LN1's two addends)
             g[f"b{b}_o_wgrad"] = dense_wgrad(f"b{b}_ctx", HK, gout, D, pre + "o_w", pre + "o_b", T)
-            g[f"b{b}_o_dgrad"] = dense_dgrad(gout, D, pre + "o_w", "g_ctx", HK, T)
+            o_dgrad_descs = [_d(off[gout], D, po[pre + "o_w"], D, off["g_ctx"], HK, T, HK, D)]
+            mk = _SkinnyKGemm if skinny and _SkinnyKGemm.fits(1, o_dgrad_descs) else _Gemm
+            g[f"b{b}_o_dgrad"] = mk(1, o_dgrad_descs, ws, self.params, ws)
             if gemm_attn:
                 g[f"b{b}_dv"] = _Gemm(2, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off["g_ctx"] + bi * P * HK + hi * K, HK,
                                            off["g_v"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,

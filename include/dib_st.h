@@ -42,6 +42,15 @@ int dib_gemm_grouped(int mode, int n_groups, const dib_gemm_desc* dev_desc, int 
                      int rows_per_split, int64_t split_stride, dib_stream_t stream);
 int dib_reduce_splits(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream);
 
+/* The same products for a SKINNY contraction (K <= 32, K % 4 == 0) with a large output - the set transformer's q / k / v
+ * projections of the 32-wide residual stream (dense layers of ...set_transformer.ipynb:332-389's MultiHeadAttention) and the
+ * gradient of the attention context: a streaming kernel bound by its output stores (no LDS, B columns register-resident).
+ * Every group has the same M, N, K (passed by value; the descriptors' M / N / K are ignored) and its own offsets / leading
+ * dimensions.  mode 0: C = A[M,K] @ B[K,N] + bias[N];  mode 1: C = A[M,K] @ B[N,K]^T.  No activation.  N % 32 == 0.
+ * DIB_E_UNSUPPORTED for shapes outside that (use dib_gemm_grouped). */
+int dib_gemm_skinny_k(int mode, int n_groups, const dib_gemm_desc* dev_desc, int M, int N, int K, const float* A,
+                      const float* B, float* C, const float* bias, dib_stream_t stream);
+
 /* Keras MultiHeadAttention softmax over the key axis, in place: S[row][0..P) <- softmax(scale * S[row][0..P)); rows are ld
  * floats apart.  Backward (in place on dP): dS = scale * P * (dP - sum_j dP_j P_j), the gradient w.r.t. the unscaled q.k. */
 int dib_softmax_rows_fwd(float* S, int64_t rows, int P, int ld, float scale, dib_stream_t stream);

@@ -77,6 +77,60 @@ def test_gemm_vs_numpy(mode, M, N, K):
         assert np.abs(gb - ref_bias).max() / (np.abs(ref_bias).max() + 1e-6) < 2e-5
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("M,N,K,groups,pad", [(4096, 1536, 32, 3, 0), (1000, 96, 32, 1, 0), (77, 32, 12, 2, 0), (64, 128, 4, 1, 0),
+                                              (513, 160, 20, 2, 3), (1, 32, 32, 1, 0), (300000, 256, 32, 1, 0)])
+def test_skinny_k_gemm_vs_numpy(mode, M, N, K, groups, pad):
+    """dib_gemm_skinny_k (the streaming kernel of the set transformer's q / k / v projections and of the context gradient):
+    every group against float64 numpy - ragged row counts, N not a multiple of 128, K < 32, leading dimensions wider than
+    the matrices (pad: unaligned rows take the same path), a 300 000-row launch whose output is stored non-temporally."""
+    from dib_amd import _lib
+    from dib_amd._gemm_plan import DESC
+    lib = _lib.load_library()
+    rng = np.random.default_rng(M + 7 * N + 13 * K + mode)
+    dev = torch.device("cuda:0")
+    lda, ldc = K + pad, N + pad
+    ldb = (N if mode == 0 else K) + pad
+    brows = K if mode == 0 else N
+    A = rng.standard_normal((groups, M, lda)).astype(np.float32)
+    B = rng.standard_normal((groups, brows, ldb)).astype(np.float32)
+    bias = rng.standard_normal((groups, N)).astype(np.float32)
+    At, Bt, bt = (torch.from_numpy(x).to(dev) for x in (A, B, bias))
+    Ct = torch.full((groups, M, ldc), float("nan"), dtype=torch.float32, device=dev)
+    arr = np.zeros(groups, dtype=DESC)
+    for g in range(groups):
+        arr[g]["a_off"], arr[g]["b_off"], arr[g]["c_off"] = g * M * lda, g * brows * ldb, g * M * ldc
+        arr[g]["bias_off"] = g * N if (mode == 0 and g != 1) else -1        # group 1: no bias
+        arr[g]["lda"], arr[g]["ldb"], arr[g]["ldc"] = lda, ldb, ldc
+        arr[g]["M"], arr[g]["N"], arr[g]["K"] = M, N, K
+    desc = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.dib_gemm_skinny_k(mode, groups, _ptr(desc), M, N, K, _ptr(At), _ptr(Bt), _ptr(Ct), _ptr(bt) if mode == 0 else None, st)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = Ct.cpu().numpy()
+    for g in range(groups):
+        a64 = A[g, :, :K].astype(np.float64)
+        if mode == 0:
+            ref = a64 @ B[g, :, :N].astype(np.float64) + (bias[g].astype(np.float64) if g != 1 else 0.0)
+        else:
+            ref = a64 @ B[g, :, :K].astype(np.float64).T
+        out = got[g, :, :N]
+        assert np.isfinite(out).all()
+        assert np.abs(out - ref).max() / (np.abs(ref).max() + 1e-6) < 2e-6, (g, np.abs(out - ref).max())
+        if pad:
+            assert np.isnan(got[g, :, N:]).all(), "wrote outside the matrix"
+
+
+def test_skinny_k_gemm_refuses_what_it_does_not_cover():
+    from dib_amd import _lib
+    lib = _lib.load_library()
+    t = torch.zeros(4096, device="cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (mode, M, N, K) in [(0, 64, 128, 36), (0, 64, 128, 30), (0, 64, 100, 32), (2, 64, 128, 32)]:
+        assert lib.dib_gemm_skinny_k(mode, 1, _ptr(t), M, N, K, _ptr(t), _ptr(t), _ptr(t), None, st) < 0
+
+
 def test_gemm_is_transpose_detecting():
     """A = I with ASYMMETRIC B (cdna guide: symmetric inputs hide a row/col swap in the C write)."""
     from dib_amd import _lib
