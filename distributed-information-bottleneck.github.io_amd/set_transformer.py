@@ -134,7 +134,8 @@ class SetTransformerDIB:
         self.attention = attention
         self.attention_score_stash_bytes = int(attention_score_stash_bytes)
         # token count from which the q / k / v projections and the context gradient run as streaming skinny-K launches
-        self.skinny_k_min_tokens = int(os.environ.get("DIB_SKINNY_K_MIN_TOKENS", "2048"))
+        # (same-box A/B, profiles/r03ad_*: 400 tokens +1.5 %, 1024 -1 %, 1600 -1.7 %, 2048 -5.7 %, 16 384 -1 % of the step)
+        self.skinny_k_min_tokens = int(os.environ.get("DIB_SKINNY_K_MIN_TOKENS", "1024"))
         self.attention_impl = "flash" if (attention == "flash" or (attention == "auto" and self.key_dim == 128)) else "gemm"
         assert self.bottleneck_dimension <= 256 and self.bottleneck_dimension % 4 == 0
         # ---- flat parameter layout (Keras creation order) ----
