@@ -347,3 +347,20 @@ def test_per_particle_feature_set_matches_the_notebook_function_executed():
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "set_transformer_forward.npz"))
     got = convert_to_per_particle_feature_set(g["raw_pos"], g["raw_types"], number_particles_to_use=6)
     assert got.shape == g["ref_feats"].shape and np.abs(got - g["ref_feats"]).max() < 1e-12
+
+
+def test_streaming_projection_launch_record_only_claims_shapes_the_kernel_covers():
+    """`_SkinnyKGemm.fits` (the host-side rule in front of dib_gemm_skinny_k) must mirror the entry's own refusals
+    (include/dib_st.h: K <= 32, K % 4 == 0, N % 32 == 0, uniform groups, no activation / act' mask, modes 0 / 1 only)."""
+    from dib_amd._gemm_plan import _SkinnyKGemm, _d
+    ok = [_d(0, 32, 0, 1536, 0, 1536, 4096, 1536, 32, bias_off=5) for _ in range(3)]
+    assert _SkinnyKGemm.fits(0, ok) and _SkinnyKGemm.fits(1, ok[:1])
+    assert not _SkinnyKGemm.fits(2, ok)                                   # weight gradients stay on the tiled kernel
+    assert not _SkinnyKGemm.fits(0, ok, act=1)                            # no activation epilogue
+    assert not _SkinnyKGemm.fits(1, ok, aux=object())                     # no act' mask
+    for bad in (dict(K=36), dict(K=30), dict(N=1000), dict(K=0)):
+        d = dict(ok[0], **bad)
+        assert not _SkinnyKGemm.fits(0, [d]), bad
+    assert not _SkinnyKGemm.fits(0, [ok[0], dict(ok[0], M=2048)])         # all groups share M, N, K
+    rec = _SkinnyKGemm(0, ok, None, None, None)
+    assert (rec.mode, rec.n, rec.max_m, rec.max_n) == (0, 3, 4096, 1536) and rec.host["K"].tolist() == [32, 32, 32]
