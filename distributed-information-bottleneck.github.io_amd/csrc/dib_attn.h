@@ -294,7 +294,14 @@ __device__ long long dib_attn_dbg[16];
 #define DIB_T(i) do { } while (0)
 #endif
 constexpr int kAttnPatch = 32 * 36;
-constexpr int DibAttnBwdLds = 2 * kAttnTile * kAttnPitch + 128 * kAttnPitch + 4 * kAttnPatch + 2 * kAttnTile;
+// DIB_ATTN_DQ_ROWSTORE = 1: a wave turns its dQ^T accumulators (lane = query, registers = d) through a private 32 x 36 LDS patch
+// into row-major pieces, so that ONE store instruction writes whole 128-byte lines (8 lanes per query row) instead of 32-byte
+// pieces of 32 rows: the non-temporal partial stores are then full-line writes (WRITE_SIZE of the launch 6.7 -> 3.4 GB)
+#ifndef DIB_ATTN_DQ_ROWSTORE
+#define DIB_ATTN_DQ_ROWSTORE 1
+#endif
+constexpr int DibAttnBwdLds = 2 * kAttnTile * kAttnPitch + 128 * kAttnPitch + 4 * kAttnPatch + 2 * kAttnTile +
+                              (DIB_ATTN_DQ_ROWSTORE ? 4 * kAttnPatch : 0);
 
 template <bool STASH>   // STASH: scores read back from the forward's stash (4 tile products); else S recomputed (5)
 __global__ void __launch_bounds__(256, 1)
@@ -307,6 +314,9 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
   float* Ls = patches + 4 * kAttnPatch;              // lse / delta of the tile's queries
   float* Ds = Ls + kAttnTile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+#if DIB_ATTN_DQ_ROWSTORE
+  float* my_dqs = Ds + kAttnTile + wave * kAttnPatch;   // this wave's [32 queries][36] transposition patch (nobody else touches it)
+#endif
   const int head = blockIdx.y, b = blockIdx.z, P = a.P;
   const long long tok0 = (long long)b * P;
   const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
@@ -647,15 +657,40 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] += dq1[r];
       // dq[r] = dQ^T[d = 32*wave + (r&3) + 8(r>>2) + 4h][query l31]
+      // non-temporal: the 3.4 GB of partials are read once, by the reduce kernel, after the whole launch (same-box A/B:
+      // backward 7.73 -> 7.66 ms, profiles/r03u_attention_dq_partial_nt_ab.txt)
+#if DIB_ATTN_DQ_ROWSTORE
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(my_dqs + l31 * 36 + 8 * g + 4 * h) =
+            make_float4(dq[4 * g] * dq_mul, dq[4 * g + 1] * dq_mul, dq[4 * g + 2] * dq_mul, dq[4 * g + 3] * dq_mul);
+      __builtin_amdgcn_wave_barrier();   // wave-private patch: LDS operations of one wave complete in order
+      // store instruction j: query rows 8j .. 8j + 7, eight lanes x 16 bytes per row
+      float4 rv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rv[j] = *reinterpret_cast<const float4*>(my_dqs + ((lane >> 3) + 8 * j) * 36 + (lane & 7) * 4);
+      float* dst = dq_out + (long long)(qt * kAttnTile + (lane >> 3)) * dq_ld + 32 * wave + (lane & 7) * 4;
+      if ((qt + 1) * kAttnTile <= P) {   // workgroup-uniform: every tile but a ragged last one
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_nontemporal_store(dib_nt4a{rv[j].x, rv[j].y, rv[j].z, rv[j].w}, reinterpret_cast<dib_nt4a*>(dst + 8 * j * dq_ld));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (qt * kAttnTile + (lane >> 3) + 8 * j < P)
+            __builtin_nontemporal_store(dib_nt4a{rv[j].x, rv[j].y, rv[j].z, rv[j].w}, reinterpret_cast<dib_nt4a*>(dst + 8 * j * dq_ld));
+      }
+      __builtin_amdgcn_wave_barrier();
+#else
       const int qrow = qt * kAttnTile + l31;
       if (qrow < P) {
         float* dst = dq_out + (long long)qrow * dq_ld + 32 * wave + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)   // non-temporal: the 3.4 GB of partials are read once, by the reduce kernel, after the whole
-                                      // launch (same-box A/B: backward 7.73 -> 7.66 ms, profiles/r03u_attention_dq_partial_nt_ab.txt)
+        for (int g = 0; g < 4; ++g)
           __builtin_nontemporal_store(dib_nt4a{dq[4 * g] * dq_mul, dq[4 * g + 1] * dq_mul, dq[4 * g + 2] * dq_mul, dq[4 * g + 3] * dq_mul},
                                       reinterpret_cast<dib_nt4a*>(dst + 8 * g));
       }
+#endif
     }
     DIB_T(5);   // next-tile loads issued, dQ product, dQ store
     DIB_ATTN_STAGE_TILE();
