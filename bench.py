@@ -62,6 +62,11 @@ def _load_hbm_traffic():
 
 
 HBM_TRAFFIC = _load_hbm_traffic()
+# `roofline.traffic` is NOT collected by this run (PMC counters need rocprofv3 around the process): it is the per-launch
+# FETCH_SIZE + WRITE_SIZE of the same kernel at the same workload from the committed counter passes named here.
+TRAFFIC_SOURCE = ("profiles/hbm_traffic_per_kernel.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                  "(tools/collect_profiles.sh + tools/summarize_profiles.py), committed with the round's profiles - a constant "
+                  "read from that file, not measured in this run")
 
 
 def synthetic(n_rows, n_features=64, seed=20241008):
@@ -102,6 +107,21 @@ def flops_by_kernel(F=64):
 
 
 assert gemm_flops_per_sample(64) == FLOPS_PER_SAMPLE
+
+
+def per_kernel_roofline(prof, n_features, rows_per_step, steps):
+    """{kernel symbol: launches, avg ms, ms/step, algorithmic FLOPs per launch, achieved TFLOP/s, fraction of the fp32-MFMA peak}
+    from the library's live HIP-event timing (dib_profile_summary) of `steps` steps of `rows_per_step` rows."""
+    fl = flops_by_kernel(n_features)
+    per = {}
+    for name, (ms, cnt) in prof.items():
+        if name in fl and cnt:
+            tf = fl[name] * rows_per_step * steps / (ms * 1e-3) / 1e12
+            per[name] = {"launches": cnt, "avg_launch_ms": round(ms / cnt, 5), "ms_per_step": round(ms / steps, 4),
+                         "flops_per_launch": fl[name] * rows_per_step * steps // cnt, "achieved": round(tf, 2),
+                         "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+    rest = {n: round(ms / steps, 4) for n, (ms, cnt) in prof.items() if n not in fl and cnt}
+    return per, rest
 
 
 def _cpu_baseline_worker(threads, budget_s):
@@ -222,7 +242,8 @@ def config5_set_transformer(dev, nb=4, npart=4096, nfeat=16, steps=4, warmup=2):
     if by:
         dom = max(by, key=lambda k: by[k]["ms_per_step"])
         out["roofline"] = {"bound": "mfma", "achieved": by[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": by[dom]["frac"], "traffic": HBM_TRAFFIC.get(dom + "@config5"), "kernel": dom,
+                           "frac": by[dom]["frac"], "traffic": HBM_TRAFFIC.get(dom + "@config5"),
+                           "traffic_source": TRAFFIC_SOURCE, "kernel": dom,
                            "avg_launch_ms": by[dom]["avg_launch_ms"], "launches": by[dom]["launches"],
                            "flops_per_launch": by[dom]["flops_per_launch"],
                            "note": "algorithmic FLOPs: the 4 backward tile products = 2 x forward; " +
@@ -234,6 +255,44 @@ def config5_set_transformer(dev, nb=4, npart=4096, nfeat=16, steps=4, warmup=2):
     del st, xs, ys
     torch.cuda.empty_cache()
     return out
+
+
+def fit_surface(dev, batch, engine_s_per_step):
+    """Throughput of the surface north_star names - DistributedIBNet.compile + fit (reference train.py:138-166) - on BASELINE
+    config 3: epochs of 16 steps of `batch` rows over the 2^20-row dataset, shuffle on, the annealing callback and the History
+    accounting on; next to the engine-level number of the headline (HipEngine.train_step + adam_step called directly).
+    One warm-up epoch (workspace allocation, dataset upload), then two timed epochs."""
+    import dib_amd
+    x, y = synthetic(N_ROWS, 64)
+    model = dib_amd.DistributedIBNet([1] * 64, ENC, INTEG, 1, feature_embedding_dimension=E, device=dev)
+    opt = dib_amd.optimizers.get("adam")
+    opt.learning_rate = 3e-4
+    model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+    cb = dib_amd.InfoBottleneckAnnealingCallback(1e-3, 1.0, 1, 2)
+    times = []
+
+    class _Clock:   # a Keras-style callback: wall time of every epoch, device drained at both ends
+        model = None
+
+        def set_model(self, m):
+            self.model = m
+
+        def on_epoch_begin(self, epoch, logs=None):
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+        def on_epoch_end(self, epoch, logs=None):
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - self.t0)
+
+    hist = model.fit(x, y[:, 0], epochs=3, shuffle=True, batch_size=batch, callbacks=[cb, _Clock()], verbose=False)
+    steps = N_ROWS // batch
+    dt = statistics.median(times[1:]) / steps
+    return {"workload": f"DistributedIBNet.fit on BASELINE config 3: epochs of {steps} steps x {batch} rows, shuffle=True, "
+                        "InfoBottleneckAnnealingCallback + History on; median of 2 timed epochs after 1 warm-up epoch",
+            "value": round(batch / dt, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt, 4),
+            "engine_ms_per_step": round(1e3 * engine_s_per_step, 4), "fit_over_engine": round(dt / engine_s_per_step, 4),
+            "epochs_ms": [round(1e3 * t, 2) for t in times], "final_loss": round(float(hist.history["loss"][-1]), 5)}
 
 
 def config2_infonce_loop(dev, batch):
@@ -406,6 +465,9 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default, SURVEY 8e): the 65536-row global batch is sharded over the GPUs; weak: 65536 rows per GPU")
     ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="global batch (strong) / per-GPU batch (weak)")
+    ap.add_argument("--features", type=int, default=64,
+                    help="number of scalar features of the synthetic workload: 64 = BASELINE config 3 (the headline), 50 = "
+                         "BASELINE config 4 (what the rocprofv3 passes of profiles/*_config4_* wrap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` measurements (other scaling mode, config 4)")
     ap.add_argument("--dp-buckets", type=int, default=3, choices=[1, 2, 3],
@@ -462,7 +524,8 @@ def main():
         assert world == 1
         print(json.dumps(config5_set_transformer(dev, steps=max(2, min(args.steps, 6)))), flush=True)
         return 0
-    wl = Workload(64, dev, rank, world, dist, args.scaling, args.batch, args.dp_buckets)
+    wl = Workload(args.features, dev, rank, world, dist, args.scaling, args.batch, args.dp_buckets)
+    flops_per_sample = gemm_flops_per_sample(args.features)
     eng = wl.eng
     med, times = wl.measure(args.warmup, args.steps, args.blocks, dev)
 
@@ -478,16 +541,18 @@ def main():
     if rank == 0:  # the headline line, assembled before any extra touches the workload object
         gb, B = wl.gb, wl.B
         sps = args.steps * gb / med
-        per_gpu_tf = sps * FLOPS_PER_SAMPLE / 1e12 / world
+        per_gpu_tf = sps * flops_per_sample / 1e12 / world
         out = {"metric": "DIB train samples/sec (fwd+KL+bwd+Adam)", "value": round(sps, 1), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * med / args.steps, 4), "higher_is_better": True, "scaling": args.scaling,
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BASELINE config 3: synthetic tabular, 2^20 rows x 64 scalar features resident in HBM, "
+               "config": {"workload": ("BASELINE config 3" if args.features == 64 else
+                                       "BASELINE config 4 (--features 50)" if args.features == 50 else f"--features {args.features}") +
+                                      f": synthetic tabular, 2^20 rows x {args.features} scalar features resident in HBM, "
                                       "posenc [2,4,8,16], encoder [128,128], E=32, integration [256,256], out=1, "
                                       "BCE-from-logits, Adam",
                           "per_gpu_batch": B, "global_batch": gb, "parallelism": f"dp{world}", "rccl_ranks_joined": joined,
-                          "dataset_rows": N_ROWS, "params": eng.n_params, "flops_per_sample": FLOPS_PER_SAMPLE},
+                          "dataset_rows": N_ROWS, "params": eng.n_params, "flops_per_sample": flops_per_sample},
                "timing": {"protocol": f"median of {args.blocks} blocks x {args.steps} steps, barrier + synchronize on both "
                                       "sides of every block, max over ranks, no per-kernel events",
                           "blocks_ms_per_step": [round(1e3 * t / args.steps, 4) for t in times]},
@@ -496,24 +561,17 @@ def main():
                                  "note": "whole-step algorithmic GEMM FLOPs / wall time, per GPU"}}
         if prof:
             out["ms_per_step_kernel_timing"] = round(1e3 * t_prof / args.steps, 4)
-            fl = flops_by_kernel()
-            per = {}
-            for name, (ms, cnt) in prof.items():
-                if name in fl and cnt:
-                    tf = fl[name] * B * args.steps / (ms * 1e-3) / 1e12
-                    per[name] = {"launches": cnt, "avg_launch_ms": round(ms / cnt, 5), "ms_per_step": round(ms / args.steps, 4),
-                                 "flops_per_launch": fl[name] * B * args.steps // cnt, "achieved": round(tf, 2),
-                                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+            per, rest = per_kernel_roofline(prof, args.features, B, args.steps)
             if per:
                 dom = max(per, key=lambda k: per[k]["ms_per_step"])
                 out["roofline"] = {"bound": "mfma", "achieved": per[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS,
                                    "unit": "TFLOP/s", "frac": per[dom]["frac"],
-                                   "traffic": HBM_TRAFFIC.get(dom) if B == GLOBAL_BATCH else None,
+                                   "traffic": HBM_TRAFFIC.get(dom) if (B, args.features) == (GLOBAL_BATCH, 64) else None,
+                                   "traffic_source": TRAFFIC_SOURCE,
                                    "kernel": dom, "avg_launch_ms": per[dom]["avg_launch_ms"],
                                    "launches": per[dom]["launches"], "flops_per_launch": per[dom]["flops_per_launch"]}
                 out["roofline_by_kernel"] = per
                 out["mfma_kernels_ms_per_step"] = round(sum(v["ms_per_step"] for v in per.values()), 4)
-            rest = {n: round(ms / args.steps, 4) for n, (ms, cnt) in prof.items() if n not in fl and cnt}
             if rest:  # tile shapes the rule picks at other batch sizes (no per-symbol FLOP split for them)
                 out["other_timed_kernels_ms_per_step"] = rest
         if "roofline" not in out:
@@ -556,6 +614,20 @@ def main():
                                     "value": round(sps4, 1), "unit": "samples/s", "ms_per_step": round(1e3 * m4 / k4, 4),
                                     "steps": k4, "blocks_ms_per_step": [round(1e3 * t / k4, 4) for t in t4], "batch": w4.gb, "params": w4.eng.n_params, "flops_per_sample": fl4,
                                     "step_roofline_frac": round(sps4 * fl4 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+            if not args.no_kernel_timing:   # the same per-kernel table as the headline (HIP events inside the library)
+                w4.eng.profile_enable(True)
+                tp4 = w4.timed_block(3 + 3 * k4, k4, dev)
+                per4, rest4 = per_kernel_roofline(w4.eng.profile_summary(), 50, w4.gb, k4)
+                w4.eng.profile_enable(False)
+                extra["config4_F50"].update(ms_per_step_kernel_timing=round(1e3 * tp4 / k4, 4), roofline_by_kernel=per4,
+                                            mfma_kernels_ms_per_step=round(sum(v["ms_per_step"] for v in per4.values()), 4),
+                                            other_timed_kernels_ms_per_step=rest4)
+            del w4
+            torch.cuda.empty_cache()
+            try:
+                extra["fit_surface"] = fit_surface(dev, args.batch, med / args.steps)
+            except Exception as e:  # noqa: BLE001
+                extra["fit_surface"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_extra:
             # BASELINE config 5: per-particle set-transformer DIB, 4096 particles per neighbourhood, 3-D positions
             # (16 derived per-particle features), the notebook's architecture; one step = fwd + KL + BCE + bwd + Adam

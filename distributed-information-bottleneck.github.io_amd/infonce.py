@@ -58,27 +58,79 @@ def infonce_data_parallel(emb_x: torch.Tensor, emb_y: torch.Tensor, infonce_fn, 
     return loss, (None if gx is None else gx[sl]), (None if gy is None else gy[sl])
 
 
+def _epoch_mean(values, scalar: bool):
+    """np.mean(running) / np.mean(running, axis=0) of train.py:271-274; device tensors are stacked and reduced on the device
+    (one read-back per epoch boundary instead of one per step)."""
+    if values and isinstance(values[0], torch.Tensor):
+        m = torch.stack(values).double().mean(0).cpu().numpy()
+        return float(m.reshape(-1)[0]) if scalar else m
+    return np.mean(values) if scalar else np.mean(values, axis=0)
+
+
+def run_custom_loop(*, dataset_length: int, validation_set_length: int, batch_size: int, number_pretraining_epochs: int,
+                    number_annealing_epochs: int, beta_start: float, beta_end: float, train_step, validation_step,
+                    assign_beta, epoch_callback=None) -> Dict[str, np.ndarray]:
+    """Host bookkeeping of the reference's custom loop (train.py:222-279) around the device step functions:
+    `train_step(step_num)` / `validation_step(epoch_num, batch_number)` -> (loss_infonce, kl), `assign_beta(v)` =
+    model.beta.assign.  Epoch e is closed after the step whose number is round(steps_per_epoch * e) (numpy half-to-even
+    rounding; when several epochs round to one step the first wins, train.py:245-247), beta comes from the float64 numpy
+    formula of train.py:248, the validation pass draws number_full_validation_batches + 1 full batches (train.py:231-234) and
+    the loop ends one step short of the last boundary (`take(epoch_steps[-1])`), so number_epochs - 1 epochs are recorded.
+    Pinned on the reference's own statements executed: tests/test_oracle_golden.py::test_custom_loop_accounting_*."""
+    number_epochs = number_pretraining_epochs + number_annealing_epochs
+    boundaries = np.round((dataset_length / batch_size) * np.arange(number_epochs)).astype(np.int32)
+    first_epoch_at = {}
+    for e, s in enumerate(boundaries.tolist()):
+        first_epoch_at.setdefault(s, e)
+    n_val_batches = validation_set_length // batch_size + 1
+    log_span = np.log(beta_end) - np.log(beta_start)
+    series = dict(beta=[], kl=[], loss_infonce=[], kl_validation=[], loss_infonce_validation=[])
+    pending = dict(kl=[], loss_infonce=[], kl_validation=[], loss_infonce_validation=[])
+    for step_num in range(int(boundaries[-1])):
+        loss, kl = train_step(step_num)
+        pending['loss_infonce'].append(loss)
+        pending['kl'].append(kl)
+        epoch_num = first_epoch_at.get(step_num)
+        if epoch_num is None:
+            continue
+        next_beta = np.exp(np.log(beta_start) + float(max(epoch_num - number_pretraining_epochs, 0)) / number_annealing_epochs * log_span)
+        series['beta'].append(next_beta)
+        assign_beta(next_beta)
+        if epoch_callback is not None:
+            epoch_callback(epoch_num)
+        for vb in range(n_val_batches):
+            loss, kl = validation_step(epoch_num, vb)
+            pending['loss_infonce_validation'].append(loss)
+            pending['kl_validation'].append(kl)
+        for k, vals in pending.items():
+            series[k].append(_epoch_mean(vals, scalar=k.startswith('loss')))
+            pending[k] = []
+    out = {k: np.asarray(v) for k, v in series.items()}
+    out['beta'] = np.float32(out['beta'])               # train.py:272
+    return out
+
+
 def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, number_pretraining_epochs: int,
                 number_annealing_epochs: int, beta_start: float, beta_end: float, learning_rate: float,
                 y_encoder_architecture=(128, 128), shared_dimensionality: int = 64, similarity: str = 'l2',
                 temperature: float = 1.0, use_positional_encoding: bool = True,
                 number_positional_encoding_frequencies: int = 5, activation_fn: Optional[str] = 'relu', seed: int = 0,
-                epoch_callback=None) -> Dict[str, np.ndarray]:
-    """Returns dict(beta, kl [epochs,F] nats, loss_infonce, kl_validation, loss_infonce_validation) - the series the
-    reference builds at train.py:237-279 (before its conversion to bits)."""
+                epoch_callback=None, output_encoder: Optional[DenseStack] = None) -> Dict[str, np.ndarray]:
+    """Returns dict(beta, kl [epochs-1, F] nats, loss_infonce, kl_validation, loss_infonce_validation) - the series the
+    reference builds at train.py:237-279 (before its conversion to bits) - plus kl_total / kl_total_validation.
+    The reference's own KL series is `kl_loss / model.beta` with kl_loss = model.losses, the one-element list
+    [beta * sum_f KL_f] (models.py:118): ITS series are the row sums kl_total; the per-feature columns are this project's
+    superset.  `output_encoder`: a pre-built Y encoder (default: a fresh DenseStack seeded with seed + 1)."""
     eng = model._ensure_engine()
     assert model.output_dimensionality == shared_dimensionality, "model output must be the shared embedding space"
     F = model.number_features
     xd, yd = eng.to_device(np.asarray(x_train, dtype=np.float32)), eng.to_device(np.asarray(y_train, dtype=np.float32))
     xvd, yvd = eng.to_device(np.asarray(x_valid, dtype=np.float32)), eng.to_device(np.asarray(y_valid, dtype=np.float32))
-    yenc = DenseStack(eng, yd.shape[1], list(y_encoder_architecture), shared_dimensionality, activation_fn,
-                      use_positional_encoding, number_positional_encoding_frequencies, seed=seed + 1)
+    yenc = output_encoder if output_encoder is not None else DenseStack(
+        eng, yd.shape[1], list(y_encoder_architecture), shared_dimensionality, activation_fn,
+        use_positional_encoding, number_positional_encoding_frequencies, seed=seed + 1)
     model.output_encoder = yenc
-    number_epochs = number_pretraining_epochs + number_annealing_epochs
     n, nv = xd.shape[0], xvd.shape[0]
-    steps_per_epoch = n / batch_size
-    epoch_steps = np.round(steps_per_epoch * np.arange(number_epochs)).astype(np.int32)  # train.py:236
-    n_val_batches = nv // batch_size + 1                                                 # train.py:231-234
     stream, vstream = _BatchStream(n, batch_size, seed), _BatchStream(nv, batch_size, seed + 7)
     # data parallel (one process per GPU): every rank draws the same global batch (same seed) and takes its row shard;
     # embeddings are all-gathered for the in-batch negatives, parameter gradients all-reduced (sum)
@@ -94,7 +146,7 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
         emb_y = yenc.forward(ys.index_select(0, idx.long()))
         loss, gx, gy = infonce_data_parallel(
             emb_x, emb_y, lambda a, b: eng.infonce(a, b, similarity, temperature, want_grads=training), dist)
-        kl = eng.step_out(B)[:F].clone() / B                       # kl_loss / beta (train.py:220)
+        kl = eng.step_out(B)[:F].clone() / B                       # kl_loss / beta (train.py:220), per feature
         if dist is not None:
             dist.all_reduce(kl)
             kl /= world
@@ -109,31 +161,13 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
             yenc.adam_step(learning_rate)
         return loss, kl
 
-    series = dict(beta=[], kl=[], loss_infonce=[], kl_validation=[], loss_infonce_validation=[])
-    run_l, run_k = [], []
-    step_num, total_steps = 0, int(epoch_steps[-1])
-    eng.set_beta(float(model.beta.value()))
-    for step_num in range(total_steps):
-        l, k = eval_batch(xd, yd, stream.next(), True, step_num)
-        run_l.append(l)
-        run_k.append(k)
-        hits = np.where(epoch_steps == step_num)[0]
-        if len(hits):
-            epoch_num = int(hits[0])
-            next_beta = np.exp(np.log(beta_start) + float(max(epoch_num - number_pretraining_epochs, 0)) /
-                               number_annealing_epochs * (np.log(beta_end) - np.log(beta_start)))  # train.py:248
-            series['beta'].append(next_beta)
-            model.beta.assign(next_beta)
-            if epoch_callback is not None:
-                epoch_callback(epoch_num, model)
-            vl, vk = [], []
-            for vb in range(n_val_batches):
-                l2, k2 = eval_batch(xvd, yvd, vstream.next(), False, (1 << 31) + epoch_num * 1024 + vb)
-                vl.append(l2)
-                vk.append(k2)
-            series['loss_infonce'].append(float(torch.stack(run_l).mean()))
-            series['kl'].append(torch.stack(run_k).mean(0).cpu().numpy())
-            series['loss_infonce_validation'].append(float(torch.stack(vl).mean()))
-            series['kl_validation'].append(torch.stack(vk).mean(0).cpu().numpy())
-            run_l, run_k = [], []
-    return {k: np.asarray(v) for k, v in series.items()}
+    eng.set_beta(float(model.beta.value()))                        # the first step runs at the constructor's beta (models.py:86)
+    out = run_custom_loop(
+        dataset_length=n, validation_set_length=nv, batch_size=batch_size, number_pretraining_epochs=number_pretraining_epochs,
+        number_annealing_epochs=number_annealing_epochs, beta_start=beta_start, beta_end=beta_end,
+        train_step=lambda step_num: eval_batch(xd, yd, stream.next(), True, step_num),
+        validation_step=lambda epoch_num, vb: eval_batch(xvd, yvd, vstream.next(), False, (1 << 31) + epoch_num * 1024 + vb),
+        assign_beta=model.beta.assign,
+        epoch_callback=(lambda e: epoch_callback(e, model)) if epoch_callback is not None else None)
+    out['kl_total'], out['kl_total_validation'] = out['kl'].sum(-1), out['kl_validation'].sum(-1)
+    return out

@@ -402,88 +402,94 @@ class DistributedIBNet:
         elif getattr(eng, "step_dev", None) is not None:
             eng.set_step_counter(self._step)
 
-        for epoch in range(initial_epoch, epochs):
-            for cb in cbs:
-                cb.on_epoch_begin(epoch)
-            eng.set_beta(float(self.beta.value()))
-            order = (np.random.default_rng([self.shuffle_seed, epoch]).permutation(n) if shuffle
-                     else np.arange(n)).astype(np.int32)
-            order_dev = eng.to_device(order, dtype=torch.int32)
-            nsteps = 0
-            for s0 in range(0, n, bs):
-                gb = min(bs, n - s0)  # last partial batch is kept (Keras)
-                if use_graphs and gb == bs:
-                    g, stage = graphs["train"]
-                    eng.set_lr(self.optimizer.learning_rate)
-                    stage.copy_(order_dev[s0: s0 + bs])
-                    g.replay()  # fwd + loss + bwd + optimizer + metrics + step-counter bump
-                    self._step += 1
-                    nsteps += 1
-                    continue
-                lo = (gb * rank) // world
-                hi = (gb * (rank + 1)) // world
-                # Every rank issues the SAME collectives every step, rows or no rows (a tail batch with fewer rows than
-                # ranks leaves some ranks empty: they contribute zeros).  Gradient buckets of the layer-major flat buffer
-                # (DESIGN 6), each all-reduced (RCCL, async) as soon as it is final:
-                #   1 integration network   - under the whole encoder-bank backward
-                #   2 encoder front layers  - under the last encoder layer's weight gradient      (dp_buckets == 3)
-                #   3 last encoder layer    - the only exposed one                                (dp_buckets == 3)
-                #   0 = 2 + 3 as one bucket after the backward                                    (dp_buckets == 2)
-                pending = []
-                nb = self.dp_buckets if (dist is not None and hasattr(eng, "part_range")) else 1
-                issue = lambda g: pending.append(dist.all_reduce(g, async_op=True))
-                if hi > lo:
-                    eng.train_step(xd, yd, order_dev[s0 + lo: s0 + hi], 0, hi - lo, self.noise_seed, self._step, kind,
-                                   inv_global_batch=1.0 / gb, on_integration_grads_ready=issue if nb >= 2 else None,
-                                   **(dict(on_encoder_front_grads_ready=issue) if nb == 3 else {}))
-                else:
-                    eng.grads.zero_()
-                    for part in ((1,) if nb == 2 else (1, 2) if nb == 3 else ()):
-                        off, cnt = eng.part_range(part)
-                        issue(eng.grads[off: off + cnt])
-                if nb >= 2:
-                    off, cnt = eng.part_range(3 if nb == 3 else 0)
-                    issue(eng.grads[off: off + cnt])
-                    for w in pending:
-                        w.wait()
-                elif dist is not None:
-                    dist.all_reduce(eng.grads)
-                self._optimizer_step(eng)
-                self._step += 1
-                nsteps += 1
-                if getattr(eng, "step_dev", None) is not None:
-                    eng.set_step_counter(self._step)  # eager step under the device counter: keep it in sync
-            logs = self._epoch_logs(reduce_metrics(eng.read_metrics()), nsteps, "")
-            if validation_data is not None:
-                nv = xvd.shape[0]
-                vsteps = 0
-                if getattr(eng, "step_dev", None) is not None:
-                    eng.set_step_counter((1 << 31) + epoch)  # validation noise stream, same key as the eager path
-                for s0 in range(0, nv, bs):
-                    gb = min(bs, nv - s0)
+        try:
+            for epoch in range(initial_epoch, epochs):
+                for cb in cbs:
+                    cb.on_epoch_begin(epoch)
+                eng.set_beta(float(self.beta.value()))
+                order = (np.random.default_rng([self.shuffle_seed, epoch]).permutation(n) if shuffle
+                         else np.arange(n)).astype(np.int32)
+                order_dev = eng.to_device(order, dtype=torch.int32)
+                nsteps = 0
+                for s0 in range(0, n, bs):
+                    gb = min(bs, n - s0)  # last partial batch is kept (Keras)
+                    if use_graphs and gb == bs:
+                        g, stage = graphs["train"]
+                        eng.set_lr(self.optimizer.learning_rate)
+                        stage.copy_(order_dev[s0: s0 + bs])
+                        g.replay()  # fwd + loss + bwd + optimizer + metrics + step-counter bump
+                        self._step += 1
+                        nsteps += 1
+                        continue
                     lo = (gb * rank) // world
                     hi = (gb * (rank + 1)) // world
+                    # Every rank issues the SAME collectives every step, rows or no rows (a tail batch with fewer rows than
+                    # ranks leaves some ranks empty: they contribute zeros).  Gradient buckets of the layer-major flat buffer
+                    # (DESIGN 6), each all-reduced (RCCL, async) as soon as it is final:
+                    #   1 integration network   - under the whole encoder-bank backward
+                    #   2 encoder front layers  - under the last encoder layer's weight gradient      (dp_buckets == 3)
+                    #   3 last encoder layer    - the only exposed one                                (dp_buckets == 3)
+                    #   0 = 2 + 3 as one bucket after the backward                                    (dp_buckets == 2)
+                    pending = []
+                    nb = self.dp_buckets if (dist is not None and hasattr(eng, "part_range")) else 1
+                    issue = lambda g: pending.append(dist.all_reduce(g, async_op=True))
                     if hi > lo:
-                        eng.eval_step(xvd, yvd, None, s0 + lo, hi - lo, self.noise_seed, (1 << 31) + epoch, kind,
-                                      inv_global_batch=1.0 / gb)
-                    vsteps += 1
-                if getattr(eng, "step_dev", None) is not None:
-                    eng.set_step_counter(self._step)
-                logs.update(self._epoch_logs(reduce_metrics(eng.read_metrics()), vsteps, "val_"))
-            for k, v in logs.items():
-                hist.history.setdefault(k, []).append(float(v))
-            hist.epoch.append(epoch)
-            if verbose and rank == 0:
-                kls = sum(logs[f"KL{f}"] for f in range(F))
-                print(f"Epoch {epoch + 1}/{epochs} - loss: {logs['loss']:.4f} - sumKL: {kls:.4f} nats - "
-                      f"beta: {logs['beta']:.3e}" + (f" - val_loss: {logs['val_loss']:.4f}" if 'val_loss' in logs else ""))
+                        eng.train_step(xd, yd, order_dev[s0 + lo: s0 + hi], 0, hi - lo, self.noise_seed, self._step, kind,
+                                       inv_global_batch=1.0 / gb, on_integration_grads_ready=issue if nb >= 2 else None,
+                                       **(dict(on_encoder_front_grads_ready=issue) if nb == 3 else {}))
+                    else:
+                        eng.grads.zero_()
+                        for part in ((1,) if nb == 2 else (1, 2) if nb == 3 else ()):
+                            off, cnt = eng.part_range(part)
+                            issue(eng.grads[off: off + cnt])
+                    if nb >= 2:
+                        off, cnt = eng.part_range(3 if nb == 3 else 0)
+                        issue(eng.grads[off: off + cnt])
+                        for w in pending:
+                            w.wait()
+                    elif dist is not None:
+                        dist.all_reduce(eng.grads)
+                    self._optimizer_step(eng)
+                    self._step += 1
+                    nsteps += 1
+                    if getattr(eng, "step_dev", None) is not None:
+                        eng.set_step_counter(self._step)  # eager step under the device counter: keep it in sync
+                logs = self._epoch_logs(reduce_metrics(eng.read_metrics()), nsteps, "")
+                if validation_data is not None:
+                    nv = xvd.shape[0]
+                    vsteps = 0
+                    if getattr(eng, "step_dev", None) is not None:
+                        eng.set_step_counter((1 << 31) + epoch)  # validation noise stream, same key as the eager path
+                    for s0 in range(0, nv, bs):
+                        gb = min(bs, nv - s0)
+                        lo = (gb * rank) // world
+                        hi = (gb * (rank + 1)) // world
+                        if hi > lo:
+                            eng.eval_step(xvd, yvd, None, s0 + lo, hi - lo, self.noise_seed, (1 << 31) + epoch, kind,
+                                          inv_global_batch=1.0 / gb)
+                        vsteps += 1
+                    if getattr(eng, "step_dev", None) is not None:
+                        eng.set_step_counter(self._step)
+                    logs.update(self._epoch_logs(reduce_metrics(eng.read_metrics()), vsteps, "val_"))
+                for k, v in logs.items():
+                    hist.history.setdefault(k, []).append(float(v))
+                hist.epoch.append(epoch)
+                if verbose and rank == 0:
+                    kls = sum(logs[f"KL{f}"] for f in range(F))
+                    print(f"Epoch {epoch + 1}/{epochs} - loss: {logs['loss']:.4f} - sumKL: {kls:.4f} nats - "
+                          f"beta: {logs['beta']:.3e}" + (f" - val_loss: {logs['val_loss']:.4f}" if 'val_loss' in logs else ""))
+                for cb in cbs:
+                    cb.on_epoch_end(epoch, logs)
+                if self.stop_training:
+                    break
             for cb in cbs:
-                cb.on_epoch_end(epoch, logs)
-            if self.stop_training:
-                break
-        for cb in cbs:
-            if hasattr(cb, "on_train_end"):
-                cb.on_train_end()
+                if hasattr(cb, "on_train_end"):
+                    cb.on_train_end()
+        finally:
+            if graphs:   # the captured step is dropped with `graphs`: its pinned workspace may be evicted again
+                torch.cuda.synchronize(eng.device)   # no replay may be in flight when the graph object dies
+                graphs.clear()
+                eng.release_step_graph(bs)
         return hist
 
     def evaluate(self, x, y, batch_size=None, verbose=0, return_dict=True):

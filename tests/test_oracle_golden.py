@@ -243,3 +243,75 @@ def test_similarities_and_mi_bounds_match_reference_utils_py_executed_on_numpy_b
         bounds.append(orc.mi_sandwich_bounds_batch(mus, lvs, u))
     got = np.mean(np.array(bounds), 0)                                                         # utils.py:73
     assert np.abs(got - g["mi_bounds"]).max() < 1e-10, (got, g["mi_bounds"])
+
+
+# ---- custom-loop accounting (train.py:222-285) pinned on the reference's own statements executed -------------------------
+def _loop_stub_run(loop_fn, case):
+    """Drive a `run_loop`-shaped function with the stubs the golden generator gave the reference's loop."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("make_golden_infonce_loop", os.path.join(GOLD, "make_golden_infonce_loop.py"))
+    gen = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(gen)
+    n, nv, bs, n_pre, n_ann, b0, b1, width = gen.CASES[case]
+    state = {"beta": np.float32(1.0), "call": 0, "log": []}
+
+    def step(training):
+        l, k = gen.stub_values(state["call"], training, state["beta"], width)
+        state["log"].append((state["call"], int(training), float(state["beta"])))
+        state["call"] += 1
+        return l, k
+
+    out = loop_fn(dataset_length=n, validation_set_length=nv, batch_size=bs, number_pretraining_epochs=n_pre,
+                  number_annealing_epochs=n_ann, beta_start=b0, beta_end=b1, train_step=lambda s: step(True),
+                  validation_step=lambda e, vb: step(False),
+                  assign_beta=lambda v: state.__setitem__("beta", np.float32(v)))
+    return out, np.array(state["log"], dtype=np.float64)
+
+
+@pytest.mark.parametrize("case", ["fractional", "bankers_half", "repeated_boundaries", "exact"])
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_custom_loop_accounting_matches_reference_statements(case, which):
+    """oracle run_loop AND the product's host loop (dib_amd.infonce.run_custom_loop) reproduce, from the same step stubs, the
+    series that train.py:224-285 itself produced: beta (float32), epoch-mean InfoNCE losses (float32), KL means, the order
+    and beta of every train / validation call (incl. the first step at beta = 1), E - 1 recorded epochs."""
+    g = np.load(os.path.join(GOLD, "infonce_loop.npz"))
+    if which == "oracle":
+        import infonce_loop_oracle as ilo
+        fn = ilo.run_loop
+    else:
+        from dib_amd.infonce import run_custom_loop as fn
+    out, log = _loop_stub_run(fn, case)
+    assert np.array_equal(log, g[f"{case}_calls"])
+    assert np.array_equal(np.float32(out["beta"]), g[f"{case}_beta"]) and np.float32(out["beta"]).dtype == g[f"{case}_beta"].dtype
+    assert np.array_equal(np.float32(out["loss_infonce"]), g[f"{case}_loss"])
+    assert np.array_equal(np.float32(out["loss_infonce_validation"]), g[f"{case}_loss_validation"])
+    assert np.allclose(np.asarray(out["kl"], dtype=np.float64) / np.log(2), g[f"{case}_kl_bits"], rtol=1e-14, atol=0)
+    assert np.allclose(np.asarray(out["kl_validation"], dtype=np.float64) / np.log(2), g[f"{case}_kl_bits_validation"], rtol=1e-14, atol=0)
+
+
+def test_infonce_loop_oracle_runs_the_composed_step():
+    """float64 loop oracle (train.py:196-279) end to end on a toy problem: one Adam over X model + Y encoder (both networks move),
+    first step at beta = 1, loss falls, kl_total is the row sum (the reference's own series)."""
+    import torch
+    import infonce_loop_oracle as ilo
+    spec = orc.DIBSpec([2, 1], [16], [16], 8, feature_embedding_dimension=4)
+    p = orc.glorot_uniform_init(spec, 1)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((96, 3)).astype(np.float32)
+    y = np.stack([np.sin(x[:, 0]) + x[:, 2], x[:, 1] * x[:, 0]], -1).astype(np.float32)
+    dims = [2 * 3, 16, 8]
+    Ws = [rng.uniform(-1, 1, (i, o)) * np.sqrt(6 / (i + o)) for i, o in zip(dims[:-1], dims[1:])]
+    ye = ilo.YEncoder(Ws, [np.zeros(o) for o in dims[1:]], "relu", True, 3)
+    w0 = [t.detach().clone() for t in ye.tensors()]
+    o = ilo.InfoNCELoopOracle(spec, p, ye, "l2", 1.0, 3e-3, noise_seed=2)
+    betas = []
+    orig = o.eval_batch
+    o.eval_batch = lambda *a, **k: (betas.append(float(o.beta)), orig(*a, **k))[1]
+    out = o.fit(x, y, x[:40], y[:40], batch_size=32, number_pretraining_epochs=4, number_annealing_epochs=6, beta_start=1e-3,
+                beta_end=1.0, seed=0)
+    assert betas[0] == 1.0 and abs(betas[1] - 1e-3) < 1e-9           # models.py:86, then train.py:248 after step 0
+    assert o.t == 27 and out["kl"].shape == (9, 2) and out["beta"].dtype == np.float32
+    assert np.allclose(out["kl_total"], out["kl"].sum(-1))
+    assert out["loss_infonce"][-1] < out["loss_infonce"][0]
+    assert all(float((a - b.detach()).abs().max()) > 0 for a, b in zip(w0, ye.tensors()))
+    assert all(float(v.abs().max()) > 0 for v in o.m)
