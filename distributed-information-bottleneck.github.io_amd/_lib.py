@@ -25,6 +25,7 @@ SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "di
 
 # error codes (include/dib_hip.h)
 DIB_OK = 0
+ABI_VERSION = 4   # include/dib_hip.h DIB_ABI_VERSION this binding's SIGNATURES were written against
 ACTIVATIONS = {None: 0, "linear": 0, "None": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "elu": 5,
                "softplus": 6}
 ACT_LEAKY_RELU_01 = 7  # tf.keras.layers.LeakyReLU(0.1) (include/dib_st.h)
@@ -72,6 +73,7 @@ _lib = None
 # name -> (restype, argtypes); must list every symbol declared in include/dib_hip.h
 SIGNATURES = {
     "dib_version": (c_char_p, []),
+    "dib_abi_version": (c_int, []),
     "dib_error_string": (c_char_p, [c_int]),
     "dib_layout_create": (c_int, [c_int, POINTER(c_int), c_int, POINTER(c_int), c_int, c_int, POINTER(c_int), c_int,
                                   c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
@@ -188,6 +190,14 @@ def load_library(build_if_missing: bool = True):
 
 def _attach(lib):
     global _lib
+    try:
+        lib.dib_abi_version.restype = c_int
+        have = int(lib.dib_abi_version())
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:   # a stale product build or a stale DIB_LIB_PATH variant: never call it with shifted arguments
+        raise RuntimeError(f"libdib_hip ABI version {have} != {ABI_VERSION} expected by this binding ({getattr(lib, '_name', '?')}): "
+                           "rebuild it (python -c 'import __graft_entry__ as g; g.build()' / tools/build_variant.sh)")
     for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_ST.items()):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

@@ -159,7 +159,7 @@ struct ProfScope {
   }
 };
 
-const char* kVersion = "dib_hip 0.2 (gfx950: fused encoder-bank fwd/bwd + grouped fp32-MFMA GEMM)";
+const char* kVersion = "dib_hip 0.4 (gfx950: fused encoder-bank fwd/bwd + grouped fp32-MFMA GEMM + flash attention)";
 
 int act_ok(int a) { return a >= 0 && a <= 7; }
 
@@ -390,6 +390,7 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
 extern "C" {
 
 const char* dib_version(void) { return kVersion; }
+int dib_abi_version(void) { return DIB_ABI_VERSION; }
 
 const char* dib_error_string(int code) {
   switch (code) {

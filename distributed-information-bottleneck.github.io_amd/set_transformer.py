@@ -156,6 +156,7 @@ class SetTransformerDIB:
         self.set_params(self.init_params(init_seed))
         self._plans: Dict[Tuple[int, int], dict] = {}
         self.max_step_plans = 4
+        self.max_graphs = 4                # captured step graphs kept (each pins its plan, workspace and score stash)
         self.use_graphs = (os.environ.get("DIB_ENABLE_GRAPHS", "0") == "1") if use_graphs is None else bool(use_graphs)
         self._graphs: Dict[Tuple[int, int], dict] = {}
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # noise step of graph replays (uint32 bits)
@@ -325,12 +326,10 @@ class SetTransformerDIB:
         ws = torch.zeros(o, dtype=torch.float32, device=self.device)
         # flash attention, stash mode: one score-tile buffer per block, outside the fp32-indexed workspace (its own allocation:
         # 3.2 GB per block at 4 x 4096); None = recompute mode
+        # It is allocated LAZILY by the first forward that a backward will follow (_ensure_stash): evaluation-only shapes
+        # (validation batches, the sampled second pass of fit) never own one.
         stash = None
-        if impl == "flash":
-            per_block = int(self.lib.dib_attention_stash_bytes(B, P, H))
-            if 0 < per_block * self.number_attention_blocks <= self.attention_score_stash_bytes:
-                stash = [torch.empty(per_block // 4, dtype=torch.float32, device=self.device)
-                         for _ in range(self.number_attention_blocks)]
+        stash_block_bytes = int(self.lib.dib_attention_stash_bytes(B, P, H)) if impl == "flash" else 0
 
         # weight-gradient target: contraction over T tokens is split into slabs when T is large (fixed-order reduce)
         # (from 512 tokens up: with one slab the q/k/v and output-projection wgrads of the reference size, 1600 tokens, ran on
@@ -474,7 +473,7 @@ class SetTransformerDIB:
         for gg in g.values():
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
-                    enc_units=enc_units, stash=stash, ksplit=ksplit)
+                    enc_units=enc_units, stash=stash, stash_block_bytes=stash_block_bytes, stash_denied=None, ksplit=ksplit)
         # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
         # (training batch, validation batch, a ragged tail), evict least recently used beyond that
         step_keys = [k for k in self._plans if k[0] != "enc" and k not in self._graphs]   # a captured graph pins its plan
@@ -482,6 +481,39 @@ class SetTransformerDIB:
             self._plans.pop(step_keys[0])
         self._plans[key] = plan
         return plan
+
+    def _ensure_stash(self, pl) -> bool:
+        """Flash-attention score stash of plan `pl` (one buffer per attention block; 19.3 GB for 4 x 4096 particles x 6 blocks),
+        allocated on first use.  It is granted only if (a) all blocks' tiles of this shape plus the stashes of every other live
+        plan fit `attention_score_stash_bytes`, (b) the device has that much memory free (free HBM + what the caching
+        allocator holds unused, less a 1 GiB reserve) and (c) the allocation itself succeeds; otherwise the plan stays in
+        recompute mode (pl["stash_denied"] says why) - a fallback in MEMORY POLICY only, the same kernels run."""
+        if pl["stash"] is not None:
+            return True
+        if pl["stash_block_bytes"] <= 0 or pl["stash_denied"] is not None:
+            return False
+        need = pl["stash_block_bytes"] * self.number_attention_blocks
+        live = sum(q["stash_block_bytes"] * self.number_attention_blocks for q in self._plans.values()
+                   if isinstance(q, dict) and q.get("stash") is not None)
+        if live + need > self.attention_score_stash_bytes:
+            pl["stash_denied"] = f"budget: {live} live + {need} needed > attention_score_stash_bytes = {self.attention_score_stash_bytes}"
+            return False
+        free, _total = torch.cuda.mem_get_info(self.device)
+        cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        if need > free + cached - (1 << 30):
+            pl["stash_denied"] = f"memory: {need} needed, {free} free + {cached} cached on the device"
+            return False
+        bufs = []
+        try:
+            for _ in range(self.number_attention_blocks):
+                bufs.append(torch.empty(pl["stash_block_bytes"] // 4, dtype=torch.float32, device=self.device))
+        except torch.cuda.OutOfMemoryError:
+            del bufs
+            torch.cuda.empty_cache()
+            pl["stash_denied"] = "memory: allocation failed"
+            return False
+        pl["stash"] = bufs
+        return True
 
     def _block_grad_names(self, b: int):
         """(buffer holding dL/d(output of block b), buffer receiving dL/d(input of block b)): "g_x" and "g_s" alternate from
@@ -515,7 +547,7 @@ class SetTransformerDIB:
         B, P, F0 = x.shape
         assert F0 == self.particle_feature_dimensions
         pl = self._plan(B, P)
-        use_stash = bool(for_backward) and pl["stash"] is not None
+        use_stash = bool(for_backward) and pl["impl"] == "flash" and self._ensure_stash(pl)
         lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
         T, D = pl["T"], self.bottleneck_dimension
         step = self._step if step is None else int(step)
@@ -722,6 +754,9 @@ class SetTransformerDIB:
             ys = torch.zeros((B, self.output_dimensionality), dtype=torch.float32, device=self.device)
             xs.copy_(x.to(self.device).reshape(xs.shape))
             ys.copy_(y.to(self.device).reshape(ys.shape))
+            while len(self._graphs) >= self.max_graphs:   # oldest captured shape first: its plan (and stash) becomes evictable
+                torch.cuda.synchronize(self.device)      # no replay may be in flight when a graph object dies
+                self._graphs.pop(next(iter(self._graphs)))
             self._graphs[(B, P)] = {}          # pins the plan against LRU eviction from here on
             try:
                 self._plan(B, P)

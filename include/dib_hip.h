@@ -60,6 +60,12 @@ enum { DIB_WS_U = 0,        /* [B, F*E]  sampled embeddings, models.py:108,122 *
        DIB_WS_INT_H0 = 32   /* + l: [B][units_l] post-activation output of integration hidden layer l */ };
 
 const char* dib_version(void);
+/* Integer revision of THIS header + dib_st.h: bumped on every change to an exported signature, to an argument's meaning or
+ * to the size of a caller-provided array.  A binding compares it with the DIB_ABI_VERSION it was written against and
+ * refuses a library that differs (dib_amd/_lib.py does): a stale variant build called with shifted arguments would corrupt
+ * memory silently.  History: 3 = round 3 (attention stash arguments, 17 profile categories); 4 = round 4. */
+#define DIB_ABI_VERSION 4
+int dib_abi_version(void);
 const char* dib_error_string(int code);
 
 /* ---- layout ------------------------------------------------------------------------------

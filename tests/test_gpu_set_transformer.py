@@ -195,6 +195,19 @@ def test_config5_size_4096_particles_flash_all_gradients():
     assert m.attention_impl == "flash" and m.last["plan"]["nsplit"] == 32 and m.last["plan"]["stash"] is not None
 
 
+@pytest.mark.timeout(1800)
+def test_config5_full_depth_six_blocks_at_4096_particles():
+    """The benchmarked object at its full DEPTH: one neighbourhood x 4096 particles through all SIX attention blocks
+    (...set_transformer.ipynb:332-389: 6 x [MHA 12 x 128, Add+LN, FF [128, 32], Add+LN]) on the flash kernels with the score
+    stash - what the two-block test above cannot show is the accumulation of float32 error along the six-deep residual /
+    LayerNorm chain in the forward and back down it in the backward.  Every gradient block against the float64 oracle at the
+    same 3e-4 (relative to the largest gradient block) as the shallow test."""
+    spec = sto.SetTransformerSpec(number_attention_blocks=6)
+    m = _masked_parity(spec, 1, 4096, seed=13, attention="flash")
+    assert m.attention_impl == "flash" and m.number_attention_blocks == 6 and m.last["plan"]["stash"] is not None
+    assert len(m.last["plan"]["stash"]) == 6
+
+
 @pytest.mark.parametrize("B,P,H", [(2, 300, 3), (1, 33, 2), (1, 1100, 1)])
 def test_attention_backward_score_stash_equals_recompute(B, P, H):
     """dib_attention_fwd/bwd in both modes on the same inputs (include/dib_st.h): the stashed score tiles are the numbers the
@@ -454,3 +467,39 @@ def test_evaluation_forward_skips_the_score_stash_and_backward_still_agrees():
     # the evaluation train_step takes the no-stash path
     m.train_step(feats, y, training=False)
     assert m.last["stash"] is False
+
+
+def test_score_stash_is_allocated_lazily_and_capped_across_plans():
+    """the flash-attention score stash (19.3 GB at 4 x 4096 x 6 blocks) is allocated by the first forward a backward
+    will follow - an evaluation-only shape never owns one - and is granted only while the stashes of ALL live plans fit
+    attention_score_stash_bytes; a shape that does not fit runs the same kernels in recompute mode."""
+    spec = sto.SetTransformerSpec(number_attention_blocks=2)
+    m, _ = _model(spec, seed=3, attention="flash")
+    rng = np.random.default_rng(2)
+    mk = lambda B, P: (rng.standard_normal((B, P, spec.particle_feature_dimensions)).astype(np.float32),
+                       (rng.random((B, 1)) > 0.5).astype(np.float32))
+    m.beta_dev.fill_(0.05)
+    fa, ya = mk(2, 150)
+    m.forward(fa, step=1, for_backward=False)
+    assert m.last["plan"]["stash"] is None and m.last["stash"] is False        # evaluation-only so far: nothing allocated
+    m.forward(fa, step=1)
+    pa = m.last["plan"]
+    assert m.last["stash"] is True and len(pa["stash"]) == 2
+    m.loss_and_backward(ya)
+    ga = m.get_grads()
+    live = pa["stash_block_bytes"] * 2
+    m.attention_score_stash_bytes = live + 8                                    # no room for a second shape's tiles
+    fb, yb = mk(1, 170)
+    m.forward(fb, step=2)
+    pb = m.last["plan"]
+    assert pb["stash"] is None and m.last["stash"] is False and "budget" in pb["stash_denied"]
+    m.loss_and_backward(yb)                                                     # recompute mode
+    torch.cuda.synchronize()
+    assert all(np.isfinite(v).all() for v in m.get_grads().values())
+    # the first shape still has its stash and still reproduces its gradients
+    m.forward(fa, step=1)
+    assert m.last["stash"] is True
+    m.loss_and_backward(ya)
+    torch.cuda.synchronize()
+    for k, v in m.get_grads().items():
+        assert np.array_equal(v, ga[k]), k
