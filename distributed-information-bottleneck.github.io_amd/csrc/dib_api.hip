@@ -11,6 +11,7 @@
 #include "../../include/dib_hip.h"
 #include "dib_elementwise.h"
 #include "dib_gemm.h"
+#include "dib_infonce_mfma.h"
 #include "dib_fused.h"
 #include "dib_gemm_bf16x6.h"
 #include "dib_st.h"
@@ -188,6 +189,9 @@ struct Knobs {
   int stream_rows = 8192;    // GEMMs with at least this many streamed rows load / store them non-temporally (1 << 30: never)
   int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
   int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
+  int split_policy = 1;      // weight gradients of the layout: 1 = pick the batch-split count per launch so that the workgroups fill
+                             // whole "rounds" of the chip's workgroup slots (pick_wgrad_splits); 0 = the layout-wide count
+  int split_overhead = 128;  // ... with this per-workgroup fixed cost, in batch rows (prologue + partial-tile store)
   int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
                              // OFF: measured slower (same box, B = 65536: 8.44-8.50 vs 8.37 ms; B = 8192: 1.345 vs 1.313 ms) -
                              // the two kernels together ask for 5.8 TB/s of HBM and evict each other's L2 lines
@@ -200,6 +204,8 @@ struct Knobs {
     if (const char* e = std::getenv("DIB_FORCE_TILE1")) force_tile[1] = std::atoi(e);
     if (const char* e = std::getenv("DIB_FORCE_TILE2")) force_tile[2] = std::atoi(e);
     if (const char* e = std::getenv("DIB_CONCURRENT_WGRAD")) concurrent_wgrad = std::atoi(e);
+    if (const char* e = std::getenv("DIB_SPLIT_POLICY")) split_policy = std::atoi(e);
+    if (const char* e = std::getenv("DIB_SPLIT_OVERHEAD")) split_overhead = std::atoi(e);
   }
 };
 inline const Knobs& knobs() { static Knobs k; return k; }
@@ -234,10 +240,37 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 }
 
 
+// Batch-split count of one weight-gradient launch.  `tiles` output tiles (all groups) x ns splits run on `slots` co-resident
+// workgroup slots (256 CUs x workgroups per CU of the tile shape); equal-length workgroups execute in ceil(tiles ns / slots)
+// rounds, so the launch takes ~ rounds x (rows per split + fixed cost).  The layout-wide rule (32 splits of 2048 rows at
+// B = 65536) is exact for F = 64 - 64 tiles x 32 = 4.0 rounds of 512 - and 22 % off for F = 50: 50 x 32 = 3.1 rounds, the
+// fourth 1/8 full (BASELINE config 4: encoder wgrads at 0.55-0.61 of the fp32-MFMA peak against 0.70-0.72 for config 3,
+// profiles/r04a_config4_*).  Candidates: 1 .. max_splits splits of a multiple of 64 rows (whole K-tiles), at least
+// DIB_SPLIT_ROWS rows; the cheapest wins, ties (within 1 %) go to the larger count (shorter dependent chains per workgroup).
+// Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace contract).
+static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits, int* ns_out, int* rps_out) {
+  double best = 1e300;
+  int bns = *ns_out, brps = *rps_out;
+  for (int ns = 1; ns <= max_splits; ++ns) {
+    const int rps = cdiv(cdiv(K, ns), 64) * 64;
+    if (ns > 1 && rps < DIB_SPLIT_ROWS) break;
+    if (cdiv(K, rps) != ns) continue;   // the same split as a smaller ns
+    const long long rounds = (tiles * ns + slots - 1) / slots;
+    const double cost = (double)rounds * (rps + knobs().split_overhead);
+    if (cost <= best * 1.01) {
+      if (cost < best) best = cost;
+      bns = ns;
+      brps = rps;
+    }
+  }
+  *ns_out = bns;
+  *rps_out = brps;
+}
+
 template <int MODE>
 int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* A, const float* B, float* C,
                 const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
-                long long split_stride, hipStream_t st) {
+                long long split_stride, hipStream_t st, bool auto_split = false) {
   if (c.count == 0) return DIB_OK;
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
@@ -258,6 +291,12 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
     if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * nsplit * c.count < 128) nj1 = true;  // tiny batches
   }
   if (const int ft = knobs().force_tile[MODE]) { ni1 = ft / 10 == 1; nj1 = (ft % 10 == 1) || N <= 64; }
+  if (MODE == 2 && auto_split && nsplit > 1 && knobs().split_policy) {
+    // co-resident workgroups per CU of each tile shape (LDS / register budget of dib_gemm_kernel<2, NI, NJ, BK>)
+    const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
+    const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
+    pick_wgrad_splits(tiles, 256 * per_cu, batch, nsplit, &nsplit, &rows_per_split);
+  }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
                                                    rows_per_split, split_stride, st)
@@ -272,8 +311,9 @@ template <int MODE>
 int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const float* B, float* C, const float* bias,
                 const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
                 long long split_stride, hipStream_t st) {
+  // the layout's weight gradients contract over the batch: their split count is chosen per launch (pick_wgrad_splits)
   return launch_gemm<MODE>(l->dev_groups, c, A, B, C, bias, aux, bias_out, batch, act, nsplit, rows_per_split, split_stride,
-                           st);
+                           st, /*auto_split=*/MODE == 2);
 }
 
 inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
@@ -924,7 +964,9 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
       // narrow outputs (the 2E-wide last layer) run 128x64 tiles at 4 workgroups/CU: half as many, twice as long batch
       // splits fill the chip in one wave (measured 0.88 -> 0.71 ms); the unused slabs of these blocks stay zero.
       // (only from 32 splits = 16384 rows up: at B = 8192 the 16 -> 8 split halving measured 117 vs 103 us)
-      const bool halve = knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
+      // (with the per-launch split policy on, pick_wgrad_splits makes this choice - 4 workgroups per CU for the narrow tile)
+      const bool halve = !knobs().split_policy && knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 &&
+                         (m.nsplit % 2) == 0;
       hipStream_t lst = st;
       if (fork && last) {
         if (hipEventRecord(l->ev_fork, st) != hipSuccess || hipStreamWaitEvent(l->side, l->ev_fork, 0) != hipSuccess)
@@ -1079,8 +1121,11 @@ int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu
 
 int64_t dib_infonce_workspace_bytes(int batch) {
   if (batch <= 0) return DIB_E_ARG;
-  // S, ST, C, CT, C2, C2T [B^2 floats each] | arg-max, its transpose [B^2 int32 each] | lse [2B] | norms [2B]
-  return (int64_t)sizeof(float) * (8ll * batch * batch + 4ll * batch + 64);
+  // VALU path (l1, linf): S, ST, C, CT, C2, C2T [B^2 floats each] | arg-max, its transpose [B^2 int32 each] | lse [2B] | norms [2B]
+  // MFMA path (l2sq, l2, cosine; csrc/dib_infonce_mfma.h): S [B^2] | 32-wide block partials of the row / column log-sum-exp
+  // [4 ceil(B/32) B] inside the same 8 B^2 | lse | norms | slice partials of C . Other [2 x 8 x B x 256 at most] and of the row
+  // sums [2 x 8 x B]
+  return (int64_t)sizeof(float) * (8ll * batch * batch + 4ll * batch + 64 + (4096ll + 16ll) * batch + 64);
 }
 
 int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int dim, int similarity, float temperature,
@@ -1108,8 +1153,44 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
     if (e != hipSuccess) return (int)e;
   }
   ProfScope ps(kProfOther, st);
-  if (similarity == 0 || similarity == 1 || similarity == 4)
+  if (similarity == 0 || similarity == 1 || similarity == 4) {
+    // dot-product similarities: S, g_x = C Y, g_y = C^T X as three MFMA products (csrc/dib_infonce_mfma.h)
+    const int nb32 = cdiv(batch, 32), t64 = cdiv(batch, 64);
+    float* prow = S + bb;
+    float* pcol = prow + 2ll * nb32 * batch;
+    float* Gp = norms + 2ll * batch + 64;
+    // partner slices per (self block, side): enough workgroups to fill 256 CUs twice, at most 8 (the partial buffers' size)
+    const int nsplit = std::max(1, std::min(std::min(t64, 8), cdiv(512, 2 * t64)));
+    float* Rp = Gp + 2ll * nsplit * batch * dim;
+    const int nacc = cdiv(dim, 64);
+    const size_t os_bytes = (size_t)64 * (64 * nacc + 4) * sizeof(float);
+    static bool attr_mfma[64] = {};
+    if (dib_attr_needed(attr_mfma)) {
+      hipError_t e = hipFuncSetAttribute((const void*)dib_infonce_grad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         64 * (64 * 3 + 4) * (int)sizeof(float));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)dib_infonce_grad_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                64 * (64 * 4 + 4) * (int)sizeof(float));
+      if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(dib_infonce_norms_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, emb_x, emb_y, batch, dim, norms);
+    hipLaunchKernelGGL(dib_infonce_sim_mfma_kernel, dim3(t64, t64), dim3(256), 0, st, emb_x, emb_y, batch, dim, similarity, inv_t,
+                       (const float*)norms, S, prow, pcol, nb32);
+    hipLaunchKernelGGL(dib_infonce_lse_combine_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, (const float*)prow,
+                       (const float*)pcol, batch, nb32, lse);
+    hipLaunchKernelGGL(dib_infonce_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)S, (const float*)lse, batch, loss_out);
+    if (g_x && g_y) {
+      const dim3 grid(t64, nsplit, 2);
+#define DIB_INCE_GRAD(NA) hipLaunchKernelGGL(dib_infonce_grad_mfma_kernel<NA>, grid, dim3(256), os_bytes, st, emb_x, emb_y, \
+                                             (const float*)S, (const float*)lse, (const float*)norms, batch, dim, similarity, inv_t, \
+                                             temperature, nsplit, Gp, Rp)
+      if (nacc == 1) DIB_INCE_GRAD(1); else if (nacc == 2) DIB_INCE_GRAD(2); else if (nacc == 3) DIB_INCE_GRAD(3); else DIB_INCE_GRAD(4);
+#undef DIB_INCE_GRAD
+      hipLaunchKernelGGL(dib_infonce_grad_final_kernel, dim3(cdiv(2ll * batch * dim, 256)), dim3(256), 0, st, emb_x, emb_y,
+                         (const float*)Gp, (const float*)Rp, batch, dim, similarity, nsplit, g_x, g_y);
+    }
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(dib_infonce_sim_kernel, dim3(tiles, tiles), dim3(256), (size_t)2 * 32 * (dim + 1) * sizeof(float), st, emb_x,
                      emb_y, batch, dim, similarity, inv_t, (const float*)norms, S, ST, amax, amaxT);
   hipLaunchKernelGGL(dib_infonce_lse_kernel, dim3(batch, 2), dim3(256), 0, st, (const float*)S, (const float*)ST, batch, lse);

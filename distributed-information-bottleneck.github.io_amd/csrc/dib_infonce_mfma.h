@@ -1,0 +1,315 @@
+// dib_infonce_mfma.h - the InfoNCE similarity matrix and its embedding gradients on the gfx950 matrix cores.
+//
+// reference: train.py:203-215 (eval_batch_infonce: S = similarity(emb_x, emb_y) / T, loss = mean_i CE(i, S[i,:]) +
+// mean_j CE(j, S[:,j])), utils.py:131-175 (get_scaled_similarity), utils.py:75-90 (pairwise squared distances as
+// |a|^2 + |b|^2 - 2 a.b^T, clamped at 0).  Default similarity of the reference: 'l2' (train.py:57-58).
+//
+// For the three similarities built on the dot product - l2sq, l2, cosine - everything that is O(B^2 D) is a matrix product:
+//   S-tile     ab = X Y^T                                [B, B]   K = D          dib_infonce_sim_mfma_kernel
+//   g_x        C Y      with C_ij   = coefficient(S_ij)  [B, D]   K = B          dib_infonce_grad_mfma_kernel (side 0)
+//   g_y        C^T X                                     [B, D]   K = B          dib_infonce_grad_mfma_kernel (side 1)
+// (round 3 evaluated all three on the VALU: 0.38 ms of the 0.73 ms step at B = 2048, D = 64.)  l1 / linf are not bilinear
+// and stay on the VALU kernels of dib_elementwise.h.
+//
+// With w_ij = dL/d(unscaled similarity)_ij = (softmax_row_i(S)_ij + softmax_col_j(S)_ij - 2 delta_ij) / (B T) the gradient wrt
+// the row's own embedding a (partner b) is
+//   l2sq   c = -2 w            (0 where the clamp max(d2, 0) is active)       g_a = sum_b c (a - b)  =  a R - C b,   R = sum_b c
+//   l2     c = -w / r,  r = sqrt(d2 + 1e-9) = -S T  (0 where d2 = 0)          same form
+//   cosine c = w / (|a||b|),  c2 = w sim / |a|^2                               g_a = C b - a R,               R = sum_b c2
+// so each side is one product C . Other (MFMA) plus one row sum R (VALU, alongside the coefficient evaluation); the final
+// combination  g = alpha a R + beta (C . Other)  is a [B, D] elementwise pass over the split partials.
+//
+// Kernels (all deterministic: fixed-order partials, no atomics):
+//   sim    64 x 64 tile of S per workgroup (4 waves x one 32 x 32 MFMA tile, K chunks of 64 through LDS), epilogue = norm /
+//          -2ab / sqrt / 1/T, S written once; per (row, 32-column block) and per (column, 32-row block) partial (max, sum exp)
+//          from the accumulator registers (half-wave shuffles along a row; in-lane + one cross-half shuffle along a column)
+//   lse    combine the partials: lse_r[i], lse_c[j]                              (then dib_infonce_loss_kernel, unchanged)
+//   grad   workgroup = 64 "self" rows x a slice of the partner tiles x side; per partner tile: read the S tile (side 1:
+//          transposed through LDS), evaluate the coefficients, G += C . Other on the MFMAs, R += row sums; partial G, R
+//          per slice
+//   final  g = alpha self R + beta G, slices summed in a fixed order
+#pragma once
+#include "dib_common.h"
+#include "dib_gemm.h"   // dib_f32x16, DIB_MFMA
+
+#define DIB_INCE_TS 64          // tile edge
+#define DIB_INCE_KP 68          // LDS pitch of a k-contiguous operand tile (b128 fragment reads: conflict-free at BK + 4)
+#define DIB_INCE_CP 65          // LDS pitch of the coefficient tile (odd: conflict-free for row-wise and transposed stores)
+
+// S_ij from the dot product.  kind: 0 l2sq, 1 l2, 4 cosine.
+__device__ __forceinline__ float dib_ince_similarity(int kind, float ab, float na, float nb, float inv_t) {
+  float s;
+  if (kind == 4) {
+    s = ab / (sqrtf(na) * sqrtf(nb));
+  } else {  // utils.py:85-90: max(|a|^2 + |b|^2 - 2 a.b, 0)
+    const float d2 = fmaxf(na + nb - 2.0f * ab, 0.f);
+    s = (kind == 0) ? -d2 : -sqrtf(d2 + 1e-9f);
+  }
+  return s * inv_t;
+}
+
+// grid (ceil(B/64) column tiles, ceil(B/64) row tiles), 256 threads.
+// prow: [2][nb32][B] (plane 0 max, plane 1 sum of exp(s - max)) over the 32-column block cb of row i;  pcol: same for columns.
+__global__ void __launch_bounds__(256)
+dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, int kind, float inv_t,
+                            const float* __restrict__ norms, float* __restrict__ S, float* __restrict__ prow,
+                            float* __restrict__ pcol, int nb32) {
+  __shared__ __attribute__((aligned(16))) float Xs[DIB_INCE_TS * DIB_INCE_KP];
+  __shared__ __attribute__((aligned(16))) float Ys[DIB_INCE_TS * DIB_INCE_KP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i0 = blockIdx.y * DIB_INCE_TS, j0 = blockIdx.x * DIB_INCE_TS;
+  const bool vec = (D & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)Y)) & 15) == 0;
+  dib_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int lr = tid >> 4, lc = (tid & 15) * 4;     // this thread stages rows lr + 16 p, k columns lc .. lc + 3
+  for (int k0 = 0; k0 < D; k0 += 64) {
+    if (k0) __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = lr + 16 * p, k = k0 + lc;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (i0 + r < B) {
+        const float* src = X + (long long)(i0 + r) * D + k;
+        if (vec && k + 3 < D) a = *reinterpret_cast<const float4*>(src);
+        else { if (k < D) a.x = src[0]; if (k + 1 < D) a.y = src[1]; if (k + 2 < D) a.z = src[2]; if (k + 3 < D) a.w = src[3]; }
+      }
+      if (j0 + r < B) {
+        const float* src = Y + (long long)(j0 + r) * D + k;
+        if (vec && k + 3 < D) b = *reinterpret_cast<const float4*>(src);
+        else { if (k < D) b.x = src[0]; if (k + 1 < D) b.y = src[1]; if (k + 2 < D) b.z = src[2]; if (k + 3 < D) b.w = src[3]; }
+      }
+      *reinterpret_cast<float4*>(Xs + r * DIB_INCE_KP + lc) = a;
+      *reinterpret_cast<float4*>(Ys + r * DIB_INCE_KP + lc) = b;
+    }
+    __syncthreads();
+    const int kq = min(8, (D - k0 + 7) >> 3);          // 8-deep k blocks that hold data (the rest of the chunk is zero)
+    for (int q = 0; q < kq; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(Xs + (wm * 32 + l31) * DIB_INCE_KP + q * 8 + h * 4);
+      const float4 b = *reinterpret_cast<const float4*>(Ys + (wn * 32 + l31) * DIB_INCE_KP + q * 8 + h * 4);
+      acc = DIB_MFMA(a.x, b.x, acc);
+      acc = DIB_MFMA(a.y, b.y, acc);
+      acc = DIB_MFMA(a.z, b.z, acc);
+      acc = DIB_MFMA(a.w, b.w, acc);
+    }
+  }
+  // ---- epilogue: C/D map of the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
+  const int j = j0 + wn * 32 + l31;
+  const bool jok = j < B;
+  const float nb = norms[B + min(j, B - 1)];
+  float s[16];
+  float cmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const bool ok = jok && i < B;
+    const float v = dib_ince_similarity(kind, acc[r], norms[min(i, B - 1)], nb, inv_t);
+    if (ok) S[(long long)i * B + j] = v;
+    s[r] = ok ? v : -INFINITY;
+    cmax = fmaxf(cmax, s[r]);
+  }
+  // column partials: 16 rows in this lane + the other half-wave's 16
+  cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+  float csum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) csum += (s[r] == -INFINITY) ? 0.f : expf(s[r] - cmax);
+  csum += __shfl_xor(csum, 32, 64);
+  const int rb = (i0 + wm * 32) >> 5, cb = (j0 + wn * 32) >> 5;
+  if (h == 0 && jok && rb < nb32) {
+    pcol[(long long)rb * B + j] = cmax;
+    pcol[(long long)(nb32 + rb) * B + j] = csum;
+  }
+  // row partials: the 32 columns of a row live in the 32 lanes of one half-wave (xor shuffles below 32 stay inside it)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float m = s[r];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float e = (s[r] == -INFINITY) ? 0.f : expf(s[r] - m);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (l31 == 0 && i < B && cb < nb32) {
+      prow[(long long)cb * B + i] = m;
+      prow[(long long)(nb32 + cb) * B + i] = e;
+    }
+  }
+}
+
+// lse[0][i] = LSE_j S[i][j], lse[1][j] = LSE_i S[i][j] from the 32-wide block partials (fixed order).  grid ceil(2B / 256).
+__global__ void __launch_bounds__(256)
+dib_infonce_lse_combine_kernel(const float* __restrict__ prow, const float* __restrict__ pcol, int B, int nb32,
+                               float* __restrict__ lse) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * B) return;
+  const float* p = idx < B ? prow : pcol;
+  const int t = idx < B ? idx : idx - B;
+  float m = -INFINITY;
+  for (int b = 0; b < nb32; ++b) m = fmaxf(m, p[(long long)b * B + t]);
+  float sum = 0.f;
+  for (int b = 0; b < nb32; ++b) {
+    const float pm = p[(long long)b * B + t];
+    if (pm != -INFINITY) sum += p[(long long)(nb32 + b) * B + t] * expf(pm - m);
+  }
+  lse[idx] = m + logf(sum);
+}
+
+// grid (ceil(B/64) self blocks, nsplit partner slices, 2 sides), 256 threads, dynamic LDS (DIB_INCE_TS * (64 NACC + 4)) floats
+// for the partner tile.  side 0: self = x rows, partners = y rows, coefficient tile read along rows of S; side 1: self = y
+// rows, partners = x rows, the S tile is read along its rows (coalesced) and stored TRANSPOSED into the coefficient tile.
+// Gp [2][nsplit][B][D], Rp [2][nsplit][B].
+template <int NACC>
+__global__ void __launch_bounds__(256)
+dib_infonce_grad_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ S,
+                             const float* __restrict__ lse, const float* __restrict__ norms, int B, int D, int kind,
+                             float inv_t, float temperature, int nsplit, float* __restrict__ Gp, float* __restrict__ Rp) {
+  constexpr int DP = 64 * NACC, OP = DP + 4;
+  extern __shared__ __attribute__((aligned(16))) float Os[];   // [64 partners][OP]
+  __shared__ float Cs[DIB_INCE_TS * DIB_INCE_CP];              // [64 self][65]
+  __shared__ float Rs[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int side = blockIdx.z, split = blockIdx.y;
+  const int s0 = blockIdx.x * DIB_INCE_TS;
+  const float* self_lse = lse + (side == 0 ? 0 : B);
+  const float* oth_lse = lse + (side == 0 ? B : 0);
+  const float* self_n = norms + (side == 0 ? 0 : B);
+  const float* oth_n = norms + (side == 0 ? B : 0);
+  const float* Oth = side == 0 ? Y : X;
+  const int ntiles = (B + DIB_INCE_TS - 1) / DIB_INCE_TS;
+  const int tbeg = (int)(((long long)ntiles * split) / nsplit), tend = (int)(((long long)ntiles * (split + 1)) / nsplit);
+  const float sc = inv_t / (float)B;
+  const bool vecS = (B & 3) == 0 && (((uintptr_t)S) & 15) == 0;
+  const bool vecO = (D & 3) == 0 && (((uintptr_t)Oth) & 15) == 0;
+  const int lr = tid >> 4, lc = (tid & 15) * 4;   // S tile staging: tile rows lr + 16 p, tile columns lc .. lc + 3
+
+  dib_f32x16 acc[NACC];
+#pragma unroll
+  for (int n = 0; n < NACC; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  float rs[4] = {0.f, 0.f, 0.f, 0.f};   // side 0: row sums of tile rows lr + 16 p;  side 1: of self columns lc + c
+
+  for (int t = tbeg; t < tend; ++t) {
+    const int o0 = t * DIB_INCE_TS;
+    __syncthreads();   // the previous tile's MFMAs have read Cs / Os
+    // ---- partner tile -> Os (zero beyond B and beyond D) ----
+    for (int idx = tid; idx < DIB_INCE_TS * (DP / 4); idx += 256) {
+      const int r = idx / (DP / 4), c = (idx - r * (DP / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o0 + r < B && c < D) {
+        const float* src = Oth + (long long)(o0 + r) * D + c;
+        if (vecO && c + 3 < D) v = *reinterpret_cast<const float4*>(src);
+        else { v.x = src[0]; if (c + 1 < D) v.y = src[1]; if (c + 2 < D) v.z = src[2]; if (c + 3 < D) v.w = src[3]; }
+      }
+      *reinterpret_cast<float4*>(Os + r * OP + c) = v;
+    }
+    // ---- S tile -> coefficients -> Cs[self][partner] ----
+    const int rbase = side == 0 ? s0 : o0, cbase = side == 0 ? o0 : s0;   // S rows = x index, S columns = y index
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int tr = lr + 16 * p, gi = rbase + tr;       // x index
+      float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gi < B) {
+        const float* src = S + (long long)gi * B + cbase + lc;
+        if (vecS && cbase + lc + 3 < B) sv = *reinterpret_cast<const float4*>(src);
+        else {
+          if (cbase + lc < B) sv.x = src[0];
+          if (cbase + lc + 1 < B) sv.y = src[1];
+          if (cbase + lc + 2 < B) sv.z = src[2];
+          if (cbase + lc + 3 < B) sv.w = src[3];
+        }
+      }
+      const float svv[4] = {sv.x, sv.y, sv.z, sv.w};
+      const float lse_i = gi < B ? lse[gi] : 0.f;                         // row (x) log-sum-exp
+      const float n_i = (kind == 4 && gi < B) ? norms[gi] : 1.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int tc = lc + c, gj = cbase + tc;      // y index
+        float cf = 0.f, c2 = 0.f;
+        if (gi < B && gj < B) {
+          const float sij = svv[c];
+          const float w = (expf(sij - lse_i) + expf(sij - lse[B + gj]) - (gi == gj ? 2.0f : 0.f)) * sc;
+          if (kind == 0) cf = sij < 0.f ? -2.0f * w : 0.f;
+          else if (kind == 1) { const float rr = -sij * temperature; cf = (rr * rr > 1.0000005e-9f) ? -w / rr : 0.f; }
+          else {
+            const float n_j = norms[B + gj];
+            const float ri = rsqrtf(n_i), rj = rsqrtf(n_j);
+            cf = w * ri * rj;
+            c2 = w * (sij * temperature) * (side == 0 ? ri * ri : rj * rj);
+          }
+        }
+        const float rterm = kind == 4 ? c2 : cf;
+        if (side == 0) { Cs[tr * DIB_INCE_CP + tc] = cf; rs[p] += rterm; }
+        else           { Cs[tc * DIB_INCE_CP + tr] = cf; rs[c] += rterm; }
+      }
+    }
+    __syncthreads();
+    // ---- G[self 32 x (32 NACC)] += C[32 x 64] . Os[64 x (32 NACC)] ----
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float* ap = Cs + (wm * 32 + l31) * DIB_INCE_CP + q * 8 + h * 4;
+      const float a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+#pragma unroll
+      for (int n = 0; n < NACC; ++n) {
+        const float* bp = Os + (q * 8 + h * 4) * OP + wn * 32 * NACC + n * 32 + l31;
+        acc[n] = DIB_MFMA(a0, bp[0], acc[n]);
+        acc[n] = DIB_MFMA(a1, bp[OP], acc[n]);
+        acc[n] = DIB_MFMA(a2, bp[2 * OP], acc[n]);
+        acc[n] = DIB_MFMA(a3, bp[3 * OP], acc[n]);
+      }
+    }
+  }
+  // ---- partial outputs ----
+  float* G = Gp + ((long long)(side * nsplit + split) * B) * D;
+#pragma unroll
+  for (int n = 0; n < NACC; ++n) {
+    const int e = wn * 32 * NACC + n * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = s0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (i < B && e < D) G[(long long)i * D + e] = acc[n][r];
+    }
+  }
+  float* R = Rp + (long long)(side * nsplit + split) * B;
+  if (side == 0) {   // tile row lr + 16 p: the 16 threads of a row are 16 consecutive lanes
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float v = rs[p];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if ((tid & 15) == 0 && s0 + lr + 16 * p < B) R[s0 + lr + 16 * p] = v;
+    }
+  } else {           // self column lc + c: threads with equal tid & 15 - lanes 16 apart in a wave, then the 4 waves via LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = rs[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) Rs[wave][lane * 4 + c] = v;
+    }
+    __syncthreads();
+    if (tid < 64 && s0 + tid < B) R[s0 + tid] = Rs[0][tid] + Rs[1][tid] + Rs[2][tid] + Rs[3][tid];
+  }
+}
+
+// g = alpha self R + beta G with the slices summed in a fixed order.  One thread per (side, row, coordinate).
+__global__ void __launch_bounds__(256)
+dib_infonce_grad_final_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ Gp,
+                              const float* __restrict__ Rp, int B, int D, int kind, int nsplit, float* __restrict__ GX,
+                              float* __restrict__ GY) {
+  const long long per = (long long)B * D;
+  const long long idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= 2 * per) return;
+  const int side = idx >= per ? 1 : 0;
+  const long long o = idx - side * per;
+  const int i = (int)(o / D);
+  float g = 0.f, r = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    g += Gp[(long long)(side * nsplit + s) * per + o];
+    r += Rp[(long long)(side * nsplit + s) * B + i];
+  }
+  const float self = (side == 0 ? X : Y)[o];
+  (side == 0 ? GX : GY)[o] = kind == 4 ? (g - self * r) : (self * r - g);
+}

@@ -402,14 +402,19 @@ class DistributedIBNet:
         elif getattr(eng, "step_dev", None) is not None:
             eng.set_step_counter(self._step)
 
+        def epoch_order(epoch):
+            """row order of `epoch` on the device (int32): Keras reshuffles every epoch; seeded by (shuffle_seed, epoch)"""
+            order = (np.random.default_rng([self.shuffle_seed, epoch]).permutation(n) if shuffle else np.arange(n)).astype(np.int32)
+            return eng.to_device(order, dtype=torch.int32)
+
+        next_order = None
         try:
             for epoch in range(initial_epoch, epochs):
                 for cb in cbs:
                     cb.on_epoch_begin(epoch)
                 eng.set_beta(float(self.beta.value()))
-                order = (np.random.default_rng([self.shuffle_seed, epoch]).permutation(n) if shuffle
-                         else np.arange(n)).astype(np.int32)
-                order_dev = eng.to_device(order, dtype=torch.int32)
+                order_dev = next_order if next_order is not None else epoch_order(epoch)
+                next_order = None
                 nsteps = 0
                 for s0 in range(0, n, bs):
                     gb = min(bs, n - s0)  # last partial batch is kept (Keras)
@@ -454,6 +459,11 @@ class DistributedIBNet:
                     nsteps += 1
                     if getattr(eng, "step_dev", None) is not None:
                         eng.set_step_counter(self._step)  # eager step under the device counter: keep it in sync
+                # host work under the device's queue: the next epoch's permutation (12 ms of numpy for 2^20 rows - with it at
+                # the top of the epoch the device idled 7 % of a config-3 epoch, bench.py extra.fit_surface) and its upload are
+                # done while this epoch's steps are still executing; the read-back below is the epoch's only synchronisation
+                if epoch + 1 < epochs and not self.stop_training:
+                    next_order = epoch_order(epoch + 1)
                 logs = self._epoch_logs(reduce_metrics(eng.read_metrics()), nsteps, "")
                 if validation_data is not None:
                     nv = xvd.shape[0]

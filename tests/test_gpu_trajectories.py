@@ -10,7 +10,7 @@ Tolerances.  The bar is BASELINE's: every per-epoch per-feature KL within 1e-3 n
 unit's subgradient and two float32-ACCURATE runs part by 1e-4..1e-3 from there on.  The tests therefore also run the oracle in
 float32 and widen the tolerance of every series entry by 3 x |oracle64 - oracle32| at that entry: where float32 arithmetic
 itself leaves the value open, the device may differ by as much - and nowhere else.  (At the seeds used here the widening is
-< 2e-4 everywhere: the assertions are, in effect, the plain 1e-3.)"""
+< 2e-4 everywhere: the assertions are, in effect, the plain 1e-3.)  Final parameters: see _check_params."""
 import numpy as np
 import pytest
 import torch
@@ -28,6 +28,22 @@ def _check(name, got, want, want32, tol_abs, tol_rel=0.0):
     err = np.abs(got - want)
     assert (err <= tol).all(), (name, float(err.max()), float(tol.flat[np.argmax(err - tol)]), np.argwhere(err > tol)[:4])
     return float(err.max())
+
+
+def _check_params(name, got, want, want32, start):
+    """Final parameters of one block after n Adam steps.  Adam normalises every element's step to ~lr whatever the size of
+    its gradient, so an element whose gradient is round-off-level noise moves by lr per step in a direction float32 does not
+    determine: a per-element absolute bound of the order of the float32 error does not exist.  What is bounded is the error
+    relative to the DISPLACEMENT the optimiser produced: rms error <= 2 % of the block's rms displacement, largest error <=
+    5 % of its largest displacement (each widened by 3 x the float64-vs-float32 oracle difference, as for the series)."""
+    got, want, want32, start = [np.asarray(a, dtype=np.float64) for a in (got, want, want32, start)]
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    disp, err, amb = want - start, got - want, want - want32
+    rms = lambda a: float(np.sqrt(np.mean(a * a)))
+    assert rms(err) <= 0.02 * rms(disp) + 3.0 * rms(amb) + 1e-7, (name, "rms", rms(err), rms(disp), rms(amb))
+    assert np.abs(err).max() <= 0.05 * np.abs(disp).max() + 3.0 * np.abs(amb).max() + 1e-6, \
+        (name, "max", float(np.abs(err).max()), float(np.abs(disp).max()), float(np.abs(amb).max()))
+    return rms(err) / max(rms(disp), 1e-30)
 
 
 @pytest.mark.parametrize("batch_size,rows", [(128, 1024), (256, 2048)])
@@ -71,15 +87,16 @@ def test_infonce_loop_trajectory_matches_float64_oracle(tmp_path, batch_size, ro
     # final parameters of both networks after 104 Adam steps (lr 3e-4: a parameter moves <= 0.03 in total)
     px = flat_to_params(model.param_blocks(), model.get_flat_weights(), spec)
     nx = len(px.tensors())
-    for i, t in enumerate(px.tensors()):
+    perr = {}
+    for i, (t, t0) in enumerate(zip(px.tensors(), p0.tensors())):
         w64, w32 = o64.vars[i].detach().numpy(), o32.vars[i].detach().double().numpy()
-        errs[f"x{i}"] = _check(f"x param {i}", t, w64, w32, tol_abs=2e-4)
+        perr[f"x{i}"] = _check_params(f"x param {i}", t, w64, w32, t0)
     for l in range(L):
         for j, t in enumerate((yenc.kernel(l), yenc.bias(l))):
             w64, w32 = o64.vars[nx + 2 * l + j].detach().numpy(), o32.vars[nx + 2 * l + j].detach().double().numpy()
-            errs[f"y{l}{j}"] = _check(f"y param {l}/{j}", t.cpu().numpy(), w64, w32, tol_abs=2e-4)
-    print("max errors:", {k: f"{v:.2e}" for k, v in errs.items() if not k[0] in "xy" or v > 5e-5},
-          "params:", max(v for k, v in errs.items() if k[0] in "xy"))
+            perr[f"y{l}{j}"] = _check_params(f"y param {l}/{j}", t.cpu().numpy(), w64, w32, y0[j][l])
+    print("max series errors:", {k: f"{v:.2e}" for k, v in errs.items()},
+          "worst parameter block (rms error / rms displacement):", max(perr, key=perr.get), f"{max(perr.values()):.2e}")
 
 
 def test_keras_path_trajectory_160_steps_through_the_ramp():
@@ -123,6 +140,6 @@ def test_keras_path_trajectory_160_steps_through_the_ramp():
         else:
             errs[k] = _check(k, hist[k], want[k], want32[k], tol_abs=0.0, tol_rel=2e-3)
     got = flat_to_params(model.param_blocks(), model.get_flat_weights(), spec)
-    perr = max(_check(f"param {i}", a, b, c.astype(np.float64), tol_abs=3e-4)
-               for i, (a, b, c) in enumerate(zip(got.tensors(), finals[np.float64].tensors(), finals[np.float32].tensors())))
-    print("max errors:", {k: f"{v:.2e}" for k, v in errs.items()}, "params:", perr)
+    perr = max(_check_params(f"param {i}", a, b, c, a0) for i, (a, b, c, a0) in enumerate(
+        zip(got.tensors(), finals[np.float64].tensors(), finals[np.float32].tensors(), p0.tensors())))
+    print("max series errors:", {k: f"{v:.2e}" for k, v in errs.items()}, "worst parameter block (rms error / rms displacement):", perr)
