@@ -189,8 +189,8 @@ struct Knobs {
   int stream_rows = 8192;    // GEMMs with at least this many streamed rows load / store them non-temporally (1 << 30: never)
   int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
   int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
-  int split_policy = 1;      // weight gradients of the layout: 1 = pick the batch-split count per launch so that the workgroups fill
-                             // whole "rounds" of the chip's workgroup slots (pick_wgrad_splits); 0 = the layout-wide count
+  int split_policy = 1;      // weight gradients of the layout: 1 = pick the batch-split count per launch so that every CU gets
+                             // the same number of workgroups (pick_wgrad_splits); 0 = the layout-wide count
   int split_overhead = 128;  // ... with this per-workgroup fixed cost, in batch rows (prologue + partial-tile store)
   int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
                              // OFF: measured slower (same box, B = 65536: 8.44-8.50 vs 8.37 ms; B = 8192: 1.345 vs 1.313 ms) -
@@ -240,23 +240,29 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 }
 
 
-// Batch-split count of one weight-gradient launch.  `tiles` output tiles (all groups) x ns splits run on `slots` co-resident
-// workgroup slots (256 CUs x workgroups per CU of the tile shape); equal-length workgroups execute in ceil(tiles ns / slots)
-// rounds, so the launch takes ~ rounds x (rows per split + fixed cost).  The layout-wide rule (32 splits of 2048 rows at
-// B = 65536) is exact for F = 64 - 64 tiles x 32 = 4.0 rounds of 512 - and 22 % off for F = 50: 50 x 32 = 3.1 rounds, the
-// fourth 1/8 full (BASELINE config 4: encoder wgrads at 0.55-0.61 of the fp32-MFMA peak against 0.70-0.72 for config 3,
-// profiles/r04a_config4_*).  Candidates: 1 .. max_splits splits of a multiple of 64 rows (whole K-tiles), at least
-// DIB_SPLIT_ROWS rows; the cheapest wins, ties (within 1 %) go to the larger count (shorter dependent chains per workgroup).
-// Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace contract).
-static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits, int* ns_out, int* rps_out) {
+// Batch-split count of one weight-gradient launch: `tiles` output tiles (all groups) x ns splits of rps batch rows.
+// Cost model (measured, profiles/r04b_split_policy_ab.txt): what a CU has to execute is SERIAL on its matrix pipe whether its
+// workgroups are co-resident or not - two workgroups sharing a CU each run at half speed, a lone one at full speed - so the
+// launch takes ~ max over CUs of the rows assigned = ceil(tiles ns / 256) x (rps + fixed cost per workgroup).  (A model in
+// whole "rounds" of all co-resident slots predicted -18 % for F = 50 and got -6 %: a partial round costs its share, not a
+// full one.)  The layout-wide rule - 32 splits of 2048 rows at B = 65536 - is exact for F = 64 (64 tiles x 32 = 8 per CU) and
+// off for F = 50: 1600 workgroups = 6.25 per CU, i.e. 7 on some (12 % over the even share), and the narrow last-layer
+// gradient with its splits halved put 800 workgroups on 256 CUs (4 x 4096 rows where 3.125 x 4096 would do).  BASELINE
+// config 4: encoder wgrads 0.55-0.61 of the fp32-MFMA peak against 0.70-0.72 for config 3 (profiles/r04a_config4_*).
+// Candidates: 1 .. max_splits splits of a multiple of 64 rows (whole K-tiles), at least DIB_SPLIT_ROWS rows; fewer than two
+// workgroups per CU cost 5 % (nothing to overlap a workgroup's prologue with); the cheapest wins, ties within 1 % go to the
+// larger count.  Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace
+// contract).
+static void pick_wgrad_splits(long long tiles, int K, int max_splits, int* ns_out, int* rps_out) {
   double best = 1e300;
   int bns = *ns_out, brps = *rps_out;
   for (int ns = 1; ns <= max_splits; ++ns) {
     const int rps = cdiv(cdiv(K, ns), 64) * 64;
     if (ns > 1 && rps < DIB_SPLIT_ROWS) break;
     if (cdiv(K, rps) != ns) continue;   // the same split as a smaller ns
-    const long long rounds = (tiles * ns + slots - 1) / slots;
-    const double cost = (double)rounds * (rps + knobs().split_overhead);
+    const long long per_cu = (tiles * ns + 255) / 256;
+    double cost = (double)per_cu * (rps + knobs().split_overhead);
+    if (tiles * ns < 512) cost *= 1.05;
     if (cost <= best * 1.01) {
       if (cost < best) best = cost;
       bns = ns;
@@ -292,10 +298,8 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
   }
   if (const int ft = knobs().force_tile[MODE]) { ni1 = ft / 10 == 1; nj1 = (ft % 10 == 1) || N <= 64; }
   if (MODE == 2 && auto_split && nsplit > 1 && knobs().split_policy) {
-    // co-resident workgroups per CU of each tile shape (LDS / register budget of dib_gemm_kernel<2, NI, NJ, BK>)
-    const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
     const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
-    pick_wgrad_splits(tiles, 256 * per_cu, batch, nsplit, &nsplit, &rows_per_split);
+    pick_wgrad_splits(tiles, batch, nsplit, &nsplit, &rows_per_split);
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
@@ -1158,36 +1162,41 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
     const int nb32 = cdiv(batch, 32), t64 = cdiv(batch, 64);
     float* prow = S + bb;
     float* pcol = prow + 2ll * nb32 * batch;
+    unsigned* arrive = (unsigned*)(norms + 2ll * batch + 16);
     float* Gp = norms + 2ll * batch + 64;
-    // partner slices per (self block, side): enough workgroups to fill 256 CUs twice, at most 8 (the partial buffers' size)
-    const int nsplit = std::max(1, std::min(std::min(t64, 8), cdiv(512, 2 * t64)));
+    // partner slices per (self block, side): one up to B = 256 (the gradient kernel then writes g itself: 3 launches in all);
+    // above, enough workgroups to fill 256 CUs twice, at most 8 (the partial buffers' size)
+    const int nsplit = t64 <= 4 ? 1 : std::max(1, std::min(std::min(t64, 8), cdiv(512, 2 * t64)));
     float* Rp = Gp + 2ll * nsplit * batch * dim;
     const int nacc = cdiv(dim, 64);
     const size_t os_bytes = (size_t)64 * (64 * nacc + 4) * sizeof(float);
     static bool attr_mfma[64] = {};
     if (dib_attr_needed(attr_mfma)) {
-      hipError_t e = hipFuncSetAttribute((const void*)dib_infonce_grad_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         64 * (64 * 3 + 4) * (int)sizeof(float));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)dib_infonce_grad_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                64 * (64 * 4 + 4) * (int)sizeof(float));
-      if (e != hipSuccess) return (int)e;
+#define DIB_INCE_ATTR(NA, KD)                                                                                          \
+      if (hipFuncSetAttribute((const void*)dib_infonce_grad_mfma_kernel<NA, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              64 * (64 * NA + 4) * (int)sizeof(float)) != hipSuccess) return DIB_E_ARG;
+      DIB_INCE_ATTR(3, 0) DIB_INCE_ATTR(3, 1) DIB_INCE_ATTR(3, 4) DIB_INCE_ATTR(4, 0) DIB_INCE_ATTR(4, 1) DIB_INCE_ATTR(4, 4)
+#undef DIB_INCE_ATTR
     }
-    hipLaunchKernelGGL(dib_infonce_norms_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, emb_x, emb_y, batch, dim, norms);
-    hipLaunchKernelGGL(dib_infonce_sim_mfma_kernel, dim3(t64, t64), dim3(256), 0, st, emb_x, emb_y, batch, dim, similarity, inv_t,
-                       (const float*)norms, S, prow, pcol, nb32);
-    hipLaunchKernelGGL(dib_infonce_lse_combine_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, (const float*)prow,
-                       (const float*)pcol, batch, nb32, lse);
-    hipLaunchKernelGGL(dib_infonce_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)S, (const float*)lse, batch, loss_out);
+#define DIB_INCE_SIM(KD) hipLaunchKernelGGL(dib_infonce_sim_mfma_kernel<KD>, dim3(t64, t64), dim3(256), 0, st, emb_x, emb_y, batch, \
+                                            dim, inv_t, norms, S, prow, pcol, nb32, arrive)
+    if (similarity == 0) DIB_INCE_SIM(0); else if (similarity == 1) DIB_INCE_SIM(1); else DIB_INCE_SIM(4);
+#undef DIB_INCE_SIM
+    hipLaunchKernelGGL(dib_infonce_lse_loss_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, (const float*)prow,
+                       (const float*)pcol, (const float*)S, batch, nb32, lse, arrive, loss_out);
     if (g_x && g_y) {
       const dim3 grid(t64, nsplit, 2);
-#define DIB_INCE_GRAD(NA) hipLaunchKernelGGL(dib_infonce_grad_mfma_kernel<NA>, grid, dim3(256), os_bytes, st, emb_x, emb_y, \
-                                             (const float*)S, (const float*)lse, (const float*)norms, batch, dim, similarity, inv_t, \
-                                             temperature, nsplit, Gp, Rp)
-      if (nacc == 1) DIB_INCE_GRAD(1); else if (nacc == 2) DIB_INCE_GRAD(2); else if (nacc == 3) DIB_INCE_GRAD(3); else DIB_INCE_GRAD(4);
+#define DIB_INCE_GRAD(NA, KD) hipLaunchKernelGGL((dib_infonce_grad_mfma_kernel<NA, KD>), grid, dim3(256), os_bytes, st, emb_x, emb_y, \
+                                                 (const float*)S, (const float*)lse, (const float*)norms, batch, dim, inv_t,            \
+                                                 temperature, nsplit, Gp, Rp, g_x, g_y)
+#define DIB_INCE_GRAD_K(KD) do { if (nacc == 1) DIB_INCE_GRAD(1, KD); else if (nacc == 2) DIB_INCE_GRAD(2, KD);              \
+                                 else if (nacc == 3) DIB_INCE_GRAD(3, KD); else DIB_INCE_GRAD(4, KD); } while (0)
+      if (similarity == 0) DIB_INCE_GRAD_K(0); else if (similarity == 1) DIB_INCE_GRAD_K(1); else DIB_INCE_GRAD_K(4);
+#undef DIB_INCE_GRAD_K
 #undef DIB_INCE_GRAD
-      hipLaunchKernelGGL(dib_infonce_grad_final_kernel, dim3(cdiv(2ll * batch * dim, 256)), dim3(256), 0, st, emb_x, emb_y,
-                         (const float*)Gp, (const float*)Rp, batch, dim, similarity, nsplit, g_x, g_y);
+      if (nsplit > 1)
+        hipLaunchKernelGGL(dib_infonce_grad_final_kernel, dim3(cdiv(2ll * batch * dim, 256)), dim3(256), 0, st, emb_x, emb_y,
+                           (const float*)Gp, (const float*)Rp, batch, dim, similarity, nsplit, g_x, g_y);
     }
     return (int)hipGetLastError();
   }

@@ -16,18 +16,20 @@
 //   l2sq   c = -2 w            (0 where the clamp max(d2, 0) is active)       g_a = sum_b c (a - b)  =  a R - C b,   R = sum_b c
 //   l2     c = -w / r,  r = sqrt(d2 + 1e-9) = -S T  (0 where d2 = 0)          same form
 //   cosine c = w / (|a||b|),  c2 = w sim / |a|^2                               g_a = C b - a R,               R = sum_b c2
-// so each side is one product C . Other (MFMA) plus one row sum R (VALU, alongside the coefficient evaluation); the final
-// combination  g = alpha a R + beta (C . Other)  is a [B, D] elementwise pass over the split partials.
+// so each side is one product C . Other (MFMA) plus one row sum R (VALU, alongside the coefficient evaluation).
 //
-// Kernels (all deterministic: fixed-order partials, no atomics):
-//   sim    64 x 64 tile of S per workgroup (4 waves x one 32 x 32 MFMA tile, K chunks of 64 through LDS), epilogue = norm /
-//          -2ab / sqrt / 1/T, S written once; per (row, 32-column block) and per (column, 32-row block) partial (max, sum exp)
-//          from the accumulator registers (half-wave shuffles along a row; in-lane + one cross-half shuffle along a column)
-//   lse    combine the partials: lse_r[i], lse_c[j]                              (then dib_infonce_loss_kernel, unchanged)
+// Launches (all deterministic: fixed-order partials, the one atomic is an arrival counter):
+//   sim    64 x 64 tile of S per workgroup (4 waves x one 32 x 32 MFMA tile, K chunks of 64 through LDS).  The row norms come
+//          out of the staged tiles (sum of squares of what each thread stages, 16-lane DPP reduction); epilogue = norm /
+//          -2ab / sqrt / 1/T, S written once; per (row, 32-column block) and per (column, 32-row block) partial
+//          (max, sum exp) from the accumulator registers: along a column in-lane + one cross-half swizzle, along a row a
+//          16-lane DPP butterfly + one swizzle (the first version's 162 ds_bpermute per tile were most of the kernel)
+//   lse    combine the partials: lse_r[i], lse_c[j]; the LAST workgroup to finish (arrival counter) adds up the loss
 //   grad   workgroup = 64 "self" rows x a slice of the partner tiles x side; per partner tile: read the S tile (side 1:
-//          transposed through LDS), evaluate the coefficients, G += C . Other on the MFMAs, R += row sums; partial G, R
-//          per slice
+//          transposed through LDS), evaluate the coefficients, G += C . Other on the MFMAs, R += row sums.  With one slice
+//          (B <= 256) the epilogue writes g = alpha self R + beta G itself; else partial G, R per slice and
 //   final  g = alpha self R + beta G, slices summed in a fixed order
+// = 3 launches at the reference's default batch of 128 (6 in the first version), 4 from B = 320.
 #pragma once
 #include "dib_common.h"
 #include "dib_gemm.h"   // dib_f32x16, DIB_MFMA
@@ -36,34 +38,72 @@
 #define DIB_INCE_KP 68          // LDS pitch of a k-contiguous operand tile (b128 fragment reads: conflict-free at BK + 4)
 #define DIB_INCE_CP 65          // LDS pitch of the coefficient tile (odd: conflict-free for row-wise and transposed stores)
 
-// S_ij from the dot product.  kind: 0 l2sq, 1 l2, 4 cosine.
-__device__ __forceinline__ float dib_ince_similarity(int kind, float ab, float na, float nb, float inv_t) {
+// ---- cross-lane helpers: DPP within a row of 16 lanes, ds_swizzle across the two rows of a 32-lane half ----
+template <int CTRL>
+__device__ __forceinline__ float dib_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dib_swz_xor16(float v) {   // lane ^ 16 (bit-mask mode: and 0x1f, or 0, xor 0x10)
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
+// reductions over the 32 lanes of a half-wave (all 32 get the result): quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+// (symmetric reductions: a mirror pairs what an xor would), then the other row of 16
+__device__ __forceinline__ float dib_half_max(float v) {
+  v = fmaxf(v, dib_dpp<0xB1>(v));
+  v = fmaxf(v, dib_dpp<0x4E>(v));
+  v = fmaxf(v, dib_dpp<0x141>(v));
+  v = fmaxf(v, dib_dpp<0x140>(v));
+  return fmaxf(v, dib_swz_xor16(v));
+}
+__device__ __forceinline__ float dib_half_sum(float v) {
+  v += dib_dpp<0xB1>(v);
+  v += dib_dpp<0x4E>(v);
+  v += dib_dpp<0x141>(v);
+  v += dib_dpp<0x140>(v);
+  return v + dib_swz_xor16(v);
+}
+__device__ __forceinline__ float dib_row16_sum(float v) {   // over the 16 lanes of a DPP row
+  v += dib_dpp<0xB1>(v);
+  v += dib_dpp<0x4E>(v);
+  v += dib_dpp<0x141>(v);
+  return v + dib_dpp<0x140>(v);
+}
+
+// S_ij from the dot product.  KIND: 0 l2sq, 1 l2, 4 cosine.
+template <int KIND>
+__device__ __forceinline__ float dib_ince_similarity(float ab, float na, float nb, float inv_t) {
   float s;
-  if (kind == 4) {
+  if (KIND == 4) {
     s = ab / (sqrtf(na) * sqrtf(nb));
   } else {  // utils.py:85-90: max(|a|^2 + |b|^2 - 2 a.b, 0)
     const float d2 = fmaxf(na + nb - 2.0f * ab, 0.f);
-    s = (kind == 0) ? -d2 : -sqrtf(d2 + 1e-9f);
+    s = (KIND == 0) ? -d2 : -sqrtf(d2 + 1e-9f);
   }
   return s * inv_t;
 }
 
 // grid (ceil(B/64) column tiles, ceil(B/64) row tiles), 256 threads.
 // prow: [2][nb32][B] (plane 0 max, plane 1 sum of exp(s - max)) over the 32-column block cb of row i;  pcol: same for columns.
+// norms [2B] (|x_i|^2, then |y_j|^2) is an OUTPUT: written by the first tile column / row, read by the gradient kernel.
+// arrive: the log-sum-exp kernel's arrival counter, reset here (this launch precedes it on the stream).
+template <int KIND>
 __global__ void __launch_bounds__(256)
-dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, int kind, float inv_t,
-                            const float* __restrict__ norms, float* __restrict__ S, float* __restrict__ prow,
-                            float* __restrict__ pcol, int nb32) {
+dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, float inv_t,
+                            float* __restrict__ norms, float* __restrict__ S, float* __restrict__ prow,
+                            float* __restrict__ pcol, int nb32, unsigned* __restrict__ arrive) {
   __shared__ __attribute__((aligned(16))) float Xs[DIB_INCE_TS * DIB_INCE_KP];
   __shared__ __attribute__((aligned(16))) float Ys[DIB_INCE_TS * DIB_INCE_KP];
+  __shared__ float Nx[DIB_INCE_TS], Ny[DIB_INCE_TS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int i0 = blockIdx.y * DIB_INCE_TS, j0 = blockIdx.x * DIB_INCE_TS;
+  if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) arrive[0] = 0u;
   const bool vec = (D & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)Y)) & 15) == 0;
   dib_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int lr = tid >> 4, lc = (tid & 15) * 4;     // this thread stages rows lr + 16 p, k columns lc .. lc + 3
+  float nx[4] = {0.f, 0.f, 0.f, 0.f}, ny[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < D; k0 += 64) {
     if (k0) __syncthreads();
 #pragma unroll
@@ -80,6 +120,8 @@ dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict
         if (vec && k + 3 < D) b = *reinterpret_cast<const float4*>(src);
         else { if (k < D) b.x = src[0]; if (k + 1 < D) b.y = src[1]; if (k + 2 < D) b.z = src[2]; if (k + 3 < D) b.w = src[3]; }
       }
+      nx[p] += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      ny[p] += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
       *reinterpret_cast<float4*>(Xs + r * DIB_INCE_KP + lc) = a;
       *reinterpret_cast<float4*>(Ys + r * DIB_INCE_KP + lc) = b;
     }
@@ -94,17 +136,28 @@ dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict
       acc = DIB_MFMA(a.w, b.w, acc);
     }
   }
+  // row norms of both tiles: the 16 threads that staged a row are the 16 lanes of one DPP row
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float sx = dib_row16_sum(nx[p]), sy = dib_row16_sum(ny[p]);
+    if ((tid & 15) == 0) { Nx[lr + 16 * p] = sx; Ny[lr + 16 * p] = sy; }
+  }
+  __syncthreads();
+  if (tid < DIB_INCE_TS) {
+    if (blockIdx.x == 0 && i0 + tid < B) norms[i0 + tid] = Nx[tid];
+    if (blockIdx.y == 0 && j0 + tid < B) norms[B + j0 + tid] = Ny[tid];
+  }
   // ---- epilogue: C/D map of the 32 x 32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
   const int j = j0 + wn * 32 + l31;
   const bool jok = j < B;
-  const float nb = norms[B + min(j, B - 1)];
+  const float nb = Ny[wn * 32 + l31];
   float s[16];
   float cmax = -INFINITY;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int il = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, i = i0 + il;
     const bool ok = jok && i < B;
-    const float v = dib_ince_similarity(kind, acc[r], norms[min(i, B - 1)], nb, inv_t);
+    const float v = dib_ince_similarity<KIND>(acc[r], Nx[il], nb, inv_t);
     if (ok) S[(long long)i * B + j] = v;
     s[r] = ok ? v : -INFINITY;
     cmax = fmaxf(cmax, s[r]);
@@ -113,22 +166,18 @@ dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict
   cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
   float csum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) csum += (s[r] == -INFINITY) ? 0.f : expf(s[r] - cmax);
+  for (int r = 0; r < 16; ++r) csum += (s[r] == -INFINITY) ? 0.f : __expf(s[r] - cmax);
   csum += __shfl_xor(csum, 32, 64);
   const int rb = (i0 + wm * 32) >> 5, cb = (j0 + wn * 32) >> 5;
   if (h == 0 && jok && rb < nb32) {
     pcol[(long long)rb * B + j] = cmax;
     pcol[(long long)(nb32 + rb) * B + j] = csum;
   }
-  // row partials: the 32 columns of a row live in the 32 lanes of one half-wave (xor shuffles below 32 stay inside it)
+  // row partials: the 32 columns of a row live in the 32 lanes of one half-wave
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    float m = s[r];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    float e = (s[r] == -INFINITY) ? 0.f : expf(s[r] - m);
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+    const float m = dib_half_max(s[r]);
+    const float e = dib_half_sum((s[r] == -INFINITY) ? 0.f : __expf(s[r] - m));
     const int i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
     if (l31 == 0 && i < B && cb < nb32) {
       prow[(long long)cb * B + i] = m;
@@ -137,45 +186,59 @@ dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict
   }
 }
 
-// lse[0][i] = LSE_j S[i][j], lse[1][j] = LSE_i S[i][j] from the 32-wide block partials (fixed order).  grid ceil(2B / 256).
+// lse[0][i] = LSE_j S[i][j], lse[1][j] = LSE_i S[i][j] from the 32-wide block partials (fixed order); the workgroup that
+// arrives last (all lse values are then in memory) computes loss = (1/B) sum_i (lse_r[i] + lse_c[i] - 2 S_ii).
+// grid ceil(2B / 256).
 __global__ void __launch_bounds__(256)
-dib_infonce_lse_combine_kernel(const float* __restrict__ prow, const float* __restrict__ pcol, int B, int nb32,
-                               float* __restrict__ lse) {
+dib_infonce_lse_loss_kernel(const float* __restrict__ prow, const float* __restrict__ pcol, const float* __restrict__ S, int B,
+                            int nb32, float* __restrict__ lse, unsigned* __restrict__ arrive, float* __restrict__ loss_out) {
+  __shared__ float red[4];
+  __shared__ bool last;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 2 * B) return;
-  const float* p = idx < B ? prow : pcol;
-  const int t = idx < B ? idx : idx - B;
-  float m = -INFINITY;
-  for (int b = 0; b < nb32; ++b) m = fmaxf(m, p[(long long)b * B + t]);
-  float sum = 0.f;
-  for (int b = 0; b < nb32; ++b) {
-    const float pm = p[(long long)b * B + t];
-    if (pm != -INFINITY) sum += p[(long long)(nb32 + b) * B + t] * expf(pm - m);
+  if (idx < 2 * B) {
+    const float* p = idx < B ? prow : pcol;
+    const int t = idx < B ? idx : idx - B;
+    float m = -INFINITY;
+    for (int b = 0; b < nb32; ++b) m = fmaxf(m, p[(long long)b * B + t]);
+    float sum = 0.f;
+    for (int b = 0; b < nb32; ++b) {
+      const float pm = p[(long long)b * B + t];
+      if (pm != -INFINITY) sum += p[(long long)(nb32 + b) * B + t] * expf(pm - m);
+    }
+    lse[idx] = m + logf(sum);
   }
-  lse[idx] = m + logf(sum);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(arrive, 1u) == gridDim.x - 1);
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B; i += 256)   // the other workgroups' lse values: bypass this CU's vector cache
+    s += __builtin_nontemporal_load(lse + i) + __builtin_nontemporal_load(lse + B + i) - 2.0f * S[(long long)i * B + i];
+  const float tot = dib_block_sum_256(s, red);
+  if (threadIdx.x == 0) loss_out[0] = tot / (float)B;
 }
 
 // grid (ceil(B/64) self blocks, nsplit partner slices, 2 sides), 256 threads, dynamic LDS (DIB_INCE_TS * (64 NACC + 4)) floats
 // for the partner tile.  side 0: self = x rows, partners = y rows, coefficient tile read along rows of S; side 1: self = y
 // rows, partners = x rows, the S tile is read along its rows (coalesced) and stored TRANSPOSED into the coefficient tile.
-// Gp [2][nsplit][B][D], Rp [2][nsplit][B].
-template <int NACC>
+// nsplit == 1: GX / GY written directly; else Gp [2][nsplit][B][D], Rp [2][nsplit][B] for dib_infonce_grad_final_kernel.
+template <int NACC, int KIND>
 __global__ void __launch_bounds__(256)
 dib_infonce_grad_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ S,
-                             const float* __restrict__ lse, const float* __restrict__ norms, int B, int D, int kind,
-                             float inv_t, float temperature, int nsplit, float* __restrict__ Gp, float* __restrict__ Rp) {
+                             const float* __restrict__ lse, const float* __restrict__ norms, int B, int D, float inv_t,
+                             float temperature, int nsplit, float* __restrict__ Gp, float* __restrict__ Rp,
+                             float* __restrict__ GX, float* __restrict__ GY) {
   constexpr int DP = 64 * NACC, OP = DP + 4;
   extern __shared__ __attribute__((aligned(16))) float Os[];   // [64 partners][OP]
   __shared__ float Cs[DIB_INCE_TS * DIB_INCE_CP];              // [64 self][65]
   __shared__ float Rs[4][64];
+  __shared__ float Rtot[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int side = blockIdx.z, split = blockIdx.y;
   const int s0 = blockIdx.x * DIB_INCE_TS;
-  const float* self_lse = lse + (side == 0 ? 0 : B);
-  const float* oth_lse = lse + (side == 0 ? B : 0);
-  const float* self_n = norms + (side == 0 ? 0 : B);
-  const float* oth_n = norms + (side == 0 ? B : 0);
   const float* Oth = side == 0 ? Y : X;
   const int ntiles = (B + DIB_INCE_TS - 1) / DIB_INCE_TS;
   const int tbeg = (int)(((long long)ntiles * split) / nsplit), tend = (int)(((long long)ntiles * (split + 1)) / nsplit);
@@ -207,6 +270,13 @@ dib_infonce_grad_mfma_kernel(const float* __restrict__ X, const float* __restric
     }
     // ---- S tile -> coefficients -> Cs[self][partner] ----
     const int rbase = side == 0 ? s0 : o0, cbase = side == 0 ? o0 : s0;   // S rows = x index, S columns = y index
+    float lse_j[4], rn_j[4];                                              // column (y) log-sum-exp, 1 / |y_j|
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gj = min(cbase + lc + c, B - 1);
+      lse_j[c] = lse[B + gj];
+      rn_j[c] = KIND == 4 ? rsqrtf(norms[B + gj]) : 1.f;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int tr = lr + 16 * p, gi = rbase + tr;       // x index
@@ -222,25 +292,23 @@ dib_infonce_grad_mfma_kernel(const float* __restrict__ X, const float* __restric
         }
       }
       const float svv[4] = {sv.x, sv.y, sv.z, sv.w};
-      const float lse_i = gi < B ? lse[gi] : 0.f;                         // row (x) log-sum-exp
-      const float n_i = (kind == 4 && gi < B) ? norms[gi] : 1.f;
+      const float lse_i = lse[min(gi, B - 1)];                            // row (x) log-sum-exp
+      const float rn_i = KIND == 4 ? rsqrtf(norms[min(gi, B - 1)]) : 1.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int tc = lc + c, gj = cbase + tc;      // y index
         float cf = 0.f, c2 = 0.f;
         if (gi < B && gj < B) {
           const float sij = svv[c];
-          const float w = (expf(sij - lse_i) + expf(sij - lse[B + gj]) - (gi == gj ? 2.0f : 0.f)) * sc;
-          if (kind == 0) cf = sij < 0.f ? -2.0f * w : 0.f;
-          else if (kind == 1) { const float rr = -sij * temperature; cf = (rr * rr > 1.0000005e-9f) ? -w / rr : 0.f; }
+          const float w = (__expf(sij - lse_i) + __expf(sij - lse_j[c]) - (gi == gj ? 2.0f : 0.f)) * sc;
+          if (KIND == 0) cf = sij < 0.f ? -2.0f * w : 0.f;
+          else if (KIND == 1) { const float rr = -sij * temperature; cf = (rr * rr > 1.0000005e-9f) ? -w * __builtin_amdgcn_rcpf(rr) : 0.f; }
           else {
-            const float n_j = norms[B + gj];
-            const float ri = rsqrtf(n_i), rj = rsqrtf(n_j);
-            cf = w * ri * rj;
-            c2 = w * (sij * temperature) * (side == 0 ? ri * ri : rj * rj);
+            cf = w * rn_i * rn_j[c];
+            c2 = w * (sij * temperature) * (side == 0 ? rn_i * rn_i : rn_j[c] * rn_j[c]);
           }
         }
-        const float rterm = kind == 4 ? c2 : cf;
+        const float rterm = KIND == 4 ? c2 : cf;
         if (side == 0) { Cs[tr * DIB_INCE_CP + tc] = cf; rs[p] += rterm; }
         else           { Cs[tc * DIB_INCE_CP + tr] = cf; rs[c] += rterm; }
       }
@@ -261,7 +329,44 @@ dib_infonce_grad_mfma_kernel(const float* __restrict__ X, const float* __restric
       }
     }
   }
-  // ---- partial outputs ----
+  // ---- row sums of the coefficients: R[self] ----
+  if (side == 0) {   // tile row lr + 16 p: the 16 threads of a row are the 16 lanes of one DPP row
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float v = dib_row16_sum(rs[p]);
+      if ((tid & 15) == 0) Rtot[lr + 16 * p] = v;
+    }
+    __syncthreads();
+  } else {           // self column lc + c: threads with equal tid & 15 - lanes 16 apart in a wave, then the 4 waves via LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = rs[c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) Rs[wave][lane * 4 + c] = v;
+    }
+    __syncthreads();
+    if (tid < 64) Rtot[tid] = Rs[0][tid] + Rs[1][tid] + Rs[2][tid] + Rs[3][tid];
+    __syncthreads();
+  }
+  // ---- outputs ----
+  if (nsplit == 1) {   // g = alpha self R + beta G
+    const float* Self = side == 0 ? X : Y;
+    float* Gout = side == 0 ? GX : GY;
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+      const int e = wn * 32 * NACC + n * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, i = s0 + il;
+        if (i < B && e < D) {
+          const float sr = Self[(long long)i * D + e] * Rtot[il];
+          Gout[(long long)i * D + e] = KIND == 4 ? (acc[n][r] - sr) : (sr - acc[n][r]);
+        }
+      }
+    }
+    return;
+  }
   float* G = Gp + ((long long)(side * nsplit + split) * B) * D;
 #pragma unroll
   for (int n = 0; n < NACC; ++n) {
@@ -272,26 +377,7 @@ dib_infonce_grad_mfma_kernel(const float* __restrict__ X, const float* __restric
       if (i < B && e < D) G[(long long)i * D + e] = acc[n][r];
     }
   }
-  float* R = Rp + (long long)(side * nsplit + split) * B;
-  if (side == 0) {   // tile row lr + 16 p: the 16 threads of a row are 16 consecutive lanes
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float v = rs[p];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if ((tid & 15) == 0 && s0 + lr + 16 * p < B) R[s0 + lr + 16 * p] = v;
-    }
-  } else {           // self column lc + c: threads with equal tid & 15 - lanes 16 apart in a wave, then the 4 waves via LDS
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float v = rs[c];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (lane < 16) Rs[wave][lane * 4 + c] = v;
-    }
-    __syncthreads();
-    if (tid < 64 && s0 + tid < B) R[s0 + tid] = Rs[0][tid] + Rs[1][tid] + Rs[2][tid] + Rs[3][tid];
-  }
+  if (tid < 64 && s0 + tid < B) Rp[(long long)(side * nsplit + split) * B + s0 + tid] = Rtot[tid];
 }
 
 // g = alpha self R + beta G with the slices summed in a fixed order.  One thread per (side, row, coordinate).

@@ -64,10 +64,12 @@ def beta_at_boundary(epoch_num: int, beta_start: float, beta_end: float, number_
 def run_loop(*, dataset_length: int, validation_set_length: int, batch_size: int, number_pretraining_epochs: int,
              number_annealing_epochs: int, beta_start: float, beta_end: float,
              train_step: Callable[[int], tuple], validation_step: Callable[[int, int], tuple],
-             assign_beta: Callable[[float], None]) -> Dict[str, np.ndarray]:
+             assign_beta: Callable[[float], None], on_boundary: Optional[Callable[[int], None]] = None) -> Dict[str, np.ndarray]:
     """The bookkeeping of train.py:222-279 around abstract step functions.
     train_step(step_num) -> (loss_infonce, kl) ; validation_step(epoch_num, batch_number) -> (loss_infonce, kl);
-    assign_beta(value) = model.beta.assign.  kl may be a scalar or a vector (mean is taken over axis 0, train.py:276-277)."""
+    assign_beta(value) = model.beta.assign.  kl may be a scalar or a vector (mean is taken over axis 0, train.py:276-277).
+    on_boundary(epoch_num) (not in the reference): called after an epoch's series entries are recorded - the trajectory tests
+    re-synchronise the checker's state with the device's there (tests/test_gpu_trajectories.py)."""
     number_epochs = number_pretraining_epochs + number_annealing_epochs
     steps_per_epoch = dataset_length / batch_size                                            # train.py:224
     number_full_validation_batches = validation_set_length // batch_size                     # train.py:231
@@ -92,6 +94,8 @@ def run_loop(*, dataset_length: int, validation_set_length: int, batch_size: int
             series["kl"].append(np.mean(run_k, axis=0))
             series["kl_validation"].append(np.mean(run_kv, axis=0))
             run_l, run_lv, run_k, run_kv = [], [], [], []
+            if on_boundary is not None:
+                on_boundary(epoch_num)
     out = {k: np.asarray(v) for k, v in series.items()}
     out["beta"] = np.float32(out["beta"])                                                    # train.py:272
     return out
@@ -143,6 +147,19 @@ class InfoNCELoopOracle:
     def assign_beta(self, value: float) -> None:
         self.beta = np.float32(value)                                                        # float32 tf.Variable
 
+    def load_state(self, params: Sequence[np.ndarray], m: Sequence[np.ndarray], v: Sequence[np.ndarray], t: int) -> None:
+        """Overwrite every variable, both Adam moments and the Adam step count (order of self.vars: X model tensors in
+        TorchCpuDIB.tensors() order, then the Y encoder's kernel / bias pairs)."""
+        assert len(params) == len(m) == len(v) == len(self.vars)
+        with torch.no_grad():
+            for dst, src in zip(self.vars, params):
+                dst.copy_(torch.as_tensor(np.asarray(src), dtype=self.dtype).reshape(dst.shape))
+            for dst, src in zip(self.m, m):
+                dst.copy_(torch.as_tensor(np.asarray(src), dtype=self.dtype).reshape(dst.shape))
+            for dst, src in zip(self.v, v):
+                dst.copy_(torch.as_tensor(np.asarray(src), dtype=self.dtype).reshape(dst.shape))
+        self.t = int(t)
+
     def _adam(self, grads, b1=0.9, b2=0.999, e=1e-7) -> None:
         self.t += 1
         lr_t = self.lr * math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
@@ -171,7 +188,8 @@ class InfoNCELoopOracle:
         return float(loss_infonce.detach()), kl.detach().numpy().copy()
 
     def fit(self, x_train, y_train, x_valid, y_valid, *, batch_size: int, number_pretraining_epochs: int,
-            number_annealing_epochs: int, beta_start: float, beta_end: float, seed: int = 0) -> Dict[str, np.ndarray]:
+            number_annealing_epochs: int, beta_start: float, beta_end: float, seed: int = 0,
+            on_boundary: Optional[Callable[[int], None]] = None) -> Dict[str, np.ndarray]:
         x_train, y_train, x_valid, y_valid = [np.asarray(a, dtype=np.float32).astype(np.float64)
                                               for a in (x_train, y_train, x_valid, y_valid)]
         stream, vstream = BatchStream(len(x_train), batch_size, seed), BatchStream(len(x_valid), batch_size, seed + 7)
@@ -181,7 +199,7 @@ class InfoNCELoopOracle:
             beta_start=beta_start, beta_end=beta_end,
             train_step=lambda step: self.eval_batch(x_train, y_train, stream.next(), step, True),
             validation_step=lambda ep, vb: self.eval_batch(x_valid, y_valid, vstream.next(), (1 << 31) + ep * 1024 + vb, False),
-            assign_beta=self.assign_beta)
+            assign_beta=self.assign_beta, on_boundary=on_boundary)
         out["kl_total"] = out["kl"].sum(-1)                                                  # the reference's [sum_f KL_f] series
         out["kl_total_validation"] = out["kl_validation"].sum(-1)
         return out
