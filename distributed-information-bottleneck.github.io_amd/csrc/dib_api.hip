@@ -254,6 +254,30 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 // larger count.  Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace
 // contract).
 static void pick_wgrad_splits(long long tiles, int K, int max_splits, int* ns_out, int* rps_out) {
+  // measurement override (tools/runs/r04d.sh): DIB_WGRAD_NS="tiles:ns,tiles:ns,..." forces the split count of the launches with
+  // that many output tiles
+  static const std::vector<std::pair<long long, int>> forced = [] {
+    std::vector<std::pair<long long, int>> v;
+    if (const char* e = std::getenv("DIB_WGRAD_NS")) {
+      const char* p = e;
+      while (*p) {
+        char* q;
+        const long long t = std::strtoll(p, &q, 10);
+        if (*q != ':') break;
+        const int n = (int)std::strtol(q + 1, &q, 10);
+        v.emplace_back(t, n);
+        p = *q == ',' ? q + 1 : q;
+      }
+    }
+    return v;
+  }();
+  for (const auto& f : forced)
+    if (f.first == tiles && f.second >= 1 && f.second <= max_splits) {
+      const int rps = cdiv(cdiv(K, f.second), 64) * 64;
+      *ns_out = cdiv(K, rps);
+      *rps_out = rps;
+      return;
+    }
   double best = 1e300;
   int bns = *ns_out, brps = *rps_out;
   for (int ns = 1; ns <= max_splits; ++ns) {
@@ -1182,7 +1206,7 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
                                             dim, inv_t, norms, S, prow, pcol, nb32, arrive)
     if (similarity == 0) DIB_INCE_SIM(0); else if (similarity == 1) DIB_INCE_SIM(1); else DIB_INCE_SIM(4);
 #undef DIB_INCE_SIM
-    hipLaunchKernelGGL(dib_infonce_lse_loss_kernel, dim3(cdiv(2 * batch, 256)), dim3(256), 0, st, (const float*)prow,
+    hipLaunchKernelGGL(dib_infonce_lse_loss_kernel, dim3(cdiv(2 * batch, 32)), dim3(256), 0, st, (const float*)prow,
                        (const float*)pcol, (const float*)S, batch, nb32, lse, arrive, loss_out);
     if (g_x && g_y) {
       const dim3 grid(t64, nsplit, 2);

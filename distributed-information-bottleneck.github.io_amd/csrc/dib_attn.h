@@ -120,9 +120,6 @@ __device__ __forceinline__ void dib_attn_store_rows(float* __restrict__ base, lo
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: grid (ceil(P / 128), H, B), 256 threads
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef DIB_ATTN_BWD_EXP_UNDER_MFMA
-#define DIB_ATTN_BWD_EXP_UNDER_MFMA 1
-#endif
 #ifndef DIB_ATTN_FWD_WAVES
 #define DIB_ATTN_FWD_WAVES 2   // measured (tools/attn_bench.py, 4 x 4096 x 12 heads, same box): 2 waves/SIMD (206 registers, no spills)
 #endif                         // 3.16-3.19 ms = 130 TFLOP/s = 0.83 of peak; 3 waves/SIMD (168 registers, 36 spilled) 3.78-3.80 ms.
@@ -294,14 +291,11 @@ __device__ long long dib_attn_dbg[16];
 #define DIB_T(i) do { } while (0)
 #endif
 constexpr int kAttnPatch = 32 * 36;
-// DIB_ATTN_DQ_ROWSTORE = 1: a wave turns its dQ^T accumulators (lane = query, registers = d) through a private 32 x 36 LDS patch
+// dQ partial stores: a wave turns its dQ^T accumulators (lane = query, registers = d) through a private 32 x 36 LDS patch
 // into row-major pieces, so that ONE store instruction writes whole 128-byte lines (8 lanes per query row) instead of 32-byte
 // pieces of 32 rows: the non-temporal partial stores are then full-line writes (WRITE_SIZE of the launch 6.7 -> 3.4 GB)
-#ifndef DIB_ATTN_DQ_ROWSTORE
-#define DIB_ATTN_DQ_ROWSTORE 1
-#endif
 constexpr int DibAttnBwdLds = 2 * kAttnTile * kAttnPitch + 128 * kAttnPitch + 4 * kAttnPatch + 2 * kAttnTile +
-                              (DIB_ATTN_DQ_ROWSTORE ? 4 * kAttnPatch : 0);
+                              4 * kAttnPatch;
 
 template <bool STASH>   // STASH: scores read back from the forward's stash (4 tile products); else S recomputed (5)
 __global__ void __launch_bounds__(256, 1)
@@ -314,9 +308,7 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
   float* Ls = patches + 4 * kAttnPatch;              // lse / delta of the tile's queries
   float* Ds = Ls + kAttnTile;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-#if DIB_ATTN_DQ_ROWSTORE
   float* my_dqs = Ds + kAttnTile + wave * kAttnPatch;   // this wave's [32 queries][36] transposition patch (nobody else touches it)
-#endif
   const int head = blockIdx.y, b = blockIdx.z, P = a.P;
   const long long tok0 = (long long)b * P;
   const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
@@ -475,7 +467,6 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) qv[dt] = dib_attn_mc(Qs, 0, 32 * dt + l31, h);
     __builtin_amdgcn_sched_barrier(0);
-#if DIB_ATTN_BWD_EXP_UNDER_MFMA
     // P and dS of query group g (register r = 4g + t <-> query qt*32 + t + 8g + 4h; lane <-> key).  Group 0 is computed here,
     // group g + 1 inside the dV step of group g - VALU in the shadow of 16 MFMAs instead of 64 exposed exponentials per tile.
     // The accumulators are made opaque at the top of every step (or the exponentials would be hoisted back up here) and the
@@ -545,68 +536,6 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
         for (int dt = 0; dt < 4; ++dt) { gv[dt] = gvn[dt]; qv[dt] = qvn[dt]; }
       }
     }
-#else
-    // register r <-> query qt*32 + (r&3) + 8(r>>2) + 4h ; lane <-> key
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float lv[4] = {lq[g].x, lq[g].y, lq[g].z, lq[g].w};
-      const float dl[4] = {dq4[g].x, dq4[g].y, dq4[g].z, dq4[g].w};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = 4 * g + t;
-        const float p = __expf(sv[r] - lv[t]) * kmul;
-        dp[r] = p * (dp[r] - dl[t]);                   // dS
-        sv[r] = p;                                     // P
-      }
-    }
-    // dS^T into this wave's patch: patch[query][key]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) my_patch[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = dp[r];
-    DIB_T(2);   // exponentials, dS, patch store
-    // dV^T += dO^T P, dK^T += Q^T dS.  Consecutive MFMAs go to DIFFERENT accumulators (dependent distance 4): a filler
-    // instruction between two MFMAs on the same accumulator costs ~43 cycles, between independent ones only its issue slot
-    // (MI355X_MICROARCH.md); the fragments of the next 8 queries are fetched under the current products
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float4 gvn[4], qvn[4];
-      if (q < 3) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) gvn[dt] = dib_attn_mc(Gs, q + 1, 32 * dt + l31, h);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].x, sv[4 * q + 0], dv[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].y, sv[4 * q + 1], dv[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].z, sv[4 * q + 2], dv[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dv[dt] = DIB_MFMA(gv[dt].w, sv[4 * q + 3], dv[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) DIB_PIN_ACC_A(dv[dt]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (q < 3) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) qvn[dt] = dib_attn_mc(Qs, q + 1, 32 * dt + l31, h);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].x, dp[4 * q + 0], dk[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].y, dp[4 * q + 1], dk[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].z, dp[4 * q + 2], dk[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dk[dt] = DIB_MFMA(qv[dt].w, dp[4 * q + 3], dk[dt]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) DIB_PIN_ACC_A(dk[dt]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (q < 3) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { gv[dt] = gvn[dt]; qv[dt] = qvn[dt]; }
-      }
-    }
-#endif
     DIB_T(3);   // dV / dK products issued
     // first K fragments of the dQ product: the K block is static, so they can be in flight across the barrier
     const float4 ka0 = dib_attn_mc(Kblk, 0, 32 * wave + l31, h), kb0 = dib_attn_mc(Kblk, 1, 32 * wave + l31, h);
@@ -659,7 +588,6 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
       // dq[r] = dQ^T[d = 32*wave + (r&3) + 8(r>>2) + 4h][query l31]
       // non-temporal: the 3.4 GB of partials are read once, by the reduce kernel, after the whole launch (same-box A/B:
       // backward 7.73 -> 7.66 ms, profiles/r03u_attention_dq_partial_nt_ab.txt)
-#if DIB_ATTN_DQ_ROWSTORE
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(my_dqs + l31 * 36 + 8 * g + 4 * h) =
@@ -681,16 +609,6 @@ dib_attn_bwd_kernel(DibAttnArgs a, float* __restrict__ dq_part, int n_key_blocks
             __builtin_nontemporal_store(dib_nt4a{rv[j].x, rv[j].y, rv[j].z, rv[j].w}, reinterpret_cast<dib_nt4a*>(dst + 8 * j * dq_ld));
       }
       __builtin_amdgcn_wave_barrier();
-#else
-      const int qrow = qt * kAttnTile + l31;
-      if (qrow < P) {
-        float* dst = dq_out + (long long)qrow * dq_ld + 32 * wave + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          __builtin_nontemporal_store(dib_nt4a{dq[4 * g] * dq_mul, dq[4 * g + 1] * dq_mul, dq[4 * g + 2] * dq_mul, dq[4 * g + 3] * dq_mul},
-                                      reinterpret_cast<dib_nt4a*>(dst + 8 * g));
-      }
-#endif
     }
     DIB_T(5);   // next-tile loads issued, dQ product, dQ store
     DIB_ATTN_STAGE_TILE();

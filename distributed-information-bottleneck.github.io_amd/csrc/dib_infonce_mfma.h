@@ -186,26 +186,44 @@ dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict
   }
 }
 
-// lse[0][i] = LSE_j S[i][j], lse[1][j] = LSE_i S[i][j] from the 32-wide block partials (fixed order); the workgroup that
-// arrives last (all lse values are then in memory) computes loss = (1/B) sum_i (lse_r[i] + lse_c[i] - 2 S_ii).
-// grid ceil(2B / 256).
+// lse[0][i] = LSE_j S[i][j], lse[1][j] = LSE_i S[i][j] from the 32-wide block partials; the workgroup that arrives last (all
+// lse values are then in memory) computes loss = (1/B) sum_i (lse_r[i] + lse_c[i] - 2 S_ii).
+// grid ceil(2B / 32): a workgroup owns 32 rows (or columns), thread (row = tid & 31, part = tid >> 5) merges every 8th block
+// partial online - (m, s) <- (max(m, pm), s e^(m - m') + ps e^(pm - m')) - and the 8 parts of a row are merged in a fixed
+// order through LDS.  (One thread per row walking all 2 x 64 partials of B = 2048 in two dependent passes took 47 us on 16
+// workgroups - 40 % of the whole InfoNCE sequence, profiles/r04c_infonce_kernel_stats.csv.)
 __global__ void __launch_bounds__(256)
 dib_infonce_lse_loss_kernel(const float* __restrict__ prow, const float* __restrict__ pcol, const float* __restrict__ S, int B,
                             int nb32, float* __restrict__ lse, unsigned* __restrict__ arrive, float* __restrict__ loss_out) {
+  __shared__ float pm_s[8][32], ps_s[8][32];
   __shared__ float red[4];
   __shared__ bool last;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx < 2 * B) {
-    const float* p = idx < B ? prow : pcol;
-    const int t = idx < B ? idx : idx - B;
-    float m = -INFINITY;
-    for (int b = 0; b < nb32; ++b) m = fmaxf(m, p[(long long)b * B + t]);
-    float sum = 0.f;
-    for (int b = 0; b < nb32; ++b) {
-      const float pm = p[(long long)b * B + t];
-      if (pm != -INFINITY) sum += p[(long long)(nb32 + b) * B + t] * expf(pm - m);
+  const int r = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + r;                      // [0, B): rows, [B, 2B): columns (B is NOT assumed a multiple of 32:
+  const bool ok = idx < 2 * B;                              //  a workgroup may straddle the two, idx decides per thread)
+  const float* p = idx < B ? prow : pcol;
+  const int t = idx < B ? idx : idx - B;
+  float m = -INFINITY, sum = 0.f;
+  if (ok) {
+    for (int b = part; b < nb32; b += 8) {
+      const float pm = p[(long long)b * B + t], ps = p[(long long)(nb32 + b) * B + t];
+      if (pm == -INFINITY) continue;
+      const float mn = fmaxf(m, pm);
+      sum = sum * expf(m - mn) + ps * expf(pm - mn);        // m = -inf on the first hit: sum = 0 * 0 + ...
+      m = mn;
     }
-    lse[idx] = m + logf(sum);
+  }
+  pm_s[part][r] = m;
+  ps_s[part][r] = sum;
+  __syncthreads();
+  if (part == 0 && ok) {
+    float mm = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mm = fmaxf(mm, pm_s[q][r]);
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tot += pm_s[q][r] == -INFINITY ? 0.f : ps_s[q][r] * expf(pm_s[q][r] - mm);
+    lse[idx] = mm + logf(tot);
   }
   __threadfence();
   __syncthreads();

@@ -145,7 +145,6 @@ class DistributedIBNet:
         self.noise_seed, self.init_seed, self.shuffle_seed = int(noise_seed), int(init_seed), int(shuffle_seed)
         self._device = device
         self._engine = None
-        self._engine_factory = None  # tests inject a checker engine here; the product default is HipEngine
         # data-parallel gradient all-reduce buckets (fit under torch.distributed): 3 = integration / encoder front layers /
         # last encoder layer, each issued as soon as it is final (default); 2 = integration / encoder bank; 1 = one all-reduce
         self.dp_buckets = int(os.environ.get("DIB_DP_BUCKETS", "3"))
@@ -174,13 +173,14 @@ class DistributedIBNet:
                     feature_embedding_dimension=self.feature_embedding_dimension,
                     output_activation_fn=self.output_activation_fn)
 
+    def _make_engine(self):
+        """The device engine of this model: HipEngine, which raises without a GPU or libdib_hip.so - there is no CPU path."""
+        from .engine import HipEngine
+        return HipEngine(**self._spec_kwargs(), device=self._device, init_seed=self.init_seed)
+
     def _ensure_engine(self):
         if self._engine is None:
-            if self._engine_factory is not None:
-                self._engine = self._engine_factory(**self._spec_kwargs(), init_seed=self.init_seed)
-            else:
-                from .engine import HipEngine  # raises without a GPU / libdib_hip.so: no CPU fallback
-                self._engine = HipEngine(**self._spec_kwargs(), device=self._device, init_seed=self.init_seed)
+            self._engine = self._make_engine()
             self._engine.set_beta(float(self.beta.value()))
             if self._pending_weights is not None:
                 self._engine.set_flat_params(self._pending_weights)

@@ -89,12 +89,8 @@ class SetTransformerDIB:
                  ff_arch_per_block: Sequence[int] = (128, 32), final_processing_arch: Sequence[int] = (256,),
                  output_dimensionality: int = 1, logvar_initialization: float = -3.0, layer_norm_epsilon: float = 1e-3,
                  *, init_seed: int = 0, noise_seed: int = 0, device: Optional[str] = None, attention: str = "auto",
-                 attention_score_stash_bytes: int = 64 << 30, use_graphs: Optional[bool] = None, _checker_backend=None):
-        """_checker_backend: TEST SEAM (like DistributedIBNet._engine_factory): the CPU tests of the host logic - train_step's
-        data-parallel protocol, fit's schedules - inject an object that implements forward / loss_and_backward / _loss_only /
-        adam_step on the float64 CPU checker (tests/_oracle_set_transformer.py).  The product never sets it: without it the
-        constructor demands a GPU and the HIP library.
-        use_graphs: replay the whole training step (copy-in, ~190 launches, Adam, noise-step bump) as one captured hipGraph
+                 attention_score_stash_bytes: int = 64 << 30, use_graphs: Optional[bool] = None):
+        """use_graphs: replay the whole training step (copy-in, ~190 launches, Adam, noise-step bump) as one captured hipGraph
         per (batch, particles) shape - the notebook's own configuration, 32 neighbourhoods x 50 particles, is bound by launch
         and dependency latency, not by arithmetic.  Default: the DIB_ENABLE_GRAPHS=1 opt-in shared with DistributedIBNet.fit.
         Single-process only (the data-parallel step has collectives between its launches).
@@ -106,14 +102,7 @@ class SetTransformerDIB:
         flash - since the round-2 rewrite of the attention kernels it is the faster path at every measured shape (ms/step flash
         vs gemm: 32 x 50: 3.08 / 4.14, 4 x 512: 4.29 / 4.88, 2 x 2048: 15.0 / 15.7, 4 x 4096: 77.2 / 100.5;
         profiles/r02am_set_transformer_bench.txt, r02final2_set_transformer_bench.txt) and it needs no [P, P] stash in HBM; key_dim != 128: gemm."""
-        self._checker = _checker_backend
-        if self._checker is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
-            self.lib = _lib.load_library()
-            self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
-        else:
-            self.lib, self.device = None, torch.device("cpu")
+        self._acquire_device(device)
         self.particle_feature_dimensions = int(particle_feature_dimensions)
         self.number_positional_encoding_frequencies = int(number_positional_encoding_frequencies)
         self.particle_encoder_arch_spec = [int(u) for u in particle_encoder_arch_spec]
@@ -147,7 +136,7 @@ class SetTransformerDIB:
             o = _align4(o + int(np.prod(shp)))
         self.n_alloc = o
         self.n_params = int(sum(int(np.prod(s)) for s in self.shapes.values()))
-        fdt = torch.float32 if self._checker is None else torch.float64   # the CPU checker keeps its state in float64
+        fdt = self.state_dtype
         z = lambda n, dt=fdt: torch.zeros(n, dtype=dt, device=self.device)
         self.params, self.grads, self.adam_m, self.adam_v = z(o), z(o), z(o), z(o)
         self.beta_dev = torch.ones(1, dtype=fdt, device=self.device)
@@ -162,6 +151,17 @@ class SetTransformerDIB:
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # noise step of graph replays (uint32 bits)
         self._step = 0
         self.last = {}
+
+    state_dtype = torch.float32   # parameters, gradients and Adam moments live on the device in the reference's own precision
+
+    def _acquire_device(self, device: Optional[str]) -> None:
+        """The GPU and the HIP library: there is no CPU path.  (The device steps - forward, loss_and_backward, _loss_only,
+        adam_step - and this method are what tests/_oracle_set_transformer.py overrides in a subclass to run the HOST logic of
+        train_step / fit on the float64 checker.)"""
+        if not torch.cuda.is_available():
+            raise RuntimeError("SetTransformerDIB needs an AMD GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.lib = _lib.load_library()
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
 
     # ---- parameters ---------------------------------------------------------------------------------------------
     def param_shapes(self) -> Dict[str, tuple]:
@@ -540,8 +540,6 @@ class SetTransformerDIB:
         sample (treated as mu + sigma * eps with its implied eps held fixed: the reparameterised gradient of that sample), or
         the deterministic forward (x0 = mu: the term vanishes).  (Round 2 regenerated the library's eps in the backward, which
         was silently wrong for the last two - advisor finding.)"""
-        if self._checker is not None:
-            return self._checker.forward(self, batch_inp, step, deterministic, row0, embs_reparam)
         x = batch_inp if isinstance(batch_inp, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(batch_inp, dtype=np.float32))
         x = x.to(device=self.device, dtype=torch.float32).contiguous()
         B, P, F0 = x.shape
@@ -605,8 +603,6 @@ class SetTransformerDIB:
     def loss_and_backward(self, is_loci, inv_global_batch: Optional[float] = None) -> None:
         """bce_losses = mean BCE(is_loci, logits); loss = bce_losses + beta_var * kl; tape.gradient(loss, variables).
         Gradients land in self.grads; self.last gets bce (device scalar)."""
-        if self._checker is not None:
-            return self._checker.loss_and_backward(self, is_loci, inv_global_batch)
         pl = self.last["plan"]
         B, P, T = self.last["B"], self.last["P"], pl["T"]
         lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
@@ -690,8 +686,6 @@ class SetTransformerDIB:
         self.last["correct"] = out3[1:2]
 
     def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7) -> None:
-        if self._checker is not None:
-            return self._checker.adam_step(self, beta_1, beta_2, epsilon)
         check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v), self.n_alloc,
                                      _ptr(self.lr_dev), _ptr(self.t_dev), beta_1, beta_2, epsilon, 1.0, self._stream()),
               "dib_adam_step")
@@ -705,7 +699,7 @@ class SetTransformerDIB:
         buffer is all-reduced (RCCL over xGMI with the nccl backend), every rank applies the same Adam update."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DP_BRANCH):
-            if training and self.use_graphs and self._checker is None:
+            if training and self.use_graphs:
                 return self._train_step_graph(batch_inp, is_loci)
             self.forward(batch_inp, for_backward=training)
             self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
@@ -790,8 +784,6 @@ class SetTransformerDIB:
         return self.last["bce"]
 
     def _loss_only(self, is_loci, inv_global_batch: Optional[float] = None):
-        if self._checker is not None:
-            return self._checker.loss_only(self, is_loci, inv_global_batch)
         pl = self.last["plan"]
         B = self.last["B"]
         inv = 1.0 / B if inv_global_batch is None else float(inv_global_batch)

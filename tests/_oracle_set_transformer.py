@@ -1,7 +1,8 @@
-"""TEST-ONLY backend for dib_amd.SetTransformerDIB (its `_checker_backend` seam): forward / backward / Adam on the float64
-CPU oracle (oracle/set_transformer_oracle.py), so the product's HOST logic - train_step's data-parallel protocol (neighbourhood
-sharding, global-token noise keys, inv_global_batch, gradient + statistics all-reduce), fit's schedules - runs without a GPU.
-Lives in tests/; the product package never imports it."""
+"""TEST-ONLY subclass of dib_amd.SetTransformerDIB whose device steps - forward / loss_and_backward / _loss_only / adam_step -
+run on the float64 CPU oracle (oracle/set_transformer_oracle.py), so the product's HOST logic - train_step's data-parallel
+protocol (neighbourhood sharding, global-token noise keys, inv_global_batch, gradient + statistics all-reduce), fit's
+schedules - runs without a GPU.  Lives in tests/; the product package never imports it and has no hook for it: the
+subclass overrides the five methods the product class itself defines."""
 import numpy as np
 import torch
 
@@ -10,6 +11,8 @@ import set_transformer_oracle as sto
 
 
 class OracleSetTransformerBackend:
+    """the five device steps on the oracle; `m` is the model object whose flat buffers they read and write"""
+
     def __init__(self, spec: sto.SetTransformerSpec):
         self.spec = spec
 
@@ -76,8 +79,30 @@ class OracleSetTransformerBackend:
 
 def make_model(spec: sto.SetTransformerSpec, **kw):
     import dib_amd
-    return dib_amd.SetTransformerDIB(spec.particle_feature_dimensions, spec.number_positional_encoding_frequencies,
-                                     spec.particle_encoder_arch_spec, spec.bottleneck_dimension, spec.key_dim,
-                                     spec.number_heads_per_mha, spec.number_attention_blocks, spec.ff_arch_per_block,
-                                     spec.final_processing_arch, spec.output_dimensionality, spec.logvar_initialization,
-                                     spec.layer_norm_epsilon, _checker_backend=OracleSetTransformerBackend(spec), **kw)
+    backend = OracleSetTransformerBackend(spec)
+
+    class OracleSetTransformerDIB(dib_amd.SetTransformerDIB):
+        state_dtype = torch.float64   # the CPU checker keeps its state in float64
+
+        def _acquire_device(self, device):
+            self.lib, self.device = None, torch.device("cpu")
+
+        def forward(self, batch_inp, step=None, deterministic=False, row0=0, embs_reparam=None, _step_from_device=False,
+                    for_backward=True):
+            return backend.forward(self, batch_inp, step, deterministic, row0, embs_reparam)
+
+        def loss_and_backward(self, is_loci, inv_global_batch=None):
+            return backend.loss_and_backward(self, is_loci, inv_global_batch)
+
+        def _loss_only(self, is_loci, inv_global_batch=None):
+            return backend.loss_only(self, is_loci, inv_global_batch)
+
+        def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+            return backend.adam_step(self, beta_1, beta_2, epsilon)
+
+    kw.setdefault("use_graphs", False)
+    return OracleSetTransformerDIB(spec.particle_feature_dimensions, spec.number_positional_encoding_frequencies,
+                                   spec.particle_encoder_arch_spec, spec.bottleneck_dimension, spec.key_dim,
+                                   spec.number_heads_per_mha, spec.number_attention_blocks, spec.ff_arch_per_block,
+                                   spec.final_processing_arch, spec.output_dimensionality, spec.logvar_initialization,
+                                   spec.layer_norm_epsilon, **kw)

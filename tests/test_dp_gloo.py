@@ -40,7 +40,7 @@ def _run(rank, world, port, out_dir, n_rows=80, buckets=3):
     y = np.tile(y, 5).astype(np.float32)
     x, y = x[:n_rows], y[:n_rows]
     model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=1, shuffle_seed=2, init_seed=3)
-    model._engine_factory = OracleEngine
+    model._make_engine = lambda: OracleEngine(**model._spec_kwargs(), init_seed=model.init_seed)
     model.dp_buckets = buckets
     opt = dib_amd.optimizers.get("adam")
     opt.learning_rate = 5e-3

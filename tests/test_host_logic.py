@@ -13,7 +13,7 @@ from _oracle_engine import OracleEngine
 def _model(spec, **kw):
     import dib_amd
     m = dib_amd.DistributedIBNet(**spec_kwargs(spec), **kw)
-    m._engine_factory = OracleEngine
+    m._make_engine = lambda: OracleEngine(**m._spec_kwargs(), init_seed=m.init_seed)
     return m
 
 
@@ -319,13 +319,9 @@ def test_train_script_end_to_end_on_the_checker_engine(monkeypatch, tmp_path):
     path without a GPU (the same call runs on the device in tests/test_gpu_parity.py)."""
     import dib_amd
     from dib_amd import models, train
-    orig_init = models.DistributedIBNet.__init__
 
-    def init_with_checker_engine(self, *a, **k):
-        orig_init(self, *a, **k)
-        self._engine_factory = OracleEngine
-
-    monkeypatch.setattr(models.DistributedIBNet, "__init__", init_with_checker_engine)
+    monkeypatch.setattr(models.DistributedIBNet, "_make_engine",
+                        lambda self: OracleEngine(**self._spec_kwargs(), init_seed=self.init_seed))
     hist = train.main(["--dataset", "boolean_circuit", "--number_pretraining_epochs", "1", "--number_annealing_epochs", "2",
                        "--batch_size", "256", "--artifact_outdir", str(tmp_path), "--save_compression_matrices_frequency", "2",
                        "--feature_encoder_architecture", "8", "8", "--integration_network_architecture", "16",

@@ -3,7 +3,7 @@
 #   bash tools/build_variant.sh TAG [-DFLAG=VALUE ...]      ->  exp/lib_TAG.so   (git-ignored, travels with gpurun)
 # then on the box:  bash tools/ab_bench.sh BASE TAG   (tools/ab_bench.sh swaps each variant in as the product library).
 # Compile-time knobs that exist today (csrc/dib_fused.h, csrc/dib_attn.h, csrc/dib_api.hip): DIB_H1_MASK, DIB_DW1_B64,
-# DIB_ATTN_FWD_WAVES, DIB_ATTN_BWD_EXP_UNDER_MFMA, DIB_BK11, DIB_BK212, DIB_SPLIT_ROWS;
+# DIB_ATTN_FWD_WAVES, DIB_BK11, DIB_BK212, DIB_SPLIT_ROWS;
 # diagnostic builds: DIB_FUSED_TIMING (tools/fused_phase_timing.py), DIB_ATTN_TIMING (tools/attn_phase_timing.py).
 set -e
 TAG=$1; shift
