@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 LIB_OVERRIDE = os.environ.get("DIB_LIB_PATH") or None
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
 INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
-SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h", "dib_attn.h",
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h", "dib_attn.h", "dib_attn_small.h", "dib_infonce_mfma.h",
            INCLUDE_ST]
 
 # error codes (include/dib_hip.h)

@@ -16,6 +16,7 @@
 #include "dib_gemm_bf16x6.h"
 #include "dib_st.h"
 #include "dib_attn.h"
+#include "dib_attn_small.h"
 #include "../../include/dib_st.h"
 
 namespace {
@@ -189,8 +190,8 @@ struct Knobs {
   int stream_rows = 8192;    // GEMMs with at least this many streamed rows load / store them non-temporally (1 << 30: never)
   int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
   int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
-  int split_policy = 1;      // weight gradients of the layout: 1 = pick the batch-split count per launch so that every CU gets
-                             // the same number of workgroups (pick_wgrad_splits); 0 = the layout-wide count
+  int split_policy = 1;      // weight gradients of the layout: 1 = pick the batch-split count per launch so that the workgroups
+                             // fill whole rounds of the chip's workgroup slots (pick_wgrad_splits); 0 = the layout-wide count
   int split_overhead = 128;  // ... with this per-workgroup fixed cost, in batch rows (prologue + partial-tile store)
   int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
                              // OFF: measured slower (same box, B = 65536: 8.44-8.50 vs 8.37 ms; B = 8192: 1.345 vs 1.313 ms) -
@@ -240,20 +241,20 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 }
 
 
-// Batch-split count of one weight-gradient launch: `tiles` output tiles (all groups) x ns splits of rps batch rows.
-// Cost model (measured, profiles/r04b_split_policy_ab.txt): what a CU has to execute is SERIAL on its matrix pipe whether its
-// workgroups are co-resident or not - two workgroups sharing a CU each run at half speed, a lone one at full speed - so the
-// launch takes ~ max over CUs of the rows assigned = ceil(tiles ns / 256) x (rps + fixed cost per workgroup).  (A model in
-// whole "rounds" of all co-resident slots predicted -18 % for F = 50 and got -6 %: a partial round costs its share, not a
-// full one.)  The layout-wide rule - 32 splits of 2048 rows at B = 65536 - is exact for F = 64 (64 tiles x 32 = 8 per CU) and
-// off for F = 50: 1600 workgroups = 6.25 per CU, i.e. 7 on some (12 % over the even share), and the narrow last-layer
-// gradient with its splits halved put 800 workgroups on 256 CUs (4 x 4096 rows where 3.125 x 4096 would do).  BASELINE
-// config 4: encoder wgrads 0.55-0.61 of the fp32-MFMA peak against 0.70-0.72 for config 3 (profiles/r04a_config4_*).
-// Candidates: 1 .. max_splits splits of a multiple of 64 rows (whole K-tiles), at least DIB_SPLIT_ROWS rows; fewer than two
-// workgroups per CU cost 5 % (nothing to overlap a workgroup's prologue with); the cheapest wins, ties within 1 % go to the
-// larger count.  Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace
-// contract).
-static void pick_wgrad_splits(long long tiles, int K, int max_splits, int* ns_out, int* rps_out) {
+// Batch-split count of one weight-gradient launch: `tiles` output tiles (all groups) x ns splits of rps batch rows on `slots`
+// co-resident workgroup slots (256 CUs x workgroups per CU of the tile shape).  Equal-length workgroups execute in
+// ceil(tiles ns / slots) rounds, so the launch takes ~ rounds x (rps + a fixed cost per workgroup).  The layout-wide rule - 32
+// splits of 2048 rows at B = 65536 - is exact for F = 64 (64 tiles x 32 = 4.0 rounds of 512) and off for F = 50: 1600
+// workgroups = 3.1 rounds, the fourth 1/8 full; the narrow last-layer gradient (4 workgroups per CU) with its splits halved
+// ran 800 workgroups of 4096 rows where 1000 of 3328 fit one round.  BASELINE config 4: encoder wgrads at 0.55-0.61 of the
+// fp32-MFMA peak against 0.70-0.72 for config 3 (profiles/r04a_config4_*).  Candidates: 1 .. max_splits splits of a multiple of
+// 64 rows (whole K-tiles), at least DIB_SPLIT_ROWS rows; the cheapest wins, ties go to FEWER, longer workgroups.
+// Measured (F = 50, B = 65536, ms/step with one launch's count forced, profiles/r04d_split_sweep_F50.txt): encoder layers 2+3,
+// 50 tiles: 32 splits 6.80, 30: 6.78, 28: 6.87, 25: 6.74, 20: 6.68 (2 full rounds), 16: 6.99, 10: 6.71 (1 round);
+// integration layer 1, 26 tiles: 32: 6.80, 29: 6.73, 24: 6.83, 19: 6.66 (1 round), 16: 6.82, 13: 7.01.  (A second model, "what
+// a CU executes is serial: ceil(tiles ns / 256) x rps", picked 25 and 29 there and measured no gain: r04c.)
+// Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace contract).
+static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits, int* ns_out, int* rps_out) {
   // measurement override (tools/runs/r04d.sh): DIB_WGRAD_NS="tiles:ns,tiles:ns,..." forces the split count of the launches with
   // that many output tiles
   static const std::vector<std::pair<long long, int>> forced = [] {
@@ -284,11 +285,10 @@ static void pick_wgrad_splits(long long tiles, int K, int max_splits, int* ns_ou
     const int rps = cdiv(cdiv(K, ns), 64) * 64;
     if (ns > 1 && rps < DIB_SPLIT_ROWS) break;
     if (cdiv(K, rps) != ns) continue;   // the same split as a smaller ns
-    const long long per_cu = (tiles * ns + 255) / 256;
-    double cost = (double)per_cu * (rps + knobs().split_overhead);
-    if (tiles * ns < 512) cost *= 1.05;
-    if (cost <= best * 1.01) {
-      if (cost < best) best = cost;
+    const long long rounds = (tiles * ns + slots - 1) / slots;
+    const double cost = (double)rounds * (rps + knobs().split_overhead);
+    if (cost < best) {
+      best = cost;
       bns = ns;
       brps = rps;
     }
@@ -322,8 +322,10 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
   }
   if (const int ft = knobs().force_tile[MODE]) { ni1 = ft / 10 == 1; nj1 = (ft % 10 == 1) || N <= 64; }
   if (MODE == 2 && auto_split && nsplit > 1 && knobs().split_policy) {
+    // co-resident workgroups per CU of each tile shape (LDS / register budget of dib_gemm_kernel<2, NI, NJ, BK>)
+    const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
     const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
-    pick_wgrad_splits(tiles, batch, nsplit, &nsplit, &rows_per_split);
+    pick_wgrad_splits(tiles, 256 * per_cu, batch, nsplit, &nsplit, &rows_per_split);
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
@@ -1492,6 +1494,7 @@ int dib_add_inplace(float* dst, const float* src, int64_t n, dib_stream_t stream
 
 int64_t dib_attention_stash_bytes(int B, int P, int H) {
   if (B <= 0 || P <= 0 || H <= 0) return DIB_E_ARG;
+  if (P <= kAttnSmallP) return 0;   // the single-workgroup path keeps the scores in LDS: nothing to stash
   const int64_t nt = cdiv(P, kAttnTile);
   return (int64_t)sizeof(float) * B * H * nt * nt * kAttnTile * kAttnTile;
 }
@@ -1504,6 +1507,16 @@ int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int
   DibAttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.s_stash = s_stash; a.P = P; a.H = H; a.ld = ld; a.scale = scale;
   ProfScope ps(kProfAttnFwd, (hipStream_t)stream);
+  if (P <= kAttnSmallP) {   // the whole head in LDS, one workgroup per (neighbourhood, head): csrc/dib_attn_small.h (no stash)
+    const size_t lds = (size_t)DibAttnSmallFwdLds * sizeof(float);
+    static bool attr_small[64] = {};
+    if (dib_attr_needed(attr_small)) {
+      hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(dib_attn_small_fwd_kernel, dim3(H, B), dim3(256), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
@@ -1525,6 +1538,20 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
         (uintptr_t)ws | (uintptr_t)s_stash) & 15) != 0)
     return DIB_E_ARG;   // every one of them is accessed with 16-byte loads / stores
   hipStream_t st = (hipStream_t)stream;
+  if (P <= kAttnSmallP) {   // csrc/dib_attn_small.h: one launch - delta, the score recompute and dQ/dK/dV inside one workgroup per head
+    DibAttnArgs a{};
+    a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
+    a.P = P; a.H = H; a.ld = ld; a.scale = scale;
+    const size_t lds = (size_t)DibAttnSmallBwdLds * sizeof(float);
+    static bool attr_small[64] = {};
+    if (dib_attr_needed(attr_small)) {
+      hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    ProfScope ps(kProfAttnBwd, st);
+    hipLaunchKernelGGL(dib_attn_small_bwd_kernel, dim3(H, B), dim3(256), lds, st, a);
+    return (int)hipGetLastError();
+  }
   float* delta = (float*)ws;
   float* part = delta + (((int64_t)B * H * P + 63) / 64) * 64;
   const int nkb = cdiv(P, 128);

@@ -230,53 +230,11 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
 #pragma unroll
       for (int r = 0; r < RPP; ++r) bsum += Bs[(part * RPP + r) * SB::MC_PITCH + colb];
     }
-#ifndef DIB_GEMM_FRAG_PREFETCH
-#define DIB_GEMM_FRAG_PREFETCH 0   // 1 (A/B): the LDS fragments of k-block q + 1 are issued BEFORE the MFMAs of k-block q
-#endif
     if (active) {  // rows/cols/k beyond the matrix edge are zero-filled in LDS, so all BK/2 k-steps always run
-#if DIB_GEMM_FRAG_PREFETCH
-      // Left to itself the compiler places a k-block's ds_reads right in front of its first MFMA (s_waitcnt lgkmcnt a few
-      // instructions after issue): with two waves per SIMD marching in step that LDS latency is exposed once per 16 MFMAs.
-      // Here the next k-block's fragments are in flight during this block's 16 x 64 cycles of MFMAs.
-      float4 a[NI], b[NJ];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = SA::frag(As, wm * 32 * NI + i * 32, 0, l31, h);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[j] = SB::frag(Bs, wn * 32 * NJ + j * 32, 0, l31, h);
-#pragma unroll
-      for (int q = 0; q < BK / 8; ++q) {
-        float4 an[NI], bn[NJ];
-        const int qn = q + 1 < BK / 8 ? q + 1 : q;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) an[i] = SA::frag(As, wm * 32 * NI + i * 32, qn, l31, h);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bn[j] = SB::frag(Bs, wn * 32 * NJ + j * 32, qn, l31, h);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kPieces > 1) {
-          if (q > 0 && (q * kPieces) % QN == 0) {
-            const int piece = q * kPieces / QN;
-            if (piece == 1) prefetch_piece(std::integral_constant<int, 1>{});
-            else if (piece == 2) prefetch_piece(std::integral_constant<int, 2>{});
-            else if (piece == 3) prefetch_piece(std::integral_constant<int, 3>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            acc[i][j] = DIB_MFMA(a[i].x, b[j].x, acc[i][j]);
-            acc[i][j] = DIB_MFMA(a[i].y, b[j].y, acc[i][j]);
-            acc[i][j] = DIB_MFMA(a[i].z, b[j].z, acc[i][j]);
-            acc[i][j] = DIB_MFMA(a[i].w, b[j].w, acc[i][j]);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) a[i] = an[i];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = bn[j];
-      }
-#else
+      // (Round 4 tried issuing the LDS fragment reads of k-block q + 1 before the 16 MFMAs of k-block q - an explicit one-block
+      // software pipeline, sched_barrier-pinned, +24 VGPRs, still 2 workgroups per CU: every GEMM shape 1-3 % SLOWER on a
+      // same-box A/B, profiles/r04d_gemm_frag_prefetch_ab.txt.  The compiler's own placement - reads hoisted between the MFMAs
+      // of the previous block where registers allow - plus the second wave on the SIMD already cover that latency.)
 #pragma unroll
       for (int q = 0; q < BK / 8; ++q) {
         if constexpr (kPieces > 1) {
@@ -304,7 +262,6 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
             acc[i][j] = DIB_MFMA(a[i].w, b[j].w, acc[i][j]);
           }
       }
-#endif
     } else if constexpr (kPieces > 1) {   // a wave without output still stages its share of the next tile
       prefetch_piece(std::integral_constant<int, 1>{});
       if constexpr (kPieces == 4) {

@@ -65,6 +65,9 @@ int dib_softmax_rows_bwd(const float* P_probs, float* dP, int64_t rows, int P, i
  * score tiles there and the backward reads them back instead of recomputing S = scale q k^T - 4 tile products per tile pair
  * instead of 5 for 4 * ceil(P/32)^2 * 4 KB per (neighbourhood, head) of HBM (3.2 GB at 4 x 4096 x 12).  NULL: recompute.
  * ws: dib_attention_bwd_workspace_bytes.
+ * P <= 64 (the reference notebook's neighbourhoods hold 50 particles): one workgroup per (neighbourhood, head) keeps q, k, v
+ * (dO) and the [P, P] scores in LDS - one launch forward, one backward, no partial buffer; dib_attention_stash_bytes is 0 and
+ * s_stash is ignored (csrc/dib_attn_small.h).
  * DIB_E_UNSUPPORTED for key_dim != 128 or P * ld >= 2^30 elements (row offsets inside one neighbourhood are 32-bit). */
 int64_t dib_attention_stash_bytes(int B, int P, int H);
 int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,

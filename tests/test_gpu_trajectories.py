@@ -123,7 +123,7 @@ def test_infonce_loop_trajectory_matches_float64_oracle(tmp_path, batch_size, ro
                for i, (a, b, c) in enumerate(zip(final[0], o.vars, snaps[12][0])))
     # ---- (b) free-running float64 checker (and its float32 twin, to know where float32 stops determining the trajectory) ----
     free, _ = oracle(torch.float64, False)
-    free32, _ = oracle(torch.float32, False)
+    free32 = oracle(torch.float32, False)[0] if batch_size == 128 else free   # the twin is reporting only: one case is enough
     fr = {k: _free_running(k, got[k], free[k], free32[k], loose=2e-2) for k in ("kl", "kl_validation")}
     print("epoch-synchronised max errors:", {k: f"{v:.2e}" for k, v in errs.items()}, "final parameters (rms error / rms "
           f"displacement over the last 7 steps): {perr:.2e};",
