@@ -74,13 +74,32 @@ dib_attn_small_fwd_kernel(DibAttnArgs a) {
   for (int r = 0; r < 16; ++r) s[r] = 0.f;
   const float* Qw = Qs + wm * 32 * kAttnPitch;
   const float* Kw = Ks + wn * 32 * kAttnPitch;
+  {   // two accumulators (even / odd k-blocks) and the next pair's fragments in flight: a single dependent MFMA chain of 64
+      // would wait out every LDS read
+    dib_f32x16 s1;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const float4 qq = dib_attn_kc(Qw, q, l31, h), kk = dib_attn_kc(Kw, q, l31, h);
-    s = DIB_MFMA(qq.x, kk.x, s);
-    s = DIB_MFMA(qq.y, kk.y, s);
-    s = DIB_MFMA(qq.z, kk.z, s);
-    s = DIB_MFMA(qq.w, kk.w, s);
+    for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+    float4 qa = dib_attn_kc(Qw, 0, l31, h), ka = dib_attn_kc(Kw, 0, l31, h);
+    float4 qb = dib_attn_kc(Qw, 1, l31, h), kb = dib_attn_kc(Kw, 1, l31, h);
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      const int qn_ = q < 14 ? q + 2 : 14;
+      const float4 qan = dib_attn_kc(Qw, qn_, l31, h), kan = dib_attn_kc(Kw, qn_, l31, h);
+      const float4 qbn = dib_attn_kc(Qw, qn_ + 1, l31, h), kbn = dib_attn_kc(Kw, qn_ + 1, l31, h);
+      __builtin_amdgcn_sched_barrier(0);
+      s = DIB_MFMA(qa.x, ka.x, s);
+      s1 = DIB_MFMA(qb.x, kb.x, s1);
+      s = DIB_MFMA(qa.y, ka.y, s);
+      s1 = DIB_MFMA(qb.y, kb.y, s1);
+      s = DIB_MFMA(qa.z, ka.z, s);
+      s1 = DIB_MFMA(qb.z, kb.z, s1);
+      s = DIB_MFMA(qa.w, ka.w, s);
+      s1 = DIB_MFMA(qb.w, kb.w, s1);
+      __builtin_amdgcn_sched_barrier(0);
+      qa = qan; ka = kan; qb = qbn; kb = kbn;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] += s1[r];
   }
   __syncthreads();                               // every wave is done reading Q and K
   float* St = Ks;
@@ -119,16 +138,25 @@ dib_attn_small_fwd_kernel(DibAttnArgs a) {
   for (int n = 0; n < 2; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+  {
+    float4 pp = *reinterpret_cast<const float4*>(St + (wm * 32 + l31) * kAttnSP + h * 4);
+    float4 v0 = dib_attn_mc(Qs, 0, wn * 64 + l31, h), v1 = dib_attn_mc(Qs, 0, wn * 64 + 32 + l31, h);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const float4 pp = *reinterpret_cast<const float4*>(St + (wm * 32 + l31) * kAttnSP + q * 8 + h * 4);
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const float4 vv = dib_attn_mc(Qs, q, wn * 64 + n * 32 + l31, h);
-      o[n] = DIB_MFMA(pp.x, vv.x, o[n]);
-      o[n] = DIB_MFMA(pp.y, vv.y, o[n]);
-      o[n] = DIB_MFMA(pp.z, vv.z, o[n]);
-      o[n] = DIB_MFMA(pp.w, vv.w, o[n]);
+    for (int q = 0; q < 8; ++q) {
+      const int qn_ = q < 7 ? q + 1 : 7;
+      const float4 ppn = *reinterpret_cast<const float4*>(St + (wm * 32 + l31) * kAttnSP + qn_ * 8 + h * 4);
+      const float4 v0n = dib_attn_mc(Qs, qn_, wn * 64 + l31, h), v1n = dib_attn_mc(Qs, qn_, wn * 64 + 32 + l31, h);
+      __builtin_amdgcn_sched_barrier(0);
+      o[0] = DIB_MFMA(pp.x, v0.x, o[0]);
+      o[1] = DIB_MFMA(pp.x, v1.x, o[1]);
+      o[0] = DIB_MFMA(pp.y, v0.y, o[0]);
+      o[1] = DIB_MFMA(pp.y, v1.y, o[1]);
+      o[0] = DIB_MFMA(pp.z, v0.z, o[0]);
+      o[1] = DIB_MFMA(pp.z, v1.z, o[1]);
+      o[0] = DIB_MFMA(pp.w, v0.w, o[0]);
+      o[1] = DIB_MFMA(pp.w, v1.w, o[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      pp = ppn; v0 = v0n; v1 = v1n;
     }
   }
   float* Ob = a.o + tok0 * a.ld + head * kAttnD;
@@ -172,9 +200,14 @@ dib_attn_small_bwd_kernel(DibAttnArgs a) {
     const float* Qw = Qs + wm * 32 * kAttnPitch;
     const float* Gw = Gs + wm * 32 * kAttnPitch;
     const float* Kw = Ks + wn * 32 * kAttnPitch;
+    // one wave per SIMD (137 KB of LDS: one workgroup per CU): nobody else hides an LDS latency, so the fragments of step
+    // q + 1 are issued before the 8 MFMAs of step q (as in dib_attn_bwd_kernel; pinned by sched_barrier)
+    float4 qq = dib_attn_kc(Qw, 0, l31, h), gg = dib_attn_kc(Gw, 0, l31, h), kk = dib_attn_kc(Kw, 0, l31, h);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float4 qq = dib_attn_kc(Qw, q, l31, h), gg = dib_attn_kc(Gw, q, l31, h), kk = dib_attn_kc(Kw, q, l31, h);
+      const int qn_ = q < 15 ? q + 1 : 15;
+      const float4 qn = dib_attn_kc(Qw, qn_, l31, h), gn = dib_attn_kc(Gw, qn_, l31, h), kn = dib_attn_kc(Kw, qn_, l31, h);
+      __builtin_amdgcn_sched_barrier(0);
       s = DIB_MFMA(qq.x, kk.x, s);
       dp = DIB_MFMA(gg.x, vf[q].x, dp);
       s = DIB_MFMA(qq.y, kk.y, s);
@@ -183,6 +216,8 @@ dib_attn_small_bwd_kernel(DibAttnArgs a) {
       dp = DIB_MFMA(gg.z, vf[q].z, dp);
       s = DIB_MFMA(qq.w, kk.w, s);
       dp = DIB_MFMA(gg.w, vf[q].w, dp);
+      __builtin_amdgcn_sched_barrier(0);
+      qq = qn; gg = gn; kk = kn;
     }
   }
   // ---- P, delta, dS ----
@@ -210,36 +245,67 @@ dib_attn_small_bwd_kernel(DibAttnArgs a) {
   for (int n = 0; n < 2; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dv[n][r] = 0.f; dk[n][r] = 0.f; dq[n][r] = 0.f; }
+  {
+    // operands of query block q: the probability / dS columns of this lane's key (A, 4 scalars each) and the dO / Q rows (B, one
+    // MC fragment per 32-wide d tile); block q + 1 is fetched before the 16 MFMAs of block q
+    struct Ops { float4 p, d, g0, g1, q0, q1; };
+    auto fetch = [&](int q) {
+      Ops o;
+      const float* pp = Pt + (q * 8 + h * 4) * kAttnSP + wm * 32 + l31;
+      const float* dd = dSt + (q * 8 + h * 4) * kAttnSP + wm * 32 + l31;
+      o.p = make_float4(pp[0], pp[kAttnSP], pp[2 * kAttnSP], pp[3 * kAttnSP]);
+      o.d = make_float4(dd[0], dd[kAttnSP], dd[2 * kAttnSP], dd[3 * kAttnSP]);
+      o.g0 = dib_attn_mc(Gs, q, wn * 64 + l31, h);
+      o.g1 = dib_attn_mc(Gs, q, wn * 64 + 32 + l31, h);
+      o.q0 = dib_attn_mc(Qs, q, wn * 64 + l31, h);
+      o.q1 = dib_attn_mc(Qs, q, wn * 64 + 32 + l31, h);
+      return o;
+    };
+    Ops cur = fetch(0);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const float* pp = Pt + (q * 8 + h * 4) * kAttnSP + wm * 32 + l31;
-    const float* dd = dSt + (q * 8 + h * 4) * kAttnSP + wm * 32 + l31;
-    const float p0 = pp[0], p1 = pp[kAttnSP], p2 = pp[2 * kAttnSP], p3 = pp[3 * kAttnSP];
-    const float d0 = dd[0], d1 = dd[kAttnSP], d2 = dd[2 * kAttnSP], d3 = dd[3 * kAttnSP];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const float4 gg = dib_attn_mc(Gs, q, wn * 64 + n * 32 + l31, h), qq = dib_attn_mc(Qs, q, wn * 64 + n * 32 + l31, h);
-      dv[n] = DIB_MFMA(p0, gg.x, dv[n]);
-      dk[n] = DIB_MFMA(d0, qq.x, dk[n]);
-      dv[n] = DIB_MFMA(p1, gg.y, dv[n]);
-      dk[n] = DIB_MFMA(d1, qq.y, dk[n]);
-      dv[n] = DIB_MFMA(p2, gg.z, dv[n]);
-      dk[n] = DIB_MFMA(d2, qq.z, dk[n]);
-      dv[n] = DIB_MFMA(p3, gg.w, dv[n]);
-      dk[n] = DIB_MFMA(d3, qq.w, dk[n]);
+    for (int q = 0; q < 8; ++q) {
+      const Ops nxt = fetch(q < 7 ? q + 1 : 7);
+      __builtin_amdgcn_sched_barrier(0);
+      dv[0] = DIB_MFMA(cur.p.x, cur.g0.x, dv[0]);
+      dv[1] = DIB_MFMA(cur.p.x, cur.g1.x, dv[1]);
+      dk[0] = DIB_MFMA(cur.d.x, cur.q0.x, dk[0]);
+      dk[1] = DIB_MFMA(cur.d.x, cur.q1.x, dk[1]);
+      dv[0] = DIB_MFMA(cur.p.y, cur.g0.y, dv[0]);
+      dv[1] = DIB_MFMA(cur.p.y, cur.g1.y, dv[1]);
+      dk[0] = DIB_MFMA(cur.d.y, cur.q0.y, dk[0]);
+      dk[1] = DIB_MFMA(cur.d.y, cur.q1.y, dk[1]);
+      dv[0] = DIB_MFMA(cur.p.z, cur.g0.z, dv[0]);
+      dv[1] = DIB_MFMA(cur.p.z, cur.g1.z, dv[1]);
+      dk[0] = DIB_MFMA(cur.d.z, cur.q0.z, dk[0]);
+      dk[1] = DIB_MFMA(cur.d.z, cur.q1.z, dk[1]);
+      dv[0] = DIB_MFMA(cur.p.w, cur.g0.w, dv[0]);
+      dv[1] = DIB_MFMA(cur.p.w, cur.g1.w, dv[1]);
+      dk[0] = DIB_MFMA(cur.d.w, cur.q0.w, dk[0]);
+      dk[1] = DIB_MFMA(cur.d.w, cur.q1.w, dk[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
   }
   // ---- dQ[query wm*32.., d wn*64..] = scale dS K: contraction over the 64 keys ----
+  {
+    float4 ds = *reinterpret_cast<const float4*>(dSt + (wm * 32 + l31) * kAttnSP + h * 4);
+    float4 k0 = dib_attn_mc(Ks, 0, wn * 64 + l31, h), k1 = dib_attn_mc(Ks, 0, wn * 64 + 32 + l31, h);
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const float4 ds = *reinterpret_cast<const float4*>(dSt + (wm * 32 + l31) * kAttnSP + q * 8 + h * 4);
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const float4 kk = dib_attn_mc(Ks, q, wn * 64 + n * 32 + l31, h);
-      dq[n] = DIB_MFMA(ds.x, kk.x, dq[n]);
-      dq[n] = DIB_MFMA(ds.y, kk.y, dq[n]);
-      dq[n] = DIB_MFMA(ds.z, kk.z, dq[n]);
-      dq[n] = DIB_MFMA(ds.w, kk.w, dq[n]);
+    for (int q = 0; q < 8; ++q) {
+      const int qn_ = q < 7 ? q + 1 : 7;
+      const float4 dsn = *reinterpret_cast<const float4*>(dSt + (wm * 32 + l31) * kAttnSP + qn_ * 8 + h * 4);
+      const float4 k0n = dib_attn_mc(Ks, qn_, wn * 64 + l31, h), k1n = dib_attn_mc(Ks, qn_, wn * 64 + 32 + l31, h);
+      __builtin_amdgcn_sched_barrier(0);
+      dq[0] = DIB_MFMA(ds.x, k0.x, dq[0]);
+      dq[1] = DIB_MFMA(ds.x, k1.x, dq[1]);
+      dq[0] = DIB_MFMA(ds.y, k0.y, dq[0]);
+      dq[1] = DIB_MFMA(ds.y, k1.y, dq[1]);
+      dq[0] = DIB_MFMA(ds.z, k0.z, dq[0]);
+      dq[1] = DIB_MFMA(ds.z, k1.z, dq[1]);
+      dq[0] = DIB_MFMA(ds.w, k0.w, dq[0]);
+      dq[1] = DIB_MFMA(ds.w, k1.w, dq[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      ds = dsn; k0 = k0n; k1 = k1n;
     }
   }
   float* dQb = a.dq + tok0 * a.ld + head * kAttnD;
