@@ -248,7 +248,9 @@ def test_attention_backward_score_stash_equals_recompute(B, P, H):
     gq, gk, gv = torch.autograd.grad((od * dod.detach()).sum(), [qd, kd, vd])
     for name, a, b in (("o", res["stash"][0], od), ("dq", res["stash"][2], gq), ("dk", res["stash"][3], gk), ("dv", res["stash"][4], gv)):
         b = b.detach().reshape(T, ld)
-        assert (a.double().cpu() - b).abs().max() <= 2e-5 * b.abs().max(), name
+        # (+ 1e-6 absolute: with a single particle dq and dk are exactly 0 - softmax of one score - and the device leaves the
+        # round-off of 1 - exp(s - lse), 2e-8)
+        assert (a.double().cpu() - b).abs().max() <= 2e-5 * b.abs().max() + 1e-6, name
 
 
 def test_train_steps_match_oracle_adam():
