@@ -134,6 +134,7 @@ SIGNATURES_ST = {
     "dib_gemm_grouped": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "dib_reduce_splits": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "dib_reduce_splits_add": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "dib_gemm_skinny_k": (c_int, [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_softmax_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "dib_softmax_rows_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
@@ -143,8 +144,8 @@ SIGNATURES_ST = {
     "dib_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dib_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "dib_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
-                                      c_void_p, c_void_p]),
+    "dib_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_float, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
     "dib_add_layernorm_bwd_workspace_bytes": (c_int64, [c_int64, c_int]),
     "dib_add_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),

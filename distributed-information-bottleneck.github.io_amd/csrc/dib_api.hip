@@ -1427,16 +1427,16 @@ int dib_softmax_rows_bwd(const float* Pm, float* dP, int64_t rows, int P, int ld
 
 static int ln_grid(int64_t T, int D) { return grid_for(T, D <= 32 ? 8 : 4, 512); }
 
-int dib_add_layernorm_fwd(const float* a, const float* b, int64_t T, int D, const float* gamma, const float* beta,
-                          float eps, float* y, float* xhat, float* rstd, dib_stream_t stream) {
-  if (!a || !b || !gamma || !beta || !y || !xhat || !rstd || T <= 0 || D <= 0) return DIB_E_ARG;
+int dib_add_layernorm_fwd(const float* a, const float* b, int b_slabs, int64_t b_stride, int64_t T, int D, const float* gamma,
+                          const float* beta, float eps, float* y, float* xhat, float* rstd, dib_stream_t stream) {
+  if (!a || !b || !gamma || !beta || !y || !xhat || !rstd || T <= 0 || D <= 0 || b_slabs < 1) return DIB_E_ARG;
   if (D > 256) return DIB_E_UNSUPPORTED;
   if (D <= 32)
-    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<32>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b,
-                       (long long)T, D, gamma, beta, eps, y, xhat, rstd);
+    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<32>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b, b_slabs,
+                       (long long)b_stride, (long long)T, D, gamma, beta, eps, y, xhat, rstd);
   else
-    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<64>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b,
-                       (long long)T, D, gamma, beta, eps, y, xhat, rstd);
+    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<64>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b, b_slabs,
+                       (long long)b_stride, (long long)T, D, gamma, beta, eps, y, xhat, rstd);
   return (int)hipGetLastError();
 }
 
@@ -1692,7 +1692,14 @@ int dib_loss_rows(int loss_kind, const float* pred, int out_dim, const float* y,
 int dib_reduce_splits(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream) {
   if (!partial || !out || n <= 0 || nsplit <= 0 || (n & 3) || (stride & 3)) return DIB_E_ARG;
   hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial,
-                     (long long)n, nsplit, (long long)stride, out);
+                     (long long)n, nsplit, (long long)stride, out, (const float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int dib_reduce_splits_add(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream) {
+  if (!partial || !out || n <= 0 || nsplit <= 0 || (n & 3) || (stride & 3)) return DIB_E_ARG;
+  hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial,
+                     (long long)n, nsplit, (long long)stride, out, (const float*)out);
   return (int)hipGetLastError();
 }
 

@@ -263,10 +263,10 @@ __global__ void dib_metrics_accumulate_kernel(const float* __restrict__ step_out
 
 __global__ void dib_set_scalar_kernel(float* p, float v) { p[0] = v; }
 
-// out[i] = sum_s partial[s*stride + i], i < n   (fixed order => deterministic)
+// out[i] = (acc ? acc[i] : 0) + sum_s partial[s*stride + i], i < n   (fixed order => deterministic; acc may be out itself)
 __global__ void __launch_bounds__(256)
 dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsplit, long long stride,
-                         float* __restrict__ out) {
+                         float* out, const float* acc = nullptr) {
   const long long n4 = n >> 2;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
@@ -275,13 +275,17 @@ dib_reduce_splits_kernel(const float* __restrict__ partial, long long n, int nsp
       const float4 v = reinterpret_cast<const float4*>(partial + (long long)k * stride)[i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    if (acc) {
+      const float4 a = reinterpret_cast<const float4*>(acc)[i];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
     reinterpret_cast<float4*>(out)[i] = s;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
     float s = 0.f;
     for (int k = 0; k < nsplit; ++k) s += partial[(long long)k * stride + i];
-    out[i] = s;
+    out[i] = acc ? s + acc[i] : s;
   }
 }
 

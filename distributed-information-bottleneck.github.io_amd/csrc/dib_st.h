@@ -111,8 +111,8 @@ dib_softmax_rows_bwd_kernel(const float* __restrict__ Pm, float* __restrict__ dP
 // W = 32 lanes per row for D <= 32 (two rows per wave), else 64.  xhat and rstd are stashed for the backward.
 template <int W>
 __global__ void __launch_bounds__(256)
-dib_add_layernorm_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bv, long long T, int D,
-                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+dib_add_layernorm_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bv, int b_slabs, long long b_stride,
+                             long long T, int D, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                              float* __restrict__ Y, float* __restrict__ xhat, float* __restrict__ rstd) {
   constexpr int RPW = 64 / W;  // rows per wave
   const int lane = threadIdx.x & 63, sub = lane / W, l = lane % W;
@@ -125,7 +125,10 @@ dib_add_layernorm_fwd_kernel(const float* __restrict__ A, const float* __restric
 #pragma unroll
     for (int c = 0; c < 256 / W; ++c) {
       const int j = l + c * W;
-      x[c] = (ok && j < D) ? A[row * D + j] + Bv[row * D + j] : 0.f;
+      float bv = 0.f;   // the second addend may arrive as b_slabs split-K partials b_stride apart: summed here in slab order
+      if (ok && j < D)
+        for (int sl = 0; sl < b_slabs; ++sl) bv += Bv[sl * b_stride + row * D + j];
+      x[c] = (ok && j < D) ? A[row * D + j] + bv : 0.f;
       sum += x[c];
     }
     const float mean = dib_group_sum<W>(sum) / (float)D;

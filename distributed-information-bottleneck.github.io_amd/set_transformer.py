@@ -67,17 +67,23 @@ class _SplitKGemm:
     the whole step.  Here the contraction is cut into `ksplit` chunks that run as extra GROUPS of the same grouped launch
     (one partial slab each), summed in a fixed order by dib_reduce_splits: deterministic, no new kernel."""
 
-    def __init__(self, gemm: "_Gemm", partial, partial_off, n, nslabs, out, out_off):
-        self.gemm, self.partial, self.partial_off, self.n, self.nslabs, self.out, self.out_off = \
-            gemm, partial, partial_off, n, nslabs, out, out_off
+    def __init__(self, gemm: "_Gemm", partial, partial_off, n, nslabs, out, out_off, mode: str = "store"):
+        """mode: "store" out = sum of the slabs; "add" out += sum (a residual branch's gradient joins the one already there:
+        one launch instead of reduce + add); "defer" no reduce here - the consumer sums the slabs itself
+        (dib_add_layernorm_fwd's b_slabs)."""
+        self.gemm, self.partial, self.partial_off, self.n, self.nslabs, self.out, self.out_off, self.mode = \
+            gemm, partial, partial_off, n, nslabs, out, out_off, mode
 
     def upload(self, device):
         self.gemm.upload(device)
 
     def run(self, lib, stream):
         self.gemm.run(lib, stream)
-        check(lib.dib_reduce_splits(_ptr(self.partial, self.partial_off), self.n, self.nslabs, self.n,
-                                    _ptr(self.out, self.out_off), stream), "dib_reduce_splits")
+        if self.mode == "defer":
+            return
+        fn = lib.dib_reduce_splits_add if self.mode == "add" else lib.dib_reduce_splits
+        check(fn(_ptr(self.partial, self.partial_off), self.n, self.nslabs, self.n, _ptr(self.out, self.out_off), stream),
+              "dib_reduce_splits")
 
 
 class SetTransformerDIB:
@@ -395,7 +401,7 @@ class SetTransformerDIB:
                     _Gemm(0, [_d(off[f"b{b}_ctx"] + s_ * ck, HK, po[pre + "o_w"] + s_ * ck * D, D, off["ksplit_ws"] + s_ * T * D, D,
                                  T, D, ck, bias_off=po[pre + "o_b"] if s_ == 0 else -1) for s_ in range(ksplit)],
                           ws, self.params, ws, bias=self.params),
-                    ws, off["ksplit_ws"], T * D, ksplit, ws, off[f"b{b}_mha"])
+                    ws, off["ksplit_ws"], T * D, ksplit, ws, off[f"b{b}_mha"], mode="defer")   # LN1 sums the slabs
             else:
                 g[f"b{b}_o_fwd"] = dense_fwd(f"b{b}_ctx", HK, pre + "o_w", pre + "o_b", f"b{b}_mha", D, ACT_NONE, T)
             d, src = D, f"b{b}_h"
@@ -444,7 +450,7 @@ class SetTransformerDIB:
                     _Gemm(1, [_d(off[f"g_{nm}"] + s_ * ck, HK, po[pre + nm + "_w"] + s_ * ck, HK,
                                  off["ksplit_ws"] + (i_ * ksplit + s_) * T * D, D, T, D, ck)
                               for i_, nm in enumerate("qkv") for s_ in range(ksplit)], ws, self.params, ws),
-                    ws, off["ksplit_ws"], T * D, 3 * ksplit, ws, off["g_xq"])
+                    ws, off["ksplit_ws"], T * D, 3 * ksplit, ws, off[self._block_grad_names(b)[1]], mode="add")
             else:
                 g[f"b{b}_qkv_dgrad"] = _Gemm(1, [_d(off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, off[f"g_x{nm}"], D, T, D, HK)
                                                  for nm in "qkv"], ws, self.params, ws)
@@ -578,14 +584,16 @@ class SetTransformerDIB:
                                             self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
                                             _ptr(pl["stash"][b]) if use_stash else c_void_p(0), st), "dib_attention_fwd")
             g[f"b{b}_o_fwd"].run(lib, st)
-            check(lib.dib_add_layernorm_fwd(_ptr(ws, off[xin]), _ptr(ws, off[f"b{b}_mha"]), T, D,
+            ks = pl["ksplit"]   # split-K output projection: its slabs are the second addend
+            check(lib.dib_add_layernorm_fwd(_ptr(ws, off[xin]), _ptr(ws, off["ksplit_ws"] if ks > 1 else off[f"b{b}_mha"]),
+                                            max(ks, 1), T * D, T, D,
                                             _ptr(self.params, self.offsets[pre + "ln1_g"]), _ptr(self.params, self.offsets[pre + "ln1_b"]),
                                             self.layer_norm_epsilon, _ptr(ws, off[f"b{b}_h"]), _ptr(ws, off[f"b{b}_xhat1"]),
                                             _ptr(ws, off[f"b{b}_rstd1"]), st), "dib_add_layernorm_fwd")
             for l in range(len(self.ff_arch_per_block)):
                 g[f"b{b}_ff{l}_fwd"].run(lib, st)
             last_ff = f"b{b}_ff{len(self.ff_arch_per_block) - 1}"
-            check(lib.dib_add_layernorm_fwd(_ptr(ws, off[f"b{b}_h"]), _ptr(ws, off[last_ff]), T, D,
+            check(lib.dib_add_layernorm_fwd(_ptr(ws, off[f"b{b}_h"]), _ptr(ws, off[last_ff]), 1, 0, T, D,
                                             _ptr(self.params, self.offsets[pre + "ln2_g"]), _ptr(self.params, self.offsets[pre + "ln2_b"]),
                                             self.layer_norm_epsilon, _ptr(ws, off[f"b{b}_x"]), _ptr(ws, off[f"b{b}_xhat2"]),
                                             _ptr(ws, off[f"b{b}_rstd2"]), st), "dib_add_layernorm_fwd")
@@ -663,8 +671,8 @@ class SetTransformerDIB:
             g[f"b{b}_qkv_wgrad"].run(lib, st)
             g[f"b{b}_qkv_dgrad"].run(lib, st)
             # gradient w.r.t. the block's input = residual (already in gout) + the three projection inputs
-            check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off["g_xq"]), T * D, st), "dib_add_inplace")
-            if pl["ksplit"] == 1:   # (split-K: the slab reduce already summed the three projections' gradients into g_xq)
+            if pl["ksplit"] == 1:   # (split-K: the slab reduce ADDS the three projections' gradients to gout itself)
+                check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off["g_xq"]), T * D, st), "dib_add_inplace")
                 check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off["g_xk"]), T * D, st), "dib_add_inplace")
                 check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off["g_xv"]), T * D, st), "dib_add_inplace")
         # bottleneck: d(mu | raw logvar), beta * KL included

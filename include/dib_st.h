@@ -41,6 +41,9 @@ int dib_gemm_grouped(int mode, int n_groups, const dib_gemm_desc* dev_desc, int 
                      const float* B, float* C, const float* bias, const float* aux, float* bias_out, int act, int nsplit,
                      int rows_per_split, int64_t split_stride, dib_stream_t stream);
 int dib_reduce_splits(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream);
+/* out[i] += sum of the slabs (the split-K gradient of a residual branch added to the gradient already in `out`: one launch
+ * instead of reduce + add) */
+int dib_reduce_splits_add(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream);
 
 /* The same products for a SKINNY contraction (K <= 32, K % 4 == 0) with a large output - the set transformer's q / k / v
  * projections of the 32-wide residual stream (dense layers of ...set_transformer.ipynb:332-389's MultiHeadAttention) and the
@@ -78,10 +81,12 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
                       float* dv, void* ws, dib_stream_t stream);
 
 /* tf.keras.layers.Add()([a, b]) -> LayerNormalization(epsilon): y = (s - mean)/sqrt(var + eps) * gamma + beta over the last
- * axis (D <= 256); xhat [T, D] and rstd [T] are stashed for the backward.  Backward: ds [T, D] (gradient of BOTH addends)
+ * axis (D <= 256); xhat [T, D] and rstd [T] are stashed for the backward.  b may arrive as b_slabs >= 1 split-K partials
+ * b_stride elements apart (the attention output projection at small token counts): they are summed here, in slab order,
+ * instead of by a separate dib_reduce_splits launch.  Backward: ds [T, D] (gradient of BOTH addends)
  * and dgamma_dbeta = [dgamma (D) | dbeta (D)] (contiguous, Keras variable order gamma, beta). */
-int dib_add_layernorm_fwd(const float* a, const float* b, int64_t T, int D, const float* gamma, const float* beta,
-                          float eps, float* y, float* xhat, float* rstd, dib_stream_t stream);
+int dib_add_layernorm_fwd(const float* a, const float* b, int b_slabs, int64_t b_stride, int64_t T, int D, const float* gamma,
+                          const float* beta, float eps, float* y, float* xhat, float* rstd, dib_stream_t stream);
 int64_t dib_add_layernorm_bwd_workspace_bytes(int64_t T, int D);
 int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t T, int D,
                           float* ds, float* dgamma_dbeta, void* ws, dib_stream_t stream);
