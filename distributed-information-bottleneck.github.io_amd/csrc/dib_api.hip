@@ -279,20 +279,31 @@ static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits,
       *rps_out = rps;
       return;
     }
+  // The caller's (layout-wide) split is kept whenever it fills its rounds to at least 85 %: BASELINE config 3 (F = 64: 64 or 32
+  // tiles x 32 or 16 splits = whole rounds at every batch size) then runs exactly the launches rounds 2-3 measured and
+  // validated (same-box A/B of an unconditional rule vs no rule there: 8.00-8.08 vs 7.99-8.02 ms/step,
+  // profiles/r04e_split_policy_final_ab.txt).
+  const auto cost_of = [&](int ns, int rps) {
+    return (double)((tiles * ns + slots - 1) / slots) * (rps + knobs().split_overhead);
+  };
+  {
+    const long long wgs = tiles * *ns_out, rounds = (wgs + slots - 1) / slots;
+    if ((double)wgs >= 0.85 * (double)(rounds * slots)) return;
+  }
   double best = 1e300;
   int bns = *ns_out, brps = *rps_out;
   for (int ns = 1; ns <= max_splits; ++ns) {
     const int rps = cdiv(cdiv(K, ns), 64) * 64;
     if (ns > 1 && rps < DIB_SPLIT_ROWS) break;
     if (cdiv(K, rps) != ns) continue;   // the same split as a smaller ns
-    const long long rounds = (tiles * ns + slots - 1) / slots;
-    const double cost = (double)rounds * (rps + knobs().split_overhead);
+    const double cost = cost_of(ns, rps);
     if (cost < best) {
       best = cost;
       bns = ns;
       brps = rps;
     }
   }
+  if (best >= cost_of(*ns_out, *rps_out)) return;
   *ns_out = bns;
   *rps_out = brps;
 }
@@ -300,7 +311,7 @@ static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits,
 template <int MODE>
 int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* A, const float* B, float* C,
                 const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
-                long long split_stride, hipStream_t st, bool auto_split = false) {
+                long long split_stride, hipStream_t st, bool auto_split = false, int max_splits = 0) {
   if (c.count == 0) return DIB_OK;
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
@@ -325,7 +336,7 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
     // co-resident workgroups per CU of each tile shape (LDS / register budget of dib_gemm_kernel<2, NI, NJ, BK>)
     const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
     const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
-    pick_wgrad_splits(tiles, 256 * per_cu, batch, nsplit, &nsplit, &rows_per_split);
+    pick_wgrad_splits(tiles, 256 * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
@@ -340,10 +351,11 @@ __global__ void dib_write_desc_kernel(DibGemmGroup* dst, DibGemmGroup g) { *dst 
 template <int MODE>
 int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const float* B, float* C, const float* bias,
                 const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
-                long long split_stride, hipStream_t st) {
-  // the layout's weight gradients contract over the batch: their split count is chosen per launch (pick_wgrad_splits)
+                long long split_stride, hipStream_t st, int slab_count = 0) {
+  // the layout's weight gradients contract over the batch: their split count is chosen per launch (pick_wgrad_splits) among
+  // 1 .. slab_count (the partial slabs the workspace holds)
   return launch_gemm<MODE>(l->dev_groups, c, A, B, C, bias, aux, bias_out, batch, act, nsplit, rows_per_split, split_stride,
-                           st, /*auto_split=*/MODE == 2);
+                           st, /*auto_split=*/MODE == 2, slab_count);
 }
 
 inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
@@ -892,7 +904,7 @@ static int integration_bwd_impl(dib_layout* l, int batch, const float* params, f
       continue;
     }
     rc = launch_gemm<2>(l, l->int_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
-                        m.rows_per_split, sstride, st);
+                        m.rows_per_split, sstride, st, m.nsplit);
     if (rc) return rc;
     // u is not an activation output (no mask for ly == 0)
     rc = launch_gemm<1>(l, l->int_dgrad[ly], gout, params, gin, nullptr, ly == 0 ? nullptr : hin, nullptr, batch,
@@ -994,9 +1006,8 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
       // narrow outputs (the 2E-wide last layer) run 128x64 tiles at 4 workgroups/CU: half as many, twice as long batch
       // splits fill the chip in one wave (measured 0.88 -> 0.71 ms); the unused slabs of these blocks stay zero.
       // (only from 32 splits = 16384 rows up: at B = 8192 the 16 -> 8 split halving measured 117 vs 103 us)
-      // (with the per-launch split policy on, pick_wgrad_splits makes this choice - 4 workgroups per CU for the narrow tile)
-      const bool halve = !knobs().split_policy && knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 &&
-                         (m.nsplit % 2) == 0;
+      // (the per-launch split rule, pick_wgrad_splits, starts from this choice and leaves it unless it predicts > 5 % better)
+      const bool halve = knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
       hipStream_t lst = st;
       if (fork && last) {
         if (hipEventRecord(l->ev_fork, st) != hipSuccess || hipStreamWaitEvent(l->side, l->ev_fork, 0) != hipSuccess)
@@ -1004,7 +1015,8 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
         lst = l->side;
       }
       rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0,
-                          halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, lst);
+                          halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, lst,
+                          m.nsplit);
       if (rc) return rc;
       if (fork && last && hipEventRecord(l->ev_join, l->side) != hipSuccess) return DIB_E_ARG;
     }
