@@ -227,7 +227,10 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 #ifndef DIB_BK212
 #define DIB_BK212 64   // 64x128 wgrad tile (the 256x256 integration layer): 0.136 -> 0.124 ms with 64-deep K-tiles (same-box A/B)
 #endif
-  constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
+#ifndef DIB_BK22W
+#define DIB_BK22W 64   // A/B knob: K-tile depth of the 128 x 128 weight-gradient tile (32: half the LDS, 3-4 workgroups per CU)
+#endif
+  constexpr int BK = (NI == 2 && NJ == 2) ? (MODE == 2 ? DIB_BK22W : 64) : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
   // cache policy of the streamed operands / outputs (dib_gemm.h: stream_flags): non-temporal from 8192 streamed rows up
   // (DIB_GEMM_STREAM_ROWS; M for forward / dgrad, the contracted rows for a weight gradient)
   const long long streamed_rows = MODE == 2 ? (long long)nsplit * rows_per_split : (long long)M;
@@ -334,7 +337,7 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
   if (const int ft = knobs().force_tile[MODE]) { ni1 = ft / 10 == 1; nj1 = (ft % 10 == 1) || N <= 64; }
   if (MODE == 2 && auto_split && nsplit > 1 && knobs().split_policy) {
     // co-resident workgroups per CU of each tile shape (LDS / register budget of dib_gemm_kernel<2, NI, NJ, BK>)
-    const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
+    const int per_cu = (!ni1 && !nj1) ? (DIB_BK22W == 32 ? DIB_GEMM_WGRAD_WG : 2) : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
     const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
     pick_wgrad_splits(tiles, 256 * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
   }

@@ -120,7 +120,10 @@ struct DibStage {
 #define DIB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 template <int MODE, int NI, int NJ, int BK>
-__global__ void __launch_bounds__(256, 2)  // >= 2 workgroups per CU: keep VGPR+AGPR <= 256
+#ifndef DIB_GEMM_WGRAD_WG
+#define DIB_GEMM_WGRAD_WG 2   // A/B knob: workgroups per CU the register budget of the 128 x 128 x 32 WEIGHT-GRADIENT tile must allow
+#endif
+__global__ void __launch_bounds__(256, (MODE == 2 && NI == 2 && NJ == 2 && BK == 32) ? DIB_GEMM_WGRAD_WG : 2)
 dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict__ Abase,
                 const float* __restrict__ Bbase, float* __restrict__ Cbase, const float* __restrict__ bias,
                 const float* __restrict__ aux, float* __restrict__ bias_out, int batch, int act, int tiles_m,
