@@ -46,6 +46,7 @@ struct dib_layout {
   std::vector<int> enc_width;             // [n_enc+1] per-feature output width of each encoder layer
   std::vector<int> int_width;             // [n_int+1]
   int64_t n_params = 0;
+  long long max_wgrad_tiles64 = 0;        // most 64 x 64 output tiles any one weight-gradient launch has (all groups)
   std::vector<std::vector<int64_t>> enc_w_off, enc_b_off;  // [layer][feature]
   std::vector<int64_t> int_w_off, int_b_off;
   // descriptor table
@@ -97,8 +98,13 @@ struct dib_layout {
     m.kl_partial = take((int64_t)std::max(m.kl_blocks, 8 * 256) * F);  // fused fwd: one row per wave of the persistent grid
     m.loss_blocks = cdiv(B, 256);
     m.loss_partial = take((int64_t)std::max(m.loss_blocks, 512) * 2);  // also the fused output head's per-workgroup partials (<= 512)
-    // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= DIB_SPLIT_ROWS rows per split
+    // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= DIB_SPLIT_ROWS rows per split ...
     int ns = std::min(DIB_MAX_SPLITS, std::max(1, B / DIB_SPLIT_ROWS));
+    // ... unless the layout is so narrow that even its largest weight gradient stays under one workgroup per CU with that
+    // many splits (BASELINE config 2, the pendulum layout [2,1,2,1]: 16 tiles x 4 splits of 512 rows at B = 2048 - five
+    // launches of 18-24 us, each a workgroup walking 16 dependent K-tiles, 100 of the 510 us step,
+    // profiles/r04i_config2_loop_kernel_stats_b2048.csv): then slabs of >= 128 rows
+    if (B >= 256 && max_wgrad_tiles64 * ns < 256) ns = std::min(DIB_MAX_SPLITS, std::max(ns, B / 128));
     int rps = cdiv(cdiv(B, ns), 32) * 32;
     ns = cdiv(B, rps);
     m.nsplit = ns;
@@ -258,6 +264,7 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 // a CU executes is serial: ceil(tiles ns / 256) x rps", picked 25 and 29 there and measured no gain: r04c.)
 // Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace contract).
 static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits, int* ns_out, int* rps_out) {
+  const int min_rows = std::min(DIB_SPLIT_ROWS, std::max(64, *rps_out));   // narrow layouts come in with shorter slabs (WsMap)
   // measurement override (tools/runs/r04d.sh): DIB_WGRAD_NS="tiles:ns,tiles:ns,..." forces the split count of the launches with
   // that many output tiles
   static const std::vector<std::pair<long long, int>> forced = [] {
@@ -297,7 +304,7 @@ static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits,
   int bns = *ns_out, brps = *rps_out;
   for (int ns = 1; ns <= max_splits; ++ns) {
     const int rps = cdiv(cdiv(K, ns), 64) * 64;
-    if (ns > 1 && rps < DIB_SPLIT_ROWS) break;
+    if (ns > 1 && rps < min_rows) break;
     if (cdiv(K, rps) != ns) continue;   // the same split as a smaller ns
     const double cost = cost_of(ns, rps);
     if (cost < best) {
@@ -584,6 +591,7 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
       max_in = std::max(max_in, win);
     }
     wg.count = F; wg.max_m = max_in; wg.max_n = wout;
+    l->max_wgrad_tiles64 = std::max(l->max_wgrad_tiles64, (long long)cdiv(max_in, 64) * cdiv(wout, 64) * F);
     l->enc_wgrad.push_back(wg);
   }
   for (int ly = 0; ly < LI; ++ly) {
@@ -603,6 +611,7 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
     T.push_back(make_group(Off(), win, Off(), wout, fixed_off(l->int_w_off[ly]), wout, l->int_b_off[ly], Off(), 0, win,
                            wout, -1));
     wg.count = 1; wg.max_m = win; wg.max_n = wout;
+    l->max_wgrad_tiles64 = std::max(l->max_wgrad_tiles64, (long long)cdiv(win, 64) * cdiv(wout, 64));
     l->int_wgrad.push_back(wg);
   }
   // fused encoder-bank path: two hidden layers, instantiated (H1,H2,E), encoder inputs <= 16 wide
@@ -1223,8 +1232,9 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
                                             dim, inv_t, norms, S, prow, pcol, nb32, arrive)
     if (similarity == 0) DIB_INCE_SIM(0); else if (similarity == 1) DIB_INCE_SIM(1); else DIB_INCE_SIM(4);
 #undef DIB_INCE_SIM
+    float* lpart = pcol + 2ll * nb32 * batch;   // one loss partial per lse workgroup (still inside the 8 B^2 region)
     hipLaunchKernelGGL(dib_infonce_lse_loss_kernel, dim3(cdiv(2 * batch, 32)), dim3(256), 0, st, (const float*)prow,
-                       (const float*)pcol, (const float*)S, batch, nb32, lse, arrive, loss_out);
+                       (const float*)pcol, (const float*)S, batch, nb32, lse, arrive, lpart, loss_out);
     if (g_x && g_y) {
       const dim3 grid(t64, nsplit, 2);
 #define DIB_INCE_GRAD(NA, KD) hipLaunchKernelGGL((dib_infonce_grad_mfma_kernel<NA, KD>), grid, dim3(256), os_bytes, st, emb_x, emb_y, \

@@ -187,15 +187,18 @@ dib_infonce_sim_mfma_kernel(const float* __restrict__ X, const float* __restrict
 }
 
 // lse[0][i] = LSE_j S[i][j], lse[1][j] = LSE_i S[i][j] from the 32-wide block partials; the workgroup that arrives last (all
-// lse values are then in memory) computes loss = (1/B) sum_i (lse_r[i] + lse_c[i] - 2 S_ii).
+// lse values are then in memory) adds up loss = (1/B) sum_i (lse_r[i] + lse_c[i] - 2 S_ii) from one partial per workgroup
+// (each workgroup sums lse - S_tt over its own 32 rows or columns).
 // grid ceil(2B / 32): a workgroup owns 32 rows (or columns), thread (row = tid & 31, part = tid >> 5) merges every 8th block
 // partial online - (m, s) <- (max(m, pm), s e^(m - m') + ps e^(pm - m')) - and the 8 parts of a row are merged in a fixed
 // order through LDS.  (One thread per row walking all 2 x 64 partials of B = 2048 in two dependent passes took 47 us on 16
 // workgroups - 40 % of the whole InfoNCE sequence, profiles/r04c_infonce_kernel_stats.csv.)
 __global__ void __launch_bounds__(256)
 dib_infonce_lse_loss_kernel(const float* __restrict__ prow, const float* __restrict__ pcol, const float* __restrict__ S, int B,
-                            int nb32, float* __restrict__ lse, unsigned* __restrict__ arrive, float* __restrict__ loss_out) {
+                            int nb32, float* __restrict__ lse, unsigned* __restrict__ arrive, float* __restrict__ lpart,
+                            float* __restrict__ loss_out) {
   __shared__ float pm_s[8][32], ps_s[8][32];
+  __shared__ float term[32];
   __shared__ float red[4];
   __shared__ bool last;
   const int r = threadIdx.x & 31, part = threadIdx.x >> 5;
@@ -223,18 +226,28 @@ dib_infonce_lse_loss_kernel(const float* __restrict__ prow, const float* __restr
     float tot = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) tot += pm_s[q][r] == -INFINITY ? 0.f : ps_s[q][r] * expf(pm_s[q][r] - mm);
-    lse[idx] = mm + logf(tot);
+    const float l = mm + logf(tot);
+    lse[idx] = l;
+    term[r] = l - S[(long long)t * B + t];      // this row's (column's) share of the loss: lse - S_tt
+  } else if (part == 0) {
+    term[r] = 0.f;
   }
-  __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) last = (atomicAdd(arrive, 1u) == gridDim.x - 1);
+  if (threadIdx.x == 0) {   // the workgroup's 32 terms in a fixed order, then the arrival
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) sum += term[q];
+    lpart[blockIdx.x] = sum;
+    __threadfence();
+    last = (atomicAdd(arrive, 1u) == gridDim.x - 1);
+  }
   __syncthreads();
   if (!last) return;
   __threadfence();
-  float s = 0.f;
-  for (int i = threadIdx.x; i < B; i += 256)   // the other workgroups' lse values: bypass this CU's vector cache
-    s += __builtin_nontemporal_load(lse + i) + __builtin_nontemporal_load(lse + B + i) - 2.0f * S[(long long)i * B + i];
-  const float tot = dib_block_sum_256(s, red);
+  float sacc = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256)   // the other workgroups' partials: bypass this CU's vector cache
+    sacc += __builtin_nontemporal_load(lpart + i);
+  const float tot = dib_block_sum_256(sacc, red);
   if (threadIdx.x == 0) loss_out[0] = tot / (float)B;
 }
 

@@ -100,30 +100,43 @@ class DenseStack:
         o = pl["off"][name]
         return pl["ws"][o: o + rows * cols].view(rows, cols)
 
-    def forward(self, y: torch.Tensor) -> torch.Tensor:
+    def forward(self, y: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[n, input_dim] -> [n, output_dim].  The result is a view into the plan's workspace: valid until the next forward
-        with the same batch size."""
+        with the same batch size.  rows (int64 device tensor): encode y[rows] - gathered straight into the workspace."""
         y = y.to(device=self.device, dtype=torch.float32)
-        n = y.shape[0]
+        n = y.shape[0] if rows is None else int(rows.shape[0])
         pl = self._plan(n)
         st = self.eng._stream()
+        stage = self._view(pl, "y" if self.n_freq > 1 else "a0", n, self.input_dim)
+        if rows is not None:
+            torch.index_select(y, 0, rows, out=stage)
         if self.n_freq > 1:
-            self._view(pl, "y", n, self.input_dim).copy_(y)
+            if rows is None:
+                stage.copy_(y)
             check(self.lib.dib_positional_encoding(_ptr(pl["ws"], pl["off"]["y"]), self.input_dim, n, self.input_dim, self.n_freq,
                                                    _ptr(pl["ws"], pl["off"]["a0"]), st), "dib_positional_encoding")
-        else:
-            self._view(pl, "a0", n, self.input_dim).copy_(y)
+        elif rows is None:
+            stage.copy_(y)
         for l in range(len(self.dims)):
             pl["g"][f"fwd{l}"].run(self.lib, st)
         self._last = pl
         return self._view(pl, f"a{len(self.dims)}", n, self.dims[-1][1])
+
+    def output_grad_buffer(self) -> torch.Tensor:
+        """[n, output_dim] view that backward() reads d loss / d output from (of the last forward's plan): a loss kernel can
+        write its gradient there directly."""
+        pl = self._last
+        assert pl is not None
+        return self._view(pl, f"g{len(self.dims)}", pl["n"], self.dims[-1][1])
 
     def backward(self, g_out: torch.Tensor) -> None:
         """grads <- d loss / d params given d loss / d output of the last forward (overwrites self.grads)."""
         pl = self._last
         assert pl is not None and g_out.shape[0] == pl["n"], "backward follows a forward with the same batch"
         n, L, st = pl["n"], len(self.dims), self.eng._stream()
-        self._view(pl, f"g{L}", n, self.dims[-1][1]).copy_(g_out)
+        dst = self._view(pl, f"g{L}", n, self.dims[-1][1])
+        if g_out.data_ptr() != dst.data_ptr():
+            dst.copy_(g_out)
         if pl["nsplit"] == 1:
             self.grads.zero_()
         for l in reversed(range(L)):
@@ -134,8 +147,13 @@ class DenseStack:
             check(self.lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_params, pl["nsplit"], self.n_params, _ptr(self.grads), st),
                   "dib_reduce_splits")
 
-    def adam_step(self, lr: float, beta1=0.9, beta2=0.999, eps=1e-7) -> None:
+    def set_lr(self, lr: float) -> None:
         self.lr_dev.fill_(float(lr))
+
+    def adam_step(self, lr: Optional[float] = None, beta1=0.9, beta2=0.999, eps=1e-7) -> None:
+        """lr None: the learning rate last set (set_lr) - a loop with a constant rate sets it once"""
+        if lr is not None:
+            self.lr_dev.fill_(float(lr))
         check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
                                      self.n_params, _ptr(self.lr_dev), _ptr(self.t_dev), beta1, beta2, eps, 1.0,
                                      self.eng._stream()), "dib_adam_step")

@@ -392,6 +392,10 @@ class HipEngine:
     def g_u(self, batch: int) -> torch.Tensor:
         return self.ws_view(batch, _lib.WS_G_U, batch * self.F * self.E).view(batch, self.F * self.E)
 
+    def g_pred(self, batch: int) -> torch.Tensor:
+        """dL/d(model output) [batch, out_dim]: what backward_from_pred_grad consumes (a view of the step workspace)."""
+        return self.ws_view(batch, _lib.WS_G_PRED, batch * self.out_dim).view(batch, self.out_dim)
+
     def step_out(self, batch: int) -> torch.Tensor:
         return self.ws_view(batch, _lib.WS_STEP_OUT, self.F + 3)
 
@@ -415,14 +419,20 @@ class HipEngine:
         return out
 
     def infonce(self, emb_x: torch.Tensor, emb_y: torch.Tensor, similarity: str = "l2", temperature: float = 1.0,
-                want_grads: bool = True):
-        """Symmetric InfoNCE (reference train.py:201-214, utils.py:131-175) -> (loss [1] device tensor, g_x, g_y)."""
+                want_grads: bool = True, out_gx: Optional[torch.Tensor] = None, out_gy: Optional[torch.Tensor] = None):
+        """Symmetric InfoNCE (reference train.py:201-214, utils.py:131-175) -> (loss [1] device tensor, g_x, g_y).
+        out_gx / out_gy: contiguous [B, D] tensors to receive the gradients (e.g. the model's dL/d(output) workspace view and
+        the Y encoder's gradient buffer: the training loop then needs no copies)."""
         emb_x, emb_y = emb_x.contiguous(), emb_y.contiguous()
         b, d = emb_x.shape
         ws = torch.empty(int(self.lib.dib_infonce_workspace_bytes(b)) // 4, dtype=torch.float32, device=self.device)
-        loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        gx = torch.empty_like(emb_x) if want_grads else None
-        gy = torch.empty_like(emb_y) if want_grads else None
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)   # always written by the library
+        gx = gy = None
+        if want_grads:
+            for o in (out_gx, out_gy):
+                assert o is None or (o.is_contiguous() and tuple(o.shape) == (b, d) and o.dtype == torch.float32)
+            gx = out_gx if out_gx is not None else torch.empty_like(emb_x)
+            gy = out_gy if out_gy is not None else torch.empty_like(emb_y)
         check(self.lib.dib_infonce_fwd_bwd(_ptr(emb_x), _ptr(emb_y), b, d, _lib.SIMILARITIES[similarity], float(temperature),
                                            _ptr(gx), _ptr(gy), _ptr(loss), _ptr(ws), self._stream()), "dib_infonce_fwd_bwd")
         return loss, gx, gy
@@ -432,7 +442,9 @@ class HipEngine:
         """Backward of the model given dL/d(model output) from a custom loss (reference train.py:216-219): the
         beta*KL term (models.py:118) is added inside the encoder-bank backward.  Gradients land in self.grads."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
-        self.ws_view(batch, _lib.WS_G_PRED, batch * self.out_dim).view(batch, self.out_dim).copy_(g_pred)
+        dst = self.g_pred(batch)
+        if g_pred.data_ptr() != dst.data_ptr():   # (a custom loss may have written its gradient straight into the view)
+            dst.copy_(g_pred)
         self.backward(row_idx, row0, batch, seed, step, inv)
 
     def mi_sandwich_bounds(self, enc_out: torch.Tensor, seed: int, step: int, feature: int):

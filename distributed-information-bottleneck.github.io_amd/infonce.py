@@ -139,14 +139,23 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
     assert batch_size % world == 0, "batch_size must be divisible by the number of ranks"
     B = batch_size // world
 
+    # the learning rate is constant over this loop (train.py:128-129): one device scalar per network, set once
+    eng.set_lr(learning_rate)
+    yenc.set_lr(learning_rate)
+
     def eval_batch(xs, ys, rows_np, training, step):
         idx = eng.to_device(rows_np[rank * B: (rank + 1) * B].astype(np.int32), dtype=torch.int32)
         eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training)  # noise always on (train.py:263-265)
         emb_x = eng.pred(B)
-        emb_y = yenc.forward(ys.index_select(0, idx.long()))
-        loss, gx, gy = infonce_data_parallel(
-            emb_x, emb_y, lambda a, b: eng.infonce(a, b, similarity, temperature, want_grads=training), dist)
-        kl = eng.step_out(B)[:F].clone() / B                       # kl_loss / beta (train.py:220), per feature
+        emb_y = yenc.forward(ys, rows=idx.long())                  # gathered straight into the encoder's workspace
+        if dist is None:   # the loss kernels write dL/d(embedding) where the two backward passes read it: no copies
+            loss, gx, gy = eng.infonce(emb_x, emb_y, similarity, temperature, want_grads=training,
+                                       out_gx=eng.g_pred(B) if training else None,
+                                       out_gy=yenc.output_grad_buffer() if training else None)
+        else:
+            loss, gx, gy = infonce_data_parallel(
+                emb_x, emb_y, lambda a, b: eng.infonce(a, b, similarity, temperature, want_grads=training), dist)
+        kl = eng.step_out(B)[:F] * (1.0 / B)                       # kl_loss / beta (train.py:220), per feature
         if dist is not None:
             dist.all_reduce(kl)
             kl /= world
@@ -156,9 +165,8 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
             if dist is not None:
                 dist.all_reduce(eng.grads)
                 dist.all_reduce(yenc.grads)
-            eng.set_lr(learning_rate)
             eng.adam_step()                                        # one Keras Adam over all variables (train.py:196,219)
-            yenc.adam_step(learning_rate)
+            yenc.adam_step()
         return loss, kl
 
     eng.set_beta(float(model.beta.value()))                        # the first step runs at the constructor's beta (models.py:86)
