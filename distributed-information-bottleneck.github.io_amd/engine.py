@@ -169,12 +169,17 @@ class HipEngine:
 
     def set_beta(self, v: float) -> None:
         self.beta_dev.fill_(float(v))
+        self._beta_host = float(v)
 
     def get_beta(self) -> float:
         return float(self.beta_dev.item())
 
     def set_lr(self, v: float) -> None:
-        self.lr_dev.fill_(float(v))
+        """device learning rate; a repeated value costs nothing (fit sets it every step - a 4 us fill kernel per step of the
+        reference's default 140 us B = 128 step otherwise)"""
+        if getattr(self, "_lr_host", None) != float(v):
+            self.lr_dev.fill_(float(v))
+            self._lr_host = float(v)
 
     def to_device(self, a, dtype=torch.float32) -> torch.Tensor:
         if isinstance(a, torch.Tensor):

@@ -55,7 +55,11 @@ def _device_eps(eng, rows, seed, step, check_rows=4096):
     eps = eng.eps(idx, 0, len(rows), seed, step).cpu()
     pick = np.random.default_rng(step).choice(len(rows), size=min(check_rows, len(rows)), replace=False)
     ref = orc.philox_normal_all(seed, step & 0xFFFFFFFF, rows[pick].astype(np.uint32), eng.F, eng.E)
-    assert np.abs(eps[pick].numpy() - ref).max() < 1e-5 * (1 + np.abs(ref).max()), "device Philox noise != oracle Philox noise"
+    # same Philox bits; the device evaluates Box-Muller in float32 with the hardware log / sqrt / sin / cos: mean |diff| 1e-7,
+    # and for u0 within a few ulp of 1 (z ~ 0) the float32 log leaves up to ~1e-4 ABSOLUTE (6.5e-5 seen on 2 M values) - with
+    # 96 rows the old 1e-5 bound never met such a value
+    d = np.abs(eps[pick].numpy() - ref)
+    assert d.mean() < 5e-7 and d.max() < 2e-4, ("device Philox noise != oracle Philox noise", float(d.mean()), float(d.max()))
     return eps.to(torch.float64)
 
 
