@@ -208,12 +208,21 @@ dib_infonce_lse_loss_kernel(const float* __restrict__ prow, const float* __restr
   const int t = idx < B ? idx : idx - B;
   float m = -INFINITY, sum = 0.f;
   if (ok) {
-    for (int b = part; b < nb32; b += 8) {
-      const float pm = p[(long long)b * B + t], ps = p[(long long)(nb32 + b) * B + t];
-      if (pm == -INFINITY) continue;
-      const float mn = fmaxf(m, pm);
-      sum = sum * expf(m - mn) + ps * expf(pm - mn);        // m = -inf on the first hit: sum = 0 * 0 + ...
-      m = mn;
+    for (int b0 = part; b0 < nb32; b0 += 32) {   // four partials per trip, their eight loads issued together (a load per
+      float pm[4], ps[4];                        // dependent trip made this kernel 14-20 us at B = 2048)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 8 * u;
+        pm[u] = b < nb32 ? p[(long long)b * B + t] : -INFINITY;
+        ps[u] = b < nb32 ? p[(long long)(nb32 + b) * B + t] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (pm[u] == -INFINITY) continue;
+        const float mn = fmaxf(m, pm[u]);
+        sum = sum * expf(m - mn) + ps[u] * expf(pm[u] - mn);   // m = -inf on the first hit: sum = 0 * 0 + ...
+        m = mn;
+      }
     }
   }
   pm_s[part][r] = m;

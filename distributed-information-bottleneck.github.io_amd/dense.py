@@ -102,7 +102,7 @@ class DenseStack:
 
     def forward(self, y: torch.Tensor, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[n, input_dim] -> [n, output_dim].  The result is a view into the plan's workspace: valid until the next forward
-        with the same batch size.  rows (int64 device tensor): encode y[rows] - gathered straight into the workspace."""
+        with the same batch size.  rows (int32 / int64 device tensor): encode y[rows] - gathered straight into the workspace."""
         y = y.to(device=self.device, dtype=torch.float32)
         n = y.shape[0] if rows is None else int(rows.shape[0])
         pl = self._plan(n)

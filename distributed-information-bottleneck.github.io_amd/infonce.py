@@ -147,7 +147,7 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
         idx = eng.to_device(rows_np[rank * B: (rank + 1) * B].astype(np.int32), dtype=torch.int32)
         eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training)  # noise always on (train.py:263-265)
         emb_x = eng.pred(B)
-        emb_y = yenc.forward(ys, rows=idx.long())                  # gathered straight into the encoder's workspace
+        emb_y = yenc.forward(ys, rows=idx)                         # gathered straight into the encoder's workspace
         if dist is None:   # the loss kernels write dL/d(embedding) where the two backward passes read it: no copies
             loss, gx, gy = eng.infonce(emb_x, emb_y, similarity, temperature, want_grads=training,
                                        out_gx=eng.g_pred(B) if training else None,
