@@ -115,8 +115,10 @@ struct dib_layout {
     // [F][B][2] x 64-bit act' masks (fused fwd -> fused bwd), one bit per hidden unit
     m.h2mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
     m.h1mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
-    // skinny output layer wgrad: row chunks of >= 64 rows, <= 512 chunks
-    m.skinny_rows = std::max(64, cdiv(B, 512));
+    // skinny output layer wgrad: row chunks of >= 64 rows (>= 16 up to B = 2048), <= 512 chunks
+    // (16-row chunks for small batches: with 64 the fused output head of the reference's default B = 128 step ran on 2
+    // workgroups, each wave walking 16 rows one after the other - 21 us, profiles/r04l_default_batch_kernel_stats.csv)
+    m.skinny_rows = std::max(B <= 2048 ? 16 : 64, cdiv(B, 512));
     m.skinny_chunks = cdiv(B, m.skinny_rows);
     {
       const int win = n_int == 0 ? F * E : int_units[n_int - 1];

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-4 GPU call L: kernel trace of the reference's default run (Boolean circuit, F = 10, B = 128) through fit
+export TMPDIR=/tmp
+R=$(pwd); O=$R/gpurun_out/r04l; mkdir -p $O
+cd /tmp
+DIB_SMALL_EPOCHS=50 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/tools/small_batch_bench.py > $O/kt.log 2>&1
+find $O/kt -mindepth 2 -type f -exec mv {} $O/kt/ \; 2>/dev/null
+cd $R
+tail -n 1 $O/kt.log
+python - <<'PY'
+import csv,glob
+f=glob.glob("gpurun_out/r04l/kt/kt_kernel_stats.csv")
+rows=list(csv.DictReader(open(f[0])))
+tot=sum(float(r["TotalDurationNs"]) for r in rows)
+pairs=(3+50)*8
+print("kernel us per (train + validation) step pair", round(tot/1e3/pairs,1))
+for r in rows[:30]: print("  ", r["Name"][:80].ljust(80), round(int(r["Calls"])/pairs,2), round(float(r["AverageNs"])/1e3,2), r["Percentage"])
+PY
