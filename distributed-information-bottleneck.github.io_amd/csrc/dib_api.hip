@@ -232,13 +232,16 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 #ifndef DIB_BK11
 #define DIB_BK11 32
 #endif
+#ifndef DIB_BK11D
+#define DIB_BK11D 32   // 64 x 64 dgrad tile
+#endif
 #ifndef DIB_BK212
 #define DIB_BK212 64   // 64x128 wgrad tile (the 256x256 integration layer): 0.136 -> 0.124 ms with 64-deep K-tiles (same-box A/B)
 #endif
 #ifndef DIB_BK22W
 #define DIB_BK22W 64   // A/B knob: K-tile depth of the 128 x 128 weight-gradient tile (32: half the LDS, 3-4 workgroups per CU)
 #endif
-  constexpr int BK = (NI == 2 && NJ == 2) ? (MODE == 2 ? DIB_BK22W : 64) : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
+  constexpr int BK = (NI == 2 && NJ == 2) ? (MODE == 2 ? DIB_BK22W : 64) : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((NI == 1 && NJ == 1 && MODE == 1) ? DIB_BK11D : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32)));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
   // cache policy of the streamed operands / outputs (dib_gemm.h: stream_flags): non-temporal from 8192 streamed rows up
   // (DIB_GEMM_STREAM_ROWS; M for forward / dgrad, the contracted rows for a weight gradient)
   const long long streamed_rows = MODE == 2 ? (long long)nsplit * rows_per_split : (long long)M;
