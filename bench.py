@@ -285,14 +285,31 @@ def fit_surface(dev, batch, engine_s_per_step):
             torch.cuda.synchronize()
             times.append(time.perf_counter() - self.t0)
 
+    torch.cuda.synchronize()
+    t_fit = time.perf_counter()
     hist = model.fit(x, y[:, 0], epochs=3, shuffle=True, batch_size=batch, callbacks=[cb, _Clock()], verbose=False)
+    torch.cuda.synchronize()
+    t_fit = time.perf_counter() - t_fit
     steps = N_ROWS // batch
     dt = statistics.median(times[1:]) / steps
+    # the boundary hands over HOST arrays: fit uploads the dataset once (it stays resident in HBM for every epoch) - the
+    # PCIe-inclusive rate is the whole call (upload + workspace allocation + first-touch + 3 epochs) over its 3 * steps steps
+    t0 = time.perf_counter()
+    xd = torch.from_numpy(x).to(dev)
+    torch.cuda.synchronize()
+    t_up = time.perf_counter() - t0
+    del xd
     return {"workload": f"DistributedIBNet.fit on BASELINE config 3: epochs of {steps} steps x {batch} rows, shuffle=True, "
                         "InfoBottleneckAnnealingCallback + History on; median of 2 timed epochs after 1 warm-up epoch",
             "value": round(batch / dt, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt, 4),
             "engine_ms_per_step": round(1e3 * engine_s_per_step, 4), "fit_over_engine": round(dt / engine_s_per_step, 4),
-            "epochs_ms": [round(1e3 * t, 2) for t in times], "final_loss": round(float(hist.history["loss"][-1]), 5)}
+            "epochs_ms": [round(1e3 * t, 2) for t in times], "final_loss": round(float(hist.history["loss"][-1]), 5),
+            "whole_call_incl_upload": {"ms": round(1e3 * t_fit, 2), "steps": 3 * steps,
+                                       "samples_per_s": round(3 * steps * batch / t_fit, 1),
+                                       "note": "model.fit from host numpy arrays to History, 3 epochs: dataset upload over PCIe, "
+                                               "workspace allocation and the warm-up epoch included - never the headline"},
+            "dataset_upload": {"bytes": int(x.nbytes), "ms": round(1e3 * t_up, 2), "GB_per_s": round(x.nbytes / t_up / 1e9, 2),
+                               "note": "pageable numpy -> HBM, once per fit"}}
 
 
 def config2_infonce_loop(dev, batch):
