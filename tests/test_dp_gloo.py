@@ -133,6 +133,77 @@ def test_infonce_data_parallel_gather_protocol(tmp_path):
     mp.spawn(_run_infonce_dp, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
 
 
+def _infonce_loop_case():
+    """pendulum-shaped toy of BASELINE config 2: features [2, 1, 2, 1] -> 6-d shared space, Y encoder 6 -> [8] -> 6."""
+    import dib_oracle as orc
+    spec = orc.DIBSpec([2, 1, 2, 1], [8], [8], 6, feature_embedding_dimension=3, number_positional_encoding_frequencies=3)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((64, 6)).astype(np.float32)
+    y = (x + 0.3 * rng.standard_normal((64, 6))).astype(np.float32)
+    xv, yv = x[:24] + 0.1, y[:24] - 0.1
+    y_in = 6 * 3                                                 # positional encoding: x and sin(f x) for 2 frequencies
+    yk = [rng.uniform(-0.4, 0.4, (y_in, 8)), rng.uniform(-0.4, 0.4, (8, 6))]
+    yb = [0.1 * rng.standard_normal(8), 0.1 * rng.standard_normal(6)]
+    kw = dict(batch_size=16, number_pretraining_epochs=2, number_annealing_epochs=3, beta_start=1e-3, beta_end=2.0)
+    return spec, orc.glorot_uniform_init(spec, 5), yk, yb, (x, y, xv, yv), kw
+
+
+def _run_infonce_loop(rank, world, port, out_dir):
+    """dib_amd.infonce.fit_infonce - the product's loop, data-parallel branch included - over the float64 checker engines
+    of tests/_oracle_infonce_engine.py."""
+    for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dib_amd
+    from dib_amd.infonce import fit_infonce
+    from _helpers import spec_kwargs
+    from _oracle_infonce_engine import CheckerXEngine, CheckerYEncoder
+    spec, xp, yk, yb, data, kw = _infonce_loop_case()
+    model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=21)
+    model._make_engine = lambda: CheckerXEngine(spec, xp)
+    yenc = CheckerYEncoder(yk, yb, "relu", True, 3)
+    out = fit_infonce(model, *data, learning_rate=2e-3, shared_dimensionality=6, similarity="l2", temperature=0.7, seed=4,
+                      output_encoder=yenc, **kw)
+    np.savez(os.path.join(out_dir, f"loop_w{world}_r{rank}.npz"), x_params=model._engine.flat_params(),
+             y_params=yenc.flat_params(), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_infonce_loop_data_parallel_equals_float64_loop_oracle(tmp_path):
+    """The COMPOSED custom loop (reference train.py:180-289) through the product's host code at world sizes 1, 2 and 4 against
+    the independent single-process float64 oracle of the loop: every series it returns and the final parameters of both
+    networks.  (The gather-protocol test above checks the sharded loss / gradient rows against a full-batch autograd; this
+    one checks what fit_infonce builds around it - shard selection, KL scaling by the GLOBAL batch, the two parameter
+    all-reduces, one Adam step per network per training step, validation without gradients, the beta hand-over.)"""
+    sys.path[:0] = [p for p in (os.path.join(os.path.dirname(HERE), "oracle"), HERE) if p not in sys.path]
+    from infonce_loop_oracle import InfoNCELoopOracle, YEncoder
+    spec, xp, yk, yb, data, kw = _infonce_loop_case()
+    oracle = InfoNCELoopOracle(spec, xp, YEncoder(yk, yb, "relu", True, 3), "l2", 0.7, 2e-3, noise_seed=21)
+    want = oracle.fit(*data, seed=4, **kw)
+    want_x = np.concatenate([t.detach().numpy().reshape(-1) for t in oracle.model.tensors()])
+    want_y = np.concatenate([t.detach().numpy().reshape(-1) for t in oracle.yenc.tensors()])
+    out = str(tmp_path)
+    _run_infonce_loop(0, 1, _free_port(), out)
+    mp.spawn(_run_infonce_loop, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_run_infonce_loop, args=(4, _free_port(), out), nprocs=4, join=True)
+    assert want["kl"].shape == (4, 4) and want["beta"][-1] > want["beta"][0]
+    for world in (1, 2, 4):
+        runs = [np.load(os.path.join(out, f"loop_w{world}_r{r}.npz")) for r in range(world)]
+        for r in runs:
+            assert np.array_equal(r["x_params"], runs[0]["x_params"]) and np.array_equal(r["y_params"], runs[0]["y_params"]), \
+                "ranks diverged"
+            for k in ("beta", "kl", "loss_infonce", "kl_validation", "loss_infonce_validation", "kl_total", "kl_total_validation"):
+                assert np.allclose(r[k], want[k], rtol=1e-9, atol=1e-11), (world, k, r[k], want[k])
+            assert np.allclose(r["x_params"], want_x, rtol=0, atol=1e-9) and np.allclose(r["y_params"], want_y, rtol=0, atol=1e-9)
+
+
 def _run_set_transformer_dp(rank, world, port, out_dir, batch):
     """SetTransformerDIB.train_step (notebook `train_step`, DP over neighbourhoods - BASELINE config 5) on the CPU checker
     backend: product host code, oracle arithmetic."""
