@@ -653,6 +653,27 @@ def test_science_level_si_circuit_information_allocation():
     assert kl[-1].sum() < 0.02 and abs(loss_bits[-1] - 0.811) < 0.05 and abs(acc[-1] - 0.75) < 1e-6
 
 
+def test_science_level_paper_circuit_gates_are_dropped_in_the_order_the_reference_notebook_printed():
+    """The paper's 10-input circuit (`train.py --dataset boolean_circuit`, reference data.py:21-81) through DistributedIBNet.fit
+    with the train.py architecture on a compressed schedule, against an outcome of the REFERENCE'S OWN TensorFlow run: cell 7 of
+    complex_systems/InfoDecomp_Boolean_circuits.ipynb printed "Sequence of selected subsets: [0 1 2 5 6 7 8 9], [0 1 2 5 7 8 9],
+    [2 5 7 8 9], [2 5 9], [2 9], [2], []" (threshold 0.1 bits) - gates {3, 4} lose their information first, then 6, then {0, 1},
+    then {7, 8}, then 5, then 9, gate 2 last.  Also: pre-training reaches accuracy 1, and at the end of the ramp every KL is 0 and
+    the loss is H(Y) = 0.758 bits (the notebook's "Entropy of Y", cell 5)."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location(
+        "paper_circuit_run", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "paper_circuit_run.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    for kw in (dict(epochs_pre=1000, beta_start=1e-5, seed=2), dict(epochs_pre=500, beta_start=1e-6, seed=4)):
+        drop, kl, loss_bits, acc, beta = mod.run(**kw)
+        pre = kw["epochs_pre"]
+        assert acc[pre - 1] == 1.0 and loss_bits[pre - 1] < 0.02, (kw, acc[pre - 1], loss_bits[pre - 1])
+        assert drop.min() > pre, (kw, drop)                                  # nothing is given up before the ramp starts
+        assert mod.group_order_violations(drop) == [], (kw, drop.tolist())
+        assert kl[-1].sum() < 0.02 and abs(loss_bits[-1] - 0.758) < 0.02, (kw, kl[-1].sum(), loss_bits[-1])
+
+
 def test_north_star_architecture_multi_step_trajectory():
     """The exact BASELINE config-3 architecture (F=64 scalar features, encoder [128,128], E=32, integration [256,256],
     1-unit logit; fused fwd/bwd + skinny output-layer kernels + split-batch wgrads + Keras-Adam) over 3 optimizer steps
