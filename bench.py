@@ -153,7 +153,27 @@ def _cpu_baseline_worker(threads, budget_s):
         if time.perf_counter() - t0 > budget_s / 2:
             break
     el = time.perf_counter() - t0
+    # the reference's own default size (train.py:30-34 on the Boolean circuit: F = 10, B = 128, BASELINE configs[0]) - a step is
+    # ~100 tiny eager ops, so fewer threads are faster: best of 1 and 4 threads, about 2 s each
+    small = {}
+    spec_s = orc.DIBSpec([1] * 10, ENC, INTEG, 1)
+    xs_, ys_ = synthetic(128, 10)
+    xs_, ys_, eps_s = torch.from_numpy(xs_), torch.from_numpy(ys_), torch.randn(128, 10, E)
+    for nt in (1, 4):
+        torch.set_num_threads(nt)
+        ms = TorchCpuDIB(spec_s, orc.glorot_uniform_init(spec_s, 0, dtype=np.float32))
+        for _ in range(3):
+            ms.train_step(xs_, ys_, eps_s, 1e-3, "bce_logits")
+        t1, n = time.perf_counter(), 0
+        while time.perf_counter() - t1 < 2.0:
+            ms.train_step(xs_, ys_, eps_s, 1e-3, "bce_logits")
+            n += 1
+        small[nt] = (time.perf_counter() - t1) / n
+    nt_best = min(small, key=small.get)
     print(json.dumps({"value": round(steps * b / el, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+                      "reference_default_size": {"workload": "F = 10, B = 128 training step (Boolean-circuit default of train.py)",
+                                                 "ms_per_train_step": round(1e3 * small[nt_best], 3), "cores": nt_best,
+                                                 "seconds_for_the_reference_88000_steps": round(small[nt_best] * 88000, 1)},
                       "sample": f"{steps} steps x {b} rows of the same 64-feature workload (fwd+KL+bwd+Keras-Adam), "
                                 f"PyTorch-CPU eager restatement of the TF graph (oracle/dib_torch_cpu.py; not "
                                 f"TensorFlow), {threads} threads of {os.cpu_count()} host cpus, {el:.1f}s"}))
