@@ -5,8 +5,10 @@ X is encoded by the DistributedIBNet (its output is the shared-space embedding),
 beta * sum KL (models.py:118).  Epoch bookkeeping follows the reference: full batches from a repeating shuffled
 stream, epoch boundaries at round(steps_per_epoch * epoch) (train.py:222-236), beta updated with numpy maths at each
 boundary (train.py:248), validation with noise on over number_full_validation_batches + 1 batches (train.py:230-234,
-262-268).  Differences, by intent: the tf.data shuffle buffer is replaced by seeded whole-dataset permutations, and
-`infonce_space_dimensionality` (a typo'd attribute in the reference) is the
+262-268).  The batch order is tf.data's `repeat().shuffle(min(n, 10_000)).batch(B)` (train.py:226-227: a 10 000-element shuffle
+buffer over the repeating SEQUENTIAL stream - `_BatchStream`); the validation dataset object is iterated afresh at every epoch
+boundary (train.py:262: a new iterator = the source restarts at row 0, the buffer is refilled and reshuffled).  One difference,
+by intent: `infonce_space_dimensionality` (a typo'd attribute in the reference) is the
 `--infonce_shared_dimensionality` flag.
 """
 from __future__ import annotations
@@ -19,18 +21,50 @@ import torch
 from .dense import DenseStack
 
 
-class _BatchStream:
-    """repeat().shuffle().batch(batch_size): endless full batches of row indices."""
+_IDX_BLOCK = 256          # training steps whose row indices travel to the device in one upload
+SHUFFLE_BUFFER = 10_000   # train.py:227,234: shuffle(min(dataset_length, 10_000))
 
-    def __init__(self, n: int, batch_size: int, seed: int):
-        self.n, self.bs, self.rng = n, batch_size, np.random.default_rng(seed)
-        self.buf = np.empty(0, dtype=np.int64)
+
+class _BatchStream:
+    """tf.data's `from_tensor_slices(...).repeat().shuffle(min(n, 10_000)).batch(batch_size)` (train.py:226-227, 233-234) as a
+    stream of dataset ROW INDICES: the source is the endless sequential stream 0, 1, ..., n-1, 0, 1, ... (repeat() comes BEFORE
+    shuffle(), so passes over the data blend into each other); the shuffle buffer is filled with its first min(n, 10_000)
+    elements; every draw emits a uniformly chosen slot of the buffer and refills that slot with the next element of the source.
+    So the element emitted as draw t comes from source positions < t + buffer: for a dataset larger than the buffer - the
+    pendulum's 240 000 time-ordered rows (data.py:122-123) - a batch's in-batch negatives all lie in a 10 000-row window
+    (+ batch) of the sequential order, and no source position is ever emitted twice or skipped.
+
+    Slots are drawn from numpy's default_rng(seed).integers(0, buffer) - one draw per emitted element, so the stream does not
+    depend on how many elements a call asks for (oracle/infonce_loop_oracle.BatchStream draws them one by one).  TensorFlow's
+    own Philox-seeded slot choice cannot be reproduced (and is unseeded in the reference): the DISTRIBUTION is tf.data's, the
+    random numbers are this project's."""
+
+    def __init__(self, n: int, batch_size: int, seed, buffer_size: int = SHUFFLE_BUFFER):
+        self.n, self.bs, self.rng = int(n), int(batch_size), np.random.default_rng(seed)
+        self.nbuf = min(self.n, int(buffer_size))
+        self.buf = np.arange(self.nbuf, dtype=np.int64) % self.n      # source positions 0 .. nbuf-1
+        self.pos = self.nbuf                                          # next source position
+
+    def draw(self, m: int) -> np.ndarray:
+        """the next m emitted row indices (vectorised form of m sequential draw-emit-refill steps)"""
+        slots = self.rng.integers(0, self.nbuf, size=m)
+        incoming = (self.pos + np.arange(m, dtype=np.int64)) % self.n
+        self.pos += m
+        # a slot drawn again inside this call holds the element an EARLIER draw of the call refilled it with
+        order = np.argsort(slots, kind="stable")
+        ss = slots[order]
+        again = np.flatnonzero(ss[1:] == ss[:-1]) + 1
+        out = self.buf[slots]
+        out[order[again]] = incoming[order[again - 1]]
+        self.buf[slots] = incoming            # duplicates: numpy keeps the last assignment = the last refill
+        return out
 
     def next(self) -> np.ndarray:
-        while len(self.buf) < self.bs:
-            self.buf = np.concatenate([self.buf, self.rng.permutation(self.n)])
-        out, self.buf = self.buf[: self.bs], self.buf[self.bs:]
-        return out
+        return self.draw(self.bs)
+
+    def next_batches(self, k: int) -> np.ndarray:
+        """[k, batch_size]: the next k batches in one call (one host-to-device upload for k steps)"""
+        return self.draw(k * self.bs).reshape(k, self.bs)
 
 
 def _dist():
@@ -115,12 +149,14 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
                 y_encoder_architecture=(128, 128), shared_dimensionality: int = 64, similarity: str = 'l2',
                 temperature: float = 1.0, use_positional_encoding: bool = True,
                 number_positional_encoding_frequencies: int = 5, activation_fn: Optional[str] = 'relu', seed: int = 0,
-                epoch_callback=None, output_encoder: Optional[DenseStack] = None) -> Dict[str, np.ndarray]:
+                epoch_callback=None, output_encoder: Optional[DenseStack] = None,
+                shuffle_buffer: int = SHUFFLE_BUFFER) -> Dict[str, np.ndarray]:
     """Returns dict(beta, kl [epochs-1, F] nats, loss_infonce, kl_validation, loss_infonce_validation) - the series the
     reference builds at train.py:237-279 (before its conversion to bits) - plus kl_total / kl_total_validation.
     The reference's own KL series is `kl_loss / model.beta` with kl_loss = model.losses, the one-element list
     [beta * sum_f KL_f] (models.py:118): ITS series are the row sums kl_total; the per-feature columns are this project's
-    superset.  `output_encoder`: a pre-built Y encoder (default: a fresh DenseStack seeded with seed + 1)."""
+    superset.  `output_encoder`: a pre-built Y encoder (default: a fresh DenseStack seeded with seed + 1).  `shuffle_buffer`: the
+    reference's 10 000 (train.py:227); tools/stream_effect.py passes the dataset length to measure what the buffer does."""
     eng = model._ensure_engine()
     assert model.output_dimensionality == shared_dimensionality, "model output must be the shared embedding space"
     F = model.number_features
@@ -131,20 +167,39 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
         use_positional_encoding, number_positional_encoding_frequencies, seed=seed + 1)
     model.output_encoder = yenc
     n, nv = xd.shape[0], xvd.shape[0]
-    stream, vstream = _BatchStream(n, batch_size, seed), _BatchStream(nv, batch_size, seed + 7)
     # data parallel (one process per GPU): every rank draws the same global batch (same seed) and takes its row shard;
     # embeddings are all-gathered for the in-batch negatives, parameter gradients all-reduced (sum)
     dist = _dist()
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
     assert batch_size % world == 0, "batch_size must be divisible by the number of ranks"
     B = batch_size // world
+    shard = slice(rank * B, (rank + 1) * B)
+    n_val_batches = nv // batch_size + 1
+    # batch order (see _BatchStream).  Row indices go to the device a block of steps at a time - one upload per _IDX_BLOCK
+    # training steps / per validation pass instead of one per step.
+    stream = _BatchStream(n, batch_size, seed, shuffle_buffer)
+    train_idx = dict(first=0, dev=None)
+    val_idx = dict(epoch=None, dev=None)
+
+    def train_rows(step_num):
+        k = step_num - train_idx["first"]
+        if train_idx["dev"] is None or k >= train_idx["dev"].shape[0]:
+            blk = np.ascontiguousarray(stream.next_batches(_IDX_BLOCK)[:, shard]).astype(np.int32)
+            train_idx["first"], train_idx["dev"], k = step_num, eng.to_device(blk, dtype=torch.int32), 0
+        return train_idx["dev"][k]
+
+    def validation_rows(epoch_num, vb):
+        if val_idx["epoch"] != epoch_num:      # `for ... in tf_dataset_validation` (train.py:262): a fresh iterator per pass
+            blk = _BatchStream(nv, batch_size, [seed + 7, epoch_num], shuffle_buffer).next_batches(n_val_batches)
+            val_idx["epoch"] = epoch_num
+            val_idx["dev"] = eng.to_device(np.ascontiguousarray(blk[:, shard]).astype(np.int32), dtype=torch.int32)
+        return val_idx["dev"][vb]
 
     # the learning rate is constant over this loop (train.py:128-129): one device scalar per network, set once
     eng.set_lr(learning_rate)
     yenc.set_lr(learning_rate)
 
-    def eval_batch(xs, ys, rows_np, training, step):
-        idx = eng.to_device(rows_np[rank * B: (rank + 1) * B].astype(np.int32), dtype=torch.int32)
+    def eval_batch(xs, ys, idx, training, step):
         eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training)  # noise always on (train.py:263-265)
         emb_x = eng.pred(B)
         emb_y = yenc.forward(ys, rows=idx)                         # gathered straight into the encoder's workspace
@@ -173,8 +228,9 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
     out = run_custom_loop(
         dataset_length=n, validation_set_length=nv, batch_size=batch_size, number_pretraining_epochs=number_pretraining_epochs,
         number_annealing_epochs=number_annealing_epochs, beta_start=beta_start, beta_end=beta_end,
-        train_step=lambda step_num: eval_batch(xd, yd, stream.next(), True, step_num),
-        validation_step=lambda epoch_num, vb: eval_batch(xvd, yvd, vstream.next(), False, (1 << 31) + epoch_num * 1024 + vb),
+        train_step=lambda step_num: eval_batch(xd, yd, train_rows(step_num), True, step_num),
+        validation_step=lambda epoch_num, vb: eval_batch(xvd, yvd, validation_rows(epoch_num, vb), False,
+                                                         (1 << 31) + epoch_num * 1024 + vb),
         assign_beta=model.beta.assign,
         epoch_callback=(lambda e: epoch_callback(e, model)) if epoch_callback is not None else None)
     out['kl_total'], out['kl_total_validation'] = out['kl'].sum(-1), out['kl_validation'].sum(-1)

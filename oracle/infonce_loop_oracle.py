@@ -18,9 +18,11 @@ PARITY PINNING STATUS
     constructor's beta = 1 (models.py:86), non-integer steps_per_epoch with banker's rounding, E - 1 recorded epochs.
   * The similarity functions are pinned on utils.py:75-175 executed (tests/golden/models_forward.npz, round 2).
   * tf.data's shuffle-buffer order, tf.random.normal's stream and Keras Adam internals cannot be executed here (no
-    TensorFlow): the batch order is the product's documented convention (`BatchStream`, restated below), the noise is the
-    counter-based Philox stream shared by product and oracle, Adam is the Keras form restated from its documentation -
-    parity unpinned for those three, as everywhere else in this repo.
+    TensorFlow): the batch order follows tf.data's documented shuffle-buffer ALGORITHM (`BatchStream`: buffer of min(n, 10 000)
+    over the repeating sequential stream, uniform slot, refill; the validation dataset re-iterated from row 0 at every
+    boundary) with numpy's random numbers in place of TensorFlow's, the noise is the counter-based Philox stream shared by
+    product and oracle, Adam is the Keras form restated from its documentation - parity unpinned for those three, as
+    everywhere else in this repo.
   * One deliberate superset: the reference's `kl_loss / model.beta` is the ONE-element list [sum_f KL_f] (model.losses holds a
     single add_loss term), so its kl series are [epochs-1, 1]; product and oracle record the per-feature vector [epochs-1, F]
     whose row sums are the reference's series (`kl_total`).
@@ -38,20 +40,26 @@ from dib_torch_cpu import TorchCpuDIB, _act, scaled_similarity_torch
 
 
 class BatchStream:
-    """tf_dataset.repeat().shuffle(min(n, 10_000)).batch(batch_size) (train.py:226-227) as the product defines it: endless full
-    batches of row indices cut from concatenated whole-dataset permutations of numpy's default_rng(seed)."""
+    """tf_dataset.repeat().shuffle(min(n, 10_000)).batch(batch_size) (train.py:226-227, 233-234), literally, one element at a
+    time: the source is the sequential, repeating stream of dataset rows 0, 1, ..., n-1, 0, 1, ...; tf.data's shuffle holds a
+    buffer of min(n, 10_000) elements, filled from the source in order; each output element is a uniformly chosen slot of the
+    buffer, and that slot is refilled with the next source element.  (TensorFlow's own random numbers are not reproducible
+    here - and unseeded in the reference: slot j of draw t = default_rng(seed).integers(0, buffer), the t-th call.)"""
 
-    def __init__(self, n: int, batch_size: int, seed: int):
+    def __init__(self, n: int, batch_size: int, seed, buffer_size: int = 10_000):
         self.n, self.bs = int(n), int(batch_size)
         self.rng = np.random.default_rng(seed)
-        self.pending = np.zeros(0, dtype=np.int64)
+        self.buffer: List[int] = [i % self.n for i in range(min(self.n, int(buffer_size)))]
+        self.source_position = len(self.buffer)
 
     def next(self) -> np.ndarray:
-        while self.pending.size < self.bs:
-            self.pending = np.concatenate([self.pending, self.rng.permutation(self.n)])
-        batch = self.pending[: self.bs]
-        self.pending = self.pending[self.bs:]
-        return batch
+        batch = []
+        for _ in range(self.bs):
+            slot = int(self.rng.integers(0, len(self.buffer)))
+            batch.append(self.buffer[slot])
+            self.buffer[slot] = self.source_position % self.n
+            self.source_position += 1
+        return np.asarray(batch, dtype=np.int64)
 
 
 def beta_at_boundary(epoch_num: int, beta_start: float, beta_end: float, number_pretraining_epochs: int,
@@ -129,7 +137,9 @@ class YEncoder:
 class InfoNCELoopOracle:
     """eval_batch_infonce (train.py:201-220) + the loop, float64, with the product's noise / batch-order conventions:
     eps keyed by (noise_seed, step key, DATASET row, feature, dim); training step key = step_num, validation step key =
-    2^31 + 1024 * epoch_num + batch_number; BatchStream(seed) for training rows and BatchStream(seed + 7) for validation."""
+    2^31 + 1024 * epoch_num + batch_number; ONE BatchStream(seed) for the training rows of the whole run; the validation
+    dataset object is iterated anew at every boundary (`for ... in tf_dataset_validation`, train.py:262): a fresh
+    BatchStream([seed + 7, epoch_num]) per validation pass, source restarting at row 0."""
 
     def __init__(self, spec: orc.DIBSpec, x_params: orc.DIBParams, y_encoder: YEncoder, similarity: str, temperature: float,
                  learning_rate: float, noise_seed: int, dtype=torch.float64):
@@ -192,13 +202,21 @@ class InfoNCELoopOracle:
             on_boundary: Optional[Callable[[int], None]] = None) -> Dict[str, np.ndarray]:
         x_train, y_train, x_valid, y_valid = [np.asarray(a, dtype=np.float32).astype(np.float64)
                                               for a in (x_train, y_train, x_valid, y_valid)]
-        stream, vstream = BatchStream(len(x_train), batch_size, seed), BatchStream(len(x_valid), batch_size, seed + 7)
+        stream = BatchStream(len(x_train), batch_size, seed)
+        vstreams: Dict[int, BatchStream] = {}
+
+        def validation_rows(ep: int) -> np.ndarray:
+            if ep not in vstreams:
+                vstreams.clear()
+                vstreams[ep] = BatchStream(len(x_valid), batch_size, [seed + 7, ep])
+            return vstreams[ep].next()
+
         out = run_loop(
             dataset_length=len(x_train), validation_set_length=len(x_valid), batch_size=batch_size,
             number_pretraining_epochs=number_pretraining_epochs, number_annealing_epochs=number_annealing_epochs,
             beta_start=beta_start, beta_end=beta_end,
             train_step=lambda step: self.eval_batch(x_train, y_train, stream.next(), step, True),
-            validation_step=lambda ep, vb: self.eval_batch(x_valid, y_valid, vstream.next(), (1 << 31) + ep * 1024 + vb, False),
+            validation_step=lambda ep, vb: self.eval_batch(x_valid, y_valid, validation_rows(ep), (1 << 31) + ep * 1024 + vb, False),
             assign_beta=self.assign_beta, on_boundary=on_boundary)
         out["kl_total"] = out["kl"].sum(-1)                                                  # the reference's [sum_f KL_f] series
         out["kl_total_validation"] = out["kl_validation"].sum(-1)

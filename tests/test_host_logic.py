@@ -360,3 +360,64 @@ def test_streaming_projection_launch_record_only_claims_shapes_the_kernel_covers
     assert not _SkinnyKGemm.fits(0, [ok[0], dict(ok[0], M=2048)])         # all groups share M, N, K
     rec = _SkinnyKGemm(0, ok, None, None, None)
     assert (rec.mode, rec.n, rec.max_m, rec.max_n) == (0, 3, 4096, 1536) and rec.host["K"].tolist() == [32, 32, 32]
+
+
+def test_batch_stream_is_tf_data_shuffle_buffer_over_the_repeating_sequential_stream():
+    """reference train.py:226-227 / 233-234: `from_tensor_slices(...).repeat().shuffle(min(n, 10_000)).batch(B)` - a 10 000-element
+    shuffle BUFFER over the sequential, repeating stream, not a permutation of the dataset (VERDICT r04 missing item 2).  The
+    pendulum rows are time-ordered, trajectory after trajectory (data.py:122-123): a batch's in-batch negatives come from a
+    window of the sequential order.  Checked: (1) the product's vectorised stream = the oracle's one-element-at-a-time restatement
+    of tf.data's algorithm, however the draws are grouped into calls; (2) the conservation law of a shuffle buffer - emitted
+    elements + buffer content = a prefix of the source, nothing skipped, nothing twice; (3) draw t never runs ahead of source
+    position t + buffer, and the time an element waits in the buffer is geometric with mean = buffer; (4) a dataset that fits
+    the buffer is NOT reshuffled pass by pass either: repeat() comes first, so passes blend - the first draw is uniform over the
+    whole dataset, a row can recur before every row was seen, but the counts stay balanced by the conservation law."""
+    from collections import Counter
+    from dib_amd.infonce import SHUFFLE_BUFFER, _BatchStream
+    from infonce_loop_oracle import BatchStream
+    assert SHUFFLE_BUFFER == 10_000
+    # (1) product == literal restatement, any call grouping
+    for n, bs, nbuf in ((50, 16, 10_000), (7, 5, 10_000), (1000, 128, 100), (30_000, 64, 10_000), (5, 64, 3)):
+        lit = BatchStream(n, bs, 3, nbuf)
+        want = np.stack([lit.next() for _ in range(40)])
+        a = _BatchStream(n, bs, 3, nbuf)
+        assert np.array_equal(np.stack([a.next() for _ in range(40)]), want)
+        b = _BatchStream(n, bs, 3, nbuf)
+        assert np.array_equal(np.concatenate([b.next_batches(7), b.next_batches(1), b.next_batches(32)]), want)
+        assert sorted(b.buf.tolist()) == sorted(lit.buffer) and b.pos == lit.source_position
+    # (2) + (3): the pendulum's size, ordered rows (row index = source position for the first pass)
+    n, bs, nb = 240_000, 128, 500
+    s = _BatchStream(n, bs, 11)
+    assert s.nbuf == 10_000
+    rows = s.next_batches(nb)
+    T = nb * bs
+    assert T + s.nbuf <= n                                         # still in the first pass: rows ARE source positions
+    flat = rows.reshape(-1)
+    assert np.array_equal(np.sort(np.concatenate([flat, s.buf])), np.arange(T + s.nbuf))
+    t = np.arange(T)
+    assert (flat < t + s.nbuf).all()                               # never ahead of the source
+    lag = t + s.nbuf - 1 - flat                                    # draws an element waited beyond the minimum
+    steady = lag[5 * s.nbuf:]
+    assert abs(steady.mean() / s.nbuf - 1.0) < 0.06                # geometric residence, mean = buffer size
+    # every batch lives in a window of the sequential order: >= 90 % of its rows within the newest 4 buffers
+    in_window = (lag.reshape(nb, bs) < 4 * s.nbuf).mean(axis=1)
+    assert in_window.min() >= 0.9, in_window.min()
+    # a permutation of the dataset would spread a batch over all 240 000 rows: here its spread is a few buffers
+    spread = np.median(rows.max(axis=1) - rows.min(axis=1))
+    assert spread < 6 * s.nbuf, spread
+    # (4) dataset smaller than the buffer: buffer = n, conservation law across many passes, passes blend
+    n, bs = 300, 32
+    s = _BatchStream(n, bs, 5)
+    assert s.nbuf == n
+    out = s.next_batches(200).reshape(-1)
+    have = Counter(out.tolist()) + Counter(s.buf.tolist())
+    want = Counter((np.arange(len(out) + n) % n).tolist())
+    assert have == want
+    firsts = {int(_BatchStream(n, bs, k).next()[0]) for k in range(200)}
+    assert len(firsts) > 100 and max(firsts) > 250                 # first draw: anywhere in the dataset
+    first_pass = out[:n]
+    assert len(set(first_pass.tolist())) < n                       # not a permutation: repeat() precedes shuffle()
+    # the validation pass of every boundary is a fresh iterator (train.py:262): same rows reachable, different order
+    v0 = _BatchStream(5000, 128, [7, 0]).next_batches(40)
+    v1 = _BatchStream(5000, 128, [7, 1]).next_batches(40)
+    assert not np.array_equal(v0, v1) and v0.max() < 5000
