@@ -431,6 +431,52 @@ def test_info_per_feature_callback_and_train_script(tmp_path):
     assert (b[:, 1] <= np.log(2) + 0.2).all()  # a binary input carries at most 1 bit
 
 
+def test_ib_flag_one_wide_feature_on_the_boolean_circuit(tmp_path):
+    """reference train.py:111-113 `--ib`: "just treat everything as one feature" - the Boolean circuit's ten +-1 inputs become ONE
+    feature of width 10, positionally encoded to a 50-wide encoder input (beyond the fused encoder kernels' 16 columns: the
+    grouped-GEMM path with ONE group), train.py's default architecture otherwise.  (1) forward, the single KL, the task loss and
+    every gradient block on a batch of circuit rows against the oracle; (2) `python -m dib_amd.train --ib True` end to end: the
+    History has KL0 and nothing else, the net learns the circuit during pre-training and pays for it with one channel."""
+    import dib_amd
+    from dib_amd import train
+    d = dib_amd.data.fetch_boolean_circuit()
+    spec = orc.DIBSpec([int(np.sum(d["feature_dimensionalities"]))], [128, 128], [256, 256], 1, feature_embedding_dimension=32)
+    assert spec.feature_dimensionalities == [10]
+    eng, p = _engine(spec, seed=3)
+    assert eng.F == 1 and eng.sum_d == 10
+    B, beta, seed, step = 128, 0.05, 9, 2
+    x, y = np.asarray(d["x_train"], dtype=np.float32), np.asarray(d["y_train"], dtype=np.float32).reshape(-1, 1)
+    rows = np.random.default_rng(1).permutation(len(x))[:B].astype(np.int32)
+    eng.set_beta(beta)
+    eng.train_step(eng.to_device(x), eng.to_device(y), eng.to_device(rows, dtype=torch.int32), 0, B, seed, step, "bce_logits")
+    torch.cuda.synchronize()
+    c = orc.forward(spec, p, x[rows].astype(np.float64), orc.philox_normal_all(seed, step, rows, 1, 32))
+    task, grads, g_u = orc.backward(spec, p, x[rows].astype(np.float64), y[rows], c, beta, "bce_logits")
+    close = lambda got, ref, tol=2e-4: np.abs(np.asarray(got, dtype=np.float64) - ref).max() <= tol * (1.0 + np.abs(ref).max())
+    enc_out = eng.enc_out(B).cpu().numpy()
+    assert close(enc_out[:, :, :32], c.mu) and close(enc_out[:, :, 32:], c.logvar) and close(eng.u(B).cpu().numpy(), c.u)
+    assert close(eng.pred(B).cpu().numpy(), c.pred)
+    so = eng.step_out(B).cpu().numpy()
+    assert c.kl.shape == (1,) and abs(so[0] / B - c.kl[0]) < 1e-3, "the one KL (nats)"
+    assert abs(so[1] / B - task) < 2e-4 * (1 + abs(task)) and so[3] == B
+    assert close(eng.g_u(B).cpu().numpy(), g_u, 3e-4)
+    gflat = eng.get_flat_grads()
+    gref = params_to_flat(eng.blocks, grads, eng.params.numel()).astype(np.float64)
+    assert [b["rows"] for b in eng.blocks if b["net"] == 0 and b["layer"] == 0 and b["what"] == 0] == [50]
+    for b in eng.blocks:
+        sl = slice(b["offset"], b["offset"] + b["rows"] * b["cols"])
+        err = np.abs(gflat[sl] - gref[sl]).max()
+        assert err <= 3e-4 * (np.abs(gref[sl]).max() + 1e-3), (b, err)
+    hist = train.main(["--dataset", "boolean_circuit", "--ib", "True", "--number_pretraining_epochs", "300",
+                       "--number_annealing_epochs", "200", "--beta_start", "1e-5", "--beta_end", "5", "--learning_rate", "1e-3",
+                       "--batch_size", "128", "--artifact_outdir", str(tmp_path)]).history
+    assert sorted(k for k in hist if "KL" in k) == ["KL0", "val_KL0"] and len(hist["loss"]) == 500
+    assert hist["accuracy"][299] >= 0.98, hist["accuracy"][299]            # the truth table is learnt through one channel
+    assert hist["KL0"][299] > 0.758 * np.log(2) - 0.1                        # ... which must carry about H(Y) = 0.758 bits at least
+    assert hist["KL0"][-1] < 0.02 and abs(hist["loss"][-1] / np.log(2) - 0.758) < 0.03   # and is closed by the end of the ramp
+    assert os.path.exists(os.path.join(str(tmp_path), "distributed_info_plane.png"))
+
+
 @pytest.mark.parametrize("kind", ["l2sq", "l2", "l1", "linf", "cosine"])
 def test_infonce_loss_and_grads_match_oracle(kind):
     """dib_infonce_fwd_bwd vs the numpy restatement of train.py:203-215 / utils.py:131-175 (grads by central differences)."""
@@ -672,6 +718,17 @@ def test_science_level_paper_circuit_gates_are_dropped_in_the_order_the_referenc
         assert drop.min() > pre, (kw, drop)                                  # nothing is given up before the ramp starts
         assert mod.group_order_violations(drop) == [], (kw, drop.tolist())
         assert kl[-1].sum() < 0.02 and abs(loss_bits[-1] - 0.758) < 0.02, (kw, kl[-1].sum(), loss_bits[-1])
+        # the exhaustive subset informations I(X_S;Y) of Boolean_circuits.ipynb:425-434 (the notebook's own statements
+        # executed: tests/golden/subset_mi.npz) are a CEILING on the info-plane point of every recorded epoch - the predictive
+        # information H(Y) - loss can never exceed what the gates still being transmitted carry about Y (plus the few hundredths
+        # of a bit the nearly-closed channels may leak, bounded by their KL).  0.03 bits: sampling noise of one epoch's draws.
+        fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "subset_mi.npz"))
+        info = {int((c.astype(np.int64) << np.arange(10)).sum()): float(v) for c, v in zip(fx["all_on_off_combos"], fx["all_mis_bits"])}
+        excess, masks = mod.info_ceiling_excess(kl, loss_bits, info, float(fx["entropy_y_bits"]))
+        assert excess[5:].max() <= 0.03, (kw, float(excess.max()), int(excess.argmax()), bin(int(masks[excess.argmax()])))
+        assert len(set(masks.tolist())) >= 6                                 # the ramp walks through a sequence of subsets
+        late = masks[-1] == 0 and abs((float(fx["entropy_y_bits"]) - loss_bits[-1])) < 0.02
+        assert late, (kw, masks[-1], loss_bits[-1])                          # empty subset at the end: no predictive information
 
 
 def test_north_star_architecture_multi_step_trajectory():

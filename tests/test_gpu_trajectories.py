@@ -15,10 +15,11 @@ test makes two comparisons of the device's ONE free-running trajectory:
       step count (downloaded there) and runs the NEXT epoch's steps and validation from that state.  Every step of the
       device's own trajectory through the whole ramp is checked - 8 (4) consecutive steps at a time from a common state -
       at tolerances far INSIDE the BASELINE bar: KL 3e-4 nats absolute, losses 5e-4 relative;
-  (b) free-running float64 checker, no synchronisation: every KL within 2e-2 nats over the whole run (same basin, same
-      collapse; KL values reach 3-7 nats), and the test PRINTS the first epoch - if any - at which the 1e-3 bar is exceeded
-      next to the first epoch at which the checker's own float32 twin has left its float64 run by 1e-5: where float32
-      arithmetic stops determining the trajectory, whose last bits decide is not a property of either implementation."""
+  (b) free-running float64 checker, no synchronisation: every KL within the BASELINE bar, 1e-3 nats, for every epoch BEFORE
+      the first one at which the checker's own float32 twin has left its float64 run by 1e-5 (where float32 arithmetic stops
+      determining the trajectory, whose last bits decide is not a property of either implementation), and within 2e-2 nats
+      over the rest of the run (same basin, same collapse; KL values reach 3-7 nats); the test prints the first epoch - if
+      any - above the 1e-3 bar next to the twin's divergence epoch."""
 import numpy as np
 import pytest
 import torch
@@ -38,14 +39,20 @@ def _close(name, got, want, tol_abs=0.0, tol_rel=0.0):
 
 
 def _free_running(name, got, want, want32, loose):
-    """(b) of the module docstring.  Returns (max error, first epoch with an error above the 1e-3 bar or None, first epoch where
-    the checker's own float32 twin is more than 1e-5 from its float64 run or None)."""
+    """(b) of the module docstring: the BASELINE bar - 1e-3 nats - is ASSERTED on the free-running trajectory for every epoch
+    before the one at which the checker's own float32 twin has left its float64 run by 1e-5 (from there on float32 round-off,
+    not the implementation, decides the path); `loose` holds afterwards.  Returns (max error, first epoch with an error above
+    the 1e-3 bar or None, the twin's divergence epoch or None)."""
     got, want, want32 = [np.asarray(a, dtype=np.float64) for a in (got, want, want32)]
     err = np.abs(got - want).reshape(len(want), -1).max(1)
     amb = np.abs(want - want32).reshape(len(want), -1).max(1)
-    assert (err <= loose).all(), (name, "free-running", float(err.max()), int(np.argmax(err)))
     first = lambda mask: int(np.argmax(mask)) if mask.any() else None
-    return float(err.max()), first(err > 1e-3), first(amb > 1e-5)
+    parts = first(amb > 1e-5)
+    determined = len(err) if parts is None else parts
+    assert (err[:determined] <= 1e-3).all(), (name, "free-running, epochs float32 still determines", float(err[:determined].max()),
+                                              int(np.argmax(err[:determined])), "twin parts at", parts)
+    assert (err <= loose).all(), (name, "free-running", float(err.max()), int(np.argmax(err)))
+    return float(err.max()), first(err > 1e-3), parts
 
 
 def _displacement_error(name, got, want, start):
@@ -123,7 +130,7 @@ def test_infonce_loop_trajectory_matches_float64_oracle(tmp_path, batch_size, ro
                for i, (a, b, c) in enumerate(zip(final[0], o.vars, snaps[12][0])))
     # ---- (b) free-running float64 checker (and its float32 twin, to know where float32 stops determining the trajectory) ----
     free, _ = oracle(torch.float64, False)
-    free32 = oracle(torch.float32, False)[0] if batch_size == 128 else free   # the twin is reporting only: one case is enough
+    free32 = oracle(torch.float32, False)[0]
     fr = {k: _free_running(k, got[k], free[k], free32[k], loose=2e-2) for k in ("kl", "kl_validation")}
     print("epoch-synchronised max errors:", {k: f"{v:.2e}" for k, v in errs.items()}, "final parameters (rms error / rms "
           f"displacement over the last 7 steps): {perr:.2e};",

@@ -315,3 +315,30 @@ def test_infonce_loop_oracle_runs_the_composed_step():
     assert out["loss_infonce"][-1] < out["loss_infonce"][0]
     assert all(float((a - b.detach()).abs().max()) > 0 for a, b in zip(w0, ye.tensors()))
     assert all(float(v.abs().max()) > 0 for v in o.m)
+
+
+def test_subset_informations_match_the_notebook_statements_executed():
+    """Boolean_circuits.ipynb:425-434 - the exhaustive I(X_S;Y) over all 2^10 subsets of the paper circuit's input gates, the
+    notebook's own compute_info / meshgrid statements executed (tests/golden/make_golden_subset_mi.py) - against the oracle's
+    restatement on the product's truth table (dib_amd.data.fetch_boolean_circuit) and against the table the GPU KAT's ceiling
+    uses (tools/paper_circuit_run.subset_information_bits)."""
+    import importlib.util
+    import dib_amd
+    fx = np.load(os.path.join(GOLD, "subset_mi.npz"))
+    d = dib_amd.data.fetch_boolean_circuit()
+    x, y = np.asarray(d["x_train"]), np.asarray(d["y_train"]).reshape(-1).astype(np.int64)
+    tt = fx["truth_table"]
+    assert np.array_equal((x > 0).astype(np.int8), tt[:, :10]) and np.array_equal(y, tt[:, 10])
+    assert abs(float(fx["entropy_y_bits"]) - 0.7578784625) < 1e-9
+    combos, want = fx["all_on_off_combos"], fx["all_mis_bits"]
+    spec_ = importlib.util.spec_from_file_location("paper_circuit_run", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "paper_circuit_run.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    table = mod.subset_information_bits(x, y)
+    for k in range(0, 1024, 7):
+        s = [int(i) for i in np.where(combos[k])[0]]
+        assert abs(orc.subset_mutual_information_bits(x, y, s) - want[k]) < 1e-12, s
+    for c, w in zip(combos, want):
+        assert abs(table[int((c.astype(np.int64) << np.arange(10)).sum())] - w) < 1e-12
+    # monotone in the subset (more gates never carry less) and the full set carries all of H(Y)
+    assert abs(want[-1] - float(fx["entropy_y_bits"])) < 1e-12 and want[0] == 0

@@ -48,8 +48,37 @@ def group_order_violations(drop, slack=0):
     return bad
 
 
+def subset_information_bits(x, y):
+    """{bitmask of kept gates (bit i = gate i): I(X_S;Y) in bits} for all 2^10 subsets of the uniform truth table (the quantity
+    of Boolean_circuits.ipynb:425-434; the tests use the notebook's own numbers, tests/golden/subset_mi.npz)."""
+    bits = (np.asarray(x) > 0).astype(np.int64)
+    y = np.asarray(y).reshape(-1).astype(np.int64)
+    n, G = bits.shape
+    h = lambda c: float(-(c[c > 0] / n * np.log2(c[c > 0] / n)).sum())
+    out = {}
+    for mask in range(1 << G):
+        key = (bits[:, [i for i in range(G) if mask >> i & 1]] @ (1 << np.arange(bin(mask).count("1")))) if mask else np.zeros(n, np.int64)
+        out[mask] = h(np.bincount(key)) + h(np.bincount(y)) - h(np.bincount(key * 2 + y))
+    return out
+
+
+def info_ceiling_excess(kl_bits, loss_bits, subset_info, entropy_y_bits, kept_threshold_bits=0.02):
+    """Data-processing ceiling on every recorded epoch.  With S = the gates whose encoders still transmit
+    (KL_i > kept_threshold_bits; KL_i upper-bounds I(U_i;X_i)):
+        H(Y) - task loss  <=  I(U;Y)  <=  I(X_S;Y) + sum_{i not in S} KL_i
+    (cross-entropy >= H(Y|U); chain rule + I(U_i;Y|.) <= I(U_i;X_i) <= KL_i for the gates outside S).  Returns per epoch
+    (H(Y) - loss) - ceiling: positive values are violations (up to the sampling noise of one epoch of reparameterised draws)."""
+    kl_bits, loss_bits = np.asarray(kl_bits, dtype=np.float64), np.asarray(loss_bits, dtype=np.float64)
+    kept = kl_bits > kept_threshold_bits
+    masks = (kept.astype(np.int64) << np.arange(kl_bits.shape[1])).sum(1)
+    ceiling = np.array([subset_info[int(m)] for m in masks]) + np.where(kept, 0.0, kl_bits).sum(1)
+    return (entropy_y_bits - loss_bits) - ceiling, masks
+
+
 if __name__ == "__main__":
     import time
+    _d = dib_amd.data.fetch_boolean_circuit()
+    _info = subset_information_bits(_d["x_train"], _d["y_train"])
     # (beta_start = 1e-3, the notebook's value for ITS encoders - two trainable scalars per gate that start informative, mu = +-1 and
     # logvar = -3 - is too strong a bottleneck for MLP encoders that start uninformative: the XOR pair {7, 8} is priced out
     # before the integration network has learnt to use it (accuracy stays at 0.89, profiles/r04p_paper_circuit.txt); with
@@ -63,3 +92,6 @@ if __name__ == "__main__":
         print(kw, f"{time.time() - t0:.1f}s", "drop epochs", drop.tolist(), "order", np.argsort(drop, kind="stable").tolist(),
               "violations", group_order_violations(drop), f"acc@pre {acc[kw.get('epochs_pre', 100) - 1]:.3f} loss@pre {loss[kw.get('epochs_pre', 100) - 1]:.3f} "
               f"final KL {kl[-1].sum():.3f} final loss {loss[-1]:.3f} bits", flush=True)
+        exc, masks = info_ceiling_excess(kl, loss, _info, _info[1023])
+        print(f"   subset-information ceiling: max (H(Y) - loss) - [I(X_S;Y) + sum KL outside S] = {exc.max():+.4f} bits at epoch "
+              f"{int(exc.argmax())}; {len(set(masks.tolist()))} distinct kept subsets visited", flush=True)
