@@ -51,7 +51,8 @@ class _BatchStream:
         incoming = (self.pos + np.arange(m, dtype=np.int64)) % self.n
         self.pos += m
         # a slot drawn again inside this call holds the element an EARLIER draw of the call refilled it with
-        order = np.argsort(slots, kind="stable")
+        # (stable sort of 16-bit keys = numpy's radix sort: 4 x faster than the 64-bit merge sort at 500 000 draws)
+        order = np.argsort(slots.astype(np.uint16) if self.nbuf <= 65536 else slots, kind="stable")
         ss = slots[order]
         again = np.flatnonzero(ss[1:] == ss[:-1]) + 1
         out = self.buf[slots]
@@ -178,13 +179,20 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
     # batch order (see _BatchStream).  Row indices go to the device a block of steps at a time - one upload per _IDX_BLOCK
     # training steps / per validation pass instead of one per step.
     stream = _BatchStream(n, batch_size, seed, shuffle_buffer)
-    train_idx = dict(first=0, dev=None)
+    block_steps = max(8, min(_IDX_BLOCK, (1 << 16) // batch_size))
+    draw_block = lambda: np.ascontiguousarray(stream.next_batches(block_steps)[:, shard]).astype(np.int32)
+    # the NEXT block is drawn on a worker thread while the device runs this one (numpy's sort / gather release the GIL): 100 ns per
+    # drawn row is 0.2 ms per step at B = 2048 - half a step - if the launch thread pays it
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+    train_idx = dict(first=0, dev=None, next=pool.submit(draw_block))
     val_idx = dict(epoch=None, dev=None)
 
     def train_rows(step_num):
         k = step_num - train_idx["first"]
         if train_idx["dev"] is None or k >= train_idx["dev"].shape[0]:
-            blk = np.ascontiguousarray(stream.next_batches(_IDX_BLOCK)[:, shard]).astype(np.int32)
+            blk = train_idx["next"].result()
+            train_idx["next"] = pool.submit(draw_block)
             train_idx["first"], train_idx["dev"], k = step_num, eng.to_device(blk, dtype=torch.int32), 0
         return train_idx["dev"][k]
 
@@ -233,5 +241,7 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
                                                          (1 << 31) + epoch_num * 1024 + vb),
         assign_beta=model.beta.assign,
         epoch_callback=(lambda e: epoch_callback(e, model)) if epoch_callback is not None else None)
+    train_idx["next"].cancel()
+    pool.shutdown(wait=True)
     out['kl_total'], out['kl_total_validation'] = out['kl'].sum(-1), out['kl_validation'].sum(-1)
     return out
