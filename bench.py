@@ -458,28 +458,81 @@ class Workload:
             return (i % self.n_batches) * self.stride + self.lo
         return ((i * self.world + self.rank) % self.n_batches) * self.stride
 
-    def step(self, i):
+    ADAM = ("adam", 0.9, 0.999, 1e-7)
+
+    def step(self, i, comm="real"):
+        """one training step.  comm: "real" = the product protocol; "none" = the same launches with every collective
+        replaced by a no-op (what the step costs a rank before a byte is exchanged); used by dp_breakdown only."""
         eng, dist = self.eng, self.dist
         inv_gb = 1.0 / self.gb
-        if dist is None:
-            eng.train_step(self.xd, self.yd, None, self.row0(i), self.B, 0, i, "bce_logits", inv_global_batch=inv_gb)
-        elif self.dp_buckets == 1:  # single all-reduce of the whole flat gradient buffer after the backward
-            eng.train_step(self.xd, self.yd, None, self.row0(i), self.B, 0, i, "bce_logits", inv_global_batch=inv_gb)
-            dist.all_reduce(eng.grads)
-        else:
-            # gradient buckets, each all-reduced (RCCL over xGMI, async) as soon as it is final: the integration
-            # network's under the whole encoder-bank backward; with 3 buckets the encoder front layers' under the last
-            # encoder layer's weight gradient, which alone trails the backward; with 2 the whole encoder bank trails it
-            pending = []
-            issue = lambda g: pending.append(dist.all_reduce(g, async_op=True))
-            kw = dict(on_encoder_front_grads_ready=issue) if self.dp_buckets == 3 else {}
+        if dist is None:   # the step's last launch also reduces the partials, accumulates the metrics and applies Adam
             eng.train_step(self.xd, self.yd, None, self.row0(i), self.B, 0, i, "bce_logits", inv_global_batch=inv_gb,
-                           on_integration_grads_ready=issue, **kw)
-            off, cnt = self.tail_range if self.dp_buckets == 3 else (self.enc_off, self.enc_cnt)
-            issue(eng.grads[off: off + cnt])
-            for w in pending:
+                           optimizer=self.ADAM)
+            return
+        if self.dp_buckets == 1:  # single all-reduce of the whole flat gradient buffer after the backward
+            eng.train_step(self.xd, self.yd, None, self.row0(i), self.B, 0, i, "bce_logits", inv_global_batch=inv_gb)
+            if comm == "real":
+                dist.all_reduce(eng.grads)
+            eng.optimizer_step_part(self.B, -1, self.ADAM, bump=True)
+            return
+        # gradient buckets (DESIGN 6), each all-reduced (RCCL over xGMI, async) as soon as it is final: the integration
+        # network's under the whole encoder-bank backward; with 3 buckets the encoder front layers' under the last
+        # encoder layer's weight gradient, which alone trails the backward; with 2 the whole encoder bank trails it.
+        # Each bucket is Adam-stepped as soon as ITS all-reduce has landed (buckets 1-2 while bucket 3 is on the wire).
+        pending = []
+        issue = (lambda g: pending.append(dist.all_reduce(g, async_op=True))) if comm == "real" else (lambda g: pending.append(None))
+        kw = dict(on_encoder_front_grads_ready=issue) if self.dp_buckets == 3 else {}
+        eng.train_step(self.xd, self.yd, None, self.row0(i), self.B, 0, i, "bce_logits", inv_global_batch=inv_gb,
+                       on_integration_grads_ready=issue, **kw)
+        off, cnt = self.tail_range if self.dp_buckets == 3 else (self.enc_off, self.enc_cnt)
+        issue(eng.grads[off: off + cnt])
+        parts = (1, 2, 3) if self.dp_buckets == 3 else (1, 0)
+        for k, (w, part) in enumerate(zip(pending, parts)):
+            if w is not None:
                 w.wait()
-        eng.adam_step()
+            eng.optimizer_step_part(self.B, part, self.ADAM, bump=k == len(parts) - 1)
+
+    def dp_breakdown(self, steps, dev):
+        """N > 1: where a data-parallel step's time goes, so that the scaling record explains itself - the step with the
+        collectives replaced by no-ops, each bucket's all-reduce alone (back to back, nothing to overlap with), and the
+        step under each bucket protocol.  All max-over-ranks, barrier + synchronize on both sides."""
+        dist, eng = self.dist, self.eng
+        out = {"per_gpu_batch": self.B, "global_batch": self.gb, "steps": steps}
+
+        def timed(fn, n):
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return 1e3 * float(t.item()) / n
+
+        keep = self.dp_buckets
+        for i in range(2):
+            self.step(i, comm="none")
+        out["step_ms_no_collectives"] = round(timed(lambda i: self.step(100 + i, comm="none"), steps), 4)
+        comm = {}
+        for part, name in ((1, "integration"), (2, "encoder_front"), (3, "encoder_last"), (0, "encoder_bank"), (-1, "all")):
+            off, cnt = (0, eng.n_params) if part == -1 else eng.part_range(part)
+            buf = torch.zeros(cnt, dtype=torch.float32, device=dev)
+            for _ in range(3):
+                dist.all_reduce(buf)
+            ms = timed(lambda i: dist.all_reduce(buf), 20)
+            comm[name] = {"floats": int(cnt), "all_reduce_ms": round(ms, 4),
+                          "bus_GBps": round(2 * (self.world - 1) / self.world * cnt * 4 / (ms * 1e-3) / 1e9, 2)}
+        out["all_reduce_alone"] = comm
+        prot = {}
+        for nb in (1, 2, 3):
+            self.dp_buckets = nb
+            for i in range(2):
+                self.step(i)
+            prot[f"buckets_{nb}"] = round(timed(lambda i: self.step(200 + i), steps), 4)
+        self.dp_buckets = keep
+        out["step_ms_by_protocol"] = prot
+        out["exposed_communication_ms"] = {k: round(v - out["step_ms_no_collectives"], 4) for k, v in prot.items()}
+        return out
 
     def timed_block(self, first_step, steps, dev):
         dist = self.dist
@@ -560,6 +613,8 @@ def main():
     ap.add_argument("--config5-only", action="store_true",
                     help="run only the BASELINE config-5 set-transformer step (the `extra.config5_set_transformer` object) and "
                          "print it: the command the rocprofv3 passes of profiles/*_config5_* wrap")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
+                    help="dib_set_tuning(KEY, VALUE) before any layout is created (include/dib_hip.h lists the keys; A/B runs)")
     ap.add_argument("--dry-run-backend", default=None, help=argparse.SUPPRESS)  # CPU test of the launcher path (gloo)
     args = ap.parse_args()
 
@@ -601,6 +656,11 @@ def main():
         assert joined == args.gpus, f"{joined} RCCL ranks joined, expected {args.gpus}"
 
     import dib_amd  # noqa: F401
+    if args.tuning:
+        from dib_amd import _lib as _dib_lib
+        for kv in args.tuning:
+            k, v = kv.split("=")
+            _dib_lib.set_tuning(k, int(v))
     if args.config5_only:
         assert world == 1
         print(json.dumps(config5_set_transformer(dev, steps=max(2, min(args.steps, 6)))), flush=True)
@@ -661,6 +721,10 @@ def main():
     if not args.no_extra and world > 1:
         deadline = _ExtrasDeadline(args.extra_timeout, rank, out, extra)
         deadline.start()
+        try:  # exposed communication of the headline configuration
+            extra["dp_breakdown"] = wl.dp_breakdown(max(5, args.steps // 2), dev)
+        except Exception as e:  # noqa: BLE001
+            extra["dp_breakdown"] = {"error": f"{type(e).__name__}: {e}"}
         try:  # the other scaling mode, same engine
             other = "weak" if args.scaling == "strong" else "strong"
             wl.set_scaling(other, args.batch)
@@ -731,23 +795,6 @@ def main():
                     "runs": [config2_infonce_loop(dev, 128), config2_infonce_loop(dev, 2048)]}
             except Exception as e:  # noqa: BLE001
                 extra["config2_infonce_loop"] = {"error": f"{type(e).__name__}: {e}"}
-        if world == 1 and not args.no_extra:
-            # opt-in mode, separately labelled (never the headline): the integration network's two hidden-layer FORWARD
-            # products evaluated as six bf16 piece products per fp32 product on the bf16 matrix pipe (fp32-accurate, see
-            # csrc/dib_gemm_bf16x6.h); everything else unchanged.  Same workload, same protocol, its own process.
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", "2",
-                                    "--blocks", "1", "--batch", str(args.batch), "--no-cpu-baseline", "--no-extra",
-                                    "--no-kernel-timing"], env=dict(os.environ, DIB_GEMM_MODE="bf16x6"), capture_output=True,
-                                   text=True, timeout=300)
-                j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-                extra["bf16x6_integration_fwd"] = {
-                    "value": j["value"], "unit": "samples/s", "ms_per_step": j["ms_per_step"],
-                    "dtype": "f32, with the 2 integration forward GEMMs fp32-emulated on the bf16 MFMA pipe (bf16x6: 6 exact "
-                             "piece products per product, fp32 accumulate); DIB_GEMM_MODE=bf16x6",
-                    "roofline_note": "those GEMMs: bf16 MFMA peak 2500 / 6 = 417 TFLOP/s fp32-equivalent ceiling"}
-            except Exception as e:  # noqa: BLE001
-                extra["bf16x6_integration_fwd"] = {"error": f"{type(e).__name__}: {e}"}
         if extra:
             out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:

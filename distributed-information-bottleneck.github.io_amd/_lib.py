@@ -20,18 +20,23 @@ LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 LIB_OVERRIDE = os.environ.get("DIB_LIB_PATH") or None
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
 INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
-SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_gemm_bf16x6.h", "dib_st.h", "dib_attn.h", "dib_attn_small.h", "dib_infonce_mfma.h",
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_tail.h", "dib_st.h", "dib_attn.h", "dib_attn_small.h", "dib_infonce_mfma.h",
            INCLUDE_ST]
 
 # error codes (include/dib_hip.h)
 DIB_OK = 0
-ABI_VERSION = 4   # include/dib_hip.h DIB_ABI_VERSION this binding's SIGNATURES were written against
+ABI_VERSION = 5   # include/dib_hip.h DIB_ABI_VERSION this binding's SIGNATURES were written against
 ACTIVATIONS = {None: 0, "linear": 0, "None": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "elu": 5,
                "softplus": 6}
 ACT_LEAKY_RELU_01 = 7  # tf.keras.layers.LeakyReLU(0.1) (include/dib_st.h)
 LOSS_KINDS = {"bce_logits": 0, "bce": 1, "sparse_cce_logits": 2, "mse": 3}
 WS_U, WS_PRED, WS_ENC_OUT, WS_G_U, WS_STEP_OUT, WS_G_PRED = range(6)
 WS_ENC_H0, WS_INT_H0 = 16, 32
+# include/dib_hip.h flag bits
+FWD_DETERMINISTIC, FWD_INFERENCE, FWD_DEFER_SUMS = 1, 2, 4
+HEAD_DEFER_SUMS, HEAD_NO_GRAD = 1, 2
+TAIL_FINALIZE, TAIL_KL, TAIL_LOSS, TAIL_ADAM, TAIL_BUMP, TAIL_METRICS, TAIL_SGD, TAIL_HEAD_WGRAD, TAIL_LOSS_HEAD = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256
 SIMILARITIES = {"l2sq": 0, "l2": 1, "l1": 2, "linf": 3, "cosine": 4}
 
 
@@ -91,13 +96,13 @@ SIGNATURES = {
     "dib_encoder_bank_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_uint64,
                                      c_uint32, c_int, c_void_p, c_void_p]),
     "dib_integration_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "dib_loss_fwd_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p,
+    "dib_loss_fwd_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_int, c_void_p,
                                  c_void_p]),
     "dib_integration_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_output_head_fused_supported": (c_int, [c_void_p, c_int]),
     "dib_integration_fwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "dib_output_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
-                                      c_void_p, c_void_p]),
+    "dib_output_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
     "dib_integration_bwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
@@ -105,6 +110,10 @@ SIGNATURES = {
     "dib_grads_finalize_part": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dib_layout_part_range": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
     "dib_metrics_accumulate": (c_int, [c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "dib_step_tail": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                              c_float, c_float, c_float, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "dib_set_tuning": (c_int, [c_char_p, c_int]),
+    "dib_get_tuning": (c_int, [c_char_p, POINTER(c_int)]),
     "dib_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_float,
                               c_float, c_float, c_void_p]),
     "dib_sgd_step": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p]),
@@ -122,9 +131,6 @@ SIGNATURES = {
     "dib_philox_normal_ref": (c_float, [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32]),
     "dib_profile_enable": (c_int, [c_int]),
     "dib_profile_summary": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
-    "dib_split_weights_bytes": (c_int64, [c_int, c_int]),
-    "dib_split_weights": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "dib_gemm_bf16x6": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "dib_gemm": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
                          c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
@@ -189,6 +195,24 @@ def load_library(build_if_missing: bool = True):
     return _attach(ctypes.CDLL(LIB_PATH))
 
 
+# entry points with the same signature, argument meaning and workspace sizes in every ABI revision since 3
+_ABI_STABLE = {"dib_version", "dib_abi_version", "dib_error_string", "dib_layout_create", "dib_layout_destroy",
+               "dib_layout_param_count", "dib_layout_param_block", "dib_layout_table_bytes", "dib_layout_upload_tables",
+               "dib_layout_set_step_counter", "dib_workspace_bytes", "dib_workspace_init", "dib_workspace_offset",
+               "dib_layout_wgrad_splits", "dib_encoder_bank_fwd", "dib_integration_fwd", "dib_integration_bwd",
+               "dib_output_head_fused_supported", "dib_integration_fwd_hidden", "dib_integration_bwd_hidden",
+               "dib_encoder_bank_bwd", "dib_encoder_bank_bwd_stage", "dib_grads_finalize", "dib_grads_finalize_part",
+               "dib_layout_part_range", "dib_metrics_accumulate", "dib_adam_step", "dib_sgd_step", "dib_profile_enable",
+               "dib_profile_summary", "dib_philox_normal_fill", "dib_philox_normal_ref"}
+
+
+def _refuse(name, have):
+    def fn(*_a, **_k):
+        raise RuntimeError(f"{name}: not ABI-stable between library version {have} and binding version {ABI_VERSION} "
+                           "(DIB_LIB_ABI_CHECK=0 binds only the unchanged entry points)")
+    return fn
+
+
 def _attach(lib):
     global _lib
     try:
@@ -196,20 +220,37 @@ def _attach(lib):
         have = int(lib.dib_abi_version())
     except AttributeError:
         have = None
-    # (DIB_LIB_ABI_CHECK=0: same-box A/B against a library built from an older round, whose config-3 entry points have not
-    # changed - tools/runs/r04g.sh; never set outside such an experiment)
-    if have != ABI_VERSION and os.environ.get("DIB_LIB_ABI_CHECK", "1") != "0":
+    # DIB_LIB_ABI_CHECK=0 (a same-box A/B against a library built from an older round, tools/runs/r04g.sh; never set outside
+    # such an experiment): only the entry points whose signature and meaning have not changed since ABI 3 are bound - the
+    # config-3 step of bench.py as round 3 drove it; every other name raises on use instead of misbinding its arguments.
+    lenient = os.environ.get("DIB_LIB_ABI_CHECK", "1") == "0"
+    if have != ABI_VERSION and not lenient:
         raise RuntimeError(f"libdib_hip ABI version {have} != {ABI_VERSION} expected by this binding ({getattr(lib, '_name', '?')}): "
                            "rebuild it (python -c 'import __graft_entry__ as g; g.build()' / tools/build_variant.sh)")
-    lenient = os.environ.get("DIB_LIB_ABI_CHECK", "1") == "0"
+    if lenient and have != ABI_VERSION:
+        import warnings
+        warnings.warn(f"DIB_LIB_ABI_CHECK=0: binding ONLY the ABI-stable entry points of a version-{have} library "
+                      f"(this binding is version {ABI_VERSION}); everything else raises", RuntimeWarning)
     for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_ST.items()):
-        if lenient and not hasattr(lib, name):
-            continue   # an older round's library in an A/B: entry points it lacks are simply not bound
+        if lenient and have != ABI_VERSION and name not in _ABI_STABLE:
+            setattr(lib, name, _refuse(name, have))
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def set_tuning(key: str, value: int) -> None:
+    """include/dib_hip.h dib_set_tuning: the library's only hidden inputs (it reads no environment variable)."""
+    check(load_library().dib_set_tuning(key.encode(), int(value)), f"dib_set_tuning({key})")
+
+
+def get_tuning(key: str) -> int:
+    v = c_int()
+    check(load_library().dib_get_tuning(key.encode(), ctypes.byref(v)), f"dib_get_tuning({key})")
+    return int(v.value)
 
 
 class DibError(RuntimeError):

@@ -13,7 +13,7 @@
 #include "dib_gemm.h"
 #include "dib_infonce_mfma.h"
 #include "dib_fused.h"
-#include "dib_gemm_bf16x6.h"
+#include "dib_tail.h"
 #include "dib_st.h"
 #include "dib_attn.h"
 #include "dib_attn_small.h"
@@ -22,12 +22,8 @@
 namespace {
 
 constexpr int64_t kAlign = 64;  // floats (256 B)
-#ifndef DIB_MAX_SPLITS
-#define DIB_MAX_SPLITS 32
-#endif
-#ifndef DIB_SPLIT_ROWS
-#define DIB_SPLIT_ROWS 512   // minimum batch rows per wgrad split: 8 K-tiles of 64 (measured: 2048 left mid-size batches with 16-256 workgroups)
-#endif
+constexpr int kMaxSplits = 32;   // partial slabs of a split-batch weight gradient
+constexpr int kSplitRows = 512;  // minimum batch rows per wgrad split: 8 K-tiles of 64 (measured: 2048 left mid-size batches with 16-256 workgroups)
 inline int64_t align_up(int64_t v, int64_t a = kAlign) { return (v + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
@@ -62,17 +58,12 @@ struct dib_layout {
   const long long* dev_fused_offs = nullptr;
   const int4* dev_featmap = nullptr;
   const unsigned* step_dev = nullptr;  // optional device-resident noise step (dib_layout_set_step_counter)
-  bool bf16x6 = false;                 // DIB_GEMM_MODE=bf16x6: integration forward GEMMs on the bf16 pipe (fp32-emulated)
-  // fork / join inside dib_encoder_bank_bwd: the HBM-bound narrow wgrad runs beside the MFMA-bound one (created with the
-  // descriptor tables, i.e. outside any stream capture; the fork-join itself is capturable)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
-    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, h1mask, skinny_partial, bf16_planes, total;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, h1mask, skinny_partial, sync, total;
     int skinny_chunks, skinny_rows;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
@@ -98,13 +89,13 @@ struct dib_layout {
     m.kl_partial = take((int64_t)std::max(m.kl_blocks, 8 * 256) * F);  // fused fwd: one row per wave of the persistent grid
     m.loss_blocks = cdiv(B, 256);
     m.loss_partial = take((int64_t)std::max(m.loss_blocks, 512) * 2);  // also the fused output head's per-workgroup partials (<= 512)
-    // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= DIB_SPLIT_ROWS rows per split ...
-    int ns = std::min(DIB_MAX_SPLITS, std::max(1, B / DIB_SPLIT_ROWS));
+    // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= kSplitRows rows per split ...
+    int ns = std::min(kMaxSplits, std::max(1, B / kSplitRows));
     // ... unless the layout is so narrow that even its largest weight gradient stays under one workgroup per CU with that
     // many splits (BASELINE config 2, the pendulum layout [2,1,2,1]: 16 tiles x 4 splits of 512 rows at B = 2048 - five
     // launches of 18-24 us, each a workgroup walking 16 dependent K-tiles, 100 of the 510 us step,
     // profiles/r04i_config2_loop_kernel_stats_b2048.csv): then slabs of >= 128 rows
-    if (B >= 256 && max_wgrad_tiles64 * ns < 256) ns = std::min(DIB_MAX_SPLITS, std::max(ns, B / 128));
+    if (B >= 256 && max_wgrad_tiles64 * ns < 256) ns = std::min(kMaxSplits, std::max(ns, B / 128));
     int rps = cdiv(cdiv(B, ns), 32) * 32;
     ns = cdiv(B, rps);
     m.nsplit = ns;
@@ -124,15 +115,7 @@ struct dib_layout {
       const int win = n_int == 0 ? F * E : int_units[n_int - 1];
       m.skinny_partial = take(out_dim <= 8 ? (int64_t)m.skinny_chunks * ((int64_t)win * out_dim + out_dim) : 0);
     }
-    {  // DIB_GEMM_MODE=bf16x6: three bf16 planes [N][Kp] of the largest integration hidden-layer kernel
-      int64_t need = 0;
-      if (bf16x6)
-        for (int ly = 0; ly < n_int; ++ly) {
-          const int64_t K = ly == 0 ? (int64_t)F * E : int_units[ly - 1];
-          need = std::max<int64_t>(need, 3ll * int_units[ly] * ((K + 31) / 32 * 32) * 2 / 4 + 4);
-        }
-      m.bf16_planes = take(need);
-    }
+    m.sync = take(DIB_TAIL_SYNC_WORDS);   // arrival counters of dib_step_tail (zeroed by dib_workspace_init, self-cleaning)
     m.total = o;
     return m;
   }
@@ -189,35 +172,23 @@ DibGemmGroup make_group(Off a, int lda, Off b, int ldb, Off c, int ldc, int64_t 
   return g;
 }
 
-// Tile-rule knobs, overridable from the environment for A/B measurements on the GPU (tools/ab_bench.sh); the defaults
-// are the measured choices.
-struct Knobs {
+// Tile / split rules.  The defaults are the measured choices; dib_set_tuning (include/dib_hip.h) is the ONE documented way to
+// change them (A/B measurements, tools/ab_bench.sh) - the library reads no environment variable.
+struct Tuning {
   int fwd_small_wgs = 512;   // forward/dgrad: below this many 128-row workgroups use 64-row tiles
   int fwd_narrow_wgs = 1024; // forward: below this many 64x128 workgroups use 64x64 tiles (round 3: 512 -> 1024, the set
                              // transformer's q/k/v projection at 1600 tokens: step 1.99 -> 1.87 ms; profiles/r03l_forward_tile_rule.txt)
   int stream_rows = 8192;    // GEMMs with at least this many streamed rows load / store them non-temporally (1 << 30: never)
-  int l3_halve = 1;          // narrow (N <= 64) wgrads: half as many, twice as long batch splits
-  int force_tile[3] = {0, 0, 0};  // per MODE: 0 = rule, else 11 / 12 / 21 / 22 = (NI, NJ)
   int split_policy = 1;      // weight gradients of the layout: 1 = pick the batch-split count per launch so that the workgroups
                              // fill whole rounds of the chip's workgroup slots (pick_wgrad_splits); 0 = the layout-wide count
   int split_overhead = 128;  // ... with this per-workgroup fixed cost, in batch rows (prologue + partial-tile store)
-  int concurrent_wgrad = 0;  // encoder-bank backward: narrow (HBM-bound) wgrad on a second stream beside the MFMA-bound one.
-                             // OFF: measured slower (same box, B = 65536: 8.44-8.50 vs 8.37 ms; B = 8192: 1.345 vs 1.313 ms) -
-                             // the two kernels together ask for 5.8 TB/s of HBM and evict each other's L2 lines
-  Knobs() {
-    if (const char* e = std::getenv("DIB_FWD_SMALL_WGS")) fwd_small_wgs = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FWD_NARROW_WGS")) fwd_narrow_wgs = std::atoi(e);
-    if (const char* e = std::getenv("DIB_GEMM_STREAM_ROWS")) stream_rows = std::atoi(e);
-    if (const char* e = std::getenv("DIB_L3_HALVE")) l3_halve = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FORCE_TILE0")) force_tile[0] = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FORCE_TILE1")) force_tile[1] = std::atoi(e);
-    if (const char* e = std::getenv("DIB_FORCE_TILE2")) force_tile[2] = std::atoi(e);
-    if (const char* e = std::getenv("DIB_CONCURRENT_WGRAD")) concurrent_wgrad = std::atoi(e);
-    if (const char* e = std::getenv("DIB_SPLIT_POLICY")) split_policy = std::atoi(e);
-    if (const char* e = std::getenv("DIB_SPLIT_OVERHEAD")) split_overhead = std::atoi(e);
-  }
+  int fused_encoder = 1;     // layouts created from now on may use the fused encoder-bank kernels (0: grouped-GEMM path)
+  int fused_head = 1;        // dib_output_head_fused_supported may answer 1
+  int small_batch = 1;       // batches <= 1024 rows: row-tile kernels (csrc/dib_small.h) where the layout allows
+  int num_cus = 256;         // compute units of the device (set from hipDeviceProp by the first dib_layout_upload_tables)
 };
-inline const Knobs& knobs() { static Knobs k; return k; }
+inline Tuning& tuning() { static Tuning t; return t; }
+inline const Tuning& knobs() { return tuning(); }
 
 template <int MODE, int NI, int NJ>
 int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int N, const float* A, const float* B, float* C,
@@ -229,19 +200,10 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
   dim3 grid;
   if (MODE == 2) grid = dim3(nsplit, tm * tn, c.count);
   else grid = dim3(8 * cdiv(tm, 8) * tn, 1, c.count);  // XCD-aware 1-D tile order, see dib_gemm.h
-#ifndef DIB_BK11
-#define DIB_BK11 32
-#endif
-#ifndef DIB_BK11D
-#define DIB_BK11D 32   // 64 x 64 dgrad tile
-#endif
-#ifndef DIB_BK212
-#define DIB_BK212 64   // 64x128 wgrad tile (the 256x256 integration layer): 0.136 -> 0.124 ms with 64-deep K-tiles (same-box A/B)
-#endif
-#ifndef DIB_BK22W
-#define DIB_BK22W 64   // A/B knob: K-tile depth of the 128 x 128 weight-gradient tile (32: half the LDS, 3-4 workgroups per CU)
-#endif
-  constexpr int BK = (NI == 2 && NJ == 2) ? (MODE == 2 ? DIB_BK22W : 64) : ((NI == 1 && NJ == 1 && MODE == 0) ? DIB_BK11 : ((NI == 1 && NJ == 1 && MODE == 1) ? DIB_BK11D : ((MODE == 2 && NI == 1 && NJ == 2) ? DIB_BK212 : 32)));  // deep K-tiles for the big tile: one prefetch+barrier pair per 64-deep MFMA phase hides HBM latency (measured +18%; narrower tiles measured slower with 64)
+  // K-tile depth per tile shape (each a same-box A/B, profiles/HISTORY.md): 64 for the 128 x 128 tile of every mode - one
+  // prefetch + barrier pair per 64-deep MFMA phase hides the HBM latency a 32-deep phase exposes (+18 %) - and for the 64 x 128
+  // weight-gradient tile of the 256 x 256 integration layer (0.136 -> 0.124 ms); 32 for the other narrow tiles.
+  constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((MODE == 2 && NI == 1 && NJ == 2) ? 64 : 32);
   // cache policy of the streamed operands / outputs (dib_gemm.h: stream_flags): non-temporal from 8192 streamed rows up
   // (DIB_GEMM_STREAM_ROWS; M for forward / dgrad, the contracted rows for a weight gradient)
   const long long streamed_rows = MODE == 2 ? (long long)nsplit * rows_per_split : (long long)M;
@@ -262,38 +224,14 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
 // workgroups = 3.1 rounds, the fourth 1/8 full; the narrow last-layer gradient (4 workgroups per CU) with its splits halved
 // ran 800 workgroups of 4096 rows where 1000 of 3328 fit one round.  BASELINE config 4: encoder wgrads at 0.55-0.61 of the
 // fp32-MFMA peak against 0.70-0.72 for config 3 (profiles/r04a_config4_*).  Candidates: 1 .. max_splits splits of a multiple of
-// 64 rows (whole K-tiles), at least DIB_SPLIT_ROWS rows; the cheapest wins, ties go to FEWER, longer workgroups.
+// 64 rows (whole K-tiles), at least kSplitRows rows; the cheapest wins, ties go to FEWER, longer workgroups.
 // Measured (F = 50, B = 65536, ms/step with one launch's count forced, profiles/r04d_split_sweep_F50.txt): encoder layers 2+3,
 // 50 tiles: 32 splits 6.80, 30: 6.78, 28: 6.87, 25: 6.74, 20: 6.68 (2 full rounds), 16: 6.99, 10: 6.71 (1 round);
 // integration layer 1, 26 tiles: 32: 6.80, 29: 6.73, 24: 6.83, 19: 6.66 (1 round), 16: 6.82, 13: 7.01.  (A second model, "what
 // a CU executes is serial: ceil(tiles ns / 256) x rps", picked 25 and 29 there and measured no gain: r04c.)
 // Slabs beyond the chosen count are never written by this launch and stay zero (include/dib_hip.h workspace contract).
 static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits, int* ns_out, int* rps_out) {
-  const int min_rows = std::min(DIB_SPLIT_ROWS, std::max(64, *rps_out));   // narrow layouts come in with shorter slabs (WsMap)
-  // measurement override (tools/runs/r04d.sh): DIB_WGRAD_NS="tiles:ns,tiles:ns,..." forces the split count of the launches with
-  // that many output tiles
-  static const std::vector<std::pair<long long, int>> forced = [] {
-    std::vector<std::pair<long long, int>> v;
-    if (const char* e = std::getenv("DIB_WGRAD_NS")) {
-      const char* p = e;
-      while (*p) {
-        char* q;
-        const long long t = std::strtoll(p, &q, 10);
-        if (*q != ':') break;
-        const int n = (int)std::strtol(q + 1, &q, 10);
-        v.emplace_back(t, n);
-        p = *q == ',' ? q + 1 : q;
-      }
-    }
-    return v;
-  }();
-  for (const auto& f : forced)
-    if (f.first == tiles && f.second >= 1 && f.second <= max_splits) {
-      const int rps = cdiv(cdiv(K, f.second), 64) * 64;
-      *ns_out = cdiv(K, rps);
-      *rps_out = rps;
-      return;
-    }
+  const int min_rows = std::min(kSplitRows, std::max(64, *rps_out));   // narrow layouts come in with shorter slabs (WsMap)
   // The caller's (layout-wide) split is kept whenever it fills its rounds to at least 85 %: BASELINE config 3 (F = 64: 64 or 32
   // tiles x 32 or 16 splits = whole rounds at every batch size) then runs exactly the launches rounds 2-3 measured and
   // validated (same-box A/B of an unconditional rule vs no rule there: 8.00-8.08 vs 7.99-8.02 ms/step,
@@ -346,12 +284,11 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
     if (wgs < 256) ni1 = true;
     if (ni1 && !nj1 && (long long)cdiv(M, 64) * cdiv(N, 128) * nsplit * c.count < 128) nj1 = true;  // tiny batches
   }
-  if (const int ft = knobs().force_tile[MODE]) { ni1 = ft / 10 == 1; nj1 = (ft % 10 == 1) || N <= 64; }
   if (MODE == 2 && auto_split && nsplit > 1 && knobs().split_policy) {
     // co-resident workgroups per CU of each tile shape (LDS / register budget of dib_gemm_kernel<2, NI, NJ, BK>)
-    const int per_cu = (!ni1 && !nj1) ? (DIB_BK22W == 32 ? DIB_GEMM_WGRAD_WG : 2) : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
+    const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
     const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
-    pick_wgrad_splits(tiles, 256 * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
+    pick_wgrad_splits(tiles, knobs().num_cus * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
@@ -622,11 +559,9 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
   // fused encoder-bank path: two hidden layers, instantiated (H1,H2,E), encoder inputs <= 16 wide
   {
     static const int kFused[][3] = {{128, 128, 32}, {32, 32, 32}, {32, 32, 8}, {64, 64, 16}};
-    if (const char* gm = std::getenv("DIB_GEMM_MODE")) l->bf16x6 = std::strcmp(gm, "bf16x6") == 0;
-    const char* dis = std::getenv("DIB_DISABLE_FUSED");
     bool in_ok = true;
     for (int f = 0; f < F; ++f) in_ok = in_ok && l->in_dim[f] <= 16;
-    if (!(dis && dis[0] == '1') && n_enc == 2 && in_ok && act >= 0 && act <= 2)
+    if (knobs().fused_encoder && n_enc == 2 && in_ok && act >= 0 && act <= 2)
       for (int i = 0; i < 4; ++i)
         if (kFused[i][0] == enc_units[0] && kFused[i][1] == enc_units[1] && kFused[i][2] == E) l->fused_id = i;
     for (int ly = 0; ly < LE && ly < 3; ++ly)
@@ -645,9 +580,6 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
 
 void dib_layout_destroy(dib_layout* l) {
   if (!l) return;
-  if (l->ev_fork) (void)hipEventDestroy(l->ev_fork);
-  if (l->ev_join) (void)hipEventDestroy(l->ev_join);
-  if (l->side) (void)hipStreamDestroy(l->side);
   delete l;
 }
 
@@ -699,13 +631,11 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
   char* fmp = fo + align_up((int64_t)l->fused_offs.size() * sizeof(long long), 256);
   e = hipMemcpyAsync(fmp, l->featmap.data(), l->featmap.size() * sizeof(int4), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
-  if (!l->side) {  // host-side objects only (no device memory): a second stream + two events for the wgrad fork / join
-    if (hipStreamCreateWithFlags(&l->side, hipStreamNonBlocking) != hipSuccess) l->side = nullptr;
-    if (l->side && (hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess)) {
-      (void)hipStreamDestroy(l->side);
-      l->side = nullptr;
-    }
+  {  // the split rule prices rounds of the chip's workgroup slots: take the CU count from the device, not from a constant
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      tuning().num_cus = prop.multiProcessorCount;
   }
   l->dev_groups = (const DibGemmGroup*)base;
   l->dev_colmap = (const int4*)cm;
@@ -728,6 +658,9 @@ int64_t dib_workspace_bytes(const dib_layout* l, int batch) {
 int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t stream) {
   if (!l || !ws || batch <= 0) return DIB_E_ARG;
   const auto m = l->map(batch);
+  // the arrival counters of dib_step_tail (self-cleaning afterwards)
+  hipError_t e0 = hipMemsetAsync((float*)ws + m.sync, 0, (size_t)DIB_TAIL_SYNC_WORDS * sizeof(unsigned), (hipStream_t)stream);
+  if (e0 != hipSuccess) return (int)e0;
   if (m.nsplit <= 1) return DIB_OK;
   // the split-batch weight-gradient slabs: dib_grads_finalize sums all nsplit slabs of every block, including the slabs
   // a launch never writes (halved splits of narrow layers, slabs >= 1 of the skinny output layer, the layer-1 block
@@ -798,6 +731,7 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
     int gx = 1;
     rc = fused_encoder_fwd(l, m, w, x, ldx, row_idx, row0, batch, params, seed, step, deterministic, st, &gx);
     if (rc) return rc;
+    if (deterministic & DIB_FWD_DEFER_SUMS) return DIB_OK;   // dib_step_tail(DIB_TAIL_KL) sums the partials
     { ProfScope ps(kProfOther, (hipStream_t)stream);
     hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, gx * 8, l->F,
                        w + m.step_out); }
@@ -811,6 +745,7 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
                      (unsigned long long)seed, (unsigned)step, deterministic & DIB_FWD_DETERMINISTIC, l->step_dev); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
+  if (deterministic & DIB_FWD_DEFER_SUMS) return DIB_OK;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, m.kl_blocks, l->F,
                      w + m.step_out); }
@@ -837,17 +772,6 @@ static int integration_fwd_impl(dib_layout* l, int batch, const float* params, v
       hipLaunchKernelGGL(dib_skinny_fwd_kernel, dim3(grid_for((int64_t)batch * 64, 256, 2048)), dim3(256), 0, st, A, batch,
                          win, params + l->int_w_off[ly], params + l->int_b_off[ly], l->out_dim, act, C);
       rc = (int)hipGetLastError();
-    } else if (l->bf16x6 && ly < LI - 1 && batch >= 128) {
-      // opt-in mode: the hidden layers' forward products as six bf16 piece products per fp32 product (dib_gemm_bf16x6.h):
-      // split this step's kernel into three transposed bf16 planes, then the 128x128x32 bf16-MFMA GEMM
-      const int K = ly == 0 ? l->F * l->E : l->int_width[ly - 1], N = l->int_width[ly], Kp = (K + 31) / 32 * 32;
-      __bf16* planes = (__bf16*)(w + m.bf16_planes);
-      ProfScope ps(kProfOther, st);
-      hipLaunchKernelGGL(dib_split_weights_kernel, dim3(grid_for((int64_t)N * Kp)), dim3(256), 0, st, params + l->int_w_off[ly], K,
-                         N, Kp, planes);
-      hipLaunchKernelGGL(dib_gemm_bf16x6_kernel, dim3(8 * cdiv(cdiv(batch, 128), 8) * cdiv(N, 128)), dim3(256), 0, st, A, K,
-                         (const __bf16*)planes, Kp, C, N, params + l->int_b_off[ly], batch, N, K, act);
-      rc = (int)hipGetLastError();
     } else {
       rc = launch_gemm<0>(l, l->int_fwd[ly], A, params, C, params, nullptr, nullptr, batch, act, 1, 0, 0, st);
     }
@@ -866,7 +790,7 @@ int dib_integration_fwd_hidden(dib_layout* l, int batch, const float* params, vo
 
 // ---- loss + backward ----------------------------------------------------------------------------
 int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
-                     int batch, float inv_global_batch, void* ws, dib_stream_t stream) {
+                     int batch, float inv_global_batch, int flags, void* ws, dib_stream_t stream) {
   if (!l || !y || !ws || batch <= 0) return DIB_E_ARG;
   if (loss_kind < 0 || loss_kind > 3) return DIB_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -878,6 +802,7 @@ int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, 
                      w + m.g_pred, w + m.loss_partial); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
+  if (flags & DIB_HEAD_DEFER_SUMS) return DIB_OK;   // dib_step_tail(DIB_TAIL_LOSS) sums the partials
   { ProfScope ps(kProfOther, (hipStream_t)stream);
   hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), m.loss_blocks,
                      (float)batch, w + m.step_out + l->F); }
@@ -943,7 +868,7 @@ int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, fl
 // MSE, at least one integration hidden layer whose width is a multiple of 4 and <= 1024
 int dib_output_head_fused_supported(const dib_layout* l, int loss_kind) {
   if (!l) return 0;
-  if (const char* e = std::getenv("DIB_DISABLE_FUSED_HEAD")) if (e[0] == '1') return 0;  // A/B switch
+  if (!knobs().fused_head) return 0;   // dib_set_tuning("fused_head", 0): A/B switch
   if (l->out_dim != 1 || l->out_act != DIB_ACT_LINEAR || l->n_int < 1) return 0;
   if (loss_kind != DIB_LOSS_BCE_LOGITS && loss_kind != DIB_LOSS_MSE) return 0;
   const int K = l->int_width[l->n_int - 1];
@@ -951,14 +876,15 @@ int dib_output_head_fused_supported(const dib_layout* l, int loss_kind) {
 }
 
 int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
-                          int batch, float inv_global_batch, const float* params, float* grads, void* ws,
+                          int batch, float inv_global_batch, int flags, const float* params, float* grads, void* ws,
                           dib_stream_t stream) {
-  if (!l || !y || !params || !grads || !ws || batch <= 0) return DIB_E_ARG;
+  const bool no_grad = (flags & DIB_HEAD_NO_GRAD) != 0;
+  if (!l || !y || !params || (!grads && !no_grad) || !ws || batch <= 0) return DIB_E_ARG;
   if (!dib_output_head_fused_supported(l, loss_kind)) return DIB_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
-  float* gt = wgrad_target(m, w, grads);
+  float* gt = no_grad ? nullptr : wgrad_target(m, w, grads);
   const int ly = l->n_int, K = l->int_width[ly - 1];
   const int nblk = m.skinny_chunks, rpb = m.skinny_rows;
   const float* A = w + m.int_h[ly - 1];
@@ -967,13 +893,16 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
 #define DIB_HEAD(NC) hipLaunchKernelGGL(dib_head_fused_kernel<NC>, dim3(nblk), dim3(256), 0, st, loss_kind, A, batch, K,      \
                                         params + l->int_w_off[ly], params + l->int_b_off[ly], y, (long long)ldy,                 \
                                         (const int*)row_idx, (long long)row0, inv_global_batch, l->act, rpb, w + m.pred,          \
-                                        w + m.g_pred, w + m.g_int_h[ly - 1], w + m.skinny_partial, w + m.loss_partial)
+                                        no_grad ? (float*)nullptr : w + m.g_pred, no_grad ? (float*)nullptr : w + m.g_int_h[ly - 1], \
+                                        w + m.skinny_partial, w + m.loss_partial)
     if (K <= 256) DIB_HEAD(1); else if (K <= 512) DIB_HEAD(2); else DIB_HEAD(4);
 #undef DIB_HEAD
     int rc = (int)hipGetLastError();
     if (rc) return rc;
-    hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(K + 1), dim3(256), 0, st, (const float*)(w + m.skinny_partial), nblk,
-                       K, 1, gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
+    if (flags & DIB_HEAD_DEFER_SUMS) return DIB_OK;   // dib_step_tail(DIB_TAIL_HEAD_WGRAD | DIB_TAIL_LOSS_HEAD) finishes both
+    if (!no_grad)
+      hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(K + 1), dim3(256), 0, st, (const float*)(w + m.skinny_partial), nblk,
+                         K, 1, gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
     hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), nblk, (float)batch,
                        w + m.step_out + l->F);
   }
@@ -1007,12 +936,6 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
     }
     if (rc) return rc;
   }
-  // Optional fork / join (DIB_CONCURRENT_WGRAD=1, default off - measured slower, see Knobs): the last layer's weight gradient
-  // (N = 2E <= 64 columns: HBM-bound, 4.5 TB/s with the matrix pipe 2/3 busy) is independent of the other layers' and can run
-  // on the layout's side stream beside the MFMA-bound wide wgrad that follows it on the caller's stream; the caller's stream
-  // waits for it before this entry returns its work.  Never while the per-kernel event timing of bench.py is on.
-  const bool fork = stages == 3 && fused && knobs().concurrent_wgrad && l->side && !g_prof.on && LE >= 3 &&
-                    l->enc_wgrad[LE - 1].max_n <= 64 && batch >= 4096;
   for (int ly = LE - 1; ly >= 0; --ly) {
     const bool last = ly == LE - 1;
     const float* gout = last ? w + m.dout : w + m.g_enc_h[ly];
@@ -1024,18 +947,11 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
       // splits fill the chip in one wave (measured 0.88 -> 0.71 ms); the unused slabs of these blocks stay zero.
       // (only from 32 splits = 16384 rows up: at B = 8192 the 16 -> 8 split halving measured 117 vs 103 us)
       // (the per-launch split rule, pick_wgrad_splits, starts from this choice and leaves it unless it predicts > 5 % better)
-      const bool halve = knobs().l3_halve && l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
-      hipStream_t lst = st;
-      if (fork && last) {
-        if (hipEventRecord(l->ev_fork, st) != hipSuccess || hipStreamWaitEvent(l->side, l->ev_fork, 0) != hipSuccess)
-          return DIB_E_ARG;
-        lst = l->side;
-      }
+      const bool halve = l->enc_wgrad[ly].max_n <= 64 && m.nsplit >= 32 && (m.nsplit % 2) == 0;
       rc = launch_gemm<2>(l, l->enc_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0,
-                          halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, lst,
+                          halve ? m.nsplit / 2 : m.nsplit, halve ? 2 * m.rows_per_split : m.rows_per_split, sstride, st,
                           m.nsplit);
       if (rc) return rc;
-      if (fork && last && hipEventRecord(l->ev_join, l->side) != hipSuccess) return DIB_E_ARG;
     }
     if ((stages & 1) && ly >= 1 && !fused) {
       rc = launch_gemm<1>(l, l->enc_dgrad[ly], gout, params, w + m.g_enc_h[ly - 1], nullptr, hin, nullptr, batch,
@@ -1043,7 +959,6 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
       if (rc) return rc;
     }
   }
-  if (fork && hipStreamWaitEvent(st, l->ev_join, 0) != hipSuccess) return DIB_E_ARG;
   return DIB_OK;
 }
 
@@ -1122,6 +1037,99 @@ int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, floa
   hipLaunchKernelGGL(dib_metrics_accumulate_kernel, dim3(cdiv(l->F + 3, 64)), dim3(64), 0, (hipStream_t)stream,
                      w + m.step_out, l->F, beta_dev, inv_global_batch, metrics_acc); }
   return (int)hipGetLastError();
+}
+
+// ---- the end of a step in one launch (csrc/dib_tail.h) ------------------------------------------------------------
+int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, float* grads, float* adam_m, float* adam_v,
+                  const float* lr_dev, int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale,
+                  const float* beta_dev, float inv_global_batch, float* metrics_acc, void* ws, dib_stream_t stream) {
+  if (!l || !ws || batch <= 0 || part < -1 || part > 3 || flags <= 0) return DIB_E_ARG;
+  const bool adam = (flags & DIB_TAIL_ADAM) != 0, sgd = (flags & DIB_TAIL_SGD) != 0, finalize = (flags & DIB_TAIL_FINALIZE) != 0;
+  if (adam && sgd) return DIB_E_ARG;
+  if ((finalize || adam || sgd || (flags & DIB_TAIL_HEAD_WGRAD)) && !grads) return DIB_E_ARG;
+  if ((adam || sgd) && (!params || !lr_dev)) return DIB_E_ARG;
+  if (adam && (!adam_m || !adam_v || !t_dev)) return DIB_E_ARG;
+  if ((flags & DIB_TAIL_BUMP) && !t_dev) return DIB_E_ARG;
+  if ((flags & DIB_TAIL_METRICS) && (!beta_dev || !metrics_acc)) return DIB_E_ARG;
+  if ((flags & DIB_TAIL_LOSS) && (flags & DIB_TAIL_LOSS_HEAD)) return DIB_E_ARG;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  const long long stride = align_up(l->n_params, 4);
+  DibTailArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.params = params; a.grads = grads; a.m = adam_m; a.v = adam_v; a.lr_dev = lr_dev; a.t_dev = (long long*)t_dev;
+  a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.gscale = grad_scale; a.flags = flags; a.F = l->F;
+  const bool touches = finalize || adam || sgd;   // this launch walks the part's gradient range
+  long long beg = 0, end = 0;
+  part_bounds(l, part, &beg, &end);
+  if (part == -1 || part == 1) end = stride;      // the last bucket carries the alignment tail of the buffer
+  const bool dw1_seg = finalize && fused_bwd_ok(l) && part != 1 && part != 3;
+  const bool head_seg = (flags & DIB_TAIL_HEAD_WGRAD) && (part == -1 || part == 1);
+  if (head_seg && !dib_output_head_fused_supported(l, DIB_LOSS_BCE_LOGITS)) return DIB_E_UNSUPPORTED;
+  if (touches) {
+    a.gbeg = dw1_seg ? l->enc_w_off[1][0] : beg;
+    a.gend = head_seg ? l->int_w_off[l->n_int] : end;
+    if (finalize && m.nsplit > 1) { a.slabs = w + m.wgrad_partial; a.nsplit = m.nsplit; a.slab_stride = stride; }
+    const long long n4 = (a.gend - a.gbeg) >> 2;
+    if (n4 > 0 && (a.nsplit > 0 || adam || sgd)) a.nb_generic = (int)std::min<long long>(2048, (n4 + 255) / 256);
+  }
+  if (dw1_seg) {
+    a.dw1_partial = w + m.dw1_partial; a.dw1_parts = fused_gx(l, batch) * 8; a.H1 = l->enc_units[0];
+    a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap;
+    a.nb_dw1 = l->F * 16;
+  }
+  if (head_seg) {
+    a.head_partial = w + m.skinny_partial; a.head_chunks = m.skinny_chunks; a.head_K = l->int_width[l->n_int - 1];
+    a.head_w_off = l->int_w_off[l->n_int]; a.head_b_off = l->int_b_off[l->n_int];
+    a.nb_head = a.head_K + 1;
+  }
+  a.step_out = w + m.step_out;
+  if (flags & DIB_TAIL_KL) {
+    a.kl_partial = w + m.kl_partial; a.kl_stride = l->F; a.nb_kl = l->F;
+    a.kl_rows = l->fused_id >= 0 ? fused_gx(l, batch) * 8 : m.kl_blocks;
+  }
+  if (flags & (DIB_TAIL_LOSS | DIB_TAIL_LOSS_HEAD)) {
+    a.loss_partial = w + m.loss_partial; a.nb_loss = 2; a.rows = (float)batch;
+    a.loss_blocks = (flags & DIB_TAIL_LOSS_HEAD) ? m.skinny_chunks : m.loss_blocks;
+  }
+  a.beta_dev = beta_dev; a.inv_bg = inv_global_batch; a.metrics_acc = metrics_acc;
+  a.sync = (unsigned*)(w + m.sync);
+  int grid = a.nb_generic + a.nb_dw1 + a.nb_head + a.nb_kl + a.nb_loss;
+  if (grid == 0 && !(flags & (DIB_TAIL_BUMP | DIB_TAIL_METRICS))) return DIB_OK;   // nothing to reduce, nothing to step
+  grid = std::max(1, grid);
+  ProfScope ps(kProfOther, (hipStream_t)stream);
+  hipLaunchKernelGGL(dib_step_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// ---- tuning: the one documented switchboard (no environment variables) -------------------------------------------
+static int* tuning_slot(const char* key) {
+  Tuning& t = tuning();
+  if (!key) return nullptr;
+  if (!std::strcmp(key, "fwd_small_wgs")) return &t.fwd_small_wgs;
+  if (!std::strcmp(key, "fwd_narrow_wgs")) return &t.fwd_narrow_wgs;
+  if (!std::strcmp(key, "stream_rows")) return &t.stream_rows;
+  if (!std::strcmp(key, "split_policy")) return &t.split_policy;
+  if (!std::strcmp(key, "split_overhead")) return &t.split_overhead;
+  if (!std::strcmp(key, "fused_encoder")) return &t.fused_encoder;
+  if (!std::strcmp(key, "fused_head")) return &t.fused_head;
+  if (!std::strcmp(key, "small_batch")) return &t.small_batch;
+  if (!std::strcmp(key, "num_cus")) return &t.num_cus;
+  return nullptr;
+}
+
+int dib_set_tuning(const char* key, int value) {
+  int* p = tuning_slot(key);
+  if (!p || value < 0) return DIB_E_ARG;
+  *p = value;
+  return DIB_OK;
+}
+
+int dib_get_tuning(const char* key, int* value) {
+  const int* p = tuning_slot(key);
+  if (!p || !value) return DIB_E_ARG;
+  *value = *p;
+  return DIB_OK;
 }
 
 // ---- optimizers ------------------------------------------------------------------------------------
@@ -1343,28 +1351,6 @@ float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t
   float out[4];
   dib_eps4(seed, step, row, feature, e >> 2, out);
   return out[e & 3];
-}
-
-int64_t dib_split_weights_bytes(int K, int N) {
-  if (K <= 0 || N <= 0) return DIB_E_ARG;
-  return 3ll * N * ((K + 31) / 32 * 32) * 2;
-}
-
-int dib_split_weights(const float* W, int K, int N, void* planes, dib_stream_t stream) {
-  if (!W || !planes || K <= 0 || N <= 0) return DIB_E_ARG;
-  const int Kp = (K + 31) / 32 * 32;
-  hipLaunchKernelGGL(dib_split_weights_kernel, dim3(grid_for((int64_t)N * Kp)), dim3(256), 0, (hipStream_t)stream, W, K, N, Kp,
-                     (__bf16*)planes);
-  return (int)hipGetLastError();
-}
-
-int dib_gemm_bf16x6(int M, int N, int K, const float* A, int lda, const void* planes, float* C, int ldc,
-                    const float* bias, int act, dib_stream_t stream) {
-  if (!A || !planes || !C || M <= 0 || N <= 0 || K <= 0 || !act_ok(act)) return DIB_E_ARG;
-  const int Kp = (K + 31) / 32 * 32;
-  hipLaunchKernelGGL(dib_gemm_bf16x6_kernel, dim3(8 * cdiv(cdiv(M, 128), 8) * cdiv(N, 128)), dim3(256), 0, (hipStream_t)stream, A, lda,
-                     (const __bf16*)planes, Kp, C, ldc, bias, M, N, K, act);
-  return (int)hipGetLastError();
 }
 
 int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

@@ -120,12 +120,10 @@ __device__ __forceinline__ void dib_attn_store_rows(float* __restrict__ base, lo
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: grid (ceil(P / 128), H, B), 256 threads
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef DIB_ATTN_FWD_WAVES
-#define DIB_ATTN_FWD_WAVES 2   // measured (tools/attn_bench.py, 4 x 4096 x 12 heads, same box): 2 waves/SIMD (206 registers, no spills)
-#endif                         // 3.16-3.19 ms = 130 TFLOP/s = 0.83 of peak; 3 waves/SIMD (168 registers, 36 spilled) 3.78-3.80 ms.
-                               // (Before the by-value tile staging the order was the other way round, 4.98 vs 4.26 ms: the
-                               // stack-object traffic of the prefetched tile hurt the 2-wave build more.)
-__global__ void __launch_bounds__(256, DIB_ATTN_FWD_WAVES)   // workgroups per CU = waves per SIMD (2: <= 256 registers, 3: <= 168)
+// 2 waves / SIMD: measured (tools/attn_bench.py, 4 x 4096 x 12 heads, same box) 3.16-3.19 ms = 130 TFLOP/s = 0.83 of peak with
+// 206 registers and no spills; 3 waves / SIMD (168 registers, 36 spilled) 3.78-3.80 ms.  (Before the by-value tile staging the
+// order was the other way round, 4.98 vs 4.26 ms: the stack-object traffic of the prefetched tile hurt the 2-wave build more.)
+__global__ void __launch_bounds__(256, 2)   // workgroups per CU = waves per SIMD (2: <= 256 registers)
 dib_attn_fwd_kernel(DibAttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[kAttnTile * kAttnPitch];
   __shared__ __attribute__((aligned(16))) float Vs[kAttnTile * kAttnPitch];

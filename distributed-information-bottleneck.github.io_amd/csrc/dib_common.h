@@ -108,3 +108,34 @@ __device__ __forceinline__ float dib_block_sum_256(float v, float* red) {
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
+
+// ---------------------------------------------------------------------------------------------
+// Keras Adam on one element (reference train.py:128-129): m += (1-b1)(g-m); v += (1-b2)(g^2-v);
+// theta -= lr_t m/(sqrt(v)+eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t).  ONE definition with floating-point contraction OFF, used by
+// dib_adam_kernel and by every segment of dib_step_tail_kernel: the same (theta, m, v, g) gives the same bits whichever launch
+// applies the update (1-GPU fused tail, per-bucket data-parallel tails, the plain optimizer entry point).
+// ---------------------------------------------------------------------------------------------
+struct DibAdamCoef { float lr_t, c1, c2, eps, gscale; };   // c1 = 1 - beta_1, c2 = 1 - beta_2
+
+__device__ __forceinline__ DibAdamCoef dib_adam_coef(float lr, long long t_applied, float b1, float b2, float eps, float gscale) {
+#pragma clang fp contract(off)
+  const float t = (float)(t_applied + 1);
+  DibAdamCoef c;
+  c.lr_t = lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+  c.c1 = 1.f - b1; c.c2 = 1.f - b2; c.eps = eps; c.gscale = gscale;
+  return c;
+}
+
+__device__ __forceinline__ void dib_adam_update(float& p, float& m, float& v, float g, const DibAdamCoef& c) {
+#pragma clang fp contract(off)
+  const float gg = g * c.gscale;
+  const float d1 = gg - m, sq = gg * gg;
+  const float m1 = c.c1 * d1;
+  m = m + m1;
+  const float d2 = sq - v;
+  const float v1 = c.c2 * d2;
+  v = v + v1;
+  const float den = sqrtf(v) + c.eps;
+  const float num = c.lr_t * m;
+  p = p - num / den;
+}

@@ -300,36 +300,25 @@ __global__ void __launch_bounds__(256)
 dib_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                 long long n, const float* __restrict__ lr_dev, const long long* __restrict__ t_dev, float b1,
                 float b2, float eps, float gscale) {
-  const float t = (float)(t_dev[0] + 1);
-  const float lr_t = lr_dev[0] * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+  const DibAdamCoef c = dib_adam_coef(lr_dev[0], t_dev[0], b1, b2, eps, gscale);
   const long long n4 = n >> 2;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4;
        i += (long long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
-    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
-    gg.x *= gscale; gg.y *= gscale; gg.z *= gscale; gg.w *= gscale;
-    mm.x += (1.f - b1) * (gg.x - mm.x); vv.x += (1.f - b2) * (gg.x * gg.x - vv.x);
-    mm.y += (1.f - b1) * (gg.y - mm.y); vv.y += (1.f - b2) * (gg.y * gg.y - vv.y);
-    mm.z += (1.f - b1) * (gg.z - mm.z); vv.z += (1.f - b2) * (gg.z * gg.z - vv.z);
-    mm.w += (1.f - b1) * (gg.w - mm.w); vv.w += (1.f - b2) * (gg.w * gg.w - vv.w);
-    pp.x -= lr_t * mm.x / (sqrtf(vv.x) + eps);
-    pp.y -= lr_t * mm.y / (sqrtf(vv.y) + eps);
-    pp.z -= lr_t * mm.z / (sqrtf(vv.z) + eps);
-    pp.w -= lr_t * mm.w / (sqrtf(vv.w) + eps);
+    dib_adam_update(pp.x, mm.x, vv.x, gg.x, c);
+    dib_adam_update(pp.y, mm.y, vv.y, gg.y, c);
+    dib_adam_update(pp.z, mm.z, vv.z, gg.z, c);
+    dib_adam_update(pp.w, mm.w, vv.w, gg.w, c);
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const long long i = (n4 << 2) + threadIdx.x;
-    const float gg = g[i] * gscale;
-    const float mm = m[i] + (1.f - b1) * (gg - m[i]);
-    const float vv = v[i] + (1.f - b2) * (gg * gg - v[i]);
-    m[i] = mm;
-    v[i] = vv;
-    p[i] -= lr_t * mm / (sqrtf(vv) + eps);
+    dib_adam_update(p[i], m[i], v[i], g[i], c);
   }
 }
 
@@ -900,11 +889,12 @@ dib_head_fused_kernel(int kind, const float* __restrict__ A, int batch, int K, c
     gg *= inv_bg;
     if (lane == 0) {
       pred[b] = z;
-      g_pred[b] = gg;
+      if (g_pred != nullptr) g_pred[b] = gg;
       lsum += l;
       correct += ((z > 0.5f ? 1.f : 0.f) == yy) ? 1.f : 0.f;
       pb += gg;
     }
+    if (g_a == nullptr) continue;   // validation: prediction + loss terms only (workgroup-uniform)
     float4* ga = reinterpret_cast<float4*>(g_a + (long long)b * K);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -917,14 +907,18 @@ dib_head_fused_kernel(int kind, const float* __restrict__ A, int batch, int K, c
     }
   }
   // fixed-order sum of the four waves' partials
+  if (g_a != nullptr) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int j = lane + 64 * c;
-    if (j < K4) *reinterpret_cast<float4*>(&redw[wave][4 * j]) = pw[c];
+    for (int c = 0; c < NC; ++c) {
+      const int j = lane + 64 * c;
+      if (j < K4) *reinterpret_cast<float4*>(&redw[wave][4 * j]) = pw[c];
+    }
   }
   if (lane == 0) { redw[wave][K] = pb; redl[wave][0] = lsum; redl[wave][1] = correct; }
   __syncthreads();
-  float* dst = partial_w + (long long)blockIdx.x * (K + 1);
-  for (int i = threadIdx.x; i <= K; i += 256) dst[i] = redw[0][i] + redw[1][i] + redw[2][i] + redw[3][i];
+  if (g_a != nullptr) {
+    float* dst = partial_w + (long long)blockIdx.x * (K + 1);
+    for (int i = threadIdx.x; i <= K; i += 256) dst[i] = redw[0][i] + redw[1][i] + redw[2][i] + redw[3][i];
+  }
   if (threadIdx.x < 2) partial_l[2 * blockIdx.x + threadIdx.x] = redl[0][threadIdx.x] + redl[1][threadIdx.x] + redl[2][threadIdx.x] + redl[3][threadIdx.x];
 }

@@ -120,10 +120,7 @@ struct DibStage {
 #define DIB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 template <int MODE, int NI, int NJ, int BK>
-#ifndef DIB_GEMM_WGRAD_WG
-#define DIB_GEMM_WGRAD_WG 2   // A/B knob: workgroups per CU the register budget of the 128 x 128 x 32 WEIGHT-GRADIENT tile must allow
-#endif
-__global__ void __launch_bounds__(256, (MODE == 2 && NI == 2 && NJ == 2 && BK == 32) ? DIB_GEMM_WGRAD_WG : 2)
+__global__ void __launch_bounds__(256, 2)
 dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict__ Abase,
                 const float* __restrict__ Bbase, float* __restrict__ Cbase, const float* __restrict__ bias,
                 const float* __restrict__ aux, float* __restrict__ bias_out, int batch, int act, int tiles_m,
@@ -190,15 +187,12 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     SA::lstore(As, ra, tid);
     SB::lstore(Bs, rb, tid);
     __syncthreads();
-#ifndef DIB_GEMM_SPLIT_PREFETCH
-#define DIB_GEMM_SPLIT_PREFETCH 1   // 0 (A/B baseline, rounds 1-2): the whole prefetch issued at the top of the MFMA phase
-#endif
     // The next K-tile's global loads are issued in PIECES spread over this tile's MFMA phase instead of one burst after the
     // barrier: a workgroup's HBM request stream becomes even, and the tiled kernels' read rate moves from 4.45 TB/s towards
     // what the streaming kernels reach.  Measured per shape (same-box A/B of 2 / 4 pieces, weight gradients only / every mode,
     // profiles/r03r_gemm_prefetch_pieces_ab.txt): 64-deep forward / dgrad tiles want 4 pieces (dgrad 0.79 -> 0.73 ms), the
     // weight gradients and the 32-deep tiles 2 (layer-3 wgrad 0.70 -> 0.65 ms; 4 pieces there: 0.71).
-    constexpr int kPieces = DIB_GEMM_SPLIT_PREFETCH == 0 ? 1 : ((MODE != 2 && BK == 64) ? 4 : 2);
+    constexpr int kPieces = (MODE != 2 && BK == 64) ? 4 : 2;   // (1 = rounds 1-2: the whole prefetch at the top of the MFMA phase)
     // stream_flags bit 0 (set by the host for LARGE streamed operands, launch_gemm_t): the streamed operands - both of a
     // weight gradient, the activation matrix of a forward / dgrad - are loaded non-temporally; bit 1: the forward / dgrad
     // output is stored non-temporally.  Same-box A/Bs at B = 65536 (profiles/r03v_gemm_cache_policy_ab.txt): between -3 % and

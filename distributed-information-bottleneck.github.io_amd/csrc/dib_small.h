@@ -1,0 +1,506 @@
+// dib_small.h - the Distributed-IB step for SMALL batches (round 5): 16-row tiles instead of "one workgroup owns a feature".
+//
+// The reference's own runs are small-batch (train.py:30-34: B = 128, 11 000 epochs; chaos notebook: B = 2048).  There the
+// fused kernels of dib_fused.h put ONE workgroup on each feature - 10 workgroups on 256 CUs at the Boolean-circuit default,
+// 31 us of which 11 us are the MFMAs of one CU - and the integration network ran as five GEMM launches of 8 workgroups
+// each.  Below ~1024 rows the right decomposition is the other one: a workgroup owns 16 batch ROWS (the smallest MFMA tile,
+// v_mfma_f32_16x16x4_f32, exact fp32), keeps those rows' activations in LDS through the whole layer chain and streams the
+// weights from L2 straight into the MFMA B operand (each weight is used once per workgroup: nothing to stage).
+//   dib_small_encoder_fwd_kernel  grid (row tiles, F): gather + PositionalEncoding (models.py:22-23) + Dense chain
+//                                 (models.py:73-78,106) + reparameterisation (models.py:108) + KL partial (models.py:111-112)
+//   dib_small_integration_kernel  grid (row tiles): concat(u) -> integration MLP (models.py:122) -> [1-unit head + loss + its
+//                                 gradient | general output layer] -> dgrad chain back to dL/du; modes select the pieces
+//   dib_small_encoder_bwd_kernel  grid (row tiles, F): d(mu|logvar) incl. beta*KL, dgrads of layers 3 and 2, and the
+//                                 d(W1|b1) partial of the tile
+// Weight gradients that contract over the batch (layers >= 2) are left to the grouped wgrad GEMM on the stashed operands.
+// Every sum has a fixed order: bit-exact replay, like the large-batch path; results differ from it by fp32 rounding only.
+#pragma once
+#include "dib_common.h"
+#include "dib_fused.h"   // dib_sigma, DIB_MFMA16, dib_f32x4
+
+#define DIB_SMALL_ROWS 16
+
+__host__ __device__ inline int dib_small_pick_nt(int n) {   // column tiles of 16 per wave pass: balance the 4 waves first
+  if (n % 64 == 0 && (n / 64) % 4 == 0) return 4;
+  if (n % 32 == 0 && (n / 32) % 4 == 0) return 2;
+  if ((n / 16) % 4 == 0) return 1;
+  if (n % 64 == 0) return 4;
+  if (n % 32 == 0) return 2;
+  return 1;
+}
+
+template <int NT>
+__device__ __forceinline__ void dib_small_loadw(const float* __restrict__ p, float (&b)[NT]) {
+  if constexpr (NT == 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+  } else if constexpr (NT == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    b[0] = v.x; b[1] = v.y;
+  } else {
+    b[0] = p[0];
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void dib_small_storev(float* p, const float (&v)[NT]) {
+  if constexpr (NT == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else if constexpr (NT == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  else p[0] = v[0];
+}
+
+// out[16][N] = act(in[16][K] @ W[K][N] + bias).  in / out: LDS tiles (pitches pin / pout, pitch % 64 == 4: the A-operand
+// dword reads of a wave hit 64 distinct banks); W: global, row-major, leading dimension N, rows >= kvalid read as zero
+// (ragged first encoder layer).  Wave w owns column groups w, w + 4, ... of 16 NT columns; lane (j = lane & 15,
+// q = lane >> 4) feeds A[row j][k = 4 s + q] and B[k = 4 s + q][columns n0 + NT j .. + NT) - NT consecutive floats of a
+// weight row = one 4 NT-byte load, and the C fragment then holds NT CONSECUTIVE columns of rows 4 q .. 4 q + 3.
+// gdst (optional): row-major global stash of the tile, leading dimension gld, rows < rows_valid.
+template <int NT>
+__device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
+                                                 const float* __restrict__ bias, int act, float* out, int pout,
+                                                 float* __restrict__ gdst, long long gld, int rows_valid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  constexpr int CG = 16 * NT;
+  for (int n0 = wave * CG; n0 < N; n0 += 4 * CG) {
+    dib_f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const float bv = bias[n0 + NT * j + c];
+      acc[c] = dib_f32x4{bv, bv, bv, bv};
+    }
+    const float* ap = in + j * pin + q;
+    const float* wp = W + (long long)q * N + n0 + NT * j;
+#pragma unroll 8
+    for (int s = 0; s < K; s += 4) {
+      const float av = ap[s];
+      float b[NT];
+      const bool ok = s + q < kvalid;
+      dib_small_loadw<NT>(ok ? wp + (long long)s * N : W, b);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) acc[c] = DIB_MFMA16(av, ok ? b[c] : 0.f, acc[c]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      float v[NT];
+#pragma unroll
+      for (int c = 0; c < NT; ++c) v[c] = dib_act(act, acc[c][r]);
+      if (out != nullptr) dib_small_storev<NT>(out + row * pout + n0 + NT * j, v);
+      if (gdst != nullptr && row < rows_valid) dib_small_storev<NT>(gdst + (long long)row * gld + n0 + NT * j, v);
+    }
+  }
+}
+
+__device__ __forceinline__ void dib_small_fwd(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
+                                              const float* __restrict__ bias, int act, float* out, int pout,
+                                              float* __restrict__ gdst, long long gld, int rows_valid) {
+  switch (dib_small_pick_nt(N)) {
+    case 4: dib_small_fwd_nt<4>(in, pin, K, kvalid, W, N, bias, act, out, pout, gdst, gld, rows_valid); break;
+    case 2: dib_small_fwd_nt<2>(in, pin, K, kvalid, W, N, bias, act, out, pout, gdst, gld, rows_valid); break;
+    default: dib_small_fwd_nt<1>(in, pin, K, kvalid, W, N, bias, act, out, pout, gdst, gld, rows_valid); break;
+  }
+}
+
+// gin[16][Kin] = (g[16][N] @ W[Kin][N]^T) (.) act'(h[16][Kin])   (h == nullptr: no activation in front, e.g. dL/du).
+// The contraction runs along the weight rows: lane (j, q) feeds A[row j][n = 16 S + 4 q + c] (one ds_read_b128 per 4 MFMAs)
+// and B[n][k = k0 + 16 t + j] = W[k][16 S + 4 q + c] (one 16-byte load per tile t and 4 MFMAs).  gin: LDS tile or nullptr;
+// gdst: optional global row-major stash.
+template <int NT>
+__device__ __forceinline__ void dib_small_bwd_nt(const float* g, int pg, int N, const float* __restrict__ W, int Kin,
+                                                 const float* h, int ph, int act, float* gin, int pgi,
+                                                 float* __restrict__ gdst, long long gld, int rows_valid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  constexpr int CG = 16 * NT;
+  for (int k0 = wave * CG; k0 < Kin; k0 += 4 * CG) {
+    dib_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = dib_f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = g + j * pg + 4 * q;
+    const float* wp = W + (long long)(k0 + j) * N + 4 * q;
+#pragma unroll 2
+    for (int S = 0; S < N; S += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(ap + S);
+      float4 b[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(wp + (long long)(16 * t) * N + S);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.x, b[t].x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.y, b[t].y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.z, b[t].z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.w, b[t].w, acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r, k = k0 + 16 * t + j;
+        float v = acc[t][r];
+        if (h != nullptr) v *= dib_act_grad(act, h[row * ph + k]);
+        if (gin != nullptr) gin[row * pgi + k] = v;
+        if (gdst != nullptr && row < rows_valid) gdst[(long long)row * gld + k] = v;
+      }
+  }
+}
+
+__device__ __forceinline__ void dib_small_bwd(const float* g, int pg, int N, const float* __restrict__ W, int Kin,
+                                              const float* h, int ph, int act, float* gin, int pgi,
+                                              float* __restrict__ gdst, long long gld, int rows_valid) {
+  switch (dib_small_pick_nt(Kin)) {
+    case 4: dib_small_bwd_nt<4>(g, pg, N, W, Kin, h, ph, act, gin, pgi, gdst, gld, rows_valid); break;
+    case 2: dib_small_bwd_nt<2>(g, pg, N, W, Kin, h, ph, act, gin, pgi, gdst, gld, rows_valid); break;
+    default: dib_small_bwd_nt<1>(g, pg, N, W, Kin, h, ph, act, gin, pgi, gdst, gld, rows_valid); break;
+  }
+}
+
+// global [rows_valid][width] (leading dimension ld) -> LDS tile [16][pitch]; rows >= rows_valid are zero-filled
+__device__ __forceinline__ void dib_small_load_tile(const float* __restrict__ src, long long ld, int width, int rows_valid,
+                                                    float* dst, int pitch) {
+  const int w4 = width >> 2;
+  for (int i = threadIdx.x; i < DIB_SMALL_ROWS * w4; i += 256) {
+    const int row = i / w4, c = (i - row * w4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows_valid) v = *reinterpret_cast<const float4*>(src + (long long)row * ld + c);
+    *reinterpret_cast<float4*>(dst + row * pitch + c) = v;
+  }
+}
+
+__host__ __device__ inline int dib_small_pitch(int width) { return (width + 63) / 64 * 64 + 4; }   // pitch % 64 == 4
+
+// =====================================================================================================================
+// encoder bank forward
+// =====================================================================================================================
+struct DibSmallEncFwdArgs {
+  const float* X; long long ldx; const int* row_idx; long long row0; int batch;
+  const float* params; const long long* w_off; const long long* b_off; const int4* featmap;
+  int n_blocks, act, F, E, H1, H2;
+  float* P; float* h1; float* h2;            // stashes for the backward pass (nullptr: inference)
+  float* enc_out; float* U; float* kl_partial;   // kl_partial[row tile][F]
+  unsigned long long seed; unsigned step; int deterministic; const unsigned* step_dev;
+};
+
+__global__ void __launch_bounds__(256)
+dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4];
+  const int f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile * DIB_SMALL_ROWS, rows_valid = min(DIB_SMALL_ROWS, a.batch - r0);
+  const int4 fm = a.featmap[f];   // {d_f, in_dim_f, x column offset, sum of in_dim of earlier features}
+  const int d = fm.x, in_dim = fm.y, F = a.F, E = a.E, E2 = 2 * a.E;
+  const int p1 = dib_small_pitch(a.H1), p2 = dib_small_pitch(a.H2), p3 = dib_small_pitch(E2);
+  float* Pl = lds;                          // [16][20]: encoder input, columns >= in_dim zero
+  float* h1s = Pl + DIB_SMALL_ROWS * 20;    // [16][p1]
+  float* h2s = h1s + DIB_SMALL_ROWS * p1;   // [16][p2]
+  float* os = h2s + DIB_SMALL_ROWS * p2;    // [16][p3]
+  // ---- gather + positional encoding (the expressions of dib_posenc_kernel): P[b][j d + c] = j == 0 ? x : sin(2^j x) ----
+  for (int i = tid; i < DIB_SMALL_ROWS * 20; i += 256) Pl[i] = 0.f;
+  __syncthreads();
+  if (tid < DIB_SMALL_ROWS * d) {
+    const int row = tid / d, c = tid - row * d;
+    if (row < rows_valid) {
+      const int b = r0 + row;
+      const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
+      const float x = a.X[grow * a.ldx + fm.z + c];
+      float* pg = a.P ? a.P + (long long)fm.w * a.batch + (long long)b * in_dim + c : nullptr;
+      Pl[row * 20 + c] = x;
+      if (pg) pg[0] = x;
+      float fr = 2.0f;
+      for (int jb = 1; jb < a.n_blocks; ++jb) {
+        const float v = sinf(fr * x);
+        Pl[row * 20 + jb * d + c] = v;
+        if (pg) pg[(long long)jb * d] = v;
+        fr *= 2.0f;
+      }
+    }
+  }
+  __syncthreads();
+  const float* W1 = a.params + a.w_off[0 * F + f];
+  const float* W2 = a.params + a.w_off[1 * F + f];
+  const float* W3 = a.params + a.w_off[2 * F + f];
+  const float* b1 = a.params + a.b_off[0 * F + f];
+  const float* b2 = a.params + a.b_off[1 * F + f];
+  const float* b3 = a.params + a.b_off[2 * F + f];
+  const long long frow = (long long)f * a.batch + r0;
+  dib_small_fwd(Pl, 20, (in_dim + 3) & ~3, in_dim, W1, a.H1, b1, a.act, h1s, p1, a.h1 ? a.h1 + frow * a.H1 : nullptr, a.H1,
+                rows_valid);
+  __syncthreads();
+  dib_small_fwd(h1s, p1, a.H1, a.H1, W2, a.H2, b2, a.act, h2s, p2, a.h2 ? a.h2 + frow * a.H2 : nullptr, a.H2, rows_valid);
+  __syncthreads();
+  dib_small_fwd(h2s, p2, a.H2, a.H2, W3, E2, b3, 0 /* linear, models.py:78 */, os, p3, a.enc_out + frow * E2, E2, rows_valid);
+  __syncthreads();
+  // ---- reparameterise + KL: thread = (row, 4 consecutive embedding dims) = one Philox call ----
+  const int E4 = E >> 2;
+  float klp = 0.f;
+  const unsigned nstep = a.step_dev ? a.step_dev[0] : a.step;
+  for (int i = tid; i < DIB_SMALL_ROWS * E4; i += 256) {
+    const int row = i / E4, qq = i - row * E4;
+    if (row >= rows_valid) continue;
+    const int b = r0 + row;
+    const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
+    const float4 mu = *reinterpret_cast<const float4*>(os + row * p3 + 4 * qq);
+    const float4 lv = *reinterpret_cast<const float4*>(os + row * p3 + E + 4 * qq);
+    float eps[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!a.deterministic) dib_eps4(a.seed, nstep, (uint32_t)grow, (uint32_t)f, (uint32_t)qq, eps);
+    const float4 sg = make_float4(dib_sigma(lv.x), dib_sigma(lv.y), dib_sigma(lv.z), dib_sigma(lv.w));
+    float4 u;
+    u.x = mu.x + sg.x * eps[0];
+    u.y = mu.y + sg.y * eps[1];
+    u.z = mu.z + sg.z * eps[2];
+    u.w = mu.w + sg.w * eps[3];
+    *reinterpret_cast<float4*>(a.U + (long long)b * ((long long)F * E) + (long long)f * E + 4 * qq) = u;
+    klp += 0.5f * ((mu.x * mu.x + sg.x * sg.x - lv.x - 1.f) + (mu.y * mu.y + sg.y * sg.y - lv.y - 1.f) +
+                   (mu.z * mu.z + sg.z * sg.z - lv.z - 1.f) + (mu.w * mu.w + sg.w * sg.w - lv.w - 1.f));
+  }
+  const float tot = dib_block_sum_256(klp, red);
+  if (tid == 0) a.kl_partial[(long long)tile * F + f] = tot;
+}
+
+// =====================================================================================================================
+// integration network: forward, 1-unit head + loss, dgrad chain
+// =====================================================================================================================
+#define DIB_SMALL_INT_FWD 1        // hidden layers u -> h_0 .. h_{n-1} (stashed unless DIB_SMALL_INT_INFER)
+#define DIB_SMALL_INT_OUT 2        // general output layer -> pred (out_dim % 16 == 0)
+#define DIB_SMALL_INT_HEAD 4       // 1-unit linear output + BCE-from-logits / MSE: pred, loss partials
+#define DIB_SMALL_INT_HEAD_GRAD 8  // ... and its backward: g_pred, dL/dh_{n-1}, (W|b) gradient partial of the tile
+#define DIB_SMALL_INT_BWD_OUT 16   // dL/dh_{n-1} = (g_pred @ W_out^T) (.) act'(h_{n-1}) from a given dL/dpred (out_dim % 16 == 0)
+#define DIB_SMALL_INT_BWD 32       // dgrad chain dL/dh_{n-1} -> ... -> dL/du
+#define DIB_SMALL_INT_INFER 64     // no stashes (validation)
+#define DIB_SMALL_INT_LOAD_H 128   // hidden activations come from the global stashes (a backward launched on its own)
+
+struct DibSmallIntArgs {
+  const float* U; float* GU; int batch, K0;
+  const float* params;
+  int n_hidden; int width[4]; long long w_off[4], b_off[4];   // [n_hidden] = the output layer
+  float* h[3]; float* g[3];                                   // global stashes int_h / g_int_h, [B][width]
+  int act, out_act, out_dim, mode;
+  float* pred; float* g_pred;
+  int loss_kind; const float* Y; long long ldy; const int* row_idx; long long row0; float inv_bg;
+  float* partial_w; float* partial_l;                         // head: [tile][K + 1], [tile][2]
+};
+
+__global__ void __launch_bounds__(256)
+dib_small_integration_kernel(DibSmallIntArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = tile * DIB_SMALL_ROWS, rows_valid = min(DIB_SMALL_ROWS, a.batch - r0);
+  const int n = a.n_hidden;
+  // LDS map: u | h_0 .. h_{n-1} | g_0 .. g_{n-1} | pred / g_pred tile | head scratch
+  const int pu = dib_small_pitch(a.K0);
+  float* us = lds;
+  float* hs[3]; float* gs[3]; int ph[3];
+  float* cur = us + DIB_SMALL_ROWS * pu;
+  for (int l = 0; l < n; ++l) { ph[l] = dib_small_pitch(a.width[l]); hs[l] = cur; cur += DIB_SMALL_ROWS * ph[l]; }
+  for (int l = 0; l < n; ++l) { gs[l] = cur; cur += DIB_SMALL_ROWS * ph[l]; }
+  const int po = dib_small_pitch(a.out_dim);
+  float* ps = cur; cur += DIB_SMALL_ROWS * po;
+  float* scratch = cur;   // head: [4][K + 1] + 8
+  const bool stash = !(a.mode & DIB_SMALL_INT_INFER);
+  const int KL = a.width[n - 1];   // width of the last hidden layer
+
+  if (a.mode & DIB_SMALL_INT_FWD) {
+    dib_small_load_tile(a.U + (long long)r0 * a.K0, a.K0, a.K0, rows_valid, us, pu);
+    __syncthreads();
+    for (int l = 0; l < n; ++l) {
+      const float* in = l == 0 ? us : hs[l - 1];
+      const int K = l == 0 ? a.K0 : a.width[l - 1], pin = l == 0 ? pu : ph[l - 1];
+      dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], a.act, hs[l], ph[l],
+                    stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid);
+      __syncthreads();
+    }
+  } else if (a.mode & DIB_SMALL_INT_LOAD_H) {
+    for (int l = 0; l < n; ++l) dib_small_load_tile(a.h[l] + (long long)r0 * a.width[l], a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
+    __syncthreads();
+  }
+
+  if (a.mode & DIB_SMALL_INT_OUT) {   // general output layer (reference models.py:83)
+    dib_small_fwd(hs[n - 1], ph[n - 1], KL, KL, a.params + a.w_off[n], a.out_dim, a.params + a.b_off[n], a.out_act, nullptr, 0,
+                  a.pred + (long long)r0 * a.out_dim, a.out_dim, rows_valid);
+  }
+
+  if (a.mode & DIB_SMALL_INT_HEAD) {
+    // z = h . w + b per row (wave w: rows w, w + 4, w + 8, w + 12); Keras BinaryCrossentropy(from_logits=True) / 'mse', the
+    // expressions of dib_head_fused_kernel; dL/dh = g w (.) act'(h); per-tile partial of d(w|b) and of {loss sum, #correct}
+    const bool grad = (a.mode & DIB_SMALL_INT_HEAD_GRAD) != 0;
+    const float* wv = a.params + a.w_off[n];
+    const float b0 = a.params[a.b_off[n]];
+    const float* hl = hs[n - 1];
+    const int pl = ph[n - 1];
+    float* redw = scratch;               // [4][KL + 1]
+    float* redl = scratch + 4 * (KL + 1); // [4][2]
+    float lsum = 0.f, correct = 0.f, pb = 0.f;
+    float pw[16];                        // KL <= 1024: 16 lane-strided columns
+#pragma unroll
+    for (int c = 0; c < 16; ++c) pw[c] = 0.f;
+    for (int ri = 0; ri < 4; ++ri) {
+      const int row = wave + 4 * ri;
+      if (row >= rows_valid) continue;   // wave-uniform
+      const int b = r0 + row;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int k = lane + 64 * c;
+        if (k < KL) dot += hl[row * pl + k] * wv[k];
+      }
+      const float z = dib_wave_sum(dot) + b0;
+      const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
+      const float yy = a.Y[grow * a.ldy];
+      float l, gg;
+      if (a.loss_kind == 0) {
+        l = fmaxf(z, 0.f) - z * yy + log1pf(expf(-fabsf(z)));
+        gg = 1.0f / (1.0f + expf(-z)) - yy;
+      } else {
+        const float dd = z - yy;
+        l = dd * dd;
+        gg = 2.f * dd;
+      }
+      gg *= a.inv_bg;
+      if (lane == 0) {
+        a.pred[b] = z;
+        if (grad) a.g_pred[b] = gg;
+        lsum += l;
+        correct += ((z > 0.5f ? 1.f : 0.f) == yy) ? 1.f : 0.f;
+        pb += gg;
+      }
+      if (!grad) continue;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int k = lane + 64 * c;
+        if (k < KL) {
+          const float hv = hl[row * pl + k];
+          const float gv = gg * wv[k] * dib_act_grad(a.act, hv);
+          gs[n - 1][row * pl + k] = gv;
+          a.g[n - 1][(long long)b * KL + k] = gv;
+          pw[c] += hv * gg;
+        }
+      }
+    }
+    if (grad) {
+      // rows of the tile that do not exist carry no gradient into the dgrad chain
+      for (int row = rows_valid + wave; row < DIB_SMALL_ROWS; row += 4)
+        for (int k = lane; k < KL; k += 64) gs[n - 1][row * pl + k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int k = lane + 64 * c;
+        if (k < KL) redw[wave * (KL + 1) + k] = pw[c];
+      }
+    }
+    if (lane == 0) { redw[wave * (KL + 1) + KL] = pb; redl[2 * wave] = lsum; redl[2 * wave + 1] = correct; }
+    __syncthreads();
+    if (grad) {
+      float* dst = a.partial_w + (long long)tile * (KL + 1);
+      for (int i = tid; i <= KL; i += 256)
+        dst[i] = redw[i] + redw[(KL + 1) + i] + redw[2 * (KL + 1) + i] + redw[3 * (KL + 1) + i];
+    }
+    if (tid < 2) a.partial_l[2 * tile + tid] = redl[tid] + redl[2 + tid] + redl[4 + tid] + redl[6 + tid];
+  }
+
+  if (a.mode & DIB_SMALL_INT_BWD_OUT) {   // dL/dh_{n-1} from a given dL/dpred (custom loss: InfoNCE, train.py:216-219)
+    dib_small_load_tile(a.g_pred + (long long)r0 * a.out_dim, a.out_dim, a.out_dim, rows_valid, ps, po);
+    __syncthreads();
+    dib_small_bwd(ps, po, a.out_dim, a.params + a.w_off[n], KL, hs[n - 1], ph[n - 1], a.act, gs[n - 1], ph[n - 1],
+                  a.g[n - 1] + (long long)r0 * KL, KL, rows_valid);
+    __syncthreads();
+  }
+
+  if (a.mode & DIB_SMALL_INT_BWD) {
+    for (int l = n - 1; l >= 1; --l) {   // dL/dh_{l-1} = (dL/dh_l @ W_l^T) (.) act'(h_{l-1})
+      dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], a.act, gs[l - 1],
+                    ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid);
+      __syncthreads();
+    }
+    // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output)
+    dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 0, nullptr, 0,
+                  a.GU + (long long)r0 * a.K0, a.K0, rows_valid);
+  }
+}
+
+// =====================================================================================================================
+// encoder bank backward (dgrad chain + the layer-1 weight-gradient partial)
+// =====================================================================================================================
+struct DibSmallEncBwdArgs {
+  const float* P; int batch;
+  const float* params; const long long* w_off; const long long* b_off; const int4* featmap;
+  int act, F, E, H1, H2;
+  const float* h1; const float* h2; const float* enc_out; const float* U; const float* GU;
+  float* dout; float* dh2;
+  float* dw1_partial;   // [row tile][F][16][H1]
+  const float* beta_dev; float inv_bg;
+};
+
+__global__ void __launch_bounds__(256)
+dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = tile * DIB_SMALL_ROWS, rows_valid = min(DIB_SMALL_ROWS, a.batch - r0);
+  const int4 fm = a.featmap[f];
+  const int in_dim = fm.y, F = a.F, E = a.E, E2 = 2 * a.E;
+  const int p1 = dib_small_pitch(a.H1), p2 = dib_small_pitch(a.H2), p3 = dib_small_pitch(E2);
+  float* Pl = lds;                            // [16][20]: [P | 1 | 0], rows >= rows_valid zero
+  float* h1s = Pl + DIB_SMALL_ROWS * 20;      // [16][p1]
+  float* h2s = h1s + DIB_SMALL_ROWS * p1;     // [16][p2]
+  float* dos = h2s + DIB_SMALL_ROWS * p2;     // [16][p3]  d(mu|logvar)
+  float* dh2s = dos + DIB_SMALL_ROWS * p3;    // [16][p2]
+  float* dh1s = dh2s + DIB_SMALL_ROWS * p2;   // [16][p1]
+  const long long frow = (long long)f * a.batch + r0;
+  dib_small_load_tile(a.h1 + frow * a.H1, a.H1, a.H1, rows_valid, h1s, p1);
+  dib_small_load_tile(a.h2 + frow * a.H2, a.H2, a.H2, rows_valid, h2s, p2);
+  for (int i = tid; i < DIB_SMALL_ROWS * 20; i += 256) {
+    const int row = i / 20, c = i - row * 20;
+    float v = 0.f;
+    if (row < rows_valid) {
+      if (c < in_dim) v = a.P[(long long)fm.w * a.batch + (long long)(r0 + row) * in_dim + c];
+      else if (c == in_dim) v = 1.f;
+    }
+    Pl[i] = v;
+  }
+  // ---- d(loss + beta KL)/d(mu|logvar) (the expressions of dib_fused_encoder_bwd_kernel); eps sigma = u - mu ----
+  const float kb = a.beta_dev[0] * a.inv_bg;
+  const int E4 = E >> 2;
+  for (int i = tid; i < DIB_SMALL_ROWS * E4; i += 256) {
+    const int row = i / E4, qq = i - row * E4;
+    float4 dm = make_float4(0.f, 0.f, 0.f, 0.f), dl = dm;
+    if (row < rows_valid) {
+      const int b = r0 + row;
+      const float* eo = a.enc_out + ((long long)f * a.batch + b) * E2;
+      const float4 mu = *reinterpret_cast<const float4*>(eo + 4 * qq);
+      const float4 lv = *reinterpret_cast<const float4*>(eo + E + 4 * qq);
+      const long long so = (long long)b * ((long long)F * E) + (long long)f * E + 4 * qq;
+      const float4 g = *reinterpret_cast<const float4*>(a.GU + so);
+      const float4 u = *reinterpret_cast<const float4*>(a.U + so);
+      const float sx = dib_sigma(lv.x), sy = dib_sigma(lv.y), sz = dib_sigma(lv.z), sw = dib_sigma(lv.w);
+      dm = make_float4(g.x + kb * mu.x, g.y + kb * mu.y, g.z + kb * mu.z, g.w + kb * mu.w);
+      dl = make_float4(g.x * (u.x - mu.x) * 0.5f + kb * 0.5f * (sx * sx - 1.f), g.y * (u.y - mu.y) * 0.5f + kb * 0.5f * (sy * sy - 1.f),
+                       g.z * (u.z - mu.z) * 0.5f + kb * 0.5f * (sz * sz - 1.f), g.w * (u.w - mu.w) * 0.5f + kb * 0.5f * (sw * sw - 1.f));
+      float* dd = a.dout + ((long long)f * a.batch + b) * E2;
+      *reinterpret_cast<float4*>(dd + 4 * qq) = dm;
+      *reinterpret_cast<float4*>(dd + E + 4 * qq) = dl;
+    }
+    *reinterpret_cast<float4*>(dos + row * p3 + 4 * qq) = dm;
+    *reinterpret_cast<float4*>(dos + row * p3 + E + 4 * qq) = dl;
+  }
+  __syncthreads();
+  const float* W2 = a.params + a.w_off[1 * F + f];
+  const float* W3 = a.params + a.w_off[2 * F + f];
+  // dh2 = (dout @ W3^T) (.) act'(h2) -> stash (operand of the layer-2 weight gradient) ; dh1 = (dh2 @ W2^T) (.) act'(h1)
+  dib_small_bwd(dos, p3, E2, W3, a.H2, h2s, p2, a.act, dh2s, p2, a.dh2 + frow * a.H2, a.H2, rows_valid);
+  __syncthreads();
+  dib_small_bwd(dh2s, p2, a.H2, W2, a.H1, h1s, p1, a.act, dh1s, p1, nullptr, 0, rows_valid);
+  __syncthreads();
+  // d(W1|b1) partial of the tile = [P | 1]^T @ dh1: 16 x 16 output tiles (rows = encoder-input index, row in_dim = bias),
+  // contraction over the 16 rows in 4 MFMA steps; lane (i, q): A[i][row 4 s + q] = Pl[row][i], B[row][n0 + j] = dh1[row][n0 + j]
+  {
+    const int j = lane & 15, q = lane >> 4;
+    float* dst = a.dw1_partial + ((long long)tile * F + f) * (16ll * a.H1);
+    for (int n0 = 16 * wave; n0 < a.H1; n0 += 64) {
+      dib_f32x4 acc = dib_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = DIB_MFMA16(Pl[(4 * s + q) * 20 + j], dh1s[(4 * s + q) * p1 + n0 + j], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(long long)(4 * q + r) * a.H1 + n0 + j] = acc[r];
+    }
+  }
+}

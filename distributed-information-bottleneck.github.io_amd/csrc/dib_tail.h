@@ -48,22 +48,18 @@ struct DibTailArgs {
 };
 
 struct DibTailOpt {
-  float lr_t, lr, b1, b2, eps, gscale;
+  DibAdamCoef c;
+  float lr;
   int mode;   // 0 none, 1 Keras-Adam, 2 SGD
 };
 
-// one parameter: write the gradient, apply the optimizer (same expressions as dib_adam_kernel / dib_sgd_kernel)
+// one parameter: write the gradient, apply the optimizer (dib_adam_update: the expressions of dib_adam_kernel / dib_sgd_kernel)
 __device__ __forceinline__ void dib_tail_apply1(const DibTailArgs& a, const DibTailOpt& o, long long i, float g) {
   a.grads[i] = g;
   if (o.mode == 1) {
-    const float gg = g * o.gscale;
-    const float mm = a.m[i] + (1.f - o.b1) * (gg - a.m[i]);
-    const float vv = a.v[i] + (1.f - o.b2) * (gg * gg - a.v[i]);
-    a.m[i] = mm;
-    a.v[i] = vv;
-    a.params[i] -= o.lr_t * mm / (sqrtf(vv) + o.eps);
+    dib_adam_update(a.params[i], a.m[i], a.v[i], g, o.c);
   } else if (o.mode == 2) {
-    a.params[i] -= o.lr * o.gscale * g;
+    a.params[i] -= o.lr * o.c.gscale * g;
   }
 }
 
@@ -75,54 +71,35 @@ dib_step_tail_kernel(DibTailArgs a) {
   int bid = blockIdx.x;
   DibTailOpt o;
   o.mode = (a.flags & 8) ? 1 : ((a.flags & 64) ? 2 : 0);
-  o.b1 = a.b1; o.b2 = a.b2; o.eps = a.eps; o.gscale = a.gscale;
   o.lr = o.mode ? a.lr_dev[0] : 0.f;
-  o.lr_t = 0.f;
-  if (o.mode == 1) {
-    const float t = (float)(a.t_dev[0] + 1);
-    o.lr_t = o.lr * sqrtf(1.0f - powf(a.b2, t)) / (1.0f - powf(a.b1, t));
-  }
+  o.c = DibAdamCoef{0.f, 1.f - a.b1, 1.f - a.b2, a.eps, a.gscale};
+  if (o.mode == 1) o.c = dib_adam_coef(o.lr, a.t_dev[0], a.b1, a.b2, a.eps, a.gscale);
 
-  if (bid < a.nb_generic) {
-    const long long n4 = (a.gend - a.gbeg) >> 2;
-    float4* G = reinterpret_cast<float4*>(a.grads + a.gbeg);
-    for (long long i = bid * 256ll + tid; i < n4; i += (long long)a.nb_generic * 256) {
-      float4 s;
-      if (a.nsplit > 0) {
-        const float4* src = reinterpret_cast<const float4*>(a.slabs + a.gbeg) + i;
-        s = *src;
-        for (int k = 1; k < a.nsplit; ++k) {
-          const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (long long)k * a.slab_stride);
-          s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
-        }
-        G[i] = s;
-      } else {
-        s = G[i];
-      }
-      if (o.mode == 1) {
-        float4 pp = reinterpret_cast<float4*>(a.params + a.gbeg)[i];
-        float4 mm = reinterpret_cast<float4*>(a.m + a.gbeg)[i];
-        float4 vv = reinterpret_cast<float4*>(a.v + a.gbeg)[i];
-        s.x *= o.gscale; s.y *= o.gscale; s.z *= o.gscale; s.w *= o.gscale;
-        mm.x += (1.f - o.b1) * (s.x - mm.x); vv.x += (1.f - o.b2) * (s.x * s.x - vv.x);
-        mm.y += (1.f - o.b1) * (s.y - mm.y); vv.y += (1.f - o.b2) * (s.y * s.y - vv.y);
-        mm.z += (1.f - o.b1) * (s.z - mm.z); vv.z += (1.f - o.b2) * (s.z * s.z - vv.z);
-        mm.w += (1.f - o.b1) * (s.w - mm.w); vv.w += (1.f - o.b2) * (s.w * s.w - vv.w);
-        pp.x -= o.lr_t * mm.x / (sqrtf(vv.x) + o.eps);
-        pp.y -= o.lr_t * mm.y / (sqrtf(vv.y) + o.eps);
-        pp.z -= o.lr_t * mm.z / (sqrtf(vv.z) + o.eps);
-        pp.w -= o.lr_t * mm.w / (sqrtf(vv.w) + o.eps);
-        reinterpret_cast<float4*>(a.params + a.gbeg)[i] = pp;
-        reinterpret_cast<float4*>(a.m + a.gbeg)[i] = mm;
-        reinterpret_cast<float4*>(a.v + a.gbeg)[i] = vv;
-      } else if (o.mode == 2) {
-        float4 pp = reinterpret_cast<float4*>(a.params + a.gbeg)[i];
-        const float l = o.lr * o.gscale;
-        pp.x -= l * s.x; pp.y -= l * s.y; pp.z -= l * s.z; pp.w -= l * s.w;
-        reinterpret_cast<float4*>(a.params + a.gbeg)[i] = pp;
-      }
+  // block order: the few workgroups whose results the epilogue reads (KL / loss sums) come FIRST - they publish with a
+  // device-scope release (an L2 write-back on this multi-XCD part) while the L2s still hold few dirty lines
+  bool publishes = false;
+  if (bid < a.nb_kl) {
+    publishes = true;
+    float s = 0.f;
+    for (int i = tid; i < a.kl_rows; i += 256) s += a.kl_partial[(long long)i * a.kl_stride + bid];
+    const float tot = dib_block_sum_256(s, red);
+    if (tid == 0) a.step_out[bid] = tot;
+  } else if ((bid -= a.nb_kl) < a.nb_loss) {
+    publishes = true;
+    float s = 0.f;
+    for (int i = tid; i < a.loss_blocks; i += 256) s += a.loss_partial[(long long)i * 2 + bid];
+    const float tot = dib_block_sum_256(s, red);
+    if (tid == 0) {
+      a.step_out[a.F + bid] = tot;
+      if (bid == 0) a.step_out[a.F + 2] = a.rows;
     }
-  } else if ((bid -= a.nb_generic) < a.nb_dw1) {
+  } else if ((bid -= a.nb_loss) < a.nb_head) {
+    const int n = a.head_K + 1;   // [chunks][K + 1]: d w[0..K) then d b
+    float s = 0.f;
+    for (int c = tid; c < a.head_chunks; c += 256) s += a.head_partial[(long long)c * n + bid];
+    const float tot = dib_block_sum_256(s, red);
+    if (tid == 0) dib_tail_apply1(a, o, bid < a.head_K ? a.head_w_off + bid : a.head_b_off, tot);
+  } else if ((bid -= a.nb_head) < a.nb_dw1) {
     // grads[W1 of feature f][k][n] = sum_p partial[p][f][k][n] (k < in_dim), grads[b1][n] = sum_p partial[p][f][in_dim][n]
     const int f = bid >> 4, k = bid & 15;
     const int in_dim = a.featmap[f].y;
@@ -143,42 +120,58 @@ dib_step_tail_kernel(DibTailArgs a) {
         dib_tail_apply1(a, o, k < in_dim ? a.w_off[f] + (long long)k * a.H1 + n : a.b_off[f] + n, s);
       }
     }
-  } else if ((bid -= a.nb_dw1) < a.nb_head) {
-    const int n = a.head_K + 1;   // [chunks][K + 1]: d w[0..K) then d b
-    float s = 0.f;
-    for (int c = tid; c < a.head_chunks; c += 256) s += a.head_partial[(long long)c * n + bid];
-    const float tot = dib_block_sum_256(s, red);
-    if (tid == 0) dib_tail_apply1(a, o, bid < a.head_K ? a.head_w_off + bid : a.head_b_off, tot);
-  } else if ((bid -= a.nb_head) < a.nb_kl) {
-    float s = 0.f;
-    for (int i = tid; i < a.kl_rows; i += 256) s += a.kl_partial[(long long)i * a.kl_stride + bid];
-    const float tot = dib_block_sum_256(s, red);
-    if (tid == 0) a.step_out[bid] = tot;
-  } else {
-    bid -= a.nb_kl;
-    float s = 0.f;
-    for (int i = tid; i < a.loss_blocks; i += 256) s += a.loss_partial[(long long)i * 2 + bid];
-    const float tot = dib_block_sum_256(s, red);
-    if (tid == 0) {
-      a.step_out[a.F + bid] = tot;
-      if (bid == 0) a.step_out[a.F + 2] = a.rows;
+  } else if ((bid -= a.nb_dw1) < a.nb_generic) {
+    const long long n4 = (a.gend - a.gbeg) >> 2;
+    float4* G = reinterpret_cast<float4*>(a.grads + a.gbeg);
+    for (long long i = bid * 256ll + tid; i < n4; i += (long long)a.nb_generic * 256) {
+      float4 s;
+      if (a.nsplit > 0) {
+        const float4* src = reinterpret_cast<const float4*>(a.slabs + a.gbeg) + i;
+        s = *src;
+        for (int k = 1; k < a.nsplit; ++k) {
+          const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (long long)k * a.slab_stride);
+          s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+        G[i] = s;
+      } else {
+        s = G[i];
+      }
+      if (o.mode == 1) {
+        float4 pp = reinterpret_cast<float4*>(a.params + a.gbeg)[i];
+        float4 mm = reinterpret_cast<float4*>(a.m + a.gbeg)[i];
+        float4 vv = reinterpret_cast<float4*>(a.v + a.gbeg)[i];
+        dib_adam_update(pp.x, mm.x, vv.x, s.x, o.c);
+        dib_adam_update(pp.y, mm.y, vv.y, s.y, o.c);
+        dib_adam_update(pp.z, mm.z, vv.z, s.z, o.c);
+        dib_adam_update(pp.w, mm.w, vv.w, s.w, o.c);
+        reinterpret_cast<float4*>(a.params + a.gbeg)[i] = pp;
+        reinterpret_cast<float4*>(a.m + a.gbeg)[i] = mm;
+        reinterpret_cast<float4*>(a.v + a.gbeg)[i] = vv;
+      } else if (o.mode == 2) {
+        float4 pp = reinterpret_cast<float4*>(a.params + a.gbeg)[i];
+        const float l = o.lr * o.c.gscale;
+        pp.x -= l * s.x; pp.y -= l * s.y; pp.z -= l * s.z; pp.w -= l * s.w;
+        reinterpret_cast<float4*>(a.params + a.gbeg)[i] = pp;
+      }
     }
   }
 
   if (!(a.flags & (16 | 32))) return;     // nothing waits for the whole grid
   // ---- arrival: leaf = blockIdx % 32, the last of a leaf reports to the root; the last at the root owns the epilogue ----
+  // Only the workgroups that wrote step_out release (every workgroup doing so - one L2 write-back each, ~900 of them at the
+  // reference's default batch - made this kernel 20 us, profiles/r05c_default_batch_kernel_stats.csv); the step-count bump
+  // needs no fence at all: every workgroup's read of t has returned before its arrival (its optimizer stores depend on it).
   __syncthreads();
   if (tid == 0) {
-    __threadfence();
+    if (publishes && (a.flags & 32)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const unsigned total = gridDim.x, leaf = blockIdx.x % DIB_TAIL_LEAVES;
     const unsigned leaf_n = (total - leaf + DIB_TAIL_LEAVES - 1) / DIB_TAIL_LEAVES;
     const unsigned roots = total < DIB_TAIL_LEAVES ? total : DIB_TAIL_LEAVES;
     bool last = false;
-    if (atomicAdd(a.sync + 32 * (leaf + 1), 1u) == leaf_n - 1) {
-      a.sync[32 * (leaf + 1)] = 0u;                       // self-cleaning: the next launch finds zeros
-      __threadfence();
-      if (atomicAdd(a.sync, 1u) == roots - 1) {
-        a.sync[0] = 0u;
+    if (__hip_atomic_fetch_add(a.sync + 32 * (leaf + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaf_n - 1) {
+      __hip_atomic_store(a.sync + 32 * (leaf + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-cleaning
+      if (__hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == roots - 1) {
+        __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = true;
       }
     }
@@ -186,16 +179,16 @@ dib_step_tail_kernel(DibTailArgs a) {
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
+  if (a.flags & 32) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (a.flags & 32) {
     // step_out: [0..F) KL local sums, [F] task-loss local sum, [F+1] #correct, [F+2] rows (dib_metrics_accumulate_kernel)
     for (int i = tid; i < a.F + 3; i += 256) {
-      if (i < a.F) a.metrics_acc[i] += __builtin_nontemporal_load(a.step_out + i) * a.inv_bg;
+      if (i < a.F) a.metrics_acc[i] += __hip_atomic_load(a.step_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * a.inv_bg;
       else if (i == a.F) {
         float s = 0.f;
-        for (int f = 0; f < a.F; ++f) s += __builtin_nontemporal_load(a.step_out + f);
-        a.metrics_acc[a.F] += __builtin_nontemporal_load(a.step_out + a.F) + a.beta_dev[0] * s;
-      } else a.metrics_acc[i] += __builtin_nontemporal_load(a.step_out + i);
+        for (int f = 0; f < a.F; ++f) s += __hip_atomic_load(a.step_out + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.metrics_acc[a.F] += __hip_atomic_load(a.step_out + a.F, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + a.beta_dev[0] * s;
+      } else a.metrics_acc[i] += __hip_atomic_load(a.step_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if ((a.flags & 16) && tid == 0) a.t_dev[0] += 1;

@@ -64,6 +64,7 @@ class HipEngine:
             self.params, self.grads, self.adam_m, self.adam_v = z(n_alloc), z(n_alloc), z(n_alloc), z(n_alloc)
             self.beta_dev = torch.ones(1, dtype=torch.float32, device=self.device)  # reference models.py:86
             self.lr_dev = torch.full((1,), 1e-3, dtype=torch.float32, device=self.device)
+            self._lr_host: Optional[float] = 1e-3
             self.t_dev = z(1, torch.int64)
             self.metrics_acc = z(self.F + 3)
             tb = int(self.lib.dib_layout_table_bytes(self.layout))
@@ -169,17 +170,20 @@ class HipEngine:
 
     def set_beta(self, v: float) -> None:
         self.beta_dev.fill_(float(v))
-        self._beta_host = float(v)
 
     def get_beta(self) -> float:
         return float(self.beta_dev.item())
 
     def set_lr(self, v: float) -> None:
         """device learning rate; a repeated value costs nothing (fit sets it every step - a 4 us fill kernel per step of the
-        reference's default 140 us B = 128 step otherwise)"""
-        if getattr(self, "_lr_host", None) != float(v):
+        reference's default 140 us B = 128 step otherwise).  `lr_dev` is written ONLY here: the host-side cache below is
+        valid by construction (code that must write the device scalar itself calls invalidate_lr_cache() afterwards)."""
+        if self._lr_host != float(v):
             self.lr_dev.fill_(float(v))
             self._lr_host = float(v)
+
+    def invalidate_lr_cache(self) -> None:
+        self._lr_host = None
 
     def to_device(self, a, dtype=torch.float32) -> torch.Tensor:
         if isinstance(a, torch.Tensor):
@@ -188,15 +192,18 @@ class HipEngine:
 
     # ---- the step -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, row_idx: Optional[torch.Tensor], row0: int, batch: int, seed: int, step: int,
-                deterministic: bool = False, inference: bool = False, hidden_only: bool = False) -> None:
+                deterministic: bool = False, inference: bool = False, hidden_only: bool = False,
+                defer_sums: bool = False) -> None:
         """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT].  inference=True: no backward
-        follows (validation / predict), the fused forward skips the stashes it would write for it."""
+        follows (validation / predict), the fused forward skips the stashes it would write for it.  defer_sums=True: the KL
+        column sums are left to the step's tail launch (step_tail with TAIL_KL)."""
         ws = self.workspace(batch)
         self._ws_gen[batch] += 1
         st = self._stream()
         check(self.lib.dib_encoder_bank_fwd(self.layout, _ptr(x), x.stride(0), _ptr(row_idx), int(row0), batch,
                                             _ptr(self.params), int(seed), int(step) & 0xFFFFFFFF,
-                                            (1 if deterministic else 0) | (2 if inference else 0), _ptr(ws), st),
+                                            (_lib.FWD_DETERMINISTIC if deterministic else 0) | (_lib.FWD_INFERENCE if inference else 0)
+                                            | (_lib.FWD_DEFER_SUMS if defer_sums else 0), _ptr(ws), st),
               "dib_encoder_bank_fwd")
         if hidden_only:  # the output layer is evaluated by the fused head together with the loss (train_step)
             check(self.lib.dib_integration_fwd_hidden(self.layout, batch, _ptr(self.params), _ptr(ws), st),
@@ -204,11 +211,37 @@ class HipEngine:
         else:
             check(self.lib.dib_integration_fwd(self.layout, batch, _ptr(self.params), _ptr(ws), st), "dib_integration_fwd")
 
-    def loss(self, loss_kind: str, y: torch.Tensor, row_idx, row0: int, batch: int, inv_global_batch: float) -> None:
+    def loss(self, loss_kind: str, y: torch.Tensor, row_idx, row0: int, batch: int, inv_global_batch: float,
+             defer_sums: bool = False) -> None:
         ws = self.workspace(batch)
         check(self.lib.dib_loss_fwd_bwd(self.layout, LOSS_KINDS[loss_kind], _ptr(y), y.stride(0), _ptr(row_idx),
-                                        int(row0), batch, float(inv_global_batch), _ptr(ws), self._stream()),
+                                        int(row0), batch, float(inv_global_batch), _lib.HEAD_DEFER_SUMS if defer_sums else 0,
+                                        _ptr(ws), self._stream()),
               "dib_loss_fwd_bwd")
+
+    def step_tail(self, batch: int, part: int, flags: int, inv_global_batch: float = 0.0, optimizer=None,
+                  grad_scale: float = 1.0) -> None:
+        """ONE launch for the end of a step (include/dib_hip.h dib_step_tail): any of bucket finalize, the fused head's
+        weight-gradient reduce, KL / loss sums, metric accumulation, the optimizer on the bucket and the step-count bump.
+        optimizer: ("adam", beta_1, beta_2, epsilon) or ("sgd",) - adds TAIL_ADAM / TAIL_SGD to `flags`."""
+        b1, b2, eps = 0.9, 0.999, 1e-7
+        if optimizer is not None:
+            if optimizer[0] == "adam":
+                flags |= _lib.TAIL_ADAM
+                b1, b2, eps = (float(v) for v in optimizer[1:4])
+            elif optimizer[0] == "sgd":
+                flags |= _lib.TAIL_SGD
+            else:
+                raise ValueError(f"optimizer {optimizer[0]!r}")
+        check(self.lib.dib_step_tail(self.layout, batch, int(part), int(flags), _ptr(self.params), _ptr(self.grads),
+                                     _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.lr_dev), _ptr(self.t_dev), b1, b2, eps,
+                                     float(grad_scale), _ptr(self.beta_dev), float(inv_global_batch), _ptr(self.metrics_acc),
+                                     _ptr(self.workspace(batch)), self._stream()), "dib_step_tail")
+
+    def optimizer_step_part(self, batch: int, part: int, optimizer, bump: bool) -> None:
+        """the optimizer on ONE gradient bucket (after its all-reduce): the data-parallel fit steps buckets 1 and 2 while
+        bucket 3 is still on the wire; the launch with bump=True (the last) advances Adam's step count."""
+        self.step_tail(batch, part, _lib.TAIL_BUMP if (bump and optimizer[0] == "adam") else 0, optimizer=optimizer)
 
     def part_range(self, part: int):
         """(offset, count) of gradient bucket `part` in the flat buffers (include/dib_hip.h): 0 = encoder bank,
@@ -218,20 +251,25 @@ class HipEngine:
         return off.value, cnt.value
 
     def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float,
-                 on_integration_grads_ready=None, hidden_only: bool = False, on_encoder_front_grads_ready=None) -> None:
+                 on_integration_grads_ready=None, hidden_only: bool = False, on_encoder_front_grads_ready=None,
+                 finish_flags: int = 0, optimizer=None) -> None:
         """Backward pass, with the hooks of the data-parallel bucket protocol:
         `on_integration_grads_ready(grads_slice)` is called as soon as the integration network's gradients (bucket 1) are
         final - right after dib_integration_bwd - so their all-reduce runs under the whole encoder-bank backward;
         `on_encoder_front_grads_ready(grads_slice)` (three-bucket protocol, needs the first hook too) is called when the
         gradients of the encoder layers before the last (bucket 2) are final; the last layer's weight gradient (bucket 3)
-        is computed after it, under that all-reduce, and is the only part left for the caller to reduce afterwards."""
+        is computed after it, under that all-reduce, and is the only part left for the caller to reduce afterwards.
+        Every bucket is finalised by ONE dib_step_tail launch; the LAST of them also carries `finish_flags` (the step's
+        deferred KL / loss sums, the metric accumulation) and, without hooks, the optimizer (`optimizer`, see step_tail)."""
         ws = self.workspace(batch)
         st = self._stream()
         fn = self.lib.dib_integration_bwd_hidden if hidden_only else self.lib.dib_integration_bwd
         check(fn(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st), "dib_integration_bwd")
+        FIN = _lib.TAIL_FINALIZE
+        head = _lib.TAIL_HEAD_WGRAD if hidden_only else 0   # the fused head left its weight-gradient partials to the tail
         if on_integration_grads_ready is not None:
-            check(self.lib.dib_grads_finalize_part(self.layout, batch, 1, _ptr(self.grads), _ptr(ws), st),
-                  "dib_grads_finalize_part")
+            assert optimizer is None, "the data-parallel caller steps the optimizer after its all-reduces"
+            self.step_tail(batch, 1, FIN | head)
             off, cnt = self.part_range(1)
             on_integration_grads_ready(self.grads[off: off + cnt])
         # (row_idx / row0 / seed / step are not needed by the device backward: eps * sigma = ws[U] - mu)
@@ -241,51 +279,67 @@ class HipEngine:
                 check(self.lib.dib_encoder_bank_bwd_stage(self.layout, batch, _ptr(self.params), _ptr(self.grads),
                                                           _ptr(self.beta_dev), float(inv_global_batch), stage, _ptr(ws), st),
                       "dib_encoder_bank_bwd_stage")
-                check(self.lib.dib_grads_finalize_part(self.layout, batch, part, _ptr(self.grads), _ptr(ws), st),
-                      "dib_grads_finalize_part")
+                self.step_tail(batch, part, FIN | (finish_flags if stage == 2 else 0), inv_global_batch)
                 if stage == 1:
                     off, cnt = self.part_range(2)
                     on_encoder_front_grads_ready(self.grads[off: off + cnt])
             return
         check(self.lib.dib_encoder_bank_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads),
                                             _ptr(self.beta_dev), float(inv_global_batch), _ptr(ws), st), "dib_encoder_bank_bwd")
-        check(self.lib.dib_grads_finalize_part(self.layout, batch, 0 if on_integration_grads_ready is not None else -1,
-                                               _ptr(self.grads), _ptr(ws), st), "dib_grads_finalize_part")
+        if on_integration_grads_ready is not None:
+            self.step_tail(batch, 0, FIN | finish_flags, inv_global_batch)
+        else:
+            self.step_tail(batch, -1, FIN | head | finish_flags | (_lib.TAIL_BUMP if optimizer and optimizer[0] == "adam" else 0),
+                           inv_global_batch, optimizer=optimizer)
 
     def accumulate_metrics(self, batch: int, inv_global_batch: float) -> None:
         check(self.lib.dib_metrics_accumulate(self.layout, batch, _ptr(self.beta_dev), float(inv_global_batch),
                                               _ptr(self.metrics_acc), _ptr(self.workspace(batch)), self._stream()),
               "dib_metrics_accumulate")
 
-    def train_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
-                   inv_global_batch: Optional[float] = None, accumulate: bool = True,
-                   on_integration_grads_ready=None, on_encoder_front_grads_ready=None) -> None:
-        """fwd + loss + bwd for the local rows; grads (partial sums over local rows / B_global) land in
-        self.grads, ready for the data-parallel all-reduce(sum) and the optimizer step."""
-        inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
-        kind = LOSS_KINDS[loss_kind]
+    def _head_fused(self, kind: int) -> bool:
         fused_head = self._fused_head.get(kind)
         if fused_head is None:
             fused_head = self._fused_head[kind] = bool(self.lib.dib_output_head_fused_supported(self.layout, kind))
-        self.forward(x, row_idx, row0, batch, seed, step, hidden_only=fused_head)
+        return fused_head
+
+    fused_optimizer_tail = True   # train_step(optimizer=...) applies the optimizer in the step's last launch
+
+    def train_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
+                   inv_global_batch: Optional[float] = None, accumulate: bool = True,
+                   on_integration_grads_ready=None, on_encoder_front_grads_ready=None, optimizer=None) -> None:
+        """fwd + loss + bwd for the local rows; grads (partial sums over local rows / B_global) land in
+        self.grads, ready for the data-parallel all-reduce(sum) and the optimizer step.  optimizer=("adam", b1, b2, eps) /
+        ("sgd",) (single process only): the update is applied by the step's LAST launch, which also reduces the gradient
+        partials, sums the KL / loss partials and accumulates the History metrics (csrc/dib_tail.h)."""
+        inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
+        kind = LOSS_KINDS[loss_kind]
+        fused_head = self._head_fused(kind)
+        self.forward(x, row_idx, row0, batch, seed, step, hidden_only=fused_head, defer_sums=True)
         if fused_head:  # output Dense(1) + loss + its backward in one pass over the last hidden activation
             check(self.lib.dib_output_head_fused(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
-                                                 float(inv), _ptr(self.params), _ptr(self.grads), _ptr(self.workspace(batch)),
-                                                 self._stream()), "dib_output_head_fused")
+                                                 float(inv), _lib.HEAD_DEFER_SUMS, _ptr(self.params), _ptr(self.grads),
+                                                 _ptr(self.workspace(batch)), self._stream()), "dib_output_head_fused")
         else:
-            self.loss(loss_kind, y, row_idx, row0, batch, inv)
+            self.loss(loss_kind, y, row_idx, row0, batch, inv, defer_sums=True)
+        finish = _lib.TAIL_KL | (_lib.TAIL_LOSS_HEAD if fused_head else _lib.TAIL_LOSS) | (_lib.TAIL_METRICS if accumulate else 0)
         self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=fused_head,
-                      on_encoder_front_grads_ready=on_encoder_front_grads_ready)
-        if accumulate:
-            self.accumulate_metrics(batch, inv)
+                      on_encoder_front_grads_ready=on_encoder_front_grads_ready, finish_flags=finish, optimizer=optimizer)
 
     def eval_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
                   inv_global_batch: Optional[float] = None) -> None:
         """validation: noise stays ON and the KL term is included (reference train.py:263-265)."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
-        self.forward(x, row_idx, row0, batch, seed, step, inference=True)
-        self.loss(loss_kind, y, row_idx, row0, batch, inv)
-        self.accumulate_metrics(batch, inv)
+        kind = LOSS_KINDS[loss_kind]
+        fused_head = self._head_fused(kind)
+        self.forward(x, row_idx, row0, batch, seed, step, inference=True, hidden_only=fused_head, defer_sums=True)
+        if fused_head:
+            check(self.lib.dib_output_head_fused(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
+                                                 float(inv), _lib.HEAD_DEFER_SUMS | _lib.HEAD_NO_GRAD, _ptr(self.params), None,
+                                                 _ptr(self.workspace(batch)), self._stream()), "dib_output_head_fused")
+        else:
+            self.loss(loss_kind, y, row_idx, row0, batch, inv, defer_sums=True)
+        self.step_tail(batch, -1, _lib.TAIL_KL | (_lib.TAIL_LOSS_HEAD if fused_head else _lib.TAIL_LOSS) | _lib.TAIL_METRICS, inv)
 
     # ---- hipGraph capture of a whole step (launch-bound small-batch regime) -----------------------
     def enable_step_counter(self, value: int = 0) -> None:
@@ -318,11 +372,8 @@ class HipEngine:
 
         def body():
             if train:
-                self.train_step(x, y, idx_stage, 0, batch, seed, 0, loss_kind, inv_global_batch)
-                if optimizer == "adam":
-                    self.adam_step(*opt_args)
-                else:
-                    self.sgd_step()
+                self.train_step(x, y, idx_stage, 0, batch, seed, 0, loss_kind, inv_global_batch,
+                                optimizer=("adam", *opt_args) if optimizer == "adam" else ("sgd",))
             else:
                 self.eval_step(x, y, idx_stage, 0, batch, seed, 0, loss_kind, inv_global_batch)
             self.step_dev.add_(1)

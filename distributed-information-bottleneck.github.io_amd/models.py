@@ -309,6 +309,10 @@ class DistributedIBNet:
             return dist, dist.get_rank(), dist.get_world_size()
         return None, 0, 1
 
+    def _optimizer_tuple(self):
+        opt = self.optimizer
+        return ("adam", opt.beta_1, opt.beta_2, opt.epsilon) if opt.name == "adam" else ("sgd",)
+
     def _optimizer_step(self, eng):
         opt = self.optimizer
         eng.set_lr(opt.learning_rate)
@@ -438,6 +442,17 @@ class DistributedIBNet:
                     pending = []
                     nb = self.dp_buckets if (dist is not None and hasattr(eng, "part_range")) else 1
                     issue = lambda g: pending.append(dist.all_reduce(g, async_op=True))
+                    if dist is None and getattr(eng, "fused_optimizer_tail", False):
+                        # one process: the step's LAST launch reduces the gradient partials, sums the KL / loss partials,
+                        # accumulates the History metrics and applies the optimizer (csrc/dib_tail.h)
+                        eng.set_lr(self.optimizer.learning_rate)
+                        eng.train_step(xd, yd, order_dev[s0: s0 + gb], 0, gb, self.noise_seed, self._step, kind,
+                                       inv_global_batch=1.0 / gb, optimizer=self._optimizer_tuple())
+                        self._step += 1
+                        nsteps += 1
+                        if getattr(eng, "step_dev", None) is not None:
+                            eng.set_step_counter(self._step)
+                        continue
                     if hi > lo:
                         eng.train_step(xd, yd, order_dev[s0 + lo: s0 + hi], 0, hi - lo, self.noise_seed, self._step, kind,
                                        inv_global_batch=1.0 / gb, on_integration_grads_ready=issue if nb >= 2 else None,
@@ -450,11 +465,23 @@ class DistributedIBNet:
                     if nb >= 2:
                         off, cnt = eng.part_range(3 if nb == 3 else 0)
                         issue(eng.grads[off: off + cnt])
-                        for w in pending:
-                            w.wait()
-                    elif dist is not None:
-                        dist.all_reduce(eng.grads)
-                    self._optimizer_step(eng)
+                        if hasattr(eng, "optimizer_step_part"):
+                            # each bucket is stepped as soon as ITS all-reduce has landed: buckets 1 (and 2) are updated on
+                            # the compute stream while the last bucket is still on the wire; every launch reads the same
+                            # Adam step count, the last one advances it
+                            eng.set_lr(self.optimizer.learning_rate)
+                            parts = (1, 2, 3) if nb == 3 else (1, 0)
+                            for k, (w, part) in enumerate(zip(pending, parts)):
+                                w.wait()
+                                eng.optimizer_step_part(max(hi - lo, 1), part, self._optimizer_tuple(), bump=k == len(parts) - 1)
+                        else:
+                            for w in pending:
+                                w.wait()
+                            self._optimizer_step(eng)
+                    else:
+                        if dist is not None:
+                            dist.all_reduce(eng.grads)
+                        self._optimizer_step(eng)
                     self._step += 1
                     nsteps += 1
                     if getattr(eng, "step_dev", None) is not None:

@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
   const float inv_b = 1.0f / (float)B;
   CHECK_DIB(dib_encoder_bank_fwd(l, x, F, NULL, 0, B, params, seed, step, 0, ws, NULL));
   CHECK_DIB(dib_integration_fwd(l, B, params, ws, NULL));
-  CHECK_DIB(dib_loss_fwd_bwd(l, DIB_LOSS_BCE_LOGITS, y, 1, NULL, 0, B, inv_b, ws, NULL));
+  CHECK_DIB(dib_loss_fwd_bwd(l, DIB_LOSS_BCE_LOGITS, y, 1, NULL, 0, B, inv_b, 0, ws, NULL));
   CHECK_DIB(dib_integration_bwd(l, B, params, grads, ws, NULL));
   CHECK_DIB(dib_encoder_bank_bwd(l, B, params, grads, beta, inv_b, ws, NULL));
   CHECK_DIB(dib_grads_finalize(l, B, grads, ws, NULL));

@@ -63,8 +63,11 @@ const char* dib_version(void);
 /* Integer revision of THIS header + dib_st.h: bumped on every change to an exported signature, to an argument's meaning or
  * to the size of a caller-provided array.  A binding compares it with the DIB_ABI_VERSION it was written against and
  * refuses a library that differs (dib_amd/_lib.py does): a stale variant build called with shifted arguments would corrupt
- * memory silently.  History: 3 = round 3 (attention stash arguments, 17 profile categories); 4 = round 4. */
-#define DIB_ABI_VERSION 4
+ * memory silently.  History: 3 = round 3 (attention stash arguments, 17 profile categories); 4 = round 4; 5 = round 5
+ * (`flags` argument of dib_loss_fwd_bwd / dib_output_head_fused, dib_step_tail, dib_set_tuning; the workspace grew by the
+ * tail's arrival counters, which dib_workspace_init zeroes - re-run it on workspaces kept from an older library; the
+ * experimental bf16x6 GEMM entry points left the library). */
+#define DIB_ABI_VERSION 5
 int dib_abi_version(void);
 const char* dib_error_string(int code);
 
@@ -90,9 +93,11 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
 int dib_layout_set_step_counter(dib_layout* l, const uint32_t* step_dev);
 /* workspace (activations, activation gradients, split-batch wgrad partials) for local batch B.
  * CONTRACT: before its first use a workspace must either be zero-filled as a whole or be passed once to
- * dib_workspace_init (which zeroes the only region that needs it: the split-batch weight-gradient slabs - for batch >= 1024
- * dib_grads_finalize sums every slab of every parameter block, including slabs no launch writes).  The library never
- * writes non-zero values into unwritten slabs, so one initialisation per (workspace, batch size) is enough. */
+ * dib_workspace_init (which zeroes the only regions that need it: the split-batch weight-gradient slabs - for batch >= 1024
+ * dib_grads_finalize sums every slab of every parameter block, including slabs no launch writes - and the arrival counters
+ * of dib_step_tail, which clean themselves after every launch).  The library never writes non-zero values into unwritten
+ * slabs, so one initialisation per (workspace, layout, batch size) is enough; a workspace that is handed to ANOTHER layout
+ * or batch size must be initialised again (the per-launch split rule leaves different slabs unwritten). */
 int64_t dib_workspace_bytes(const dib_layout* l, int batch);
 int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t stream);
 int64_t dib_workspace_offset(const dib_layout* l, int batch, int which); /* byte offset, <0 on error */
@@ -112,6 +117,7 @@ int dib_layout_wgrad_splits(const dib_layout* l, int batch);
  * ws[STEP_OUT][0..F). */
 #define DIB_FWD_DETERMINISTIC 1
 #define DIB_FWD_INFERENCE 2
+#define DIB_FWD_DEFER_SUMS 4   /* leave the KL column sums to dib_step_tail(DIB_TAIL_KL): ws[STEP_OUT][0..F) is not written */
 int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32_t* row_idx, int64_t row0,
                          int batch, const float* params, uint64_t seed, uint32_t step, int deterministic,
                          void* ws, dib_stream_t stream);
@@ -122,9 +128,12 @@ int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws,
  * Keras train_step (explicit form train.py:203-219): L = mean_b loss(y, pred) + beta * sum_f KL_f
  * (models.py:118).  inv_global_batch = 1/B_global so that data-parallel ranks produce partial
  * sums that all-reduce(sum) to the global-mean gradient.
- * dib_loss_fwd_bwd: ws[PRED] -> ws[G_PRED]; task-loss sum and #correct into ws[STEP_OUT][F], [F+1]. */
+ * dib_loss_fwd_bwd: ws[PRED] -> ws[G_PRED]; task-loss sum and #correct into ws[STEP_OUT][F], [F+1].
+ * flags: DIB_HEAD_DEFER_SUMS = leave the sum of the per-workgroup loss partials to dib_step_tail(DIB_TAIL_LOSS). */
+#define DIB_HEAD_DEFER_SUMS 1
+#define DIB_HEAD_NO_GRAD 2     /* dib_output_head_fused only: validation - prediction and loss terms, no gradient (grads may be NULL) */
 int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx,
-                     int64_t row0, int batch, float inv_global_batch, void* ws, dib_stream_t stream);
+                     int64_t row0, int batch, float inv_global_batch, int flags, void* ws, dib_stream_t stream);
 int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* grads, void* ws,
                         dib_stream_t stream);
 /* Fused 1-unit output head of a TRAINING step (one pass over the last hidden activation instead of four launches):
@@ -134,11 +143,13 @@ int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* gr
  *                                 gradient of the last hidden layer)
  *   dib_integration_bwd_hidden  = dib_integration_bwd without the output layer
  * Same results as the unfused sequence fwd -> dib_loss_fwd_bwd -> bwd.  dib_output_head_fused_supported: out_dim 1, linear
- * output, BCE-from-logits or MSE, >= 1 hidden layer of width % 4 == 0 and <= 1024; otherwise use the unfused sequence. */
+ * output, BCE-from-logits or MSE, >= 1 hidden layer of width % 4 == 0 and <= 1024; otherwise use the unfused sequence.
+ * flags: DIB_HEAD_DEFER_SUMS = the reduce of the output layer's weight-gradient partials and of the loss partials is left to
+ * dib_step_tail(DIB_TAIL_HEAD_WGRAD | DIB_TAIL_LOSS_HEAD); DIB_HEAD_NO_GRAD = a validation step's head. */
 int dib_output_head_fused_supported(const dib_layout* l, int loss_kind);
 int dib_integration_fwd_hidden(dib_layout* l, int batch, const float* params, void* ws, dib_stream_t stream);
 int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
-                          int batch, float inv_global_batch, const float* params, float* grads, void* ws,
+                          int batch, float inv_global_batch, int flags, const float* params, float* grads, void* ws,
                           dib_stream_t stream);
 int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, float* grads, void* ws,
                                dib_stream_t stream);
@@ -166,6 +177,42 @@ int dib_layout_part_range(const dib_layout* l, int part, int64_t* offset, int64_
  * #correct, rows}: the History accounting of models.py:115,121 / train.py:169-172 without a host sync */
 int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, float inv_global_batch,
                            float* metrics_acc, void* ws, dib_stream_t stream);
+/* dib_step_tail: the END of a step in ONE launch (csrc/dib_tail.h) - any subset of: the fixed-order reduce of gradient
+ * bucket `part` (dib_grads_finalize_part, same summation order, bit-identical), the reduce of the fused output head's
+ * weight-gradient partials, the KL column sums and the loss sums deferred by DIB_FWD_DEFER_SUMS / DIB_HEAD_DEFER_SUMS,
+ * dib_metrics_accumulate, and Keras-Adam (dib_adam_step's expressions) or SGD applied to the bucket's parameters in the same
+ * pass with the step count t_dev bumped ONCE by the launch that carries DIB_TAIL_BUMP (every launch of a step reads the
+ * same t: the data-parallel caller steps buckets 1 and 2 while bucket 3 is on the wire and bumps with bucket 3).
+ * Without DIB_TAIL_FINALIZE the optimizer reads the gradient from `grads` (e.g. after an all-reduce).
+ * A 1-GPU training step ends with ONE call: part -1, FINALIZE | HEAD_WGRAD | KL | LOSS_HEAD | METRICS | ADAM | BUMP;
+ * a validation step with KL | LOSS[_HEAD] | METRICS.  Pointers a flag does not need may be NULL. */
+#define DIB_TAIL_FINALIZE 1     /* grads[part] = sum of the split-batch slabs (+ the fused backward's d(W1|b1) partials) */
+#define DIB_TAIL_KL 2           /* ws[STEP_OUT][0..F) = column sums of the forward's KL partials */
+#define DIB_TAIL_LOSS 4         /* ws[STEP_OUT][F..F+3) from dib_loss_fwd_bwd's partials */
+#define DIB_TAIL_ADAM 8
+#define DIB_TAIL_BUMP 16        /* *t_dev += 1 after every workgroup has read it */
+#define DIB_TAIL_METRICS 32     /* metrics_acc += ... (needs KL and LOSS sums of this step: same launch or earlier) */
+#define DIB_TAIL_SGD 64
+#define DIB_TAIL_HEAD_WGRAD 128 /* output-layer (W|b) gradient from dib_output_head_fused's partials (parts -1 and 1) */
+#define DIB_TAIL_LOSS_HEAD 256  /* ws[STEP_OUT][F..F+3) from dib_output_head_fused's partials */
+int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, float* grads, float* adam_m, float* adam_v,
+                  const float* lr_dev, int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale,
+                  const float* beta_dev, float inv_global_batch, float* metrics_acc, void* ws, dib_stream_t stream);
+
+/* ---- tuning: the library reads NO environment variable; these process-wide integer switches are its only hidden inputs.
+ * Defaults are the measured choices (profiles/HISTORY.md).  Keys:
+ *   "fwd_small_wgs"  (512)  forward / dgrad GEMMs with fewer 128-row workgroups than this use 64-row tiles
+ *   "fwd_narrow_wgs" (1024) forward GEMMs with fewer 64 x 128 workgroups than this use 64 x 64 tiles
+ *   "stream_rows"    (8192) GEMMs streaming at least this many rows load / store them non-temporally
+ *   "split_policy"   (1)    1 = per-launch batch-split count of weight gradients (whole rounds of workgroup slots); 0 = layout-wide
+ *   "split_overhead" (128)  per-workgroup fixed cost, in batch rows, of that rule's cost model
+ *   "fused_encoder"  (1)    layouts created afterwards may use the fused encoder-bank kernels (0: grouped-GEMM path; A/B, tests)
+ *   "fused_head"     (1)    dib_output_head_fused_supported may answer 1
+ *   "small_batch"    (1)    batches <= 1024 rows use the row-tile kernels of csrc/dib_small.h where the layout allows
+ *   "num_cus"        (device) compute units the split rule prices rounds with (set from hipDeviceProp at table upload)
+ * Returns DIB_E_ARG for an unknown key or a negative value. */
+int dib_set_tuning(const char* key, int value);
+int dib_get_tuning(const char* key, int* value);
 
 /* ---- optimizer ---------------------------------------------------------------------------
  * Keras Adam (train.py:128-129): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps), eps=1e-7.
@@ -212,15 +259,6 @@ float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t
 #define DIB_PROFILE_CATEGORIES 17
 int dib_profile_enable(int on);
 int dib_profile_summary(double* ms_by_category /*[17]*/, int* launches_by_category /*[17]*/);
-
-/* ---- EXPERIMENTAL: fp32 GEMM on the bf16 matrix pipe (csrc/dib_gemm_bf16x6.h) --------------------------------
- * C[M,N] = act(A[M,K] @ W[K,N] + bias) with every product formed from six bf16 piece products (three-way exact
- * split of both operands, fp32 accumulate): fp32 accuracy at ~1.8x the fp32-MFMA rate.  Not used by the training
- * path or by bench.py; exposed so that it can be tested and measured.  `planes` = dib_split_weights output. */
-int64_t dib_split_weights_bytes(int K, int N);
-int dib_split_weights(const float* W, int K, int N, void* planes, dib_stream_t stream);
-int dib_gemm_bf16x6(int M, int N, int K, const float* A, int lda, const void* planes, float* C, int ldc,
-                    const float* bias, int act, dib_stream_t stream);
 
 /* ---- raw grouped GEMM (exposed for tests/benchmarks of the dominant kernel) ----------------
  * mode 0: C[M,N] = act(A[M,K] @ B[K,N] + bias)    mode 1: C[M,N] = (A[M,K] @ B[N,K]^T) * act'(aux)

