@@ -348,11 +348,14 @@ def config2_infonce_loop(dev, batch):
               learning_rate=3e-4, shared_dimensionality=64, similarity="l2")
     infonce.fit_infonce(model, x, y, x[:batch], y[:batch], **kw)                  # warm-up: 16 train + 4 validation steps
     torch.cuda.synchronize()
+    lib = model._engine.lib
+    l0 = int(lib.dib_launch_count())
     t0 = time.perf_counter()
     kw.update(number_pretraining_epochs=2, number_annealing_epochs=3)
     infonce.fit_infonce(model, x, y, x[:batch], y[:batch], **kw)                  # 4 x 16 train steps + 4 x 2 validation steps
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (4 * 16 + 4 * 2)
+    launches = int(lib.dib_launch_count()) - l0   # library kernels of 64 training + 8 validation steps (the loop runs no torch kernel per step)
     # algorithmic GEMM FLOPs of one TRAINING step (SURVEY 8a conventions: fwd + dgrad + wgrad, first-layer dgrads excluded):
     # X model on the pendulum layout, Y encoder 30 -> 128 -> 128 -> 64, and the InfoNCE products S = X Y^T, C Y, C^T X
     x_enc = [[(5 * d, ENC[0]), (ENC[0], ENC[1]), (ENC[1], 2 * E)] for d in (2, 1, 2, 1)]
@@ -366,6 +369,7 @@ def config2_infonce_loop(dev, batch):
     # prices every timed step as a training step's FLOPs x 64/72 - a slight overstatement of the work, stated here
     tf = flops * (4 * 16) / (4 * 16 + 4 * 2) / dt / 1e12
     return {"batch": batch, "ms_per_step": round(1e3 * dt, 3), "samples_per_s": round(batch / dt, 1),
+            "library_launches_per_step": round(launches / (4 * 16 + 4 * 2), 2),
             "flops_per_train_step": int(flops), "algorithmic_TFLOPs": round(tf, 3),
             "step_roofline_frac": round(tf / PEAK_F32_MFMA_TFLOPS, 5)}
 
@@ -414,13 +418,17 @@ def keras_path_default_batch(dev, epochs=200):
     kw = dict(batch_size=128, callbacks=[cb], verbose=False, validation_data=(d["x_valid"], d["y_valid"]))
     m.fit(d["x_train"], d["y_train"], epochs=3, **kw)
     torch.cuda.synchronize()
+    lib = m._engine.lib
+    l0 = int(lib.dib_launch_count())
     t0 = time.perf_counter()
     m.fit(d["x_train"], d["y_train"], epochs=epochs, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / epochs / 8          # per (training step + validation step) pair
+    launches = (int(lib.dib_launch_count()) - l0) / epochs / 8
     fl = gemm_flops_per_sample(10, 5) * 128                # training step only (the validation forward is ~1/3 more)
     return {"workload": "reference default: Boolean circuit, F = 10, B = 128, 8 train + 8 validation steps per epoch, fit()",
             "us_per_train_plus_validation_step": round(1e6 * dt, 1), "epochs_timed": epochs,
+            "library_launches_per_train_plus_validation_step": round(launches, 2),
             "seconds_for_the_reference_11000_epochs": round(dt * 8 * 11000, 1),
             "flops_per_train_step": int(fl), "step_roofline_frac_lower_bound": round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 6)}
 

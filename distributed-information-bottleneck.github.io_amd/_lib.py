@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 LIB_OVERRIDE = os.environ.get("DIB_LIB_PATH") or None
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
 INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
-SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_tail.h", "dib_st.h", "dib_attn.h", "dib_attn_small.h", "dib_infonce_mfma.h",
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_tail.h", "dib_small.h", "dib_st.h", "dib_attn.h", "dib_attn_small.h", "dib_infonce_mfma.h",
            INCLUDE_ST]
 
 # error codes (include/dib_hip.h)
@@ -33,6 +33,7 @@ LOSS_KINDS = {"bce_logits": 0, "bce": 1, "sparse_cce_logits": 2, "mse": 3}
 WS_U, WS_PRED, WS_ENC_OUT, WS_G_U, WS_STEP_OUT, WS_G_PRED = range(6)
 WS_ENC_H0, WS_INT_H0 = 16, 32
 # include/dib_hip.h flag bits
+SYNC_WORDS = 1056   # DIB_SYNC_WORDS
 FWD_DETERMINISTIC, FWD_INFERENCE, FWD_DEFER_SUMS = 1, 2, 4
 HEAD_DEFER_SUMS, HEAD_NO_GRAD = 1, 2
 TAIL_FINALIZE, TAIL_KL, TAIL_LOSS, TAIL_ADAM, TAIL_BUMP, TAIL_METRICS, TAIL_SGD, TAIL_HEAD_WGRAD, TAIL_LOSS_HEAD = \
@@ -103,6 +104,8 @@ SIGNATURES = {
     "dib_integration_fwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dib_output_head_fused": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p]),
+    "dib_integration_head_step": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
     "dib_integration_bwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
@@ -123,12 +126,16 @@ SIGNATURES = {
     "dib_infonce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
     "dib_positional_encoding": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dib_positional_encoding_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dib_reduce_adam_step": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "dib_mi_workspace_bytes": (c_int64, [c_int, c_int]),
     "dib_mi_sandwich_rows": (c_int, [c_void_p, c_int, c_int, c_uint64, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
     "dib_philox_normal_fill": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_uint64, c_uint32,
                                        c_void_p]),
     "dib_philox_normal_ref": (c_float, [c_uint64, c_uint32, c_uint32, c_uint32, c_uint32]),
+    "dib_launch_count": (c_int64, []),
     "dib_profile_enable": (c_int, [c_int]),
     "dib_profile_summary": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
     "dib_gemm": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,

@@ -14,15 +14,21 @@
 #include "dib_infonce_mfma.h"
 #include "dib_fused.h"
 #include "dib_tail.h"
+#include "dib_small.h"
 #include "dib_st.h"
 #include "dib_attn.h"
 #include "dib_attn_small.h"
 #include "../../include/dib_st.h"
 
+// every kernel launch of the library goes through this macro: dib_launch_count() reports how many a step issues (bench.py)
+static unsigned long long g_dib_launches = 0;
+#define DIB_LAUNCH(...) do { ++g_dib_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 namespace {
 
 constexpr int64_t kAlign = 64;  // floats (256 B)
 constexpr int kMaxSplits = 32;   // partial slabs of a split-batch weight gradient
+constexpr int kSmallMaxBatch = 1024;   // batches up to this many rows may take the row-tile kernels of dib_small.h
 constexpr int kSplitRows = 512;  // minimum batch rows per wgrad split: 8 K-tiles of 64 (measured: 2048 left mid-size batches with 16-256 workgroups)
 inline int64_t align_up(int64_t v, int64_t a = kAlign) { return (v + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -58,6 +64,9 @@ struct dib_layout {
   const long long* dev_fused_offs = nullptr;
   const int4* dev_featmap = nullptr;
   const unsigned* step_dev = nullptr;  // optional device-resident noise step (dib_layout_set_step_counter)
+  // small-batch row-tile kernels (dib_small.h): which halves of the network they cover for this architecture
+  bool sb_enc = false, sb_int = false;
+  int sb_int_lds = 0;                  // dynamic LDS bytes of dib_small_integration_kernel
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
@@ -102,7 +111,9 @@ struct dib_layout {
     m.rows_per_split = rps;
     m.wgrad_partial = take(ns > 1 ? (int64_t)ns * align_up(n_params, 4) : 0);
     // fused backward: per-wave partials of d(W1|b1), [<= ceil(256/F) workgroups x 8 waves][F][16][H1]
-    m.dw1_partial = take(fused_id >= 0 && n_enc == 2 ? (int64_t)cdiv(256, F) * 8 * F * 16 * enc_units[0] : 0);
+    // (small-batch path: one partial per 16-row tile, [<= kSmallMaxBatch / 16 tiles][F][16][H1])
+    m.dw1_partial = take(std::max<int64_t>(fused_id >= 0 && n_enc == 2 ? (int64_t)cdiv(256, F) * 8 * F * 16 * enc_units[0] : 0,
+                                           sb_enc && B <= kSmallMaxBatch ? (int64_t)cdiv(B, DIB_SMALL_ROWS) * F * 16 * enc_units[0] : 0));
     // [F][B][2] x 64-bit act' masks (fused fwd -> fused bwd), one bit per hidden unit
     m.h2mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
     m.h1mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
@@ -211,7 +222,7 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
   // hidden activation of the integration network, stored non-temporally, cost the fused head that reads it next 19 us)
   const bool big_out = MODE != 2 && (long long)M * N * (long long)sizeof(float) * c.count >= (256ll << 20);
   const int stream_flags = streamed_rows >= knobs().stream_rows ? (big_out ? 3 : 1) : 0;
-  hipLaunchKernelGGL((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
+  DIB_LAUNCH((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
                      bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride, stream_flags);
   return (int)hipGetLastError();
 }
@@ -337,7 +348,7 @@ static int launch_fused_fwd(const DibFusedFwdArgs& a, int gx, int F, hipStream_t
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((dib_fused_encoder_fwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
+  DIB_LAUNCH((dib_fused_encoder_fwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -388,7 +399,7 @@ static int launch_fused_bwd(const DibFusedBwdArgs& a, int gx, int F, hipStream_t
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((dib_fused_encoder_bwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
+  DIB_LAUNCH((dib_fused_encoder_bwd_kernel<H1, H2, E, RELU>), dim3(gx, F), dim3(512), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -419,6 +430,92 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
                                 : launch_fused_bwd<32, 32, 32, false>(a, gx, l->F, st);
     default: return DIB_E_UNSUPPORTED;
   }
+}
+
+// ---- small-batch row-tile path (dib_small.h) ---------------------------------------------------------------------
+// dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize (per device): raised to what a launch needs
+static int ensure_dynamic_lds(const void* fn, size_t bytes, int (&have)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if ((int)bytes <= have[dev] || bytes <= 64 * 1024) return DIB_OK;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  have[dev] = (int)bytes;
+  return DIB_OK;
+}
+static int small_tiles(int batch) { return cdiv(batch, DIB_SMALL_ROWS); }
+static bool use_small_enc(const dib_layout* l, int batch) {
+  return knobs().small_batch && l->sb_enc && batch <= kSmallMaxBatch && (long long)small_tiles(batch) * l->F <= 8192;
+}
+static bool use_small_int(const dib_layout* l, int batch) { return knobs().small_batch && l->sb_int && batch <= kSmallMaxBatch; }
+// the backward's d(W1|b1) comes as per-workgroup partials (fused backward or small-batch backward): how many
+static int enc_dw1_parts(const dib_layout* l, int batch) {
+  if (use_small_enc(l, batch)) return small_tiles(batch);
+  return fused_bwd_ok(l) ? fused_gx(l, batch) * 8 : 0;
+}
+// rows of the KL partial table the forward of this (layout, batch) writes
+static int enc_kl_rows(const dib_layout* l, const dib_layout::WsMap& m, int batch) {
+  if (use_small_enc(l, batch)) return small_tiles(batch);
+  return l->fused_id >= 0 ? fused_gx(l, batch) * 8 : m.kl_blocks;
+}
+
+static int small_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w, const float* x, int64_t ldx,
+                             const int32_t* row_idx, int64_t row0, int batch, const float* params, uint64_t seed, uint32_t step,
+                             int flags, hipStream_t st) {
+  DibSmallEncFwdArgs a;
+  a.X = x; a.ldx = ldx; a.row_idx = (const int*)row_idx; a.row0 = row0; a.batch = batch; a.params = params;
+  a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap;
+  a.n_blocks = l->n_blocks; a.act = l->act; a.F = l->F; a.E = l->E; a.H1 = l->enc_units[0]; a.H2 = l->enc_units[1];
+  const bool infer = (flags & DIB_FWD_INFERENCE) != 0;
+  a.P = infer ? nullptr : w + m.P; a.h1 = infer ? nullptr : w + m.enc_h[0]; a.h2 = infer ? nullptr : w + m.enc_h[1];
+  a.enc_out = w + m.enc_out; a.U = w + m.U; a.kl_partial = w + m.kl_partial;
+  a.seed = seed; a.step = step; a.deterministic = flags & DIB_FWD_DETERMINISTIC; a.step_dev = l->step_dev;
+  const size_t lds = (size_t)DIB_SMALL_ROWS * (20 + dib_small_pitch(a.H1) + dib_small_pitch(a.H2) + dib_small_pitch(2 * a.E)) * sizeof(float) +
+                     (size_t)DIB_SMALL_XCH_FLOATS * sizeof(float);
+  static int lds_have[64] = {};
+  if (int rc = ensure_dynamic_lds((const void*)dib_small_encoder_fwd_kernel, lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, st);
+  DIB_LAUNCH(dib_small_encoder_fwd_kernel, dim3(small_tiles(batch), l->F), dim3(DIB_SMALL_THREADS), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+static int small_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params,
+                             const float* beta_dev, float inv_bg, hipStream_t st) {
+  DibSmallEncBwdArgs a;
+  a.P = w + m.P; a.batch = batch; a.params = params;
+  a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap;
+  a.act = l->act; a.F = l->F; a.E = l->E; a.H1 = l->enc_units[0]; a.H2 = l->enc_units[1];
+  a.h1 = w + m.enc_h[0]; a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.U = w + m.U; a.GU = w + m.g_u;
+  a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dw1_partial = w + m.dw1_partial; a.beta_dev = beta_dev; a.inv_bg = inv_bg;
+  const size_t lds = (size_t)DIB_SMALL_ROWS * (20 + 2 * dib_small_pitch(a.H1) + 2 * dib_small_pitch(a.H2) + dib_small_pitch(2 * a.E)) * sizeof(float) +
+                     (size_t)DIB_SMALL_XCH_FLOATS * sizeof(float);
+  static int lds_have[64] = {};
+  if (int rc = ensure_dynamic_lds((const void*)dib_small_encoder_bwd_kernel, lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, st);
+  DIB_LAUNCH(dib_small_encoder_bwd_kernel, dim3(small_tiles(batch), l->F), dim3(DIB_SMALL_THREADS), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+// one launch of dib_small_integration_kernel; `mode` = DIB_SMALL_INT_* bits.  Head arguments may be null / 0 without a head.
+static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params, int mode,
+                             int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0, float inv_bg,
+                             hipStream_t st) {
+  DibSmallIntArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.U = w + m.U; a.GU = w + m.g_u; a.batch = batch; a.K0 = l->F * l->E; a.params = params;
+  a.n_hidden = l->n_int;
+  for (int i = 0; i < l->n_int; ++i) { a.width[i] = l->int_units[i]; a.h[i] = w + m.int_h[i]; a.g[i] = w + m.g_int_h[i]; }
+  for (int i = 0; i <= l->n_int; ++i) { a.w_off[i] = l->int_w_off[i]; a.b_off[i] = l->int_b_off[i]; }
+  a.width[l->n_int] = l->out_dim;
+  a.act = l->act; a.out_act = l->out_act; a.out_dim = l->out_dim; a.mode = mode;
+  a.pred = w + m.pred; a.g_pred = w + m.g_pred;
+  a.loss_kind = loss_kind; a.Y = y; a.ldy = ldy; a.row_idx = (const int*)row_idx; a.row0 = row0; a.inv_bg = inv_bg;
+  a.partial_w = w + m.skinny_partial; a.partial_l = w + m.loss_partial;
+  static int lds_have[64] = {};
+  if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_kernel, (size_t)l->sb_int_lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, st);
+  DIB_LAUNCH(dib_small_integration_kernel, dim3(small_tiles(batch)), dim3(DIB_SMALL_THREADS), (size_t)l->sb_int_lds, st, a);
+  return (int)hipGetLastError();
 }
 
 extern "C" {
@@ -574,6 +671,25 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
       for (int f = 0; f < F; ++f) l->fused_offs.push_back(0);
     for (int f = 0; f < F; ++f) l->featmap.push_back(make_int4(l->dims[f], l->in_dim[f], l->x_off[f], l->in_off[f]));
   }
+  // small-batch row-tile kernels (dib_small.h): two-hidden-layer encoders of widths % 16 == 0 with inputs <= 15 wide (the 16th
+  // row of the d(W1|b1) tile carries the bias gradient), linear / relu / leaky_relu; integration networks of 1-3 hidden layers of widths
+  // % 16 == 0 (<= 1024 for the head's lane-strided dot) whose 16-row activation tiles fit the CU's LDS
+  {
+    bool in_ok = true;
+    for (int f = 0; f < F; ++f) in_ok = in_ok && l->in_dim[f] <= 15;
+    const bool pl_act = act >= 0 && act <= 2 && out_act >= 0 && out_act <= 2;   // piecewise-linear activations (dib_small.h)
+    l->sb_enc = pl_act && n_enc == 2 && in_ok && enc_units[0] % 16 == 0 && enc_units[1] % 16 == 0 && (2 * E) % 16 == 0 &&
+                enc_units[0] <= 1024 && enc_units[1] <= 1024 && E <= 512;
+    bool w_ok = n_int >= 1 && n_int <= 3 && (F * E) % 16 == 0;
+    int64_t fl = (int64_t)DIB_SMALL_ROWS * dib_small_pitch(F * E);
+    for (int i = 0; i < n_int && w_ok; ++i) {
+      w_ok = int_units[i] % 16 == 0 && int_units[i] <= 1024;
+      fl += 2ll * DIB_SMALL_ROWS * dib_small_pitch(int_units[i]);
+    }
+    fl += (int64_t)DIB_SMALL_ROWS * dib_small_pitch(out_dim) + DIB_SMALL_XCH_FLOATS + (w_ok ? 8 * (int_units[n_int - 1] + 1) + 16 : 0);
+    l->sb_int = pl_act && w_ok && fl * 4 <= 150 * 1024;
+    l->sb_int_lds = (int)(fl * 4);
+  }
   *out = l;
   return DIB_OK;
 }
@@ -661,6 +777,9 @@ int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t st
   // the arrival counters of dib_step_tail (self-cleaning afterwards)
   hipError_t e0 = hipMemsetAsync((float*)ws + m.sync, 0, (size_t)DIB_TAIL_SYNC_WORDS * sizeof(unsigned), (hipStream_t)stream);
   if (e0 != hipSuccess) return (int)e0;
+  // the per-step scalars: a caller that accumulates only the KL terms (custom loss) must not pick up stale loss sums
+  e0 = hipMemsetAsync((float*)ws + m.step_out, 0, (size_t)(l->F + 3) * sizeof(float), (hipStream_t)stream);
+  if (e0 != hipSuccess) return (int)e0;
   if (m.nsplit <= 1) return DIB_OK;
   // the split-batch weight-gradient slabs: dib_grads_finalize sums all nsplit slabs of every block, including the slabs
   // a launch never writes (halved splits of narrow layers, slabs >= 1 of the skinny output layer, the layer-1 block
@@ -718,12 +837,20 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
   hipStream_t st = (hipStream_t)stream;
   const auto m = l->map(batch);
   float* w = (float*)ws;
+  if (use_small_enc(l, batch)) {   // gather + positional encoding + Dense chain + reparameterisation + KL partials: one launch
+    int rc = small_encoder_fwd(l, m, w, x, ldx, row_idx, row0, batch, params, seed, step, deterministic, st);
+    if (rc || (deterministic & DIB_FWD_DEFER_SUMS)) return rc;
+    ProfScope ps(kProfOther, st);
+    DIB_LAUNCH(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, small_tiles(batch), l->F,
+                       w + m.step_out);
+    return (int)hipGetLastError();
+  }
   { ProfScope ps(kProfOther, (hipStream_t)stream);
   if ((long long)cdiv(l->sum_d, 64) * cdiv(batch, 64) >= 512)
-    hipLaunchKernelGGL(dib_posenc_kernel<64>, dim3(cdiv(l->sum_d, 64), cdiv(batch, 64)), dim3(256), 0, st, x, (long long)ldx,
+    DIB_LAUNCH(dib_posenc_kernel<64>, dim3(cdiv(l->sum_d, 64), cdiv(batch, 64)), dim3(256), 0, st, x, (long long)ldx,
                        (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P);
   else
-    hipLaunchKernelGGL(dib_posenc_kernel<16>, dim3(cdiv(l->sum_d, 64), cdiv(batch, 16)), dim3(256), 0, st, x, (long long)ldx,
+    DIB_LAUNCH(dib_posenc_kernel<16>, dim3(cdiv(l->sum_d, 64), cdiv(batch, 16)), dim3(256), 0, st, x, (long long)ldx,
                        (const int*)row_idx, (long long)row0, batch, l->dev_colmap, l->sum_d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
@@ -733,21 +860,21 @@ int dib_encoder_bank_fwd(dib_layout* l, const float* x, int64_t ldx, const int32
     if (rc) return rc;
     if (deterministic & DIB_FWD_DEFER_SUMS) return DIB_OK;   // dib_step_tail(DIB_TAIL_KL) sums the partials
     { ProfScope ps(kProfOther, (hipStream_t)stream);
-    hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, gx * 8, l->F,
+    DIB_LAUNCH(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, gx * 8, l->F,
                        w + m.step_out); }
     return (int)hipGetLastError();
   }
   rc = encoder_chain_fwd(l, m, w, batch, params, 0, l->F, st);
   if (rc) return rc;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
+  DIB_LAUNCH(dib_reparam_kl_fwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.U,
                      w + m.kl_partial, (const int*)row_idx, (long long)row0, batch, l->F, l->E,
                      (unsigned long long)seed, (unsigned)step, deterministic & DIB_FWD_DETERMINISTIC, l->step_dev); }
   rc = (int)hipGetLastError();
   if (rc) return rc;
   if (deterministic & DIB_FWD_DEFER_SUMS) return DIB_OK;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, m.kl_blocks, l->F,
+  DIB_LAUNCH(dib_colsum_partials_kernel, dim3(l->F), dim3(256), 0, st, w + m.kl_partial, m.kl_blocks, l->F,
                      w + m.step_out); }
   return (int)hipGetLastError();
 }
@@ -760,7 +887,15 @@ static int integration_fwd_impl(dib_layout* l, int batch, const float* params, v
   const auto m = l->map(batch);
   float* w = (float*)ws;
   const int LI = l->n_int + 1;
-  for (int ly = 0; ly < LI; ++ly) {
+  int first = 0;
+  if (use_small_int(l, batch)) {   // the hidden layers (and a general output layer of width % 16 == 0) in one launch
+    const bool out_too = with_output_layer && l->out_dim % 16 == 0;
+    int rc = small_integration(l, m, w, batch, params, DIB_SMALL_INT_FWD | (out_too ? DIB_SMALL_INT_OUT : 0), 0, nullptr, 0,
+                               nullptr, 0, 0.f, st);
+    if (rc || out_too || !with_output_layer) return rc;
+    first = LI - 1;   // the narrow output layer below
+  }
+  for (int ly = first; ly < LI; ++ly) {
     if (ly == LI - 1 && !with_output_layer) break;
     const float* A = ly == 0 ? w + m.U : w + m.int_h[ly - 1];
     float* C = ly == LI - 1 ? w + m.pred : w + m.int_h[ly];
@@ -769,7 +904,7 @@ static int integration_fwd_impl(dib_layout* l, int batch, const float* params, v
     if (ly == LI - 1 && l->out_dim <= DIB_SKINNY_MAX) {  // 1-unit logit & co: HBM-bound stream, not an MFMA tile
       const int win = ly == 0 ? l->F * l->E : l->int_width[ly - 1];
       ProfScope ps(kProfOther, st);
-      hipLaunchKernelGGL(dib_skinny_fwd_kernel, dim3(grid_for((int64_t)batch * 64, 256, 2048)), dim3(256), 0, st, A, batch,
+      DIB_LAUNCH(dib_skinny_fwd_kernel, dim3(grid_for((int64_t)batch * 64, 256, 2048)), dim3(256), 0, st, A, batch,
                          win, params + l->int_w_off[ly], params + l->int_b_off[ly], l->out_dim, act, C);
       rc = (int)hipGetLastError();
     } else {
@@ -797,14 +932,14 @@ int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, 
   const auto m = l->map(batch);
   float* w = (float*)ws;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_loss_kernel, dim3(m.loss_blocks), dim3(256), 0, st, loss_kind, w + m.pred, l->out_dim, y,
+  DIB_LAUNCH(dib_loss_kernel, dim3(m.loss_blocks), dim3(256), 0, st, loss_kind, w + m.pred, l->out_dim, y,
                      (long long)ldy, (const int*)row_idx, (long long)row0, batch, inv_global_batch, l->out_act,
                      w + m.g_pred, w + m.loss_partial); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   if (flags & DIB_HEAD_DEFER_SUMS) return DIB_OK;   // dib_step_tail(DIB_TAIL_LOSS) sums the partials
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), m.loss_blocks,
+  DIB_LAUNCH(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), m.loss_blocks,
                      (float)batch, w + m.step_out + l->F); }
   return (int)hipGetLastError();
 }
@@ -814,7 +949,7 @@ static inline float* wgrad_target(const dib_layout::WsMap& m, float* w, float* g
 }
 
 static int integration_bwd_impl(dib_layout* l, int batch, const float* params, float* grads, void* ws, dib_stream_t stream,
-                                bool with_output_layer) {
+                                bool with_output_layer, bool skip_dgrad = false) {
   if (!l || !params || !grads || !ws || batch <= 0) return DIB_E_ARG;
   if (!l->dev_groups) return DIB_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -823,6 +958,13 @@ static int integration_bwd_impl(dib_layout* l, int batch, const float* params, f
   float* gt = wgrad_target(m, w, grads);
   const long long sstride = align_up(l->n_params, 4);
   const int LI = l->n_int + 1;
+  // small batches: the whole dgrad chain dL/dpred (or the head's dL/dh) -> dL/du in one launch; the weight gradients below
+  if (!skip_dgrad && use_small_int(l, batch) && (!with_output_layer || l->out_dim % 16 == 0)) {
+    int rc = small_integration(l, m, w, batch, params, DIB_SMALL_INT_LOAD_H | DIB_SMALL_INT_BWD |
+                               (with_output_layer ? DIB_SMALL_INT_BWD_OUT : DIB_SMALL_INT_LOAD_G), 0, nullptr, 0, nullptr, 0, 0.f, st);
+    if (rc) return rc;
+    skip_dgrad = true;
+  }
   for (int ly = LI - 1; ly >= 0; --ly) {
     if (ly == LI - 1 && !with_output_layer) continue;  // done by dib_output_head_fused
     const float* gout = ly == LI - 1 ? w + m.g_pred : w + m.g_int_h[ly];
@@ -833,12 +975,12 @@ static int integration_bwd_impl(dib_layout* l, int batch, const float* params, f
       const int win = ly == 0 ? l->F * l->E : l->int_width[ly - 1];
       ProfScope ps(kProfOther, st);
       // stage 1 per row chunk, stage 2 into slab 0 (the other slabs of this block stay zero), both fixed-order
-      hipLaunchKernelGGL(dib_skinny_wgrad_kernel, dim3(m.skinny_chunks), dim3(256), 0, st, hin, gout, batch, win, l->out_dim,
+      DIB_LAUNCH(dib_skinny_wgrad_kernel, dim3(m.skinny_chunks), dim3(256), 0, st, hin, gout, batch, win, l->out_dim,
                          m.skinny_rows, w + m.skinny_partial);
-      hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(win * l->out_dim + l->out_dim), dim3(256),
+      DIB_LAUNCH(dib_skinny_wgrad_reduce_kernel, dim3(win * l->out_dim + l->out_dim), dim3(256),
                          0, st, (const float*)(w + m.skinny_partial), m.skinny_chunks, win, l->out_dim,
                          gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
-      hipLaunchKernelGGL(dib_skinny_dgrad_kernel, dim3(grid_for((int64_t)batch * win)), dim3(256), 0, st, gout, batch, win,
+      DIB_LAUNCH(dib_skinny_dgrad_kernel, dim3(grid_for((int64_t)batch * win)), dim3(256), 0, st, gout, batch, win,
                          params + l->int_w_off[ly], l->out_dim, ly == 0 ? (const float*)nullptr : hin, ly == 0 ? 0 : l->act,
                          gin);
       rc = (int)hipGetLastError();
@@ -848,6 +990,7 @@ static int integration_bwd_impl(dib_layout* l, int batch, const float* params, f
     rc = launch_gemm<2>(l, l->int_wgrad[ly], hin, gout, gt, nullptr, nullptr, gt, batch, 0, m.nsplit,
                         m.rows_per_split, sstride, st, m.nsplit);
     if (rc) return rc;
+    if (skip_dgrad) continue;   // the small-batch kernel already ran the dgrad chain
     // u is not an activation output (no mask for ly == 0)
     rc = launch_gemm<1>(l, l->int_dgrad[ly], gout, params, gin, nullptr, ly == 0 ? nullptr : hin, nullptr, batch,
                         ly == 0 ? 0 : l->act, 1, 0, 0, st);
@@ -890,7 +1033,7 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
   const float* A = w + m.int_h[ly - 1];
   {
     ProfScope ps(kProfOther, st);
-#define DIB_HEAD(NC) hipLaunchKernelGGL(dib_head_fused_kernel<NC>, dim3(nblk), dim3(256), 0, st, loss_kind, A, batch, K,      \
+#define DIB_HEAD(NC) DIB_LAUNCH(dib_head_fused_kernel<NC>, dim3(nblk), dim3(256), 0, st, loss_kind, A, batch, K,      \
                                         params + l->int_w_off[ly], params + l->int_b_off[ly], y, (long long)ldy,                 \
                                         (const int*)row_idx, (long long)row0, inv_global_batch, l->act, rpb, w + m.pred,          \
                                         no_grad ? (float*)nullptr : w + m.g_pred, no_grad ? (float*)nullptr : w + m.g_int_h[ly - 1], \
@@ -901,12 +1044,55 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
     if (rc) return rc;
     if (flags & DIB_HEAD_DEFER_SUMS) return DIB_OK;   // dib_step_tail(DIB_TAIL_HEAD_WGRAD | DIB_TAIL_LOSS_HEAD) finishes both
     if (!no_grad)
-      hipLaunchKernelGGL(dib_skinny_wgrad_reduce_kernel, dim3(K + 1), dim3(256), 0, st, (const float*)(w + m.skinny_partial), nblk,
+      DIB_LAUNCH(dib_skinny_wgrad_reduce_kernel, dim3(K + 1), dim3(256), 0, st, (const float*)(w + m.skinny_partial), nblk,
                          K, 1, gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
-    hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), nblk, (float)batch,
+    DIB_LAUNCH(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), nblk, (float)batch,
                        w + m.step_out + l->F);
   }
   return (int)hipGetLastError();
+}
+
+// The integration network's whole share of a step with the fused 1-unit head: hidden layers forward, output Dense(1) + loss,
+// and (training) the head's backward, the dgrad chain back to dL/du and the hidden layers' weight gradients.
+// = dib_integration_fwd_hidden + dib_output_head_fused(flags) + dib_integration_bwd_hidden; for batches <= 1024 rows the
+// forward, the head and the dgrad chain are ONE launch of dib_small_integration_kernel (16-row tiles, csrc/dib_small.h).
+int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
+                              int batch, float inv_global_batch, int flags, const float* params, float* grads, void* ws,
+                              dib_stream_t stream) {
+  const bool no_grad = (flags & DIB_HEAD_NO_GRAD) != 0;
+  if (!l || !y || !params || (!grads && !no_grad) || !ws || batch <= 0) return DIB_E_ARG;
+  if (!dib_output_head_fused_supported(l, loss_kind)) return DIB_E_UNSUPPORTED;
+  if (!l->dev_groups) return DIB_E_WORKSPACE;
+  int rc;
+  if (use_small_int(l, batch)) {
+    hipStream_t st = (hipStream_t)stream;
+    const auto m = l->map(batch);
+    float* w = (float*)ws;
+    const int mode = DIB_SMALL_INT_FWD | DIB_SMALL_INT_HEAD |
+                     (no_grad ? DIB_SMALL_INT_INFER : (DIB_SMALL_INT_HEAD_GRAD | DIB_SMALL_INT_BWD));
+    rc = small_integration(l, m, w, batch, params, mode, loss_kind, y, ldy, row_idx, row0, inv_global_batch, st);
+    if (rc) return rc;
+    if (!no_grad) {
+      rc = integration_bwd_impl(l, batch, params, grads, ws, stream, false, /*skip_dgrad=*/true);
+      if (rc) return rc;
+    }
+    if (flags & DIB_HEAD_DEFER_SUMS) return DIB_OK;
+    const int ly = l->n_int, K = l->int_width[ly - 1];
+    ProfScope ps(kProfOther, st);
+    if (!no_grad) {
+      float* gt = wgrad_target(m, w, grads);
+      DIB_LAUNCH(dib_skinny_wgrad_reduce_kernel, dim3(K + 1), dim3(256), 0, st, (const float*)(w + m.skinny_partial),
+                         m.skinny_chunks, K, 1, gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
+    }
+    DIB_LAUNCH(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), m.skinny_chunks,
+                       (float)batch, w + m.step_out + l->F);
+    return (int)hipGetLastError();
+  }
+  rc = integration_fwd_impl(l, batch, params, ws, stream, false);
+  if (rc) return rc;
+  rc = dib_output_head_fused(l, loss_kind, y, ldy, row_idx, row0, batch, inv_global_batch, flags, params, grads, ws, stream);
+  if (rc || no_grad) return rc;
+  return integration_bwd_impl(l, batch, params, grads, ws, stream, false);
 }
 
 // stages: bit 0 = the gradient chain (reparam/KL backward + dgrads) and every weight gradient except the last encoder
@@ -923,14 +1109,17 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
   float* gt = wgrad_target(m, w, grads);
   const long long sstride = align_up(l->n_params, 4);
   int rc = DIB_OK;
-  const bool fused = fused_bwd_ok(l);
+  const bool small = use_small_enc(l, batch);
+  const bool fused = small || fused_bwd_ok(l);   // d(W1|b1) comes as per-workgroup partials, dgrads in one launch
   const int LE = l->n_enc + 1;
   if (stages & 1) {
-    if (fused) {  // reparam/KL backward + both dgrads in one launch (dib_fused.h); wgrads below read its outputs
+    if (small) {  // 16-row tiles (dib_small.h)
+      rc = small_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, st);
+    } else if (fused) {  // reparam/KL backward + both dgrads in one launch (dib_fused.h); wgrads below read its outputs
       rc = fused_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, st);
     } else {
       { ProfScope ps(kProfOther, (hipStream_t)stream);
-      hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
+      DIB_LAUNCH(dib_reparam_kl_bwd_kernel, dim3(m.kl_blocks, l->F), dim3(256), 0, st, w + m.enc_out, w + m.g_u,
                          w + m.U, w + m.dout, beta_dev, inv_global_batch, batch, l->F, l->E); }
       rc = (int)hipGetLastError();
     }
@@ -1010,15 +1199,15 @@ int dib_grads_finalize_part(dib_layout* l, int batch, int part, float* grads, vo
     part_bounds(l, part, &beg, &end);
     if (part == -1 || part == 1) end = stride;   // the last bucket carries the alignment tail of the buffer
     { ProfScope ps(kProfOther, (hipStream_t)stream);
-    hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for((end - beg) / 4)), dim3(256), 0, st,
+    DIB_LAUNCH(dib_reduce_splits_kernel, dim3(grid_for((end - beg) / 4)), dim3(256), 0, st,
                        (const float*)(w + m.wgrad_partial + beg), end - beg, m.nsplit, stride, grads + beg); }
     int rc = (int)hipGetLastError();
     if (rc) return rc;
   }
-  if (part != 1 && part != 3 && fused_bwd_ok(l)) {  // layer-1 weight/bias gradients: fixed-order sum of the fused kernel's partials
+  if (part != 1 && part != 3 && enc_dw1_parts(l, batch) > 0) {  // layer-1 weight/bias gradients: fixed-order sum of the backward's partials
     ProfScope ps(kProfOther, (hipStream_t)stream);
-    hipLaunchKernelGGL(dib_dw1_reduce_kernel, dim3(l->F, 16), dim3(256), 0, st, (const float*)(w + m.dw1_partial),
-                       fused_gx(l, batch) * 8, l->F, l->enc_units[0], l->dev_fused_offs, l->dev_fused_offs + 3 * l->F,
+    DIB_LAUNCH(dib_dw1_reduce_kernel, dim3(l->F, 16), dim3(256), 0, st, (const float*)(w + m.dw1_partial),
+                       enc_dw1_parts(l, batch), l->F, l->enc_units[0], l->dev_fused_offs, l->dev_fused_offs + 3 * l->F,
                        l->dev_featmap, grads);
   }
   return (int)hipGetLastError();
@@ -1034,7 +1223,7 @@ int dib_metrics_accumulate(dib_layout* l, int batch, const float* beta_dev, floa
   const auto m = l->map(batch);
   float* w = (float*)ws;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_metrics_accumulate_kernel, dim3(cdiv(l->F + 3, 64)), dim3(64), 0, (hipStream_t)stream,
+  DIB_LAUNCH(dib_metrics_accumulate_kernel, dim3(cdiv(l->F + 3, 64)), dim3(64), 0, (hipStream_t)stream,
                      w + m.step_out, l->F, beta_dev, inv_global_batch, metrics_acc); }
   return (int)hipGetLastError();
 }
@@ -1063,7 +1252,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
   long long beg = 0, end = 0;
   part_bounds(l, part, &beg, &end);
   if (part == -1 || part == 1) end = stride;      // the last bucket carries the alignment tail of the buffer
-  const bool dw1_seg = finalize && fused_bwd_ok(l) && part != 1 && part != 3;
+  const bool dw1_seg = finalize && enc_dw1_parts(l, batch) > 0 && part != 1 && part != 3;
   const bool head_seg = (flags & DIB_TAIL_HEAD_WGRAD) && (part == -1 || part == 1);
   if (head_seg && !dib_output_head_fused_supported(l, DIB_LOSS_BCE_LOGITS)) return DIB_E_UNSUPPORTED;
   if (touches) {
@@ -1074,7 +1263,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
     if (n4 > 0 && (a.nsplit > 0 || adam || sgd)) a.nb_generic = (int)std::min<long long>(2048, (n4 + 255) / 256);
   }
   if (dw1_seg) {
-    a.dw1_partial = w + m.dw1_partial; a.dw1_parts = fused_gx(l, batch) * 8; a.H1 = l->enc_units[0];
+    a.dw1_partial = w + m.dw1_partial; a.dw1_parts = enc_dw1_parts(l, batch); a.H1 = l->enc_units[0];
     a.w_off = l->dev_fused_offs; a.b_off = l->dev_fused_offs + 3 * l->F; a.featmap = l->dev_featmap;
     a.nb_dw1 = l->F * 16;
   }
@@ -1086,7 +1275,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
   a.step_out = w + m.step_out;
   if (flags & DIB_TAIL_KL) {
     a.kl_partial = w + m.kl_partial; a.kl_stride = l->F; a.nb_kl = l->F;
-    a.kl_rows = l->fused_id >= 0 ? fused_gx(l, batch) * 8 : m.kl_blocks;
+    a.kl_rows = enc_kl_rows(l, m, batch);
   }
   if (flags & (DIB_TAIL_LOSS | DIB_TAIL_LOSS_HEAD)) {
     a.loss_partial = w + m.loss_partial; a.nb_loss = 2; a.rows = (float)batch;
@@ -1098,7 +1287,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
   if (grid == 0 && !(flags & (DIB_TAIL_BUMP | DIB_TAIL_METRICS))) return DIB_OK;   // nothing to reduce, nothing to step
   grid = std::max(1, grid);
   ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_step_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  DIB_LAUNCH(dib_step_tail_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1138,12 +1327,12 @@ int dib_adam_step(float* params, const float* grads, float* mm, float* vv, int64
   if (!params || !grads || !mm || !vv || !lr_dev || !t_dev || n <= 0) return DIB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
+  DIB_LAUNCH(dib_adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, params, grads, mm, vv, (long long)n,
                      lr_dev, (const long long*)t_dev, beta1, beta2, eps, grad_scale); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev); }
+  DIB_LAUNCH(dib_bump_counter_kernel, dim3(1), dim3(1), 0, st, (long long*)t_dev); }
   return (int)hipGetLastError();
 }
 
@@ -1151,7 +1340,7 @@ int dib_sgd_step(float* params, const float* grads, int64_t n, const float* lr_d
                  dib_stream_t stream) {
   if (!params || !grads || !lr_dev || n <= 0) return DIB_E_ARG;
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, (long long)n,
+  DIB_LAUNCH(dib_sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, params, grads, (long long)n,
                      lr_dev, grad_scale); }
   return (int)hipGetLastError();
 }
@@ -1167,7 +1356,7 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
   float* w = (float*)ws;
   const int d = l->dims[feature];
   { ProfScope ps(kProfOther, (hipStream_t)stream);
-  hipLaunchKernelGGL(dib_posenc_kernel<64>, dim3(cdiv(d, 64), cdiv(n, 64)), dim3(256), 0, st, x_f, (long long)d,
+  DIB_LAUNCH(dib_posenc_kernel<64>, dim3(cdiv(d, 64), cdiv(n, 64)), dim3(256), 0, st, x_f, (long long)d,
                      (const int*)nullptr, 0ll, n, l->dev_colmap + l->x_off[feature], d, l->n_blocks, w + m.P); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
@@ -1181,7 +1370,7 @@ int dib_encode_deterministic(dib_layout* l, int feature, const float* x_f, int n
 int dib_bhattacharyya(const float* mu1, const float* lv1, int n, const float* mu2, const float* lv2, int m, int dim,
                       float* out, dib_stream_t stream) {
   if (!mu1 || !lv1 || !mu2 || !lv2 || !out || n <= 0 || m <= 0 || dim <= 0) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_bhattacharyya_kernel, dim3(grid_for((int64_t)n * m)), dim3(256), 0, (hipStream_t)stream, mu1,
+  DIB_LAUNCH(dib_bhattacharyya_kernel, dim3(grid_for((int64_t)n * m)), dim3(256), 0, (hipStream_t)stream, mu1,
                      lv1, n, mu2, lv2, m, dim, out);
   return (int)hipGetLastError();
 }
@@ -1241,16 +1430,16 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
       DIB_INCE_ATTR(3, 0) DIB_INCE_ATTR(3, 1) DIB_INCE_ATTR(3, 4) DIB_INCE_ATTR(4, 0) DIB_INCE_ATTR(4, 1) DIB_INCE_ATTR(4, 4)
 #undef DIB_INCE_ATTR
     }
-#define DIB_INCE_SIM(KD) hipLaunchKernelGGL(dib_infonce_sim_mfma_kernel<KD>, dim3(t64, t64), dim3(256), 0, st, emb_x, emb_y, batch, \
+#define DIB_INCE_SIM(KD) DIB_LAUNCH(dib_infonce_sim_mfma_kernel<KD>, dim3(t64, t64), dim3(256), 0, st, emb_x, emb_y, batch, \
                                             dim, inv_t, norms, S, prow, pcol, nb32, arrive)
     if (similarity == 0) DIB_INCE_SIM(0); else if (similarity == 1) DIB_INCE_SIM(1); else DIB_INCE_SIM(4);
 #undef DIB_INCE_SIM
     float* lpart = pcol + 2ll * nb32 * batch;   // one loss partial per lse workgroup (still inside the 8 B^2 region)
-    hipLaunchKernelGGL(dib_infonce_lse_loss_kernel, dim3(cdiv(2 * batch, 32)), dim3(256), 0, st, (const float*)prow,
+    DIB_LAUNCH(dib_infonce_lse_loss_kernel, dim3(cdiv(2 * batch, 32)), dim3(256), 0, st, (const float*)prow,
                        (const float*)pcol, (const float*)S, batch, nb32, lse, arrive, lpart, loss_out);
     if (g_x && g_y) {
       const dim3 grid(t64, nsplit, 2);
-#define DIB_INCE_GRAD(NA, KD) hipLaunchKernelGGL((dib_infonce_grad_mfma_kernel<NA, KD>), grid, dim3(256), os_bytes, st, emb_x, emb_y, \
+#define DIB_INCE_GRAD(NA, KD) DIB_LAUNCH((dib_infonce_grad_mfma_kernel<NA, KD>), grid, dim3(256), os_bytes, st, emb_x, emb_y, \
                                                  (const float*)S, (const float*)lse, (const float*)norms, batch, dim, inv_t,            \
                                                  temperature, nsplit, Gp, Rp, g_x, g_y)
 #define DIB_INCE_GRAD_K(KD) do { if (nacc == 1) DIB_INCE_GRAD(1, KD); else if (nacc == 2) DIB_INCE_GRAD(2, KD);              \
@@ -1259,21 +1448,21 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
 #undef DIB_INCE_GRAD_K
 #undef DIB_INCE_GRAD
       if (nsplit > 1)
-        hipLaunchKernelGGL(dib_infonce_grad_final_kernel, dim3(cdiv(2ll * batch * dim, 256)), dim3(256), 0, st, emb_x, emb_y,
+        DIB_LAUNCH(dib_infonce_grad_final_kernel, dim3(cdiv(2ll * batch * dim, 256)), dim3(256), 0, st, emb_x, emb_y,
                            (const float*)Gp, (const float*)Rp, batch, dim, similarity, nsplit, g_x, g_y);
     }
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(dib_infonce_sim_kernel, dim3(tiles, tiles), dim3(256), (size_t)2 * 32 * (dim + 1) * sizeof(float), st, emb_x,
+  DIB_LAUNCH(dib_infonce_sim_kernel, dim3(tiles, tiles), dim3(256), (size_t)2 * 32 * (dim + 1) * sizeof(float), st, emb_x,
                      emb_y, batch, dim, similarity, inv_t, (const float*)norms, S, ST, amax, amaxT);
-  hipLaunchKernelGGL(dib_infonce_lse_kernel, dim3(batch, 2), dim3(256), 0, st, (const float*)S, (const float*)ST, batch, lse);
-  hipLaunchKernelGGL(dib_infonce_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)S, (const float*)lse, batch,
+  DIB_LAUNCH(dib_infonce_lse_kernel, dim3(batch, 2), dim3(256), 0, st, (const float*)S, (const float*)ST, batch, lse);
+  DIB_LAUNCH(dib_infonce_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)S, (const float*)lse, batch,
                      loss_out);
   if (g_x && g_y) {
-    hipLaunchKernelGGL(dib_infonce_coef_kernel, dim3(grid_for(bb, 256, 2048), 2), dim3(256), 0, st, (const float*)S,
+    DIB_LAUNCH(dib_infonce_coef_kernel, dim3(grid_for(bb, 256, 2048), 2), dim3(256), 0, st, (const float*)S,
                        (const float*)ST, (const float*)lse, (const float*)norms, batch, similarity, inv_t, temperature, C, CT, C2,
                        C2T);
-    hipLaunchKernelGGL(dib_infonce_grad_kernel, dim3(batch, 2), dim3(256), 256 * sizeof(float), st, emb_x, emb_y,
+    DIB_LAUNCH(dib_infonce_grad_kernel, dim3(batch, 2), dim3(256), 256 * sizeof(float), st, emb_x, emb_y,
                        (const float*)C, (const float*)CT, (const float*)C2, (const float*)C2T, (const int*)amax,
                        (const int*)amaxT, batch, dim, similarity, g_x, g_y);
   }
@@ -1283,8 +1472,37 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
 int dib_positional_encoding(const float* x, int64_t ldx, int n, int d, int n_freq, float* out, dib_stream_t stream) {
   if (!x || !out || n <= 0 || d <= 0) return DIB_E_ARG;
   const int n_blocks = n_freq > 1 ? n_freq : 1;
-  hipLaunchKernelGGL(dib_posenc_dense_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream, x,
+  DIB_LAUNCH(dib_posenc_dense_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream, x,
                      (long long)ldx, n, d, n_blocks, out);
+  return (int)hipGetLastError();
+}
+
+int dib_positional_encoding_rows(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, int n_freq, float* out,
+                                 dib_stream_t stream) {
+  if (!x || !row_idx || !out || n <= 0 || d <= 0) return DIB_E_ARG;
+  const int n_blocks = n_freq > 1 ? n_freq : 1;
+  DIB_LAUNCH(dib_posenc_rows_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx,
+                     (const int*)row_idx, n, d, n_blocks, out);
+  return (int)hipGetLastError();
+}
+
+// grads = sum of the nsplit partial slabs (nsplit == 0: grads as given), Keras-Adam on (params, m, v), step count bumped - ONE
+// launch (the generic segment of dib_step_tail_kernel) for parameter buffers that are not a dib_layout (dense.DenseStack)
+static_assert(DIB_SYNC_WORDS == DIB_TAIL_SYNC_WORDS, "include/dib_hip.h DIB_SYNC_WORDS must cover the tail's arrival counters");
+int dib_reduce_adam_step(const float* partial, int nsplit, int64_t stride, float* params, float* grads, float* adam_m,
+                         float* adam_v, int64_t n, const float* lr_dev, int64_t* t_dev, float beta1, float beta2, float eps,
+                         float grad_scale, uint32_t* sync, dib_stream_t stream) {
+  if (!params || !grads || !adam_m || !adam_v || !lr_dev || !t_dev || !sync || n <= 0 || (n & 3) || nsplit < 0) return DIB_E_ARG;
+  if (nsplit > 0 && (!partial || stride < n)) return DIB_E_ARG;
+  DibTailArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.params = params; a.grads = grads; a.m = adam_m; a.v = adam_v; a.lr_dev = lr_dev; a.t_dev = (long long*)t_dev;
+  a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.gscale = grad_scale; a.flags = DIB_TAIL_ADAM | DIB_TAIL_BUMP;
+  a.gbeg = 0; a.gend = n; a.slabs = partial; a.nsplit = nsplit; a.slab_stride = stride;
+  a.nb_generic = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256);
+  a.sync = sync;
+  ProfScope ps(kProfOther, (hipStream_t)stream);
+  DIB_LAUNCH(dib_step_tail_kernel, dim3(a.nb_generic), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1302,11 +1520,11 @@ int dib_mi_sandwich_rows(const float* enc_out, int n, int E, uint64_t seed, uint
   double* cj = u + (int64_t)n * E;
   double* mu_t = cj + n;
   double* is_t = mu_t + (int64_t)n * E;
-  hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, enc_out, n, E, (unsigned long long)seed,
+  DIB_LAUNCH(dib_mi_prep_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, enc_out, n, E, (unsigned long long)seed,
                      (unsigned)step, (unsigned)feature, inv_sigma, u, cj, mu_t, is_t);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(dib_mi_rows_kernel, dim3(n), dim3(256), 0, st, enc_out, n, E, (const double*)inv_sigma,
+  DIB_LAUNCH(dib_mi_rows_kernel, dim3(n), dim3(256), 0, st, enc_out, n, E, (const double*)inv_sigma,
                      (const double*)u, (const double*)cj, (const double*)mu_t, (const double*)is_t, lower_rows, upper_rows);
   return (int)hipGetLastError();
 }
@@ -1314,11 +1532,13 @@ int dib_mi_sandwich_rows(const float* enc_out, int n, int E, uint64_t seed, uint
 int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int batch, int F, int E, uint64_t seed,
                            uint32_t step, dib_stream_t stream) {
   if (!eps || batch <= 0 || F <= 0 || E <= 0) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_eps_fill_kernel, dim3(grid_for((int64_t)batch * F * ((E + 3) / 4))), dim3(256), 0,
+  DIB_LAUNCH(dib_eps_fill_kernel, dim3(grid_for((int64_t)batch * F * ((E + 3) / 4))), dim3(256), 0,
                      (hipStream_t)stream, eps, (const int*)row_idx, (long long)row0, batch, F, E,
                      (unsigned long long)seed, (unsigned)step);
   return (int)hipGetLastError();
 }
+
+int64_t dib_launch_count(void) { return (int64_t)g_dib_launches; }
 
 int dib_profile_enable(int on) {
   for (int c = 0; c < kProfCats; ++c) {
@@ -1361,19 +1581,19 @@ int dib_gemm(int mode, int M, int N, int K, const float* A, int lda, const float
   if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0) return DIB_E_ARG;  // operands must be 16-byte aligned
   // descriptor travels BY VALUE in a kernel argument and is written on the stream (capture-safe: no host-memory copy node
   // pointing at this stack frame)
-  hipLaunchKernelGGL(dib_write_desc_kernel, dim3(1), dim3(1), 0, st, (DibGemmGroup*)dev_desc, g);
+  DIB_LAUNCH(dib_write_desc_kernel, dim3(1), dim3(1), 0, st, (DibGemmGroup*)dev_desc, g);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
   const int tm = cdiv(M, 128), tn = cdiv(N, 128);
   const DibGemmGroup* dg = (const DibGemmGroup*)dev_desc;
   const dim3 g1(8 * cdiv(tm, 8) * tn, 1, 1);
   if (mode == 0)
-    hipLaunchKernelGGL((dib_gemm_kernel<0, 2, 2, 32>), g1, dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr, 0,
+    DIB_LAUNCH((dib_gemm_kernel<0, 2, 2, 32>), g1, dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr, 0,
                        act, tm, tn, 0, 0ll);
   else if (mode == 1)
-    hipLaunchKernelGGL((dib_gemm_kernel<1, 2, 2, 32>), g1, dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr, 0,
+    DIB_LAUNCH((dib_gemm_kernel<1, 2, 2, 32>), g1, dim3(256), 0, st, dg, A, B, C, bias, aux, (float*)nullptr, 0,
                        act, tm, tn, 0, 0ll);
   else  // single split over the whole contraction; bias (if given) receives the column sums of B
-    hipLaunchKernelGGL((dib_gemm_kernel<2, 2, 2, 32>), dim3(1, tm * tn, 1), dim3(256), 0, st, dg, A, B, C,
+    DIB_LAUNCH((dib_gemm_kernel<2, 2, 2, 32>), dim3(1, tm * tn, 1), dim3(256), 0, st, dg, A, B, C,
                        (const float*)nullptr, aux, (float*)bias, 0, act, tm, tn, K, 0ll);
   return (int)hipGetLastError();
 }
@@ -1414,9 +1634,9 @@ int dib_gemm_skinny_k(int mode, int n_groups, const dib_gemm_desc* dev_desc, int
   const dim3 grid(chunks, cn, n_groups);
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0)
-    hipLaunchKernelGGL(dib_gemm_skinnyk_kernel<0>, grid, dim3(256), 0, st, g, A, B, C, bias, M, N, K, tiles, nt_store);
+    DIB_LAUNCH(dib_gemm_skinnyk_kernel<0>, grid, dim3(256), 0, st, g, A, B, C, bias, M, N, K, tiles, nt_store);
   else
-    hipLaunchKernelGGL(dib_gemm_skinnyk_kernel<1>, grid, dim3(256), 0, st, g, A, B, C, (const float*)nullptr, M, N, K, tiles,
+    DIB_LAUNCH(dib_gemm_skinnyk_kernel<1>, grid, dim3(256), 0, st, g, A, B, C, (const float*)nullptr, M, N, K, tiles,
                        nt_store);
   return (int)hipGetLastError();
 }
@@ -1425,7 +1645,7 @@ int dib_softmax_rows_fwd(float* S, int64_t rows, int P, int ld, float scale, dib
   if (!S || rows <= 0 || P <= 0 || ld < P) return DIB_E_ARG;
   const dim3 grid(grid_for(rows, 4, 8192));
   hipStream_t st = (hipStream_t)stream;
-#define DIB_SM(R) hipLaunchKernelGGL(dib_softmax_rows_fwd_kernel<R>, grid, dim3(256), 0, st, S, (long long)rows, P, ld, scale)
+#define DIB_SM(R) DIB_LAUNCH(dib_softmax_rows_fwd_kernel<R>, grid, dim3(256), 0, st, S, (long long)rows, P, ld, scale)
   if (P <= 64) DIB_SM(1); else if (P <= 256) DIB_SM(4); else if (P <= 1024) DIB_SM(16); else if (P <= 4096) DIB_SM(64); else DIB_SM(0);
 #undef DIB_SM
   return (int)hipGetLastError();
@@ -1435,7 +1655,7 @@ int dib_softmax_rows_bwd(const float* Pm, float* dP, int64_t rows, int P, int ld
   if (!Pm || !dP || rows <= 0 || P <= 0 || ld < P) return DIB_E_ARG;
   const dim3 grid(grid_for(rows, 4, 8192));
   hipStream_t st = (hipStream_t)stream;
-#define DIB_SM(R) hipLaunchKernelGGL(dib_softmax_rows_bwd_kernel<R>, grid, dim3(256), 0, st, Pm, dP, (long long)rows, P, ld, scale)
+#define DIB_SM(R) DIB_LAUNCH(dib_softmax_rows_bwd_kernel<R>, grid, dim3(256), 0, st, Pm, dP, (long long)rows, P, ld, scale)
   if (P <= 64) DIB_SM(1); else if (P <= 256) DIB_SM(4); else if (P <= 1024) DIB_SM(16); else if (P <= 4096) DIB_SM(64); else DIB_SM(0);
 #undef DIB_SM
   return (int)hipGetLastError();
@@ -1448,10 +1668,10 @@ int dib_add_layernorm_fwd(const float* a, const float* b, int b_slabs, int64_t b
   if (!a || !b || !gamma || !beta || !y || !xhat || !rstd || T <= 0 || D <= 0 || b_slabs < 1) return DIB_E_ARG;
   if (D > 256) return DIB_E_UNSUPPORTED;
   if (D <= 32)
-    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<32>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b, b_slabs,
+    DIB_LAUNCH(dib_add_layernorm_fwd_kernel<32>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b, b_slabs,
                        (long long)b_stride, (long long)T, D, gamma, beta, eps, y, xhat, rstd);
   else
-    hipLaunchKernelGGL(dib_add_layernorm_fwd_kernel<64>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b, b_slabs,
+    DIB_LAUNCH(dib_add_layernorm_fwd_kernel<64>, dim3(ln_grid(T, D)), dim3(256), 0, (hipStream_t)stream, a, b, b_slabs,
                        (long long)b_stride, (long long)T, D, gamma, beta, eps, y, xhat, rstd);
   return (int)hipGetLastError();
 }
@@ -1471,15 +1691,15 @@ int dib_add_layernorm_bwd_fused(const float* dy, const float* dy2, const float* 
   const int grid = ln_grid(T, D);
   float* partial = (float*)ws;
   if (D <= 32)
-    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<32>, dim3(grid), dim3(256), 0, st, dy, dy2, xhat, rstd, gamma, (long long)T, D,
+    DIB_LAUNCH(dib_add_layernorm_bwd_kernel<32>, dim3(grid), dim3(256), 0, st, dy, dy2, xhat, rstd, gamma, (long long)T, D,
                        ds, act_src, act, dz, partial);
   else
-    hipLaunchKernelGGL(dib_add_layernorm_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, dy, dy2, xhat, rstd, gamma, (long long)T, D,
+    DIB_LAUNCH(dib_add_layernorm_bwd_kernel<64>, dim3(grid), dim3(256), 0, st, dy, dy2, xhat, rstd, gamma, (long long)T, D,
                        ds, act_src, act, dz, partial);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   // [gamma gradient (D) | beta gradient (D)] = fixed-order column sums of the per-slot partials
-  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(2 * D), dim3(256), 0, st, (const float*)partial,
+  DIB_LAUNCH(dib_colsum_partials_kernel, dim3(2 * D), dim3(256), 0, st, (const float*)partial,
                      grid * 4 * (D <= 32 ? 2 : 1), 2 * D, dgamma_dbeta);
   return (int)hipGetLastError();
 }
@@ -1491,20 +1711,20 @@ int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd,
 
 int dib_mean_pool_fwd(const float* x, int B, int P, int D, float* out, dib_stream_t stream) {
   if (!x || !out || B <= 0 || P <= 0 || D <= 0) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_mean_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, B, P, D, out);
+  DIB_LAUNCH(dib_mean_pool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, B, P, D, out);
   return (int)hipGetLastError();
 }
 
 int dib_mean_pool_bwd(const float* g, int B, int P, int D, float* dx, dib_stream_t stream) {
   if (!g || !dx || B <= 0 || P <= 0 || D <= 0) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_mean_pool_bwd_kernel, dim3(grid_for((int64_t)B * P * D)), dim3(256), 0, (hipStream_t)stream, g, B, P,
+  DIB_LAUNCH(dib_mean_pool_bwd_kernel, dim3(grid_for((int64_t)B * P * D)), dim3(256), 0, (hipStream_t)stream, g, B, P,
                      D, dx);
   return (int)hipGetLastError();
 }
 
 int dib_add_inplace(float* dst, const float* src, int64_t n, dib_stream_t stream) {
   if (!dst || !src || n <= 0) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, (long long)n);
+  DIB_LAUNCH(dib_add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dst, src, (long long)n);
   return (int)hipGetLastError();
 }
 
@@ -1530,10 +1750,10 @@ int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int
       hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(dib_attn_small_fwd_kernel, dim3(H, B), dim3(256), lds, (hipStream_t)stream, a);
+    DIB_LAUNCH(dib_attn_small_fwd_kernel, dim3(H, B), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
+  DIB_LAUNCH(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -1565,13 +1785,13 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
       if (e != hipSuccess) return (int)e;
     }
     ProfScope ps(kProfAttnBwd, st);
-    hipLaunchKernelGGL(dib_attn_small_bwd_kernel, dim3(H, B), dim3(256), lds, st, a);
+    DIB_LAUNCH(dib_attn_small_bwd_kernel, dim3(H, B), dim3(256), lds, st, a);
     return (int)hipGetLastError();
   }
   float* delta = (float*)ws;
   float* part = delta + (((int64_t)B * H * P + 63) / 64) * 64;
   const int nkb = cdiv(P, 128);
-  hipLaunchKernelGGL(dib_attn_delta_kernel, dim3(cdiv((int64_t)B * P * H, 4)), dim3(256), 0, st, o, d_o, (long long)ld, B, P, H,
+  DIB_LAUNCH(dib_attn_delta_kernel, dim3(cdiv((int64_t)B * P * H, 4)), dim3(256), 0, st, o, d_o, (long long)ld, B, P, H,
                      delta);
   DibAttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.delta = delta; a.dq = dq; a.dk = dk; a.dv = dv;
@@ -1586,12 +1806,12 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
     if (e != hipSuccess) return (int)e;
   }
   { ProfScope ps(kProfAttnBwd, st);
-    if (s_stash) hipLaunchKernelGGL(dib_attn_bwd_kernel<true>, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb);
-    else hipLaunchKernelGGL(dib_attn_bwd_kernel<false>, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb); }
+    if (s_stash) DIB_LAUNCH(dib_attn_bwd_kernel<true>, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb);
+    else DIB_LAUNCH(dib_attn_bwd_kernel<false>, dim3(nkb, H, B), dim3(256), lds, st, a, part, nkb); }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   if (nkb > 1) {
-    hipLaunchKernelGGL(dib_attn_dq_reduce_kernel, dim3(grid_for((int64_t)B * H * P * (kAttnD / 4))), dim3(256), 0, st,
+    DIB_LAUNCH(dib_attn_dq_reduce_kernel, dim3(grid_for((int64_t)B * H * P * (kAttnD / 4))), dim3(256), 0, st,
                        (const float*)part, B, P, H, nkb, (long long)ld, scale, dq);
     rc = (int)hipGetLastError();
   }
@@ -1616,7 +1836,7 @@ extern "C" int dib_attn_debug_read(long long* out16) {
 
 int dib_act_grad_mul(const float* g, const float* y, int act, int64_t n, float* out, dib_stream_t stream) {
   if (!g || !y || !out || n <= 0 || !act_ok(act)) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_act_grad_mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, y, act, (long long)n, out);
+  DIB_LAUNCH(dib_act_grad_mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, y, act, (long long)n, out);
   return (int)hipGetLastError();
 }
 
@@ -1631,12 +1851,12 @@ int dib_token_reparam_kl_fwd(const float* enc_out, int64_t T, int E, float logva
   if (!enc_out || !u || !kl_sum || !ws || T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256) return DIB_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = cdiv(T, std::max(1, 256 / ((E + 3) / 4)));
-  hipLaunchKernelGGL(dib_reparam_kl_fwd_kernel, dim3(blocks, 1), dim3(256), 0, st, enc_out, u, (float*)ws, (const int*)nullptr,
+  DIB_LAUNCH(dib_reparam_kl_fwd_kernel, dim3(blocks, 1), dim3(256), 0, st, enc_out, u, (float*)ws, (const int*)nullptr,
                      (long long)row0, (int)T, 1, E, (unsigned long long)seed, (unsigned)step, deterministic ? 1 : 0,
                      (const unsigned*)step_dev, logvar_offset);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(dib_colsum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, 1, kl_sum);
+  DIB_LAUNCH(dib_colsum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, blocks, 1, kl_sum);
   return (int)hipGetLastError();
 }
 
@@ -1645,7 +1865,7 @@ int dib_token_reparam_kl_bwd(const float* enc_out, const float* g_u, const float
   if (!enc_out || !g_u || !u || !beta_dev || !d_enc_out || T <= 0 || T > 0x7fffffff || E <= 0 || (E + 3) / 4 > 256)
     return DIB_E_ARG;
   const int blocks = cdiv(T, std::max(1, 256 / ((E + 3) / 4)));
-  hipLaunchKernelGGL(dib_reparam_kl_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, enc_out, g_u, u, d_enc_out,
+  DIB_LAUNCH(dib_reparam_kl_bwd_kernel, dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, enc_out, g_u, u, d_enc_out,
                      beta_dev, inv_batch, (int)T, 1, E, logvar_offset);
   return (int)hipGetLastError();
 }
@@ -1670,13 +1890,13 @@ int dib_mi_probe_bounds(const float* enc_probe, int n_probes, const float* enc_d
   double* c_d = u_d + (int64_t)n_data * E;
   double* mut_d = c_d + n_data;
   double* ist_d = mut_d + (int64_t)n_data * E;
-  hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n_probes, 256)), dim3(256), 0, st, enc_probe, n_probes, E,
+  DIB_LAUNCH(dib_mi_prep_kernel, dim3(cdiv(n_probes, 256)), dim3(256), 0, st, enc_probe, n_probes, E,
                      (unsigned long long)seed, (unsigned)step, (unsigned)feature, is_p, u_p, c_p, mut_p, ist_p, logvar_offset);
-  hipLaunchKernelGGL(dib_mi_prep_kernel, dim3(cdiv(n_data, 256)), dim3(256), 0, st, enc_data, n_data, E,
+  DIB_LAUNCH(dib_mi_prep_kernel, dim3(cdiv(n_data, 256)), dim3(256), 0, st, enc_data, n_data, E,
                      (unsigned long long)seed, (unsigned)step, (unsigned)feature + 1u, is_d, u_d, c_d, mut_d, ist_d, logvar_offset);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(dib_mi_probe_rows_kernel, dim3(n_probes), dim3(256), 0, st, enc_probe, (const double*)u_p,
+  DIB_LAUNCH(dib_mi_probe_rows_kernel, dim3(n_probes), dim3(256), 0, st, enc_probe, (const double*)u_p,
                      (const double*)is_p, (const double*)c_p, (const double*)mut_d, (const double*)ist_d, (const double*)c_d,
                      n_data, E, lower_rows, upper_rows);
   rc = (int)hipGetLastError();
@@ -1697,24 +1917,24 @@ int dib_loss_rows(int loss_kind, const float* pred, int out_dim, const float* y,
   if (loss_kind < 0 || loss_kind > 3) return DIB_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int blocks = cdiv(batch, 256);
-  hipLaunchKernelGGL(dib_loss_kernel, dim3(blocks), dim3(256), 0, st, loss_kind, pred, out_dim, y, (long long)ldy,
+  DIB_LAUNCH(dib_loss_kernel, dim3(blocks), dim3(256), 0, st, loss_kind, pred, out_dim, y, (long long)ldy,
                      (const int*)nullptr, 0ll, batch, inv_global_batch, 0, g_pred, (float*)ws);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)ws, blocks, (float)batch, out3);
+  DIB_LAUNCH(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)ws, blocks, (float)batch, out3);
   return (int)hipGetLastError();
 }
 
 int dib_reduce_splits(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream) {
   if (!partial || !out || n <= 0 || nsplit <= 0 || (n & 3) || (stride & 3)) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial,
+  DIB_LAUNCH(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial,
                      (long long)n, nsplit, (long long)stride, out, (const float*)nullptr);
   return (int)hipGetLastError();
 }
 
 int dib_reduce_splits_add(const float* partial, int64_t n, int nsplit, int64_t stride, float* out, dib_stream_t stream) {
   if (!partial || !out || n <= 0 || nsplit <= 0 || (n & 3) || (stride & 3)) return DIB_E_ARG;
-  hipLaunchKernelGGL(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial,
+  DIB_LAUNCH(dib_reduce_splits_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, partial,
                      (long long)n, nsplit, (long long)stride, out, (const float*)out);
   return (int)hipGetLastError();
 }

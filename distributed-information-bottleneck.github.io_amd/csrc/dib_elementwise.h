@@ -749,6 +749,22 @@ dib_posenc_dense_kernel(const float* __restrict__ X, long long ldx, int n, int d
   }
 }
 
+// the same with the batch gather fused in (rows row_idx[0..n) of X; the custom loop's Y batch, train.py:226-227): n_blocks == 1
+// is a plain row gather
+__global__ void __launch_bounds__(256)
+dib_posenc_rows_kernel(const float* __restrict__ X, long long ldx, const int* __restrict__ row_idx, int n, int d, int n_blocks,
+                       float* __restrict__ P) {
+  const long long total = (long long)n * d;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / d), c = (int)(i - (long long)r * d);
+    const float x = X[(long long)row_idx[r] * ldx + c];
+    float* dst = P + (long long)r * d * n_blocks + c;
+    dst[0] = x;
+    float fr = 2.0f;
+    for (int j = 1; j < n_blocks; ++j) { dst[(long long)j * d] = sinf(fr * x); fr *= 2.0f; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Skinny output layer (out_dim <= 8, e.g. the reference's 1-unit logit, models.py:83): a [B,K] x [K,out] product is
 // a GEMV-like HBM-bound stream, not an MFMA tile (N=1 padded to 64 columns wastes 98 % of the matrix core and ran

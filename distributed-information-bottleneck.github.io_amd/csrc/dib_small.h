@@ -19,14 +19,41 @@
 #include "dib_fused.h"   // dib_sigma, DIB_MFMA16, dib_f32x4
 
 #define DIB_SMALL_ROWS 16
+#define DIB_SMALL_THREADS 512   // 8 waves = 2 per SIMD: the contraction of every layer is split between wave w and w + 4, so
+                                // that one of the pair issues MFMAs while the other waits for its weights (each weight is read
+                                // once per workgroup, straight from L2: the kernels are latency-bound, not bandwidth-bound)
+#define DIB_SMALL_XCH_FLOATS (4 * 5 * 64 * 4)   // exchange buffer of the wave pairs: [4 column slots][<= 5 tiles][64 lanes] float4
 
-__host__ __device__ inline int dib_small_pick_nt(int n) {   // column tiles of 16 per wave pass: balance the 4 waves first
+__host__ __device__ inline int dib_small_pick_nt(int n) {   // column tiles of 16 per wave pass: balance the 4 column slots first
   if (n % 64 == 0 && (n / 64) % 4 == 0) return 4;
   if (n % 32 == 0 && (n / 32) % 4 == 0) return 2;
   if ((n / 16) % 4 == 0) return 1;
   if (n % 64 == 0) return 4;
   if (n % 32 == 0) return 2;
   return 1;
+}
+// backward (tiles of 16 input units per wave pass): one pass when the tile count is 4 x {5, 4, 2, 1} (320 = 4 x 5 x 16: the
+// dL/du of the default integration network), else like the forward
+__host__ __device__ inline int dib_small_pick_nt_bwd(int kin) {
+  const int tiles = kin / 16;
+  if (tiles % 20 == 0) return 5;
+  if (tiles % 16 == 0) return 4;
+  if (tiles % 8 == 0) return 2;
+  if (tiles % 4 == 0) return 1;
+  if (tiles % 5 == 0) return 5;
+  if (tiles % 4 == 0) return 4;
+  if (tiles % 2 == 0) return 2;
+  return 1;
+}
+
+// sum over the workgroup's 8 waves; result valid in thread 0.  `red` = 8 floats of LDS.
+__device__ __forceinline__ float dib_small_block_sum(float v, float* red) {
+  v = dib_wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 
 template <int NT>
@@ -49,111 +76,203 @@ __device__ __forceinline__ void dib_small_storev(float* p, const float (&v)[NT])
   else p[0] = v[0];
 }
 
+// Piecewise-linear activations only (linear / relu / leaky_relu, like the fused path): act(v) = max(v,0) + slope min(v,0),
+// act'(y) = y > 0 ? 1 : slope - branch-free epilogues.  Other activations take the general GEMM path.
+__device__ __forceinline__ float dib_small_act(float slope, float v) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+__device__ __forceinline__ float dib_small_act_grad(float slope, float y) { return y > 0.f ? 1.f : slope; }
+
 // out[16][N] = act(in[16][K] @ W[K][N] + bias).  in / out: LDS tiles (pitches pin / pout, pitch % 64 == 4: the A-operand
 // dword reads of a wave hit 64 distinct banks); W: global, row-major, leading dimension N, rows >= kvalid read as zero
 // (ragged first encoder layer).  Wave w owns column groups w, w + 4, ... of 16 NT columns; lane (j = lane & 15,
 // q = lane >> 4) feeds A[row j][k = 4 s + q] and B[k = 4 s + q][columns n0 + NT j .. + NT) - NT consecutive floats of a
 // weight row = one 4 NT-byte load, and the C fragment then holds NT CONSECUTIVE columns of rows 4 q .. 4 q + 3.
+// The weights come straight from L2 (latency ~ 1 us): the loads of the NEXT batch of UB k-steps are issued before the MFMAs of
+// the current one (register double buffer), so a wave always has UB loads in flight.
 // gdst (optional): row-major global stash of the tile, leading dimension gld, rows < rows_valid.
 template <int NT>
 __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
-                                                 const float* __restrict__ bias, int act, float* out, int pout,
-                                                 float* __restrict__ gdst, long long gld, int rows_valid) {
+                                                 const float* __restrict__ bias, float slope, float* out, int pout,
+                                                 float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wc = wave & 3, kh = wave >> 2;   // column slot, contraction half
   const int j = lane & 15, q = lane >> 4;
   constexpr int CG = 16 * NT;
-  for (int n0 = wave * CG; n0 < N; n0 += 4 * CG) {
+  constexpr int UB = NT == 4 ? 8 : 16;   // k-steps (of 4) per batch; batches alternate between the two waves of a pair
+  const int ngroups = N / CG;
+  for (int g0 = 0; g0 < ngroups; g0 += 4) {   // block-uniform trip count: the barriers below are reached by every wave
+    const bool active = g0 + wc < ngroups;
+    const int n0 = (active ? g0 + wc : 0) * CG;
     dib_f32x4 acc[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-      const float bv = bias[n0 + NT * j + c];
+      const float bv = kh == 0 ? bias[n0 + NT * j + c] : 0.f;
       acc[c] = dib_f32x4{bv, bv, bv, bv};
     }
-    const float* ap = in + j * pin + q;
-    const float* wp = W + (long long)q * N + n0 + NT * j;
-#pragma unroll 8
-    for (int s = 0; s < K; s += 4) {
-      const float av = ap[s];
-      float b[NT];
-      const bool ok = s + q < kvalid;
-      dib_small_loadw<NT>(ok ? wp + (long long)s * N : W, b);
+    if (active) {
+      const float* ap = in + j * pin;
+      const float* wp = W + n0 + NT * j;
+      float acur[UB], bcur[UB][NT];
+      auto load = [&](int s0, float (&av)[UB], float (&bv)[UB][NT]) {
 #pragma unroll
-      for (int c = 0; c < NT; ++c) acc[c] = DIB_MFMA16(av, ok ? b[c] : 0.f, acc[c]);
+        for (int u = 0; u < UB; ++u) {
+          const int k = s0 + 4 * u + q;
+          const bool ok = k < kvalid;
+          const int kc = ok ? k : 0;
+          av[u] = ok ? ap[kc] : 0.f;
+          dib_small_loadw<NT>(wp + (long long)kc * N, bv[u]);
+        }
+      };
+      load(4 * UB * kh, acur, bcur);
+      for (int s0 = 4 * UB * kh; s0 < K; s0 += 8 * UB) {
+        float anxt[UB], bnxt[UB][NT];
+        load(s0 + 8 * UB, anxt, bnxt);   // past the end: masked (k >= kvalid), harmless re-read of row 0
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (s0 + 4 * u < K) {   // wave-uniform: the ragged last batch skips its empty k-steps
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = DIB_MFMA16(acur[u], bcur[u][c], acc[c]);
+          }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          acur[u] = anxt[u];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bcur[u][c] = bnxt[u][c];
+        }
+      }
     }
+    // the upper half hands its partial sums to its partner, which finishes the tile (fixed order: lower + upper)
+    if (kh == 1 && active) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * q + r;
-      float v[NT];
-#pragma unroll
-      for (int c = 0; c < NT; ++c) v[c] = dib_act(act, acc[c][r]);
-      if (out != nullptr) dib_small_storev<NT>(out + row * pout + n0 + NT * j, v);
-      if (gdst != nullptr && row < rows_valid) dib_small_storev<NT>(gdst + (long long)row * gld + n0 + NT * j, v);
+      for (int c = 0; c < NT; ++c)
+        *reinterpret_cast<float4*>(xch + ((wc * 5 + c) * 64 + lane) * 4) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
     }
+    __syncthreads();
+    if (kh == 0 && active) {
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const float4 o = *reinterpret_cast<const float4*>(xch + ((wc * 5 + c) * 64 + lane) * 4);
+        acc[c][0] += o.x; acc[c][1] += o.y; acc[c][2] += o.z; acc[c][3] += o.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r;
+        float v[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) v[c] = dib_small_act(slope, acc[c][r]);
+        if (out != nullptr) dib_small_storev<NT>(out + row * pout + n0 + NT * j, v);
+        if (gdst != nullptr && row < rows_valid) dib_small_storev<NT>(gdst + (long long)row * gld + n0 + NT * j, v);
+      }
+    }
+    __syncthreads();   // the exchange buffer is free again, the output tile is visible
   }
 }
 
+// (ends with a workgroup barrier: the output tile is visible to every wave on return)
 __device__ __forceinline__ void dib_small_fwd(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
-                                              const float* __restrict__ bias, int act, float* out, int pout,
-                                              float* __restrict__ gdst, long long gld, int rows_valid) {
-  switch (dib_small_pick_nt(N)) {
-    case 4: dib_small_fwd_nt<4>(in, pin, K, kvalid, W, N, bias, act, out, pout, gdst, gld, rows_valid); break;
-    case 2: dib_small_fwd_nt<2>(in, pin, K, kvalid, W, N, bias, act, out, pout, gdst, gld, rows_valid); break;
-    default: dib_small_fwd_nt<1>(in, pin, K, kvalid, W, N, bias, act, out, pout, gdst, gld, rows_valid); break;
+                                              const float* __restrict__ bias, float slope, float* out, int pout,
+                                              float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
+  switch (dib_small_pick_nt(N)) {   // block-uniform
+    case 4: dib_small_fwd_nt<4>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch); break;
+    case 2: dib_small_fwd_nt<2>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch); break;
+    default: dib_small_fwd_nt<1>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch); break;
   }
 }
 
 // gin[16][Kin] = (g[16][N] @ W[Kin][N]^T) (.) act'(h[16][Kin])   (h == nullptr: no activation in front, e.g. dL/du).
 // The contraction runs along the weight rows: lane (j, q) feeds A[row j][n = 16 S + 4 q + c] (one ds_read_b128 per 4 MFMAs)
-// and B[n][k = k0 + 16 t + j] = W[k][16 S + 4 q + c] (one 16-byte load per tile t and 4 MFMAs).  gin: LDS tile or nullptr;
-// gdst: optional global row-major stash.
+// and B[n][k = k0 + 16 t + j] = W[k][16 S + 4 q + c] (one 16-byte load per tile t and 4 MFMAs); batches of UB S-steps are
+// double-buffered in registers like the forward's.  gin: LDS tile or nullptr; gdst: optional global row-major stash.
 template <int NT>
 __device__ __forceinline__ void dib_small_bwd_nt(const float* g, int pg, int N, const float* __restrict__ W, int Kin,
-                                                 const float* h, int ph, int act, float* gin, int pgi,
-                                                 float* __restrict__ gdst, long long gld, int rows_valid) {
+                                                 const float* h, int ph, float slope, float* gin, int pgi,
+                                                 float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wc = wave & 3, kh = wave >> 2;
   const int j = lane & 15, q = lane >> 4;
   constexpr int CG = 16 * NT;
-  for (int k0 = wave * CG; k0 < Kin; k0 += 4 * CG) {
+  constexpr int UB = NT >= 4 ? 2 : 4;   // S-steps (of 16 contraction indices) per batch
+  const int ngroups = Kin / CG;
+  for (int g0 = 0; g0 < ngroups; g0 += 4) {
+    const bool active = g0 + wc < ngroups;
+    const int k0 = (active ? g0 + wc : 0) * CG;
     dib_f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = dib_f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap = g + j * pg + 4 * q;
-    const float* wp = W + (long long)(k0 + j) * N + 4 * q;
-#pragma unroll 2
-    for (int S = 0; S < N; S += 16) {
-      const float4 a = *reinterpret_cast<const float4*>(ap + S);
-      float4 b[NT];
+    if (active) {
+      const float* ap = g + j * pg + 4 * q;
+      const float* wp = W + (long long)(k0 + j) * N + 4 * q;
+      float4 acur[UB], bcur[UB][NT];
+      auto load = [&](int S0, float4 (&av)[UB], float4 (&bv)[UB][NT]) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const float4*>(wp + (long long)(16 * t) * N + S);
+        for (int u = 0; u < UB; ++u) {
+          const int S = S0 + 16 * u;
+          const bool ok = S < N;
+          const int Sc = ok ? S : 0;
+          av[u] = ok ? *reinterpret_cast<const float4*>(ap + Sc) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.x, b[t].x, acc[t]);
+          for (int t = 0; t < NT; ++t) bv[u][t] = *reinterpret_cast<const float4*>(wp + (long long)(16 * t) * N + Sc);
+        }
+      };
+      load(16 * UB * kh, acur, bcur);
+      for (int S0 = 16 * UB * kh; S0 < N; S0 += 32 * UB) {
+        float4 anxt[UB], bnxt[UB][NT];
+        load(S0 + 32 * UB, anxt, bnxt);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.y, b[t].y, acc[t]);
+        for (int u = 0; u < UB; ++u) {
+          if (S0 + 16 * u >= N) break;   // wave-uniform
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.z, b[t].z, acc[t]);
+          for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].x, bcur[u][t].x, acc[t]);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(a.w, b[t].w, acc[t]);
-    }
+          for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].y, bcur[u][t].y, acc[t]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].z, bcur[u][t].z, acc[t]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * q + r, k = k0 + 16 * t + j;
-        float v = acc[t][r];
-        if (h != nullptr) v *= dib_act_grad(act, h[row * ph + k]);
-        if (gin != nullptr) gin[row * pgi + k] = v;
-        if (gdst != nullptr && row < rows_valid) gdst[(long long)row * gld + k] = v;
+          for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].w, bcur[u][t].w, acc[t]);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          acur[u] = anxt[u];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bcur[u][t] = bnxt[u][t];
+        }
       }
+    }
+    if (kh == 1 && active) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        *reinterpret_cast<float4*>(xch + ((wc * 5 + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+    __syncthreads();
+    if (kh == 0 && active) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 o = *reinterpret_cast<const float4*>(xch + ((wc * 5 + t) * 64 + lane) * 4);
+        acc[t][0] += o.x; acc[t][1] += o.y; acc[t][2] += o.z; acc[t][3] += o.w;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * q + r, k = k0 + 16 * t + j;
+          float v = acc[t][r];
+          if (h != nullptr) v *= dib_small_act_grad(slope, h[row * ph + k]);
+          if (gin != nullptr) gin[row * pgi + k] = v;
+          if (gdst != nullptr && row < rows_valid) gdst[(long long)row * gld + k] = v;
+        }
+    }
+    __syncthreads();
   }
 }
 
+// (ends with a workgroup barrier)
 __device__ __forceinline__ void dib_small_bwd(const float* g, int pg, int N, const float* __restrict__ W, int Kin,
-                                              const float* h, int ph, int act, float* gin, int pgi,
-                                              float* __restrict__ gdst, long long gld, int rows_valid) {
-  switch (dib_small_pick_nt(Kin)) {
-    case 4: dib_small_bwd_nt<4>(g, pg, N, W, Kin, h, ph, act, gin, pgi, gdst, gld, rows_valid); break;
-    case 2: dib_small_bwd_nt<2>(g, pg, N, W, Kin, h, ph, act, gin, pgi, gdst, gld, rows_valid); break;
-    default: dib_small_bwd_nt<1>(g, pg, N, W, Kin, h, ph, act, gin, pgi, gdst, gld, rows_valid); break;
+                                              const float* h, int ph, float slope, float* gin, int pgi,
+                                              float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
+  switch (dib_small_pick_nt_bwd(Kin)) {   // block-uniform
+    case 5: dib_small_bwd_nt<5>(g, pg, N, W, Kin, h, ph, slope, gin, pgi, gdst, gld, rows_valid, xch); break;
+    case 4: dib_small_bwd_nt<4>(g, pg, N, W, Kin, h, ph, slope, gin, pgi, gdst, gld, rows_valid, xch); break;
+    case 2: dib_small_bwd_nt<2>(g, pg, N, W, Kin, h, ph, slope, gin, pgi, gdst, gld, rows_valid, xch); break;
+    default: dib_small_bwd_nt<1>(g, pg, N, W, Kin, h, ph, slope, gin, pgi, gdst, gld, rows_valid, xch); break;
   }
 }
 
@@ -161,7 +280,7 @@ __device__ __forceinline__ void dib_small_bwd(const float* g, int pg, int N, con
 __device__ __forceinline__ void dib_small_load_tile(const float* __restrict__ src, long long ld, int width, int rows_valid,
                                                     float* dst, int pitch) {
   const int w4 = width >> 2;
-  for (int i = threadIdx.x; i < DIB_SMALL_ROWS * w4; i += 256) {
+  for (int i = threadIdx.x; i < DIB_SMALL_ROWS * w4; i += DIB_SMALL_THREADS) {
     const int row = i / w4, c = (i - row * w4) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < rows_valid) v = *reinterpret_cast<const float4*>(src + (long long)row * ld + c);
@@ -183,10 +302,10 @@ struct DibSmallEncFwdArgs {
   unsigned long long seed; unsigned step; int deterministic; const unsigned* step_dev;
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(DIB_SMALL_THREADS)
 dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ float red[4];
+  __shared__ float red[8];
   const int f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int r0 = tile * DIB_SMALL_ROWS, rows_valid = min(DIB_SMALL_ROWS, a.batch - r0);
   const int4 fm = a.featmap[f];   // {d_f, in_dim_f, x column offset, sum of in_dim of earlier features}
@@ -196,8 +315,9 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
   float* h1s = Pl + DIB_SMALL_ROWS * 20;    // [16][p1]
   float* h2s = h1s + DIB_SMALL_ROWS * p1;   // [16][p2]
   float* os = h2s + DIB_SMALL_ROWS * p2;    // [16][p3]
+  float* xch = os + DIB_SMALL_ROWS * p3;    // wave-pair exchange
   // ---- gather + positional encoding (the expressions of dib_posenc_kernel): P[b][j d + c] = j == 0 ? x : sin(2^j x) ----
-  for (int i = tid; i < DIB_SMALL_ROWS * 20; i += 256) Pl[i] = 0.f;
+  for (int i = tid; i < DIB_SMALL_ROWS * 20; i += DIB_SMALL_THREADS) Pl[i] = 0.f;
   __syncthreads();
   if (tid < DIB_SMALL_ROWS * d) {
     const int row = tid / d, c = tid - row * d;
@@ -225,18 +345,16 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
   const float* b2 = a.params + a.b_off[1 * F + f];
   const float* b3 = a.params + a.b_off[2 * F + f];
   const long long frow = (long long)f * a.batch + r0;
-  dib_small_fwd(Pl, 20, (in_dim + 3) & ~3, in_dim, W1, a.H1, b1, a.act, h1s, p1, a.h1 ? a.h1 + frow * a.H1 : nullptr, a.H1,
-                rows_valid);
-  __syncthreads();
-  dib_small_fwd(h1s, p1, a.H1, a.H1, W2, a.H2, b2, a.act, h2s, p2, a.h2 ? a.h2 + frow * a.H2 : nullptr, a.H2, rows_valid);
-  __syncthreads();
-  dib_small_fwd(h2s, p2, a.H2, a.H2, W3, E2, b3, 0 /* linear, models.py:78 */, os, p3, a.enc_out + frow * E2, E2, rows_valid);
-  __syncthreads();
+  const float slope = dib_neg_slope(a.act);
+  dib_small_fwd(Pl, 20, (in_dim + 3) & ~3, in_dim, W1, a.H1, b1, slope, h1s, p1, a.h1 ? a.h1 + frow * a.H1 : nullptr, a.H1,
+                rows_valid, xch);
+  dib_small_fwd(h1s, p1, a.H1, a.H1, W2, a.H2, b2, slope, h2s, p2, a.h2 ? a.h2 + frow * a.H2 : nullptr, a.H2, rows_valid, xch);
+  dib_small_fwd(h2s, p2, a.H2, a.H2, W3, E2, b3, 1.f /* linear, models.py:78 */, os, p3, a.enc_out + frow * E2, E2, rows_valid, xch);
   // ---- reparameterise + KL: thread = (row, 4 consecutive embedding dims) = one Philox call ----
   const int E4 = E >> 2;
   float klp = 0.f;
   const unsigned nstep = a.step_dev ? a.step_dev[0] : a.step;
-  for (int i = tid; i < DIB_SMALL_ROWS * E4; i += 256) {
+  for (int i = tid; i < DIB_SMALL_ROWS * E4; i += DIB_SMALL_THREADS) {
     const int row = i / E4, qq = i - row * E4;
     if (row >= rows_valid) continue;
     const int b = r0 + row;
@@ -255,7 +373,7 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
     klp += 0.5f * ((mu.x * mu.x + sg.x * sg.x - lv.x - 1.f) + (mu.y * mu.y + sg.y * sg.y - lv.y - 1.f) +
                    (mu.z * mu.z + sg.z * sg.z - lv.z - 1.f) + (mu.w * mu.w + sg.w * sg.w - lv.w - 1.f));
   }
-  const float tot = dib_block_sum_256(klp, red);
+  const float tot = dib_small_block_sum(klp, red);
   if (tid == 0) a.kl_partial[(long long)tile * F + f] = tot;
 }
 
@@ -270,6 +388,7 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
 #define DIB_SMALL_INT_BWD 32       // dgrad chain dL/dh_{n-1} -> ... -> dL/du
 #define DIB_SMALL_INT_INFER 64     // no stashes (validation)
 #define DIB_SMALL_INT_LOAD_H 128   // hidden activations come from the global stashes (a backward launched on its own)
+#define DIB_SMALL_INT_LOAD_G 256   // dL/dh_{n-1} comes from its global stash (written by a separately launched output head)
 
 struct DibSmallIntArgs {
   const float* U; float* GU; int batch, K0;
@@ -282,61 +401,76 @@ struct DibSmallIntArgs {
   float* partial_w; float* partial_l;                         // head: [tile][K + 1], [tile][2]
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(DIB_SMALL_THREADS)
 dib_small_integration_kernel(DibSmallIntArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = tile * DIB_SMALL_ROWS, rows_valid = min(DIB_SMALL_ROWS, a.batch - r0);
   const int n = a.n_hidden;
-  // LDS map: u | h_0 .. h_{n-1} | g_0 .. g_{n-1} | pred / g_pred tile | head scratch
+  // LDS map: u | h_0 .. h_{n-1} | g_0 .. g_{n-1} | pred / g_pred tile | head scratch.  (n <= 3; every loop over layers is
+  // unrolled with a compile-time index so that the pointer / pitch arrays stay in registers)
   const int pu = dib_small_pitch(a.K0);
   float* us = lds;
   float* hs[3]; float* gs[3]; int ph[3];
   float* cur = us + DIB_SMALL_ROWS * pu;
-  for (int l = 0; l < n; ++l) { ph[l] = dib_small_pitch(a.width[l]); hs[l] = cur; cur += DIB_SMALL_ROWS * ph[l]; }
-  for (int l = 0; l < n; ++l) { gs[l] = cur; cur += DIB_SMALL_ROWS * ph[l]; }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) { ph[l] = l < n ? dib_small_pitch(a.width[l]) : 0; hs[l] = cur; cur += DIB_SMALL_ROWS * ph[l]; }
+#pragma unroll
+  for (int l = 0; l < 3; ++l) { gs[l] = cur; cur += DIB_SMALL_ROWS * ph[l]; }
   const int po = dib_small_pitch(a.out_dim);
   float* ps = cur; cur += DIB_SMALL_ROWS * po;
-  float* scratch = cur;   // head: [4][K + 1] + 8
+  float* xch = cur; cur += DIB_SMALL_XCH_FLOATS;
+  float* scratch = cur;   // head: [8][K + 1] + 16
   const bool stash = !(a.mode & DIB_SMALL_INT_INFER);
-  const int KL = a.width[n - 1];   // width of the last hidden layer
+  const float slope = dib_neg_slope(a.act);
+  // the last hidden layer (n is block-uniform: scalar selects)
+  const int KL = n == 1 ? a.width[0] : (n == 2 ? a.width[1] : a.width[2]);
+  float* const hl = n == 1 ? hs[0] : (n == 2 ? hs[1] : hs[2]);
+  float* const gl = n == 1 ? gs[0] : (n == 2 ? gs[1] : gs[2]);
+  const int pl = n == 1 ? ph[0] : (n == 2 ? ph[1] : ph[2]);
+  float* const g_last = n == 1 ? a.g[0] : (n == 2 ? a.g[1] : a.g[2]);
+  const long long wo_off = n == 1 ? a.w_off[1] : (n == 2 ? a.w_off[2] : a.w_off[3]);
+  const long long bo_off = n == 1 ? a.b_off[1] : (n == 2 ? a.b_off[2] : a.b_off[3]);
 
   if (a.mode & DIB_SMALL_INT_FWD) {
     dib_small_load_tile(a.U + (long long)r0 * a.K0, a.K0, a.K0, rows_valid, us, pu);
     __syncthreads();
-    for (int l = 0; l < n; ++l) {
-      const float* in = l == 0 ? us : hs[l - 1];
-      const int K = l == 0 ? a.K0 : a.width[l - 1], pin = l == 0 ? pu : ph[l - 1];
-      dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], a.act, hs[l], ph[l],
-                    stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid);
-      __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+      if (l < n) {
+        const float* in = l == 0 ? us : hs[l > 0 ? l - 1 : 0];
+        const int K = l == 0 ? a.K0 : a.width[l > 0 ? l - 1 : 0], pin = l == 0 ? pu : ph[l > 0 ? l - 1 : 0];
+        dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], slope, hs[l], ph[l],
+                      stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid, xch);
+      }
     }
   } else if (a.mode & DIB_SMALL_INT_LOAD_H) {
-    for (int l = 0; l < n; ++l) dib_small_load_tile(a.h[l] + (long long)r0 * a.width[l], a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+      if (l < n) dib_small_load_tile(a.h[l] + (long long)r0 * a.width[l], a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
+    if (a.mode & DIB_SMALL_INT_LOAD_G) dib_small_load_tile(g_last + (long long)r0 * KL, KL, KL, rows_valid, gl, pl);
     __syncthreads();
   }
 
   if (a.mode & DIB_SMALL_INT_OUT) {   // general output layer (reference models.py:83)
-    dib_small_fwd(hs[n - 1], ph[n - 1], KL, KL, a.params + a.w_off[n], a.out_dim, a.params + a.b_off[n], a.out_act, nullptr, 0,
-                  a.pred + (long long)r0 * a.out_dim, a.out_dim, rows_valid);
+    dib_small_fwd(hl, pl, KL, KL, a.params + wo_off, a.out_dim, a.params + bo_off, dib_neg_slope(a.out_act), nullptr, 0,
+                  a.pred + (long long)r0 * a.out_dim, a.out_dim, rows_valid, xch);
   }
 
   if (a.mode & DIB_SMALL_INT_HEAD) {
-    // z = h . w + b per row (wave w: rows w, w + 4, w + 8, w + 12); Keras BinaryCrossentropy(from_logits=True) / 'mse', the
+    // z = h . w + b per row (wave w: rows w, w + 8); Keras BinaryCrossentropy(from_logits=True) / 'mse', the
     // expressions of dib_head_fused_kernel; dL/dh = g w (.) act'(h); per-tile partial of d(w|b) and of {loss sum, #correct}
     const bool grad = (a.mode & DIB_SMALL_INT_HEAD_GRAD) != 0;
-    const float* wv = a.params + a.w_off[n];
-    const float b0 = a.params[a.b_off[n]];
-    const float* hl = hs[n - 1];
-    const int pl = ph[n - 1];
-    float* redw = scratch;               // [4][KL + 1]
-    float* redl = scratch + 4 * (KL + 1); // [4][2]
+    const float* wv = a.params + wo_off;
+    const float b0 = a.params[bo_off];
+    float* redw = scratch;               // [8][KL + 1]
+    float* redl = scratch + 8 * (KL + 1); // [8][2]
     float lsum = 0.f, correct = 0.f, pb = 0.f;
     float pw[16];                        // KL <= 1024: 16 lane-strided columns
 #pragma unroll
     for (int c = 0; c < 16; ++c) pw[c] = 0.f;
-    for (int ri = 0; ri < 4; ++ri) {
-      const int row = wave + 4 * ri;
+    for (int ri = 0; ri < 2; ++ri) {
+      const int row = wave + 8 * ri;
       if (row >= rows_valid) continue;   // wave-uniform
       const int b = r0 + row;
       float dot = 0.f;
@@ -371,17 +505,17 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
         const int k = lane + 64 * c;
         if (k < KL) {
           const float hv = hl[row * pl + k];
-          const float gv = gg * wv[k] * dib_act_grad(a.act, hv);
-          gs[n - 1][row * pl + k] = gv;
-          a.g[n - 1][(long long)b * KL + k] = gv;
+          const float gv = gg * wv[k] * dib_small_act_grad(slope, hv);
+          gl[row * pl + k] = gv;
+          g_last[(long long)b * KL + k] = gv;
           pw[c] += hv * gg;
         }
       }
     }
     if (grad) {
       // rows of the tile that do not exist carry no gradient into the dgrad chain
-      for (int row = rows_valid + wave; row < DIB_SMALL_ROWS; row += 4)
-        for (int k = lane; k < KL; k += 64) gs[n - 1][row * pl + k] = 0.f;
+      for (int row = rows_valid + wave; row < DIB_SMALL_ROWS; row += 8)
+        for (int k = lane; k < KL; k += 64) gl[row * pl + k] = 0.f;
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const int k = lane + 64 * c;
@@ -392,29 +526,38 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
     __syncthreads();
     if (grad) {
       float* dst = a.partial_w + (long long)tile * (KL + 1);
-      for (int i = tid; i <= KL; i += 256)
-        dst[i] = redw[i] + redw[(KL + 1) + i] + redw[2 * (KL + 1) + i] + redw[3 * (KL + 1) + i];
+      for (int i = tid; i <= KL; i += DIB_SMALL_THREADS) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += redw[w * (KL + 1) + i];
+        dst[i] = t;
+      }
     }
-    if (tid < 2) a.partial_l[2 * tile + tid] = redl[tid] + redl[2 + tid] + redl[4 + tid] + redl[6 + tid];
+    if (tid < 2) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += redl[2 * w + tid];
+      a.partial_l[2 * tile + tid] = t;
+    }
   }
 
   if (a.mode & DIB_SMALL_INT_BWD_OUT) {   // dL/dh_{n-1} from a given dL/dpred (custom loss: InfoNCE, train.py:216-219)
     dib_small_load_tile(a.g_pred + (long long)r0 * a.out_dim, a.out_dim, a.out_dim, rows_valid, ps, po);
     __syncthreads();
-    dib_small_bwd(ps, po, a.out_dim, a.params + a.w_off[n], KL, hs[n - 1], ph[n - 1], a.act, gs[n - 1], ph[n - 1],
-                  a.g[n - 1] + (long long)r0 * KL, KL, rows_valid);
-    __syncthreads();
+    dib_small_bwd(ps, po, a.out_dim, a.params + wo_off, KL, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, KL, rows_valid, xch);
   }
 
   if (a.mode & DIB_SMALL_INT_BWD) {
-    for (int l = n - 1; l >= 1; --l) {   // dL/dh_{l-1} = (dL/dh_l @ W_l^T) (.) act'(h_{l-1})
-      dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], a.act, gs[l - 1],
-                    ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid);
-      __syncthreads();
+#pragma unroll
+    for (int l = 2; l >= 1; --l) {   // dL/dh_{l-1} = (dL/dh_l @ W_l^T) (.) act'(h_{l-1})
+      if (l < n) {
+        dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], slope, gs[l - 1],
+                      ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid, xch);
+      }
     }
     // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output)
-    dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 0, nullptr, 0,
-                  a.GU + (long long)r0 * a.K0, a.K0, rows_valid);
+    dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
+                  a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
   }
 }
 
@@ -431,7 +574,7 @@ struct DibSmallEncBwdArgs {
   const float* beta_dev; float inv_bg;
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(DIB_SMALL_THREADS)
 dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int f = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -445,10 +588,11 @@ dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
   float* dos = h2s + DIB_SMALL_ROWS * p2;     // [16][p3]  d(mu|logvar)
   float* dh2s = dos + DIB_SMALL_ROWS * p3;    // [16][p2]
   float* dh1s = dh2s + DIB_SMALL_ROWS * p2;   // [16][p1]
+  float* xch = dh1s + DIB_SMALL_ROWS * p1;    // wave-pair exchange
   const long long frow = (long long)f * a.batch + r0;
   dib_small_load_tile(a.h1 + frow * a.H1, a.H1, a.H1, rows_valid, h1s, p1);
   dib_small_load_tile(a.h2 + frow * a.H2, a.H2, a.H2, rows_valid, h2s, p2);
-  for (int i = tid; i < DIB_SMALL_ROWS * 20; i += 256) {
+  for (int i = tid; i < DIB_SMALL_ROWS * 20; i += DIB_SMALL_THREADS) {
     const int row = i / 20, c = i - row * 20;
     float v = 0.f;
     if (row < rows_valid) {
@@ -460,7 +604,7 @@ dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
   // ---- d(loss + beta KL)/d(mu|logvar) (the expressions of dib_fused_encoder_bwd_kernel); eps sigma = u - mu ----
   const float kb = a.beta_dev[0] * a.inv_bg;
   const int E4 = E >> 2;
-  for (int i = tid; i < DIB_SMALL_ROWS * E4; i += 256) {
+  for (int i = tid; i < DIB_SMALL_ROWS * E4; i += DIB_SMALL_THREADS) {
     const int row = i / E4, qq = i - row * E4;
     float4 dm = make_float4(0.f, 0.f, 0.f, 0.f), dl = dm;
     if (row < rows_valid) {
@@ -486,16 +630,15 @@ dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
   const float* W2 = a.params + a.w_off[1 * F + f];
   const float* W3 = a.params + a.w_off[2 * F + f];
   // dh2 = (dout @ W3^T) (.) act'(h2) -> stash (operand of the layer-2 weight gradient) ; dh1 = (dh2 @ W2^T) (.) act'(h1)
-  dib_small_bwd(dos, p3, E2, W3, a.H2, h2s, p2, a.act, dh2s, p2, a.dh2 + frow * a.H2, a.H2, rows_valid);
-  __syncthreads();
-  dib_small_bwd(dh2s, p2, a.H2, W2, a.H1, h1s, p1, a.act, dh1s, p1, nullptr, 0, rows_valid);
-  __syncthreads();
+  const float slope = dib_neg_slope(a.act);
+  dib_small_bwd(dos, p3, E2, W3, a.H2, h2s, p2, slope, dh2s, p2, a.dh2 + frow * a.H2, a.H2, rows_valid, xch);
+  dib_small_bwd(dh2s, p2, a.H2, W2, a.H1, h1s, p1, slope, dh1s, p1, nullptr, 0, rows_valid, xch);
   // d(W1|b1) partial of the tile = [P | 1]^T @ dh1: 16 x 16 output tiles (rows = encoder-input index, row in_dim = bias),
   // contraction over the 16 rows in 4 MFMA steps; lane (i, q): A[i][row 4 s + q] = Pl[row][i], B[row][n0 + j] = dh1[row][n0 + j]
   {
     const int j = lane & 15, q = lane >> 4;
     float* dst = a.dw1_partial + ((long long)tile * F + f) * (16ll * a.H1);
-    for (int n0 = 16 * wave; n0 < a.H1; n0 += 64) {
+    for (int n0 = 16 * wave; n0 < a.H1; n0 += 128) {
       dib_f32x4 acc = dib_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = DIB_MFMA16(Pl[(4 * s + q) * 20 + j], dh1s[(4 * s + q) * p1 + n0 + j], acc);

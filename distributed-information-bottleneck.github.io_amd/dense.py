@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from ._gemm_plan import _Gemm, _d, _ptr
-from ._lib import ACTIVATIONS, check
+from ._lib import ACTIVATIONS, SYNC_WORDS as _SYNC_WORDS, check
 
 
 class DenseStack:
@@ -104,19 +104,23 @@ class DenseStack:
         """[n, input_dim] -> [n, output_dim].  The result is a view into the plan's workspace: valid until the next forward
         with the same batch size.  rows (int32 / int64 device tensor): encode y[rows] - gathered straight into the workspace."""
         y = y.to(device=self.device, dtype=torch.float32)
+        if rows is not None:
+            if rows.dtype != torch.int32 or rows.device != y.device or rows.dim() != 1 or not rows.is_contiguous():
+                raise ValueError("rows must be a contiguous 1-D int32 tensor on the stack's device")
+            if y.stride(1) != 1:
+                y = y.contiguous()
         n = y.shape[0] if rows is None else int(rows.shape[0])
         pl = self._plan(n)
         st = self.eng._stream()
-        stage = self._view(pl, "y" if self.n_freq > 1 else "a0", n, self.input_dim)
-        if rows is not None:
-            torch.index_select(y, 0, rows, out=stage)
-        if self.n_freq > 1:
-            if rows is None:
-                stage.copy_(y)
+        if rows is not None:   # gather (+ positional encoding) in one launch, straight into the first layer's operand
+            check(self.lib.dib_positional_encoding_rows(_ptr(y), y.stride(0), _ptr(rows), n, self.input_dim, self.n_freq,
+                                                        _ptr(pl["ws"], pl["off"]["a0"]), st), "dib_positional_encoding_rows")
+        elif self.n_freq > 1:
+            self._view(pl, "y", n, self.input_dim).copy_(y)
             check(self.lib.dib_positional_encoding(_ptr(pl["ws"], pl["off"]["y"]), self.input_dim, n, self.input_dim, self.n_freq,
                                                    _ptr(pl["ws"], pl["off"]["a0"]), st), "dib_positional_encoding")
-        elif rows is None:
-            stage.copy_(y)
+        else:
+            self._view(pl, "a0", n, self.input_dim).copy_(y)
         for l in range(len(self.dims)):
             pl["g"][f"fwd{l}"].run(self.lib, st)
         self._last = pl
@@ -129,13 +133,14 @@ class DenseStack:
         assert pl is not None
         return self._view(pl, f"g{len(self.dims)}", pl["n"], self.dims[-1][1])
 
-    def backward(self, g_out: torch.Tensor) -> None:
-        """grads <- d loss / d params given d loss / d output of the last forward (overwrites self.grads)."""
+    def backward(self, g_out: torch.Tensor, reduce: bool = True) -> None:
+        """grads <- d loss / d params given d loss / d output of the last forward (overwrites self.grads).  reduce=False: the
+        batch-slab partials are left for adam_step(fused_reduce=True), which sums them in the optimizer's own launch."""
         pl = self._last
         assert pl is not None and g_out.shape[0] == pl["n"], "backward follows a forward with the same batch"
         n, L, st = pl["n"], len(self.dims), self.eng._stream()
         dst = self._view(pl, f"g{L}", n, self.dims[-1][1])
-        if g_out.data_ptr() != dst.data_ptr():
+        if not (g_out.data_ptr() == dst.data_ptr() and g_out.shape == dst.shape and g_out.stride() == dst.stride()):
             dst.copy_(g_out)
         if pl["nsplit"] == 1:
             self.grads.zero_()
@@ -143,17 +148,31 @@ class DenseStack:
             pl["g"][f"wgrad{l}"].run(self.lib, st)   # dW[i,o] = a_l^T @ g_{l+1}; bias gradient = column sums of g_{l+1}
             if l > 0:
                 pl["g"][f"dgrad{l}"].run(self.lib, st)
-        if pl["nsplit"] > 1:
+        self._unreduced = pl if (pl["nsplit"] > 1 and not reduce) else None
+        if pl["nsplit"] > 1 and reduce:
             check(self.lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_params, pl["nsplit"], self.n_params, _ptr(self.grads), st),
                   "dib_reduce_splits")
 
     def set_lr(self, lr: float) -> None:
         self.lr_dev.fill_(float(lr))
 
-    def adam_step(self, lr: Optional[float] = None, beta1=0.9, beta2=0.999, eps=1e-7) -> None:
-        """lr None: the learning rate last set (set_lr) - a loop with a constant rate sets it once"""
+    def adam_step(self, lr: Optional[float] = None, beta1=0.9, beta2=0.999, eps=1e-7, fused_reduce: bool = False) -> None:
+        """lr None: the learning rate last set (set_lr) - a loop with a constant rate sets it once.  fused_reduce=True: one
+        launch sums the slabs a backward(reduce=False) left, applies Keras-Adam and bumps the step count
+        (dib_reduce_adam_step) instead of reduce + Adam + bump."""
         if lr is not None:
             self.lr_dev.fill_(float(lr))
+        if fused_reduce:
+            pl = getattr(self, "_unreduced", None)
+            if getattr(self, "_sync", None) is None:
+                self._sync = torch.zeros(_SYNC_WORDS, dtype=torch.int32, device=self.device)
+            check(self.lib.dib_reduce_adam_step(_ptr(pl["slabs"]) if pl is not None else None, pl["nsplit"] if pl is not None else 0,
+                                                self.n_params, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+                                                _ptr(self.adam_v), self.n_params, _ptr(self.lr_dev), _ptr(self.t_dev), beta1,
+                                                beta2, eps, 1.0, _ptr(self._sync), self.eng._stream()), "dib_reduce_adam_step")
+            self._unreduced = None
+            return
+        assert getattr(self, "_unreduced", None) is None, "backward(reduce=False) must be followed by adam_step(fused_reduce=True)"
         check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
                                      self.n_params, _ptr(self.lr_dev), _ptr(self.t_dev), beta1, beta2, eps, 1.0,
                                      self.eng._stream()), "dib_adam_step")

@@ -77,6 +77,7 @@ class HipEngine:
         self._ws_gen: Dict[int, int] = {}           # batch -> number of forwards that (re)wrote its activations
         self._scratch: Optional[torch.Tensor] = None
         self._fused_head: Dict[int, bool] = {}      # loss kind -> dib_output_head_fused_supported
+        self._infonce_ws: Dict[int, torch.Tensor] = {}   # batch -> workspace of dib_infonce_fwd_bwd
         self.blocks = self._query_blocks()
         self.set_flat_params(self.glorot_uniform(init_seed))
 
@@ -197,19 +198,24 @@ class HipEngine:
         """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT].  inference=True: no backward
         follows (validation / predict), the fused forward skips the stashes it would write for it.  defer_sums=True: the KL
         column sums are left to the step's tail launch (step_tail with TAIL_KL)."""
-        ws = self.workspace(batch)
-        self._ws_gen[batch] += 1
-        st = self._stream()
-        check(self.lib.dib_encoder_bank_fwd(self.layout, _ptr(x), x.stride(0), _ptr(row_idx), int(row0), batch,
-                                            _ptr(self.params), int(seed), int(step) & 0xFFFFFFFF,
-                                            (_lib.FWD_DETERMINISTIC if deterministic else 0) | (_lib.FWD_INFERENCE if inference else 0)
-                                            | (_lib.FWD_DEFER_SUMS if defer_sums else 0), _ptr(ws), st),
-              "dib_encoder_bank_fwd")
-        if hidden_only:  # the output layer is evaluated by the fused head together with the loss (train_step)
+        self.encoder_forward(x, row_idx, row0, batch, seed, step, deterministic, inference, defer_sums)
+        ws, st = self.workspace(batch), self._stream()
+        if hidden_only:  # the output layer is evaluated by the fused head together with the loss
             check(self.lib.dib_integration_fwd_hidden(self.layout, batch, _ptr(self.params), _ptr(ws), st),
                   "dib_integration_fwd_hidden")
         else:
             check(self.lib.dib_integration_fwd(self.layout, batch, _ptr(self.params), _ptr(ws), st), "dib_integration_fwd")
+
+    def encoder_forward(self, x: torch.Tensor, row_idx: Optional[torch.Tensor], row0: int, batch: int, seed: int, step: int,
+                        deterministic: bool = False, inference: bool = False, defer_sums: bool = False) -> None:
+        """reference models.py:101-115 -> ws[ENC_OUT], ws[U], the KL partials (dib_encoder_bank_fwd)"""
+        ws = self.workspace(batch)
+        self._ws_gen[batch] += 1
+        check(self.lib.dib_encoder_bank_fwd(self.layout, _ptr(x), x.stride(0), _ptr(row_idx), int(row0), batch,
+                                            _ptr(self.params), int(seed), int(step) & 0xFFFFFFFF,
+                                            (_lib.FWD_DETERMINISTIC if deterministic else 0) | (_lib.FWD_INFERENCE if inference else 0)
+                                            | (_lib.FWD_DEFER_SUMS if defer_sums else 0), _ptr(ws), self._stream()),
+              "dib_encoder_bank_fwd")
 
     def loss(self, loss_kind: str, y: torch.Tensor, row_idx, row0: int, batch: int, inv_global_batch: float,
              defer_sums: bool = False) -> None:
@@ -220,7 +226,7 @@ class HipEngine:
               "dib_loss_fwd_bwd")
 
     def step_tail(self, batch: int, part: int, flags: int, inv_global_batch: float = 0.0, optimizer=None,
-                  grad_scale: float = 1.0) -> None:
+                  grad_scale: float = 1.0, metrics_acc: Optional[torch.Tensor] = None) -> None:
         """ONE launch for the end of a step (include/dib_hip.h dib_step_tail): any of bucket finalize, the fused head's
         weight-gradient reduce, KL / loss sums, metric accumulation, the optimizer on the bucket and the step-count bump.
         optimizer: ("adam", beta_1, beta_2, epsilon) or ("sgd",) - adds TAIL_ADAM / TAIL_SGD to `flags`."""
@@ -235,7 +241,8 @@ class HipEngine:
                 raise ValueError(f"optimizer {optimizer[0]!r}")
         check(self.lib.dib_step_tail(self.layout, batch, int(part), int(flags), _ptr(self.params), _ptr(self.grads),
                                      _ptr(self.adam_m), _ptr(self.adam_v), _ptr(self.lr_dev), _ptr(self.t_dev), b1, b2, eps,
-                                     float(grad_scale), _ptr(self.beta_dev), float(inv_global_batch), _ptr(self.metrics_acc),
+                                     float(grad_scale), _ptr(self.beta_dev), float(inv_global_batch),
+                                     _ptr(self.metrics_acc if metrics_acc is None else metrics_acc),
                                      _ptr(self.workspace(batch)), self._stream()), "dib_step_tail")
 
     def optimizer_step_part(self, batch: int, part: int, optimizer, bump: bool) -> None:
@@ -252,7 +259,7 @@ class HipEngine:
 
     def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float,
                  on_integration_grads_ready=None, hidden_only: bool = False, on_encoder_front_grads_ready=None,
-                 finish_flags: int = 0, optimizer=None) -> None:
+                 finish_flags: int = 0, optimizer=None, integration_done: bool = False) -> None:
         """Backward pass, with the hooks of the data-parallel bucket protocol:
         `on_integration_grads_ready(grads_slice)` is called as soon as the integration network's gradients (bucket 1) are
         final - right after dib_integration_bwd - so their all-reduce runs under the whole encoder-bank backward;
@@ -263,8 +270,9 @@ class HipEngine:
         deferred KL / loss sums, the metric accumulation) and, without hooks, the optimizer (`optimizer`, see step_tail)."""
         ws = self.workspace(batch)
         st = self._stream()
-        fn = self.lib.dib_integration_bwd_hidden if hidden_only else self.lib.dib_integration_bwd
-        check(fn(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st), "dib_integration_bwd")
+        if not integration_done:   # (dib_integration_head_step already ran the integration network's backward)
+            fn = self.lib.dib_integration_bwd_hidden if hidden_only else self.lib.dib_integration_bwd
+            check(fn(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st), "dib_integration_bwd")
         FIN = _lib.TAIL_FINALIZE
         head = _lib.TAIL_HEAD_WGRAD if hidden_only else 0   # the fused head left its weight-gradient partials to the tail
         if on_integration_grads_ready is not None:
@@ -315,15 +323,21 @@ class HipEngine:
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         kind = LOSS_KINDS[loss_kind]
         fused_head = self._head_fused(kind)
-        self.forward(x, row_idx, row0, batch, seed, step, hidden_only=fused_head, defer_sums=True)
-        if fused_head:  # output Dense(1) + loss + its backward in one pass over the last hidden activation
-            check(self.lib.dib_output_head_fused(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
-                                                 float(inv), _lib.HEAD_DEFER_SUMS, _ptr(self.params), _ptr(self.grads),
-                                                 _ptr(self.workspace(batch)), self._stream()), "dib_output_head_fused")
-        else:
-            self.loss(loss_kind, y, row_idx, row0, batch, inv, defer_sums=True)
         finish = _lib.TAIL_KL | (_lib.TAIL_LOSS_HEAD if fused_head else _lib.TAIL_LOSS) | (_lib.TAIL_METRICS if accumulate else 0)
-        self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=fused_head,
+        if fused_head:
+            # encoder bank, then the integration network's whole share in one entry: hidden layers, output Dense(1) + loss and
+            # their backward down to dL/du (one launch of 16-row tiles for batches <= 1024 rows), hidden weight gradients
+            self.encoder_forward(x, row_idx, row0, batch, seed, step, defer_sums=True)
+            check(self.lib.dib_integration_head_step(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
+                                                     float(inv), _lib.HEAD_DEFER_SUMS, _ptr(self.params), _ptr(self.grads),
+                                                     _ptr(self.workspace(batch)), self._stream()), "dib_integration_head_step")
+            self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=True,
+                          on_encoder_front_grads_ready=on_encoder_front_grads_ready, finish_flags=finish, optimizer=optimizer,
+                          integration_done=True)
+            return
+        self.forward(x, row_idx, row0, batch, seed, step, defer_sums=True)
+        self.loss(loss_kind, y, row_idx, row0, batch, inv, defer_sums=True)
+        self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=False,
                       on_encoder_front_grads_ready=on_encoder_front_grads_ready, finish_flags=finish, optimizer=optimizer)
 
     def eval_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
@@ -332,12 +346,13 @@ class HipEngine:
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         kind = LOSS_KINDS[loss_kind]
         fused_head = self._head_fused(kind)
-        self.forward(x, row_idx, row0, batch, seed, step, inference=True, hidden_only=fused_head, defer_sums=True)
         if fused_head:
-            check(self.lib.dib_output_head_fused(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
-                                                 float(inv), _lib.HEAD_DEFER_SUMS | _lib.HEAD_NO_GRAD, _ptr(self.params), None,
-                                                 _ptr(self.workspace(batch)), self._stream()), "dib_output_head_fused")
+            self.encoder_forward(x, row_idx, row0, batch, seed, step, inference=True, defer_sums=True)
+            check(self.lib.dib_integration_head_step(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
+                                                     float(inv), _lib.HEAD_DEFER_SUMS | _lib.HEAD_NO_GRAD, _ptr(self.params), None,
+                                                     _ptr(self.workspace(batch)), self._stream()), "dib_integration_head_step")
         else:
+            self.forward(x, row_idx, row0, batch, seed, step, inference=True, defer_sums=True)
             self.loss(loss_kind, y, row_idx, row0, batch, inv, defer_sums=True)
         self.step_tail(batch, -1, _lib.TAIL_KL | (_lib.TAIL_LOSS_HEAD if fused_head else _lib.TAIL_LOSS) | _lib.TAIL_METRICS, inv)
 
@@ -475,14 +490,22 @@ class HipEngine:
         return out
 
     def infonce(self, emb_x: torch.Tensor, emb_y: torch.Tensor, similarity: str = "l2", temperature: float = 1.0,
-                want_grads: bool = True, out_gx: Optional[torch.Tensor] = None, out_gy: Optional[torch.Tensor] = None):
+                want_grads: bool = True, out_gx: Optional[torch.Tensor] = None, out_gy: Optional[torch.Tensor] = None,
+                loss_out: Optional[torch.Tensor] = None):
         """Symmetric InfoNCE (reference train.py:201-214, utils.py:131-175) -> (loss [1] device tensor, g_x, g_y).
         out_gx / out_gy: contiguous [B, D] tensors to receive the gradients (e.g. the model's dL/d(output) workspace view and
-        the Y encoder's gradient buffer: the training loop then needs no copies)."""
+        the Y encoder's gradient buffer: the training loop then needs no copies).  loss_out: a 1-element float32 device tensor
+        to receive the loss (a slot of the caller's per-epoch buffer) instead of a fresh allocation."""
         emb_x, emb_y = emb_x.contiguous(), emb_y.contiguous()
         b, d = emb_x.shape
-        ws = torch.empty(int(self.lib.dib_infonce_workspace_bytes(b)) // 4, dtype=torch.float32, device=self.device)
-        loss = torch.empty(1, dtype=torch.float32, device=self.device)   # always written by the library
+        ws = self._infonce_ws.get(b)
+        if ws is None:
+            if len(self._infonce_ws) >= 4:
+                self._infonce_ws.pop(next(iter(self._infonce_ws)))
+            ws = self._infonce_ws[b] = torch.empty(int(self.lib.dib_infonce_workspace_bytes(b)) // 4, dtype=torch.float32,
+                                                   device=self.device)
+        loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=self.device)
+        assert loss.numel() == 1 and loss.dtype == torch.float32 and loss.device == self.device
         gx = gy = None
         if want_grads:
             for o in (out_gx, out_gy):
@@ -494,14 +517,16 @@ class HipEngine:
         return loss, gx, gy
 
     def backward_from_pred_grad(self, g_pred: torch.Tensor, row_idx, row0: int, batch: int, seed: int, step: int,
-                                inv_global_batch: Optional[float] = None) -> None:
+                                inv_global_batch: Optional[float] = None, finish_flags: int = 0, optimizer=None) -> None:
         """Backward of the model given dL/d(model output) from a custom loss (reference train.py:216-219): the
-        beta*KL term (models.py:118) is added inside the encoder-bank backward.  Gradients land in self.grads."""
+        beta*KL term (models.py:118) is added inside the encoder-bank backward.  Gradients land in self.grads.
+        finish_flags / optimizer: what the backward's last launch also does (step_tail: e.g. TAIL_KL | TAIL_METRICS after a
+        forward(defer_sums=True), and the optimizer update of a single-process loop)."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         dst = self.g_pred(batch)
-        if g_pred.data_ptr() != dst.data_ptr():   # (a custom loss may have written its gradient straight into the view)
-            dst.copy_(g_pred)
-        self.backward(row_idx, row0, batch, seed, step, inv)
+        if not (g_pred.data_ptr() == dst.data_ptr() and g_pred.shape == dst.shape and g_pred.stride() == dst.stride()):
+            dst.copy_(g_pred)   # (a custom loss may have written its gradient straight into the view)
+        self.backward(row_idx, row0, batch, seed, step, inv, finish_flags=finish_flags, optimizer=optimizer)
 
     def mi_sandwich_bounds(self, enc_out: torch.Tensor, seed: int, step: int, feature: int):
         """(InfoNCE lower, leave-one-out upper) in nats for one batch enc_out [N, 2E] (reference utils.py:36-62)."""

@@ -102,15 +102,32 @@ def _epoch_mean(values, scalar: bool):
     return np.mean(values) if scalar else np.mean(values, axis=0)
 
 
+class _LossSlots:
+    """1-element views of chunked device buffers: dib_infonce_fwd_bwd writes each step's loss into its own slot, the epoch
+    mean stacks the views (no per-step allocation; a full chunk is simply replaced - the views keep it alive)."""
+
+    def __init__(self, device, dtype=torch.float32, chunk: int = 4096):
+        self.device, self.dtype, self.chunk, self.buf, self.used = device, dtype, chunk, None, chunk
+
+    def next(self) -> torch.Tensor:
+        if self.used >= self.chunk:
+            self.buf, self.used = torch.empty(self.chunk, dtype=self.dtype, device=self.device), 0
+        v = self.buf[self.used: self.used + 1]
+        self.used += 1
+        return v
+
+
 def run_custom_loop(*, dataset_length: int, validation_set_length: int, batch_size: int, number_pretraining_epochs: int,
                     number_annealing_epochs: int, beta_start: float, beta_end: float, train_step, validation_step,
-                    assign_beta, epoch_callback=None) -> Dict[str, np.ndarray]:
+                    assign_beta, epoch_callback=None, epoch_mean=None) -> Dict[str, np.ndarray]:
     """Host bookkeeping of the reference's custom loop (train.py:222-279) around the device step functions:
     `train_step(step_num)` / `validation_step(epoch_num, batch_number)` -> (loss_infonce, kl), `assign_beta(v)` =
     model.beta.assign.  Epoch e is closed after the step whose number is round(steps_per_epoch * e) (numpy half-to-even
     rounding; when several epochs round to one step the first wins, train.py:245-247), beta comes from the float64 numpy
     formula of train.py:248, the validation pass draws number_full_validation_batches + 1 full batches (train.py:231-234) and
     the loop ends one step short of the last boundary (`take(epoch_steps[-1])`), so number_epochs - 1 epochs are recorded.
+    `epoch_mean(series name, values)` (optional) replaces the plain mean of a series' per-step values: a step function that
+    accumulates on the device returns placeholders and supplies the mean here.
     Pinned on the reference's own statements executed: tests/test_oracle_golden.py::test_custom_loop_accounting_*."""
     number_epochs = number_pretraining_epochs + number_annealing_epochs
     boundaries = np.round((dataset_length / batch_size) * np.arange(number_epochs)).astype(np.int32)
@@ -138,7 +155,7 @@ def run_custom_loop(*, dataset_length: int, validation_set_length: int, batch_si
             pending['loss_infonce_validation'].append(loss)
             pending['kl_validation'].append(kl)
         for k, vals in pending.items():
-            series[k].append(_epoch_mean(vals, scalar=k.startswith('loss')))
+            series[k].append(epoch_mean(k, vals) if epoch_mean is not None else _epoch_mean(vals, scalar=k.startswith('loss')))
             pending[k] = []
     out = {k: np.asarray(v) for k, v in series.items()}
     out['beta'] = np.float32(out['beta'])               # train.py:272
@@ -207,30 +224,56 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
     eng.set_lr(learning_rate)
     yenc.set_lr(learning_rate)
 
+    from . import _lib
+    adam = ("adam", 0.9, 0.999, 1e-7)                             # tf.keras.optimizers.Adam defaults (train.py:128-129)
+    slots = _LossSlots(eng.device, eng.metrics_acc.dtype)
+    # single process: the per-feature KL of every step is accumulated on the device by the step's LAST launch (metrics_acc[f] +=
+    # KL_f sum / B, dib_step_tail) - training and validation into separate accumulators, read once per epoch boundary
+    kl_acc = dict(kl=eng.metrics_acc, kl_validation=torch.zeros_like(eng.metrics_acc))
+    eng.metrics_acc.zero_()
+
     def eval_batch(xs, ys, idx, training, step):
+        if dist is None:
+            # launches of a training step: encoder bank, integration network, Y encoder (gather + 3 layers), 3 InfoNCE kernels
+            # (which write dL/d(embedding) where the two backward passes read it), the two backward chains, and ONE tail each
+            # (partials + KL sums + accumulation + Adam + counter bump) - no torch kernel in the loop
+            eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training, defer_sums=True)   # noise always on (train.py:263-265)
+            emb_y = yenc.forward(ys, rows=idx)
+            loss, gx, gy = eng.infonce(eng.pred(B), emb_y, similarity, temperature, want_grads=training,
+                                       out_gx=eng.g_pred(B) if training else None,
+                                       out_gy=yenc.output_grad_buffer() if training else None, loss_out=slots.next())
+            if training:
+                eng.backward_from_pred_grad(gx, idx, 0, B, model.noise_seed, step, inv_global_batch=1.0 / batch_size,
+                                            finish_flags=_lib.TAIL_KL | _lib.TAIL_METRICS, optimizer=adam)
+                yenc.backward(gy, reduce=False)
+                yenc.adam_step(fused_reduce=True)                  # one Keras Adam over all variables (train.py:196,219)
+            else:
+                eng.step_tail(B, -1, _lib.TAIL_KL | _lib.TAIL_METRICS, 1.0 / batch_size, metrics_acc=kl_acc["kl_validation"])
+            return loss, None
         eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training)  # noise always on (train.py:263-265)
         emb_x = eng.pred(B)
         emb_y = yenc.forward(ys, rows=idx)                         # gathered straight into the encoder's workspace
-        if dist is None:   # the loss kernels write dL/d(embedding) where the two backward passes read it: no copies
-            loss, gx, gy = eng.infonce(emb_x, emb_y, similarity, temperature, want_grads=training,
-                                       out_gx=eng.g_pred(B) if training else None,
-                                       out_gy=yenc.output_grad_buffer() if training else None)
-        else:
-            loss, gx, gy = infonce_data_parallel(
-                emb_x, emb_y, lambda a, b: eng.infonce(a, b, similarity, temperature, want_grads=training), dist)
+        loss, gx, gy = infonce_data_parallel(
+            emb_x, emb_y, lambda a, b: eng.infonce(a, b, similarity, temperature, want_grads=training), dist)
         kl = eng.step_out(B)[:F] * (1.0 / B)                       # kl_loss / beta (train.py:220), per feature
-        if dist is not None:
-            dist.all_reduce(kl)
-            kl /= world
+        dist.all_reduce(kl)
+        kl /= world
         if training:
             eng.backward_from_pred_grad(gx, idx, 0, B, model.noise_seed, step, inv_global_batch=1.0 / batch_size)
             yenc.backward(gy)
-            if dist is not None:
-                dist.all_reduce(eng.grads)
-                dist.all_reduce(yenc.grads)
+            dist.all_reduce(eng.grads)
+            dist.all_reduce(yenc.grads)
             eng.adam_step()                                        # one Keras Adam over all variables (train.py:196,219)
             yenc.adam_step()
         return loss, kl
+
+    def epoch_mean(name, values):
+        if dist is None and name in kl_acc:                        # mean over the epoch's steps of the per-step batch means
+            acc = kl_acc[name]
+            m = acc[:F].double().cpu().numpy() / max(len(values), 1)
+            acc.zero_()
+            return m
+        return _epoch_mean(values, scalar=name.startswith('loss'))
 
     eng.set_beta(float(model.beta.value()))                        # the first step runs at the constructor's beta (models.py:86)
     out = run_custom_loop(
@@ -240,7 +283,7 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
         validation_step=lambda epoch_num, vb: eval_batch(xvd, yvd, validation_rows(epoch_num, vb), False,
                                                          (1 << 31) + epoch_num * 1024 + vb),
         assign_beta=model.beta.assign,
-        epoch_callback=(lambda e: epoch_callback(e, model)) if epoch_callback is not None else None)
+        epoch_callback=(lambda e: epoch_callback(e, model)) if epoch_callback is not None else None, epoch_mean=epoch_mean)
     train_idx["next"].cancel()
     pool.shutdown(wait=True)
     out['kl_total'], out['kl_total_validation'] = out['kl'].sum(-1), out['kl_validation'].sum(-1)

@@ -153,6 +153,13 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
                           dib_stream_t stream);
 int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, float* grads, void* ws,
                                dib_stream_t stream);
+/* The three calls above as ONE entry (what a training / validation step with the fused head uses):
+ *   dib_integration_head_step = dib_integration_fwd_hidden + dib_output_head_fused(flags) [+ dib_integration_bwd_hidden unless
+ *   DIB_HEAD_NO_GRAD].  For batches <= 1024 rows the hidden layers, the head, the loss and the dgrad chain back to ws[G_U] run
+ *   as one launch of 16-row tiles (csrc/dib_small.h; "small_batch" tuning key) instead of five GEMM launches. */
+int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
+                              int batch, float inv_global_batch, int flags, const float* params, float* grads, void* ws,
+                              dib_stream_t stream);
 /* dib_encoder_bank_bwd: tape.gradient through models.py:106-118 for the encoder bank (reparameterisation + beta*KL backward,
  * dgrads, weight gradients).  The noise term of d(logvar) is recovered from the forward's own sample, eps*sigma = ws[U] -
  * mu, so the backward needs neither the noise key nor the row ids, and it is the gradient of whatever forward wrote the
@@ -221,6 +228,13 @@ int dib_adam_step(float* params, const float* grads, float* m, float* v, int64_t
                   int64_t* t_dev, float beta1, float beta2, float eps, float grad_scale, dib_stream_t stream);
 int dib_sgd_step(float* params, const float* grads, int64_t n, const float* lr_dev, float grad_scale,
                  dib_stream_t stream);
+/* For a parameter buffer that is not a dib_layout (the InfoNCE output encoder, train.py:184-192): grads = fixed-order sum of
+ * nsplit partial buffers `stride` floats apart (nsplit 0: grads as given), Keras-Adam and the step-count bump in ONE launch.
+ * n % 4 == 0.  sync: DIB_SYNC_WORDS zero-initialised uint32 words owned by the caller (arrival counters, self-cleaning). */
+#define DIB_SYNC_WORDS 1056
+int dib_reduce_adam_step(const float* partial, int nsplit, int64_t stride, float* params, float* grads, float* adam_m,
+                         float* adam_v, int64_t n, const float* lr_dev, int64_t* t_dev, float beta1, float beta2, float eps,
+                         float grad_scale, uint32_t* sync, dib_stream_t stream);
 
 /* ---- evaluation helpers ------------------------------------------------------------------
  * model.feature_encoders[f](x_f) (models.py:183, visualization.py:31): deterministic [N, 2E]. x_f is [N, d_f]. */
@@ -238,6 +252,9 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
                         float* g_x, float* g_y, float* loss_out, void* ws, dib_stream_t stream);
 /* PositionalEncoding.call (models.py:22-23) of one dense [n, d] matrix -> [n, d*n_freq] (train.py:186-188: Y encoder) */
 int dib_positional_encoding(const float* x, int64_t ldx, int n, int d, int n_freq, float* out, dib_stream_t stream);
+/* the same of rows row_idx[0..n) of x (the shuffled batch of the custom loop, train.py:226-227); n_freq <= 1: a plain gather */
+int dib_positional_encoding_rows(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, int n_freq, float* out,
+                                 dib_stream_t stream);
 
 /* Mutual-information sandwich bounds (utils.estimate_mi_sandwich_bounds, utils.py:10-73; used by
  * InfoPerFeatureCallback models.py:188-223): per-row InfoNCE-lower / leave-one-out-upper terms (nats, float64,
@@ -256,6 +273,9 @@ float dib_philox_normal_ref(uint64_t seed, uint32_t step, uint32_t row, uint32_t
  * 17 categories = kernel symbols: 0..11 dib_gemm_kernel<MODE,NI,NJ> at MODE*4 + (NI-1)*2 + (NJ-1); 12 = fused
  * encoder forward; 13 = fused encoder backward; 14 = all other (HBM-bound) kernels (not bracketed); 15 = dib_attn_fwd_kernel;
  * 16 = dib_attn_bwd_kernel (include/dib_st.h).  summary() synchronises. */
+/* number of kernel launches the library has issued in this process so far (host counter, no synchronisation): the launch
+ * inventory of a step = the difference around it */
+int64_t dib_launch_count(void);
 #define DIB_PROFILE_CATEGORIES 17
 int dib_profile_enable(int on);
 int dib_profile_summary(double* ms_by_category /*[17]*/, int* launches_by_category /*[17]*/);

@@ -29,7 +29,7 @@ class _FlatAdam:
     def set_lr(self, lr):
         self.lr = float(lr)
 
-    def adam_step(self, lr=None, beta1=0.9, beta2=0.999, eps=1e-7):
+    def adam_step(self, lr=None, beta1=0.9, beta2=0.999, eps=1e-7, fused_reduce=False):
         if lr is not None:
             self.lr = float(lr)
         self._t += 1
@@ -58,6 +58,7 @@ class CheckerXEngine(_FlatAdam):
         self.F, self.E = spec.number_features, spec.feature_embedding_dimension
         self.device, self.beta = torch.device("cpu"), 1.0
         self._gp = None
+        self.metrics_acc = torch.zeros(self.F + 3, dtype=torch.float64)   # [0, F): sum over steps of KL_f batch means
 
     def to_device(self, a, dtype=torch.float32):
         return a.to(dtype) if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
@@ -65,7 +66,7 @@ class CheckerXEngine(_FlatAdam):
     def set_beta(self, v):
         self.beta = float(v)
 
-    def forward(self, x, row_idx, row0, batch, seed, step, deterministic=False, inference=False):
+    def forward(self, x, row_idx, row0, batch, seed, step, deterministic=False, inference=False, defer_sums=False):
         rows = row_idx.numpy().astype(np.int64)
         assert len(rows) == batch
         xb = torch.tensor(x.numpy().astype(np.float64)[rows])
@@ -82,14 +83,16 @@ class CheckerXEngine(_FlatAdam):
     def step_out(self, batch):
         return torch.cat([self._kl.detach() * batch, torch.zeros(3, dtype=torch.float64)])
 
-    def infonce(self, emb_x, emb_y, similarity, temperature, want_grads=True, out_gx=None, out_gy=None):
+    def infonce(self, emb_x, emb_y, similarity, temperature, want_grads=True, out_gx=None, out_gy=None, loss_out=None):
         a = emb_x.detach().clone().requires_grad_(True)
         b = emb_y.detach().clone().requires_grad_(True)
         S = scaled_similarity_torch(a, b, similarity, temperature)
         d = torch.diagonal(S)
         loss = (torch.logsumexp(S, 1) - d).mean() + (torch.logsumexp(S, 0) - d).mean()
+        if loss_out is not None:   # the product hands a slot of its per-epoch buffer
+            loss_out.copy_(loss.detach().reshape(1))
         if not want_grads:
-            return loss.detach(), None, None
+            return (loss_out if loss_out is not None else loss.detach()), None, None
         ga, gb = torch.autograd.grad(loss, [a, b])
         if out_gx is not None:
             out_gx.copy_(ga)
@@ -97,13 +100,25 @@ class CheckerXEngine(_FlatAdam):
         if out_gy is not None:
             out_gy.copy_(gb)
             gb = out_gy
-        return loss.detach(), ga, gb
+        return (loss_out if loss_out is not None else loss.detach()), ga, gb
 
-    def backward_from_pred_grad(self, g_pred, row_idx, row0, batch, seed, step, inv_global_batch=None):
+    def step_tail(self, batch, part, flags, inv_global_batch=0.0, optimizer=None, grad_scale=1.0, metrics_acc=None):
+        """the subset fit_infonce uses: TAIL_KL | TAIL_METRICS of a validation step (include/dib_hip.h: 2 | 32)"""
+        assert flags == (2 | 32) and optimizer is None
+        acc = self.metrics_acc if metrics_acc is None else metrics_acc
+        acc[: self.F] += self._kl.detach() * batch * inv_global_batch
+
+    def backward_from_pred_grad(self, g_pred, row_idx, row0, batch, seed, step, inv_global_batch=None, finish_flags=0,
+                                optimizer=None):
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         # d/dtheta [ sum_rows <emb_x, dL/d emb_x> + beta * sum_rows sum_f KL / global batch ]; _kl is the LOCAL row mean
         obj = (self._ex * g_pred).sum() + self.beta * self._kl.sum() * batch * inv
         self._store_grads(torch.autograd.grad(obj, self.vars))
+        if finish_flags & 32:
+            self.metrics_acc[: self.F] += self._kl.detach() * batch * inv
+        if optimizer is not None:
+            assert optimizer[0] == "adam"
+            self.adam_step(None, *optimizer[1:4])
 
 
 class CheckerYEncoder(_FlatAdam):
@@ -124,5 +139,5 @@ class CheckerYEncoder(_FlatAdam):
     def output_grad_buffer(self):
         return self._gbuf
 
-    def backward(self, g_out):
+    def backward(self, g_out, reduce=True):
         self._store_grads(torch.autograd.grad((self._out * g_out).sum(), self.vars))
