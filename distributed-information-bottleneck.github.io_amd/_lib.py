@@ -35,7 +35,8 @@ WS_ENC_H0, WS_INT_H0 = 16, 32
 # include/dib_hip.h flag bits
 SYNC_WORDS = 1056   # DIB_SYNC_WORDS
 FWD_DETERMINISTIC, FWD_INFERENCE, FWD_DEFER_SUMS = 1, 2, 4
-HEAD_DEFER_SUMS, HEAD_NO_GRAD = 1, 2
+HEAD_DEFER_SUMS, HEAD_NO_GRAD, HEAD_DEFER_WGRAD = 1, 2, 4
+BWD_INTEGRATION_DONE = 1
 TAIL_FINALIZE, TAIL_KL, TAIL_LOSS, TAIL_ADAM, TAIL_BUMP, TAIL_METRICS, TAIL_SGD, TAIL_HEAD_WGRAD, TAIL_LOSS_HEAD = \
     1, 2, 4, 8, 16, 32, 64, 128, 256
 SIMILARITIES = {"l2sq": 0, "l2": 1, "l1": 2, "linf": 3, "cosine": 4}
@@ -107,6 +108,7 @@ SIGNATURES = {
     "dib_integration_head_step": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_int, c_void_p,
                                           c_void_p, c_void_p, c_void_p]),
     "dib_integration_bwd_hidden": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dib_encoder_bank_bwd_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "dib_grads_finalize": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

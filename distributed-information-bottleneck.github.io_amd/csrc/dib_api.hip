@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <vector>
 
@@ -67,12 +68,16 @@ struct dib_layout {
   // small-batch row-tile kernels (dib_small.h): which halves of the network they cover for this architecture
   bool sb_enc = false, sb_int = false;
   int sb_int_lds = 0;                  // dynamic LDS bytes of dib_small_integration_kernel
+  // merged weight-gradient table (one per batch size, kept alive for the asynchronous upload of dib_workspace_init):
+  // groups [0, n_enc F): encoder layers 1 .. n_enc (feature-major), then the integration layers 0 .. n_int
+  int wg_groups() const { return n_enc * F + n_int + 1; }
+  mutable std::map<int, std::vector<DibGemmGroup>> wg_tables;
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
-    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, h1mask, skinny_partial, sync, total;
+    int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, h1mask, skinny_partial, sync, wg_table, total;
     int skinny_chunks, skinny_rows;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
@@ -127,6 +132,9 @@ struct dib_layout {
       m.skinny_partial = take(out_dim <= 8 ? (int64_t)m.skinny_chunks * ((int64_t)win * out_dim + out_dim) : 0);
     }
     m.sync = take(DIB_TAIL_SYNC_WORDS);   // arrival counters of dib_step_tail (zeroed by dib_workspace_init, self-cleaning)
+    // descriptors of ALL weight gradients of a step with absolute workspace offsets for THIS batch size (written by
+    // dib_workspace_init): one grouped launch instead of one per layer (merged_wgrad)
+    m.wg_table = take((int64_t)wg_groups() * (int64_t)(sizeof(DibGemmGroup) / sizeof(float)));
     m.total = o;
     return m;
   }
@@ -496,6 +504,46 @@ static int small_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   return (int)hipGetLastError();
 }
 
+// ---- all weight gradients of a step in ONE grouped launch ------------------------------------------------------------
+// Descriptors with absolute workspace offsets for this batch size (the activation buffers' offsets are not linear in the batch:
+// every buffer is 256-byte aligned), A and B both relative to the workspace base, C / bias_out relative to the gradient target.
+static const std::vector<DibGemmGroup>& wg_table_host(const dib_layout* l, const dib_layout::WsMap& m, int batch) {
+  auto it = l->wg_tables.find(batch);
+  if (it != l->wg_tables.end()) return it->second;
+  std::vector<DibGemmGroup> t;
+  const int64_t B = batch;
+  for (int ly = 1; ly <= l->n_enc; ++ly) {
+    const int win = l->enc_width[ly - 1], wout = l->enc_width[ly];
+    for (int f = 0; f < l->F; ++f)
+      t.push_back(make_group(fixed_off(m.enc_h[ly - 1] + (int64_t)f * win * B), win,
+                             fixed_off((ly == l->n_enc ? m.dout : m.g_enc_h[ly]) + (int64_t)f * wout * B), wout,
+                             fixed_off(l->enc_w_off[ly][f]), wout, l->enc_b_off[ly][f], Off(), 0, win, wout, -1));
+  }
+  for (int ly = 0; ly <= l->n_int; ++ly) {
+    const int win = ly == 0 ? l->F * l->E : l->int_width[ly - 1], wout = l->int_width[ly];
+    t.push_back(make_group(fixed_off(ly == 0 ? m.U : m.int_h[ly - 1]), win, fixed_off(ly == l->n_int ? m.g_pred : m.g_int_h[ly]), wout,
+                           fixed_off(l->int_w_off[ly]), wout, l->int_b_off[ly], Off(), 0, win, wout, -1));
+  }
+  return l->wg_tables.emplace(batch, std::move(t)).first->second;
+}
+
+// groups [first, first + count) of the table (see dib_layout::wg_groups) into the gradient target gt
+static int merged_wgrad(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, float* gt, int first, int count,
+                        hipStream_t st) {
+  if (count <= 0) return DIB_OK;
+  const auto& host = wg_table_host(l, m, batch);
+  GemmCall c;
+  c.first = 0; c.count = count;
+  for (int i = first; i < first + count; ++i) { c.max_m = std::max(c.max_m, host[i].M); c.max_n = std::max(c.max_n, host[i].N); }
+  const DibGemmGroup* dev = reinterpret_cast<const DibGemmGroup*>(w + m.wg_table) + first;
+  return launch_gemm<2>(dev, c, w, w, gt, nullptr, nullptr, gt, batch, 0, m.nsplit, m.rows_per_split, align_up(l->n_params, 4), st,
+                        /*auto_split=*/true, m.nsplit);
+}
+// when one grouped launch for all weight gradients pays: the small-batch regime, where every launch is latency
+static bool use_merged_wgrad(const dib_layout* l, int batch) {
+  return use_small_enc(l, batch) && use_small_int(l, batch);
+}
+
 // one launch of dib_small_integration_kernel; `mode` = DIB_SMALL_INT_* bits.  Head arguments may be null / 0 without a head.
 static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params, int mode,
                              int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0, float inv_bg,
@@ -686,7 +734,7 @@ int dib_layout_create(int F, const int* feature_dims, int n_enc, const int* enc_
       w_ok = int_units[i] % 16 == 0 && int_units[i] <= 1024;
       fl += 2ll * DIB_SMALL_ROWS * dib_small_pitch(int_units[i]);
     }
-    fl += (int64_t)DIB_SMALL_ROWS * dib_small_pitch(out_dim) + DIB_SMALL_XCH_FLOATS + (w_ok ? 8 * (int_units[n_int - 1] + 1) + 16 : 0);
+    fl += (int64_t)DIB_SMALL_ROWS * dib_small_pitch(out_dim) + DIB_SMALL_XCH_FLOATS + (w_ok ? 9 * (int_units[n_int - 1] + 1) + 32 : 0);
     l->sb_int = pl_act && w_ok && fl * 4 <= 150 * 1024;
     l->sb_int_lds = (int)(fl * 4);
   }
@@ -777,6 +825,11 @@ int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t st
   // the arrival counters of dib_step_tail (self-cleaning afterwards)
   hipError_t e0 = hipMemsetAsync((float*)ws + m.sync, 0, (size_t)DIB_TAIL_SYNC_WORDS * sizeof(unsigned), (hipStream_t)stream);
   if (e0 != hipSuccess) return (int)e0;
+  {  // the merged weight-gradient table of this batch size (the host copy lives in the layout: the copy may be asynchronous)
+    const auto& t = wg_table_host(l, m, batch);
+    e0 = hipMemcpyAsync((float*)ws + m.wg_table, t.data(), t.size() * sizeof(DibGemmGroup), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e0 != hipSuccess) return (int)e0;
+  }
   // the per-step scalars: a caller that accumulates only the KL terms (custom loss) must not pick up stale loss sums
   e0 = hipMemsetAsync((float*)ws + m.step_out, 0, (size_t)(l->F + 3) * sizeof(float), (hipStream_t)stream);
   if (e0 != hipSuccess) return (int)e0;
@@ -1052,6 +1105,9 @@ int dib_output_head_fused(dib_layout* l, int loss_kind, const float* y, int64_t 
   return (int)hipGetLastError();
 }
 
+static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                                   float inv_global_batch, int stages, void* ws, dib_stream_t stream);
+
 // The integration network's whole share of a step with the fused 1-unit head: hidden layers forward, output Dense(1) + loss,
 // and (training) the head's backward, the dgrad chain back to dL/du and the hidden layers' weight gradients.
 // = dib_integration_fwd_hidden + dib_output_head_fused(flags) + dib_integration_bwd_hidden; for batches <= 1024 rows the
@@ -1072,7 +1128,8 @@ int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int6
                      (no_grad ? DIB_SMALL_INT_INFER : (DIB_SMALL_INT_HEAD_GRAD | DIB_SMALL_INT_BWD));
     rc = small_integration(l, m, w, batch, params, mode, loss_kind, y, ldy, row_idx, row0, inv_global_batch, st);
     if (rc) return rc;
-    if (!no_grad) {
+    // (DIB_HEAD_DEFER_WGRAD is honoured exactly when dib_backward will run the merged weight-gradient launch: same predicate)
+    if (!no_grad && !((flags & DIB_HEAD_DEFER_WGRAD) && use_merged_wgrad(l, batch))) {
       rc = integration_bwd_impl(l, batch, params, grads, ws, stream, false, /*skip_dgrad=*/true);
       if (rc) return rc;
     }
@@ -1090,10 +1147,49 @@ int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int6
   }
   rc = integration_fwd_impl(l, batch, params, ws, stream, false);
   if (rc) return rc;
-  rc = dib_output_head_fused(l, loss_kind, y, ldy, row_idx, row0, batch, inv_global_batch, flags, params, grads, ws, stream);
+  rc = dib_output_head_fused(l, loss_kind, y, ldy, row_idx, row0, batch, inv_global_batch, flags & ~DIB_HEAD_DEFER_WGRAD, params,
+                             grads, ws, stream);
   if (rc || no_grad) return rc;
+  // (large batches: DIB_HEAD_DEFER_WGRAD is ignored - each layer's weight gradient runs right after its dgrad, while the
+  // operands are still in the infinity cache; dib_backward(DIB_BWD_INTEGRATION_DONE) then only runs the encoder bank)
   return integration_bwd_impl(l, batch, params, grads, ws, stream, false);
 }
+
+// Everything of a step's backward pass that follows the loss, in one entry (single-GPU callers; the data-parallel bucket
+// protocol keeps the separate entries): [dib_integration_bwd unless DIB_BWD_INTEGRATION_DONE] + dib_encoder_bank_bwd, with
+// the weight gradients of the integration network's hidden layers that dib_integration_head_step(DIB_HEAD_DEFER_WGRAD) left
+// (DIB_BWD_INTEGRATION_DONE).  For batches <= 1024 rows ALL weight gradients of the step - encoder layers 2.., integration
+// layers - are ONE grouped launch over the per-batch descriptor table dib_workspace_init wrote into the workspace.
+int dib_backward(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev, float inv_global_batch,
+                 int flags, void* ws, dib_stream_t stream) {
+  if (!l || !params || !grads || !beta_dev || !ws || batch <= 0) return DIB_E_ARG;
+  if (!l->dev_groups) return DIB_E_WORKSPACE;
+  const bool int_done = (flags & DIB_BWD_INTEGRATION_DONE) != 0;
+  const bool merged = use_merged_wgrad(l, batch) && (int_done || l->out_dim % 16 == 0);
+  int rc;
+  if (!merged) {
+    // (int_done here means dib_integration_head_step already ran the integration network's weight gradients: it defers them
+    // only under the predicate that makes `merged` true)
+    rc = int_done ? DIB_OK : integration_bwd_impl(l, batch, params, grads, ws, stream, true);
+    if (rc) return rc;
+    return encoder_bank_bwd_stages(l, batch, params, grads, beta_dev, inv_global_batch, 3, ws, stream);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const auto m = l->map(batch);
+  float* w = (float*)ws;
+  if (!int_done) {   // dgrad chain from ws[G_PRED] (general output layer) down to ws[G_U]
+    rc = small_integration(l, m, w, batch, params, DIB_SMALL_INT_LOAD_H | DIB_SMALL_INT_BWD_OUT | DIB_SMALL_INT_BWD, 0, nullptr, 0,
+                           nullptr, 0, 0.f, st);
+    if (rc) return rc;
+  }
+  rc = small_encoder_bwd(l, m, w, batch, params, beta_dev, inv_global_batch, st);
+  if (rc) return rc;
+  // encoder layers 1 .. n_enc (layer 0 comes out of the backward kernel as partials), integration hidden layers, and the
+  // general output layer when this call ran its backward (the fused head reduces its own partials in the tail)
+  const int count = l->n_enc * l->F + l->n_int + (int_done ? 0 : 1);
+  return merged_wgrad(l, m, w, batch, wgrad_target(m, w, grads), 0, count, st);
+}
+
 
 // stages: bit 0 = the gradient chain (reparam/KL backward + dgrads) and every weight gradient except the last encoder
 // layer's; bit 1 = the last layer's weight gradient (independent of the others: it reads dout and the last hidden layer).
@@ -1823,6 +1919,14 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
 extern "C" int dib_fused_debug_read(long long* out16) {
   if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
   return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(dib_fused_dbg), 16 * sizeof(long long));
+}
+#endif
+
+#ifdef DIB_SMALL_TIMING
+// diagnostic build only (not declared in include/): phase marks of the last launches of the row-tile kernels (dib_small.h)
+extern "C" int dib_small_debug_read(long long* out64) {
+  if (hipDeviceSynchronize() != hipSuccess) return DIB_E_ARG;
+  return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(dib_small_dbg), 64 * sizeof(long long));
 }
 #endif
 

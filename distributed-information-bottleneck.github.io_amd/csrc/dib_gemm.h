@@ -154,8 +154,17 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
     kbeg = 0;
     kend = K;
   }
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0 = tm * BM, n0 = tn * BN;
   if (tm >= tiles_m || m0 >= M || n0 >= N) return;  // block-uniform
+  if (MODE == 2) {
+    // A ragged LAST tile of a weight gradient is shifted back to end at the matrix edge (it overlaps its neighbour; both
+    // write bit-identical values: the same k order per element): every operand tile is then an interior tile - unconditional
+    // 16-byte loads.  With the half-empty 13th m-tile of BASELINE config 4's 1600 x 256 integration layer on the bounds-
+    // checked load path, the 38 workgroups that own it were the stragglers of a single-round launch: 0.590 ms against
+    // 0.511 ms for the LARGER 1664 x 256 problem on the same 494 workgroups (profiles/r05g_config4_wgrad_m_pitch_split_sweep.txt).
+    if (M >= BM && (M & 3) == 0 && m0 + BM > M) m0 = M - BM;
+    if (N >= BN && (N & 3) == 0 && n0 + BN > N) n0 = N - BN;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;

@@ -19,6 +19,16 @@
 #include "dib_fused.h"   // dib_sigma, DIB_MFMA16, dib_f32x4
 
 #define DIB_SMALL_ROWS 16
+
+// Phase marks of the row-tile kernels (diagnostic build -DDIB_SMALL_TIMING; tools/small_phase_timing.py): thread 0 of
+// workgroup (0, 0) stores the 100 MHz wall clock at each phase boundary of the last launch.  K1 marks at [0, 16), the
+// integration kernel at [16, 40), the encoder backward at [40, 56).
+#ifdef DIB_SMALL_TIMING
+__device__ long long dib_small_dbg[64];
+#define DIB_ST(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dib_small_dbg[i] = wall_clock64(); } while (0)
+#else
+#define DIB_ST(i) do { } while (0)
+#endif
 #define DIB_SMALL_THREADS 512   // 8 waves = 2 per SIMD: the contraction of every layer is split between wave w and w + 4, so
                                 // that one of the pair issues MFMAs while the other waits for its weights (each weight is read
                                 // once per workgroup, straight from L2: the kernels are latency-bound, not bandwidth-bound)
@@ -317,6 +327,7 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
   float* os = h2s + DIB_SMALL_ROWS * p2;    // [16][p3]
   float* xch = os + DIB_SMALL_ROWS * p3;    // wave-pair exchange
   // ---- gather + positional encoding (the expressions of dib_posenc_kernel): P[b][j d + c] = j == 0 ? x : sin(2^j x) ----
+  DIB_ST(0);
   for (int i = tid; i < DIB_SMALL_ROWS * 20; i += DIB_SMALL_THREADS) Pl[i] = 0.f;
   __syncthreads();
   if (tid < DIB_SMALL_ROWS * d) {
@@ -338,6 +349,7 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
     }
   }
   __syncthreads();
+  DIB_ST(1);
   const float* W1 = a.params + a.w_off[0 * F + f];
   const float* W2 = a.params + a.w_off[1 * F + f];
   const float* W3 = a.params + a.w_off[2 * F + f];
@@ -348,8 +360,11 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
   const float slope = dib_neg_slope(a.act);
   dib_small_fwd(Pl, 20, (in_dim + 3) & ~3, in_dim, W1, a.H1, b1, slope, h1s, p1, a.h1 ? a.h1 + frow * a.H1 : nullptr, a.H1,
                 rows_valid, xch);
+  DIB_ST(2);
   dib_small_fwd(h1s, p1, a.H1, a.H1, W2, a.H2, b2, slope, h2s, p2, a.h2 ? a.h2 + frow * a.H2 : nullptr, a.H2, rows_valid, xch);
+  DIB_ST(3);
   dib_small_fwd(h2s, p2, a.H2, a.H2, W3, E2, b3, 1.f /* linear, models.py:78 */, os, p3, a.enc_out + frow * E2, E2, rows_valid, xch);
+  DIB_ST(4);
   // ---- reparameterise + KL: thread = (row, 4 consecutive embedding dims) = one Philox call ----
   const int E4 = E >> 2;
   float klp = 0.f;
@@ -375,6 +390,7 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
   }
   const float tot = dib_small_block_sum(klp, red);
   if (tid == 0) a.kl_partial[(long long)tile * F + f] = tot;
+  DIB_ST(5);
 }
 
 // =====================================================================================================================
@@ -432,9 +448,23 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
   const long long wo_off = n == 1 ? a.w_off[1] : (n == 2 ? a.w_off[2] : a.w_off[3]);
   const long long bo_off = n == 1 ? a.b_off[1] : (n == 2 ? a.b_off[2] : a.b_off[3]);
 
+  DIB_ST(16);
+  // the head's own inputs - output weights, bias, the rows' labels - are fetched NOW into LDS: their global round trips (two
+  // dependent ones for a gathered label) run under the hidden layers instead of in front of every row's loss
+  float* const head_w = scratch + 8 * (KL + 1) + 16;   // [KL] output-layer kernel, then [1] bias
+  float* const head_y = head_w + KL + 1;               // [16] labels of the tile's rows
+  if (a.mode & DIB_SMALL_INT_HEAD) {
+    for (int k = tid; k <= KL; k += DIB_SMALL_THREADS) head_w[k] = k < KL ? a.params[wo_off + k] : a.params[bo_off];
+    if (tid < DIB_SMALL_ROWS && tid < rows_valid) {
+      const int b = r0 + tid;
+      const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
+      head_y[tid] = a.Y[grow * a.ldy];
+    }
+  }
   if (a.mode & DIB_SMALL_INT_FWD) {
     dib_small_load_tile(a.U + (long long)r0 * a.K0, a.K0, a.K0, rows_valid, us, pu);
     __syncthreads();
+    DIB_ST(17);
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
       if (l < n) {
@@ -442,6 +472,7 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
         const int K = l == 0 ? a.K0 : a.width[l > 0 ? l - 1 : 0], pin = l == 0 ? pu : ph[l > 0 ? l - 1 : 0];
         dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], slope, hs[l], ph[l],
                       stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid, xch);
+        DIB_ST(18 + l);
       }
     }
   } else if (a.mode & DIB_SMALL_INT_LOAD_H) {
@@ -461,8 +492,8 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
     // z = h . w + b per row (wave w: rows w, w + 8); Keras BinaryCrossentropy(from_logits=True) / 'mse', the
     // expressions of dib_head_fused_kernel; dL/dh = g w (.) act'(h); per-tile partial of d(w|b) and of {loss sum, #correct}
     const bool grad = (a.mode & DIB_SMALL_INT_HEAD_GRAD) != 0;
-    const float* wv = a.params + wo_off;
-    const float b0 = a.params[bo_off];
+    const float* wv = head_w;            // LDS copies (written before the hidden layers, whose barriers publish them)
+    const float b0 = head_w[KL];
     float* redw = scratch;               // [8][KL + 1]
     float* redl = scratch + 8 * (KL + 1); // [8][2]
     float lsum = 0.f, correct = 0.f, pb = 0.f;
@@ -480,8 +511,7 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
         if (k < KL) dot += hl[row * pl + k] * wv[k];
       }
       const float z = dib_wave_sum(dot) + b0;
-      const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
-      const float yy = a.Y[grow * a.ldy];
+      const float yy = head_y[row];
       float l, gg;
       if (a.loss_kind == 0) {
         l = fmaxf(z, 0.f) - z * yy + log1pf(expf(-fabsf(z)));
@@ -541,6 +571,7 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
     }
   }
 
+  DIB_ST(22);
   if (a.mode & DIB_SMALL_INT_BWD_OUT) {   // dL/dh_{n-1} from a given dL/dpred (custom loss: InfoNCE, train.py:216-219)
     dib_small_load_tile(a.g_pred + (long long)r0 * a.out_dim, a.out_dim, a.out_dim, rows_valid, ps, po);
     __syncthreads();
@@ -548,16 +579,19 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
   }
 
   if (a.mode & DIB_SMALL_INT_BWD) {
+    DIB_ST(23);
 #pragma unroll
     for (int l = 2; l >= 1; --l) {   // dL/dh_{l-1} = (dL/dh_l @ W_l^T) (.) act'(h_{l-1})
       if (l < n) {
         dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], slope, gs[l - 1],
                       ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid, xch);
+        DIB_ST(24 + l);
       }
     }
     // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output)
     dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
                   a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
+    DIB_ST(28);
   }
 }
 
@@ -590,6 +624,7 @@ dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
   float* dh1s = dh2s + DIB_SMALL_ROWS * p2;   // [16][p1]
   float* xch = dh1s + DIB_SMALL_ROWS * p1;    // wave-pair exchange
   const long long frow = (long long)f * a.batch + r0;
+  DIB_ST(40);
   dib_small_load_tile(a.h1 + frow * a.H1, a.H1, a.H1, rows_valid, h1s, p1);
   dib_small_load_tile(a.h2 + frow * a.H2, a.H2, a.H2, rows_valid, h2s, p2);
   for (int i = tid; i < DIB_SMALL_ROWS * 20; i += DIB_SMALL_THREADS) {
@@ -627,12 +662,15 @@ dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
     *reinterpret_cast<float4*>(dos + row * p3 + E + 4 * qq) = dl;
   }
   __syncthreads();
+  DIB_ST(41);
   const float* W2 = a.params + a.w_off[1 * F + f];
   const float* W3 = a.params + a.w_off[2 * F + f];
   // dh2 = (dout @ W3^T) (.) act'(h2) -> stash (operand of the layer-2 weight gradient) ; dh1 = (dh2 @ W2^T) (.) act'(h1)
   const float slope = dib_neg_slope(a.act);
   dib_small_bwd(dos, p3, E2, W3, a.H2, h2s, p2, slope, dh2s, p2, a.dh2 + frow * a.H2, a.H2, rows_valid, xch);
+  DIB_ST(42);
   dib_small_bwd(dh2s, p2, a.H2, W2, a.H1, h1s, p1, slope, dh1s, p1, nullptr, 0, rows_valid, xch);
+  DIB_ST(43);
   // d(W1|b1) partial of the tile = [P | 1]^T @ dh1: 16 x 16 output tiles (rows = encoder-input index, row in_dim = bias),
   // contraction over the 16 rows in 4 MFMA steps; lane (i, q): A[i][row 4 s + q] = Pl[row][i], B[row][n0 + j] = dh1[row][n0 + j]
   {
@@ -646,4 +684,5 @@ dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
       for (int r = 0; r < 4; ++r) dst[(long long)(4 * q + r) * a.H1 + n0 + j] = acc[r];
     }
   }
+  DIB_ST(44);
 }

@@ -83,12 +83,13 @@ class DenseStack:
             act = self.act if l < L - 1 else 0
             g[f"fwd{l}"] = _Gemm(0, [_d(off[f"a{l}"], wi, self.w_off[l], wo, off[f"a{l + 1}"], wo, n, wo, wi,
                                         bias_off=self.b_off[l])], ws, self.params, ws, bias=self.params, act=act)
-            g[f"wgrad{l}"] = _Gemm(2, [_d(off[f"a{l}"], wi, off[f"g{l + 1}"], wo, self.w_off[l], wo, wi, wo, n,
-                                          bias_off=self.b_off[l])], ws, ws, gt, bias_out=gt, nsplit=nsplit,
-                                   rows_per_split=rps, split_stride=self.n_params)
             if l > 0:   # dL/d(pre-activation of layer l-1) = (g_l @ W_l^T) * act'(a_l)
                 g[f"dgrad{l}"] = _Gemm(1, [_d(off[f"g{l + 1}"], wo, self.w_off[l], wo, off[f"g{l}"], wi, n, wi, wo,
                                               aux_off=off[f"a{l}"], ldaux=wi)], ws, self.params, ws, aux=ws, act=self.act)
+        # every layer's weight gradient in ONE grouped launch (independent products; the dgrad chain runs first)
+        g["wgrad_all"] = _Gemm(2, [_d(off[f"a{l}"], wi, off[f"g{l + 1}"], wo, self.w_off[l], wo, wi, wo, n, bias_off=self.b_off[l])
+                                  for l, (wi, wo) in enumerate(self.dims)], ws, ws, gt, bias_out=gt, nsplit=nsplit,
+                               rows_per_split=rps, split_stride=self.n_params)
         for gg in g.values():
             gg.upload(self.device)
         if len(self._plans) >= 4:                             # train batch, validation batch, their tails
@@ -144,10 +145,9 @@ class DenseStack:
             dst.copy_(g_out)
         if pl["nsplit"] == 1:
             self.grads.zero_()
-        for l in reversed(range(L)):
-            pl["g"][f"wgrad{l}"].run(self.lib, st)   # dW[i,o] = a_l^T @ g_{l+1}; bias gradient = column sums of g_{l+1}
-            if l > 0:
-                pl["g"][f"dgrad{l}"].run(self.lib, st)
+        for l in reversed(range(1, L)):
+            pl["g"][f"dgrad{l}"].run(self.lib, st)   # dL/d(pre-activation of layer l-1)
+        pl["g"]["wgrad_all"].run(self.lib, st)       # dW_l[i,o] = a_l^T @ g_{l+1}, bias gradients = column sums of g_{l+1}, all l
         self._unreduced = pl if (pl["nsplit"] > 1 and not reduce) else None
         if pl["nsplit"] > 1 and reduce:
             check(self.lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_params, pl["nsplit"], self.n_params, _ptr(self.grads), st),

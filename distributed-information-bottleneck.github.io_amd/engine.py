@@ -270,11 +270,21 @@ class HipEngine:
         deferred KL / loss sums, the metric accumulation) and, without hooks, the optimizer (`optimizer`, see step_tail)."""
         ws = self.workspace(batch)
         st = self._stream()
+        FIN = _lib.TAIL_FINALIZE
+        head = _lib.TAIL_HEAD_WGRAD if hidden_only else 0   # the fused head left its weight-gradient partials to the tail
+        if on_integration_grads_ready is None and (integration_done or not hidden_only):
+            # no bucket protocol: the rest of the backward pass in one entry - for small batches the dgrad chains are one
+            # launch each and ALL weight gradients one grouped launch - then ONE tail launch
+            assert on_encoder_front_grads_ready is None
+            check(self.lib.dib_backward(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(self.beta_dev),
+                                        float(inv_global_batch), _lib.BWD_INTEGRATION_DONE if integration_done else 0, _ptr(ws), st),
+                  "dib_backward")
+            self.step_tail(batch, -1, FIN | head | finish_flags | (_lib.TAIL_BUMP if optimizer and optimizer[0] == "adam" else 0),
+                           inv_global_batch, optimizer=optimizer)
+            return
         if not integration_done:   # (dib_integration_head_step already ran the integration network's backward)
             fn = self.lib.dib_integration_bwd_hidden if hidden_only else self.lib.dib_integration_bwd
             check(fn(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st), "dib_integration_bwd")
-        FIN = _lib.TAIL_FINALIZE
-        head = _lib.TAIL_HEAD_WGRAD if hidden_only else 0   # the fused head left its weight-gradient partials to the tail
         if on_integration_grads_ready is not None:
             assert optimizer is None, "the data-parallel caller steps the optimizer after its all-reduces"
             self.step_tail(batch, 1, FIN | head)
@@ -328,8 +338,10 @@ class HipEngine:
             # encoder bank, then the integration network's whole share in one entry: hidden layers, output Dense(1) + loss and
             # their backward down to dL/du (one launch of 16-row tiles for batches <= 1024 rows), hidden weight gradients
             self.encoder_forward(x, row_idx, row0, batch, seed, step, defer_sums=True)
+            single = on_integration_grads_ready is None   # no bucket protocol: every weight gradient of the step in dib_backward
             check(self.lib.dib_integration_head_step(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,
-                                                     float(inv), _lib.HEAD_DEFER_SUMS, _ptr(self.params), _ptr(self.grads),
+                                                     float(inv), _lib.HEAD_DEFER_SUMS | (_lib.HEAD_DEFER_WGRAD if single else 0),
+                                                     _ptr(self.params), _ptr(self.grads),
                                                      _ptr(self.workspace(batch)), self._stream()), "dib_integration_head_step")
             self.backward(row_idx, row0, batch, seed, step, inv, on_integration_grads_ready, hidden_only=True,
                           on_encoder_front_grads_ready=on_encoder_front_grads_ready, finish_flags=finish, optimizer=optimizer,

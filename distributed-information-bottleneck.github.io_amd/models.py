@@ -147,6 +147,7 @@ class DistributedIBNet:
         self._engine = None
         # data-parallel gradient all-reduce buckets (fit under torch.distributed): 3 = integration / encoder front layers /
         # last encoder layer, each issued as soon as it is final (default); 2 = integration / encoder bank; 1 = one all-reduce
+        self.dp_small_batch_rows = 1024   # per-rank batches up to this many rows use ONE gradient bucket (see fit)
         self.dp_buckets = int(os.environ.get("DIB_DP_BUCKETS", "3"))
         if self.dp_buckets not in (1, 2, 3):
             raise ValueError(f"DIB_DP_BUCKETS={self.dp_buckets}: 1, 2 or 3")
@@ -441,6 +442,12 @@ class DistributedIBNet:
                     #   0 = 2 + 3 as one bucket after the backward                                    (dp_buckets == 2)
                     pending = []
                     nb = self.dp_buckets if (dist is not None and hasattr(eng, "part_range")) else 1
+                    if nb > 1 and gb // world <= self.dp_small_batch_rows:
+                        # small per-rank batches (<= 1024 rows: the row-tile kernels, one grouped launch for every weight
+                        # gradient): the backward is a handful of launches with nothing to hide an all-reduce under - one
+                        # bucket after it, and the launches (hence the bits) of the single-process step.  Decided from the
+                        # GLOBAL batch: identical on every rank.
+                        nb = 1
                     issue = lambda g: pending.append(dist.all_reduce(g, async_op=True))
                     if dist is None and getattr(eng, "fused_optimizer_tail", False):
                         # one process: the step's LAST launch reduces the gradient partials, sums the KL / loss partials,

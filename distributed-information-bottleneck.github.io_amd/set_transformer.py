@@ -608,9 +608,10 @@ class SetTransformerDIB:
         return self._view(pl, "pred", B, self.output_dimensionality)
 
     # ---- loss + backward ----------------------------------------------------------------------------------------------
-    def loss_and_backward(self, is_loci, inv_global_batch: Optional[float] = None) -> None:
+    def loss_and_backward(self, is_loci, inv_global_batch: Optional[float] = None, reduce: bool = True) -> None:
         """bce_losses = mean BCE(is_loci, logits); loss = bce_losses + beta_var * kl; tape.gradient(loss, variables).
-        Gradients land in self.grads; self.last gets bce (device scalar)."""
+        Gradients land in self.grads; self.last gets bce (device scalar).  reduce=False: the batch-slab partials are left for
+        adam_step(fused_reduce=True), which sums them in the optimizer's own launch (dib_reduce_adam_step)."""
         pl = self.last["plan"]
         B, P, T = self.last["B"], self.last["P"], pl["T"]
         lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
@@ -686,14 +687,30 @@ class SetTransformerDIB:
             g[f"enc{l}_wgrad"].run(lib, st)
             if l > 0:
                 g[f"enc{l}_dgrad"].run(lib, st)
-        if pl["nsplit"] > 1:
+        self._unreduced = pl if (pl["nsplit"] > 1 and not reduce) else None
+        if pl["nsplit"] > 1 and reduce:
             check(lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_alloc, pl["nsplit"], self.n_alloc, _ptr(self.grads), st),
                   "dib_reduce_splits")
         out3 = self._view(pl, "out3", 3)
         self.last["bce"] = out3[0:1] * inv
         self.last["correct"] = out3[1:2]
 
-    def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7) -> None:
+    def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7, fused_reduce: bool = False) -> None:
+        if fused_reduce and self.n_alloc % 4 == 0:   # slab reduce + Keras-Adam + step-count bump in one launch
+            pl = getattr(self, "_unreduced", None)
+            if getattr(self, "_sync", None) is None:
+                self._sync = torch.zeros(_lib.SYNC_WORDS, dtype=torch.int32, device=self.device)
+            check(self.lib.dib_reduce_adam_step(_ptr(pl["slabs"]) if pl is not None else None, pl["nsplit"] if pl is not None else 0,
+                                                self.n_alloc, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                                self.n_alloc, _ptr(self.lr_dev), _ptr(self.t_dev), beta_1, beta_2, epsilon, 1.0,
+                                                _ptr(self._sync), self._stream()), "dib_reduce_adam_step")
+            self._unreduced = None
+            return
+        pl = getattr(self, "_unreduced", None)
+        if pl is not None:   # (a deferred reduce that the fused path could not take)
+            check(self.lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_alloc, pl["nsplit"], self.n_alloc, _ptr(self.grads),
+                                             self._stream()), "dib_reduce_splits")
+            self._unreduced = None
         check(self.lib.dib_adam_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v), self.n_alloc,
                                      _ptr(self.lr_dev), _ptr(self.t_dev), beta_1, beta_2, epsilon, 1.0, self._stream()),
               "dib_adam_step")
@@ -710,9 +727,9 @@ class SetTransformerDIB:
             if training and self.use_graphs:
                 return self._train_step_graph(batch_inp, is_loci)
             self.forward(batch_inp, for_backward=training)
-            self.loss_and_backward(is_loci) if training else self._loss_only(is_loci)
+            self.loss_and_backward(is_loci, reduce=False) if training else self._loss_only(is_loci)
             if training:
-                self.adam_step()
+                self.adam_step(fused_reduce=True)
             self._step += 1
             return self.last["bce"]
         rank, world = dist.get_rank(), dist.get_world_size()
@@ -767,8 +784,8 @@ class SetTransformerDIB:
 
                 def body():
                     self.forward(xs, step=0, _step_from_device=True)
-                    self.loss_and_backward(ys)
-                    self.adam_step()
+                    self.loss_and_backward(ys, reduce=False)
+                    self.adam_step(fused_reduce=True)
 
                 self._set_step_dev(self._step)
                 body()

@@ -92,12 +92,13 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
  * caller between replays) instead of the by-value `step` arguments below; NULL restores the by-value behaviour. */
 int dib_layout_set_step_counter(dib_layout* l, const uint32_t* step_dev);
 /* workspace (activations, activation gradients, split-batch wgrad partials) for local batch B.
- * CONTRACT: before its first use a workspace must either be zero-filled as a whole or be passed once to
- * dib_workspace_init (which zeroes the only regions that need it: the split-batch weight-gradient slabs - for batch >= 1024
- * dib_grads_finalize sums every slab of every parameter block, including slabs no launch writes - and the arrival counters
- * of dib_step_tail, which clean themselves after every launch).  The library never writes non-zero values into unwritten
- * slabs, so one initialisation per (workspace, layout, batch size) is enough; a workspace that is handed to ANOTHER layout
- * or batch size must be initialised again (the per-launch split rule leaves different slabs unwritten). */
+ * CONTRACT: before its first use a workspace must be passed once to dib_workspace_init (zero-filling it is NOT enough since
+ * ABI 5).  It zeroes the regions that need it - the split-batch weight-gradient slabs (for batch >= 1024 dib_grads_finalize
+ * sums every slab of every parameter block, including slabs no launch writes), the per-step scalars, the arrival counters of
+ * dib_step_tail (which clean themselves after every launch) - and writes the descriptor table of the step's merged
+ * weight-gradient launch for THIS batch size.  The library never writes non-zero values into unwritten slabs, so one
+ * initialisation per (workspace, layout, batch size) is enough; a workspace that is handed to ANOTHER layout or batch size
+ * must be initialised again (different slabs stay unwritten, different table). */
 int64_t dib_workspace_bytes(const dib_layout* l, int batch);
 int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t stream);
 int64_t dib_workspace_offset(const dib_layout* l, int batch, int which); /* byte offset, <0 on error */
@@ -132,6 +133,7 @@ int dib_integration_fwd(dib_layout* l, int batch, const float* params, void* ws,
  * flags: DIB_HEAD_DEFER_SUMS = leave the sum of the per-workgroup loss partials to dib_step_tail(DIB_TAIL_LOSS). */
 #define DIB_HEAD_DEFER_SUMS 1
 #define DIB_HEAD_NO_GRAD 2     /* dib_output_head_fused only: validation - prediction and loss terms, no gradient (grads may be NULL) */
+#define DIB_HEAD_DEFER_WGRAD 4 /* dib_integration_head_step only: the hidden layers' weight gradients are left to dib_backward */
 int dib_loss_fwd_bwd(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx,
                      int64_t row0, int batch, float inv_global_batch, int flags, void* ws, dib_stream_t stream);
 int dib_integration_bwd(dib_layout* l, int batch, const float* params, float* grads, void* ws,
@@ -160,6 +162,14 @@ int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, fl
 int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
                               int batch, float inv_global_batch, int flags, const float* params, float* grads, void* ws,
                               dib_stream_t stream);
+/* dib_backward: everything of a step's backward pass that follows the loss, for single-GPU callers (the data-parallel bucket
+ * protocol uses the separate entries below): dib_integration_bwd (skipped with DIB_BWD_INTEGRATION_DONE: the step ran
+ * dib_integration_head_step(DIB_HEAD_DEFER_WGRAD), only its hidden-layer weight gradients are outstanding) + dib_encoder_bank_bwd.
+ * For batches <= 1024 rows all weight gradients of the step are ONE grouped launch over the descriptor table that
+ * dib_workspace_init wrote for this batch size.  Follow with dib_grads_finalize / dib_step_tail. */
+#define DIB_BWD_INTEGRATION_DONE 1
+int dib_backward(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev, float inv_global_batch,
+                 int flags, void* ws, dib_stream_t stream);
 /* dib_encoder_bank_bwd: tape.gradient through models.py:106-118 for the encoder bank (reparameterisation + beta*KL backward,
  * dgrads, weight gradients).  The noise term of d(logvar) is recovered from the forward's own sample, eps*sigma = ws[U] -
  * mu, so the backward needs neither the noise key nor the row ids, and it is the gradient of whatever forward wrote the

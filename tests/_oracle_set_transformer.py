@@ -91,13 +91,13 @@ def make_model(spec: sto.SetTransformerSpec, **kw):
                     for_backward=True):
             return backend.forward(self, batch_inp, step, deterministic, row0, embs_reparam)
 
-        def loss_and_backward(self, is_loci, inv_global_batch=None):
+        def loss_and_backward(self, is_loci, inv_global_batch=None, reduce=True):
             return backend.loss_and_backward(self, is_loci, inv_global_batch)
 
         def _loss_only(self, is_loci, inv_global_batch=None):
             return backend.loss_only(self, is_loci, inv_global_batch)
 
-        def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7, fused_reduce=False):
             return backend.adam_step(self, beta_1, beta_2, epsilon)
 
     kw.setdefault("use_graphs", False)

@@ -42,6 +42,7 @@ def _run(rank, world, port, out_dir, n_rows=80, buckets=3):
     model = dib_amd.DistributedIBNet(**spec_kwargs(spec), noise_seed=1, shuffle_seed=2, init_seed=3)
     model._make_engine = lambda: OracleEngine(**model._spec_kwargs(), init_seed=model.init_seed)
     model.dp_buckets = buckets
+    model.dp_small_batch_rows = 0     # exercise the requested bucket protocol at these toy batch sizes too
     opt = dib_amd.optimizers.get("adam")
     opt.learning_rate = 5e-3
     model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])

@@ -30,17 +30,20 @@ def _free_port():
 
 
 @pytest.mark.timeout(900)
-def test_fit_under_rccl_one_rank_equals_single_process(tmp_path):
-    """fit() launched by torch.distributed.run (nccl = RCCL backend, world size 1): the two-bucket async all-reduce
-    sequence, the empty-tail-batch branch and the metric all-reduce run on the real communicator and reproduce the
-    plain single-process run bit for bit (a 1-rank sum all-reduce is the identity)."""
+@pytest.mark.parametrize("batch", [1024, 2048])
+def test_fit_under_rccl_one_rank_equals_single_process(tmp_path, batch):
+    """fit() launched by torch.distributed.run (nccl = RCCL backend, world size 1) reproduces the plain single-process run
+    bit for bit (a 1-rank sum all-reduce is the identity).  batch 2048: the three-bucket async all-reduce sequence with the
+    per-bucket optimizer launches, the empty-tail-batch branch and the metric all-reduce on the real communicator.  batch
+    1024: the small-batch regime - row-tile kernels, one grouped weight-gradient launch, ONE gradient bucket after the
+    backward (fit's dp_small_batch_rows) and the plain optimizer entry point instead of the step's tail launch."""
     a, b = str(tmp_path / "single.npz"), str(tmp_path / "rccl.npz")
     worker = os.path.join(HERE, "_dp_gpu_worker.py")
-    r = subprocess.run([sys.executable, worker, a], capture_output=True, text=True, timeout=400, env=_env())
+    r = subprocess.run([sys.executable, worker, a, str(batch)], capture_output=True, text=True, timeout=400, env=_env())
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-                        "127.0.0.1", "--master-port", _free_port(), worker, b], capture_output=True, text=True, timeout=400,
-                       env=_env())
+                        "127.0.0.1", "--master-port", _free_port(), worker, b, str(batch)], capture_output=True, text=True,
+                       timeout=400, env=_env())
     assert r.returncode == 0, r.stderr[-3000:]
     s, d = np.load(a), np.load(b)
     assert set(s.files) == set(d.files)
