@@ -376,7 +376,7 @@ def config2_infonce_loop(dev, batch):
 
 def reference_size_set_transformer(dev, steps=30, warmup=5):
     """The notebook's own configuration (...set_transformer.ipynb:304-307, 419-431): 32 neighbourhoods x 50 particles x 12
-    features, 6 attention blocks - ~190 launches of <= 40 us per step, bound by launch / dependency latency.  Eager launches
+    features, 6 attention blocks - ~90 launches per step (190 before round 5), bound by launch / dependency latency.  Eager launches
     vs one hipGraph replay per step (SetTransformerDIB(use_graphs=True), the DIB_ENABLE_GRAPHS opt-in)."""
     from dib_amd import SetTransformerDIB
     rng = np.random.default_rng(6)
@@ -389,18 +389,22 @@ def reference_size_set_transformer(dev, steps=30, warmup=5):
         for _ in range(warmup):
             st.train_step(xs, ys)
         torch.cuda.synchronize()
+        l0 = int(st.lib.dib_launch_count())
         t0 = time.perf_counter()
         for _ in range(steps):
             st.train_step(xs, ys)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        launches = (int(st.lib.dib_launch_count()) - l0) / steps   # (a graph replay issues none from the host)
         D, H, K, P, nfeat = st.bottleneck_dimension, st.number_heads_per_mha, st.key_dim, 50, 12
         per_blk = 3 * 2 * D * H * K * P + 4 * H * K * P * P + 2 * H * K * D * P + 2 * (D * 128 + 128 * D) * P
         fwd = 2 * (nfeat * 5 * 128 + 128 * 128 + 128 * 64) * P + st.number_attention_blocks * per_blk   # per neighbourhood
         tf = 3 * fwd * 32 / dt / 1e12
         out[key] = {"ms_per_step": round(1e3 * dt, 3), "neighbourhoods_per_s": round(32 / dt, 1),
-                    "algorithmic_TFLOPs": round(tf, 2), "step_roofline_frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+                    "algorithmic_TFLOPs": round(tf, 2), "step_roofline_frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                    "library_launches_per_step": round(launches, 1)}
         out["attention"] = "single-workgroup kernels for P <= 64 (csrc/dib_attn_small.h)"
+        out["token_chain"] = "one launch per attention block and direction for the token-wise half (csrc/dib_st_chain.h)"
         del st
     return out
 

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libdib_hip.so")
 LIB_OVERRIDE = os.environ.get("DIB_LIB_PATH") or None
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include", "dib_hip.h")
 INCLUDE_ST = os.path.join(os.path.dirname(_HERE), "include", "dib_st.h")
-SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_tail.h", "dib_small.h", "dib_st.h", "dib_attn.h", "dib_attn_small.h", "dib_infonce_mfma.h",
+SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "dib_fused.h", "dib_tail.h", "dib_small.h", "dib_st_chain.h", "dib_st.h", "dib_attn.h", "dib_attn_small.h", "dib_infonce_mfma.h",
            INCLUDE_ST]
 
 # error codes (include/dib_hip.h)
@@ -166,6 +166,12 @@ SIGNATURES_ST = {
                                       c_void_p]),
     "dib_add_layernorm_bwd_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                             c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_st_chain_supported": (c_int, [c_void_p, c_int64]),
+    "dib_st_chain_workspace_bytes": (c_int64, [c_int64, c_int]),
+    "dib_st_chain_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
+    "dib_st_chain_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_mean_pool_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_mean_pool_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_add_inplace": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -19,6 +19,7 @@
 #include "dib_st.h"
 #include "dib_attn.h"
 #include "dib_attn_small.h"
+#include "dib_st_chain.h"
 #include "../../include/dib_st.h"
 
 // every kernel launch of the library goes through this macro: dib_launch_count() reports how many a step issues (bench.py)
@@ -1803,6 +1804,75 @@ int dib_add_layernorm_bwd_fused(const float* dy, const float* dy2, const float* 
 int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t T, int D,
                           float* ds, float* dgamma_dbeta, void* ws, dib_stream_t stream) {
   return dib_add_layernorm_bwd_fused(dy, nullptr, xhat, rstd, gamma, T, D, ds, nullptr, 0, nullptr, dgamma_dbeta, ws, stream);
+}
+
+// ---- the token-wise half of a set-transformer block in one launch per direction (csrc/dib_st_chain.h) ----------------
+static_assert(sizeof(dib_st_block_desc) == sizeof(DibStChainDesc), "public block descriptor must mirror the kernel's");
+static size_t st_chain_fwd_lds(const dib_st_block_desc* d) {
+  size_t fl = (size_t)DIB_SMALL_ROWS * (dib_small_pitch(d->HK) + 2 * dib_small_pitch(d->D)) + DIB_SMALL_XCH_FLOATS;
+  for (int l = 0; l < d->n_ff; ++l) fl += (size_t)DIB_SMALL_ROWS * dib_small_pitch(d->ff_width[l]);
+  return fl * sizeof(float);
+}
+static size_t st_chain_bwd_lds(const dib_st_block_desc* d) {
+  size_t fl = (size_t)DIB_SMALL_ROWS * (4 * dib_small_pitch(d->D) + 2 * d->D) + DIB_SMALL_XCH_FLOATS;
+  for (int l = 0; l < d->n_ff; ++l) fl += 2 * (size_t)DIB_SMALL_ROWS * dib_small_pitch(d->ff_width[l]);
+  return fl * sizeof(float);
+}
+
+int dib_st_chain_supported(const dib_st_block_desc* d, int64_t T) {
+  if (!d || T <= 0 || !knobs().small_batch) return 0;
+  if (d->D <= 0 || d->D % 32 || d->D > 256 || d->HK <= 0 || d->HK % 16 || d->n_ff < 1 || d->n_ff > DIB_ST_CHAIN_MAX_FF) return 0;
+  if (d->act < 0 || d->act > 2) return 0;
+  for (int l = 0; l < d->n_ff; ++l)
+    if (d->ff_width[l] <= 0 || d->ff_width[l] % 16 || d->ff_width[l] > 1024) return 0;
+  if (d->ff_width[d->n_ff - 1] != d->D) return 0;
+  if (T > 4096) return 0;   // above: one tiled GEMM per layer reads each weight once per 64-128 rows instead of once per 16
+  return st_chain_fwd_lds(d) <= 150 * 1024 && st_chain_bwd_lds(d) <= 150 * 1024;
+}
+
+int64_t dib_st_chain_workspace_bytes(int64_t T, int D) {
+  if (T <= 0 || D <= 0) return DIB_E_ARG;
+  return ((T + DIB_SMALL_ROWS - 1) / DIB_SMALL_ROWS * 4 * D + 64) * (int64_t)sizeof(float);
+}
+
+int dib_st_chain_fwd(const dib_st_block_desc* d, int64_t T, const float* params, const float* ctx, const float* x_in, float* h,
+                     float* xhat1, float* rstd1, float* const* ff, float* x_out, float* xhat2, float* rstd2, dib_stream_t stream) {
+  if (!d || !params || !ctx || !x_in || !h || !xhat1 || !rstd1 || !ff || !x_out || !xhat2 || !rstd2) return DIB_E_ARG;
+  if (!dib_st_chain_supported(d, T)) return DIB_E_UNSUPPORTED;
+  DibStChainFwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  std::memcpy(&a.d, d, sizeof(a.d));
+  a.T = T; a.params = params; a.ctx = ctx; a.x_in = x_in; a.h = h; a.xhat1 = xhat1; a.rstd1 = rstd1;
+  for (int l = 0; l < d->n_ff; ++l) { if (!ff[l]) return DIB_E_ARG; a.ff[l] = ff[l]; }
+  a.x_out = x_out; a.xhat2 = xhat2; a.rstd2 = rstd2;
+  const size_t lds = st_chain_fwd_lds(d);
+  static int lds_have[64] = {};
+  if (int rc = ensure_dynamic_lds((const void*)dib_st_chain_fwd_kernel, lds, lds_have)) return rc;
+  DIB_LAUNCH(dib_st_chain_fwd_kernel, dim3((unsigned)((T + DIB_SMALL_ROWS - 1) / DIB_SMALL_ROWS)), dim3(DIB_SMALL_THREADS), lds,
+             (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int dib_st_chain_bwd(const dib_st_block_desc* d, int64_t T, const float* params, const float* g_out, const float* xhat2,
+                     const float* rstd2, const float* const* ff, const float* xhat1, const float* rstd1, float* const* g_ff,
+                     float* g_in, float* g_ctx, float* grads, void* ws, dib_stream_t stream) {
+  if (!d || !params || !g_out || !xhat2 || !rstd2 || !ff || !xhat1 || !rstd1 || !g_ff || !g_in || !g_ctx || !grads || !ws)
+    return DIB_E_ARG;
+  if (!dib_st_chain_supported(d, T)) return DIB_E_UNSUPPORTED;
+  DibStChainBwdArgs a;
+  std::memset(&a, 0, sizeof(a));
+  std::memcpy(&a.d, d, sizeof(a.d));
+  a.T = T; a.params = params; a.g_out = g_out; a.xhat2 = xhat2; a.rstd2 = rstd2; a.xhat1 = xhat1; a.rstd1 = rstd1;
+  for (int l = 0; l < d->n_ff; ++l) { if (!ff[l] || !g_ff[l]) return DIB_E_ARG; a.ff[l] = ff[l]; a.g_ff[l] = g_ff[l]; }
+  a.g_in = g_in; a.g_ctx = g_ctx; a.grads = grads;
+  const long long tiles = (T + DIB_SMALL_ROWS - 1) / DIB_SMALL_ROWS;
+  a.ln_partial = (float*)ws;
+  a.sync = (unsigned*)((float*)ws + tiles * 4 * d->D);   // zero at first use (the caller zero-fills the workspace once)
+  const size_t lds = st_chain_bwd_lds(d);
+  static int lds_have[64] = {};
+  if (int rc = ensure_dynamic_lds((const void*)dib_st_chain_bwd_kernel, lds, lds_have)) return rc;
+  DIB_LAUNCH(dib_st_chain_bwd_kernel, dim3((unsigned)tiles), dim3(DIB_SMALL_THREADS), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
 }
 
 int dib_mean_pool_fwd(const float* x, int B, int P, int D, float* out, dib_stream_t stream) {

@@ -104,12 +104,23 @@ __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K
                                                  const float* __restrict__ bias, float slope, float* out, int pout,
                                                  float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wc = wave & 3, kh = wave >> 2;   // column slot, contraction half
   const int j = lane & 15, q = lane >> 4;
   constexpr int CG = 16 * NT;
-  constexpr int UB = NT == 4 ? 8 : 16;   // k-steps (of 4) per batch; batches alternate between the two waves of a pair
+  // k-steps (of 4) per batch = weight loads a wave has in flight (32 k-steps for single-tile groups: with one
+  // tile per group a batch of 16 steps is 0.25 us of MFMAs against a 1.3 us round trip - the set transformer's 1536 -> 32
+  // output projection ran 12 exposed round trips per wave); batches alternate between the two waves of a pair
+  constexpr int UB = NT == 4 ? 8 : (NT == 2 ? 16 : 32);
   const int ngroups = N / CG;
-  for (int g0 = 0; g0 < ngroups; g0 += 4) {   // block-uniform trip count: the barriers below are reached by every wave
+  // 8 waves = nslots column slots x kways shares of the contraction (batches interleaved between the shares).  A one-batch
+  // contraction has nothing to split; few column groups give their idle slots to the contraction (the set transformer's
+  // 1536 -> 32 output projection: 2 groups x 4 shares instead of 2 x 2 with 4 waves idle)
+  const int nb_all = (K + 4 * UB - 1) / (4 * UB);
+  // (same-box A/B against "always 4 x 2": set-transformer step 1.93 -> 1.87 ms, profiles/r05n_row_tile_variants_ab.txt)
+  const int kways = nb_all <= 1 ? 1 : (ngroups >= 4 ? 2 : (ngroups >= 2 || NT > 2 ? 4 : 8));
+  const bool ksplit = kways > 1;
+  const int nslots = 8 / kways;
+  const int wc = wave % nslots, kh = wave / nslots;   // column slot, contraction share
+  for (int g0 = 0; g0 < ngroups; g0 += nslots) {   // block-uniform trip count: the barriers below are reached by every wave
     const bool active = g0 + wc < ngroups;
     const int n0 = (active ? g0 + wc : 0) * CG;
     dib_f32x4 acc[NT];
@@ -121,47 +132,58 @@ __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K
     if (active) {
       const float* ap = in + j * pin;
       const float* wp = W + n0 + NT * j;
-      float acur[UB], bcur[UB][NT];
-      auto load = [&](int s0, float (&av)[UB], float (&bv)[UB][NT]) {
+      // the weights are double-buffered in registers; the A operand (LDS, ~100 cycles) is too for NT >= 2 - with one tile per
+      // group (NT == 1, 32-step batches) it is read when its batch is computed: the registers go to the weights in flight
+      constexpr bool kBufA = NT >= 2;
+      constexpr int UA = kBufA ? UB : 1;
+      float acur[UA], bcur[UB][NT];
+      auto load = [&](int s0, float (&av)[UA], float (&bv)[UB][NT]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           const int k = s0 + 4 * u + q;
           const bool ok = k < kvalid;
           const int kc = ok ? k : 0;
-          av[u] = ok ? ap[kc] : 0.f;
+          if constexpr (kBufA) av[u] = ok ? ap[kc] : 0.f;
           dib_small_loadw<NT>(wp + (long long)kc * N, bv[u]);
         }
       };
       load(4 * UB * kh, acur, bcur);
-      for (int s0 = 4 * UB * kh; s0 < K; s0 += 8 * UB) {
-        float anxt[UB], bnxt[UB][NT];
-        load(s0 + 8 * UB, anxt, bnxt);   // past the end: masked (k >= kvalid), harmless re-read of row 0
+      for (int s0 = 4 * UB * kh; s0 < K; s0 += 4 * UB * kways) {
+        float anxt[UA], bnxt[UB][NT];
+        load(s0 + 4 * UB * kways, anxt, bnxt);   // past the end: masked (k >= kvalid), harmless re-read of row 0
 #pragma unroll
         for (int u = 0; u < UB; ++u)
           if (s0 + 4 * u < K) {   // wave-uniform: the ragged last batch skips its empty k-steps
+            float av;
+            if constexpr (kBufA) av = acur[u];
+            else { const int k = s0 + 4 * u + q; av = k < kvalid ? ap[k] : 0.f; }
 #pragma unroll
-            for (int c = 0; c < NT; ++c) acc[c] = DIB_MFMA16(acur[u], bcur[u][c], acc[c]);
+            for (int c = 0; c < NT; ++c) acc[c] = DIB_MFMA16(av, bcur[u][c], acc[c]);
           }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-          acur[u] = anxt[u];
+          if constexpr (kBufA) acur[u] = anxt[u];
 #pragma unroll
           for (int c = 0; c < NT; ++c) bcur[u][c] = bnxt[u][c];
         }
       }
     }
-    // the upper half hands its partial sums to its partner, which finishes the tile (fixed order: lower + upper)
-    if (kh == 1 && active) {
+    // shares 1 .. kways - 1 hand their partial sums to share 0, which finishes the tile (fixed order: share 0 + 1 + 2 + ...);
+    // exchange slot (kh - 1) * nslots + wc: at most 7 x NT <= 20 entries (kways == 8 only with NT <= 2)
+    if (kh >= 1 && active) {
 #pragma unroll
       for (int c = 0; c < NT; ++c)
-        *reinterpret_cast<float4*>(xch + ((wc * 5 + c) * 64 + lane) * 4) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+        *reinterpret_cast<float4*>(xch + ((((kh - 1) * nslots + wc) * NT + c) * 64 + lane) * 4) =
+            make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
     }
     __syncthreads();
     if (kh == 0 && active) {
+      for (int p = 1; p < kways; ++p) {
 #pragma unroll
-      for (int c = 0; c < NT; ++c) {
-        const float4 o = *reinterpret_cast<const float4*>(xch + ((wc * 5 + c) * 64 + lane) * 4);
-        acc[c][0] += o.x; acc[c][1] += o.y; acc[c][2] += o.z; acc[c][3] += o.w;
+        for (int c = 0; c < NT; ++c) {
+          const float4 o = *reinterpret_cast<const float4*>(xch + ((((p - 1) * nslots + wc) * NT + c) * 64 + lane) * 4);
+          acc[c][0] += o.x; acc[c][1] += o.y; acc[c][2] += o.z; acc[c][3] += o.w;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -197,12 +219,14 @@ __device__ __forceinline__ void dib_small_bwd_nt(const float* g, int pg, int N, 
                                                  const float* h, int ph, float slope, float* gin, int pgi,
                                                  float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wc = wave & 3, kh = wave >> 2;
   const int j = lane & 15, q = lane >> 4;
   constexpr int CG = 16 * NT;
   constexpr int UB = NT >= 4 ? 2 : 4;   // S-steps (of 16 contraction indices) per batch
   const int ngroups = Kin / CG;
-  for (int g0 = 0; g0 < ngroups; g0 += 4) {
+  const bool ksplit = N > 16 * UB;   // a one-batch contraction is not split: 8 column slots instead of 4 x 2
+  const int nslots = ksplit ? 4 : 8;
+  const int wc = ksplit ? (wave & 3) : wave, kh = ksplit ? (wave >> 2) : 0;
+  for (int g0 = 0; g0 < ngroups; g0 += nslots) {
     const bool active = g0 + wc < ngroups;
     const int k0 = (active ? g0 + wc : 0) * CG;
     dib_f32x4 acc[NT];
@@ -254,10 +278,12 @@ __device__ __forceinline__ void dib_small_bwd_nt(const float* g, int pg, int N, 
     }
     __syncthreads();
     if (kh == 0 && active) {
+      if (ksplit) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float4 o = *reinterpret_cast<const float4*>(xch + ((wc * 5 + t) * 64 + lane) * 4);
-        acc[t][0] += o.x; acc[t][1] += o.y; acc[t][2] += o.z; acc[t][3] += o.w;
+        for (int t = 0; t < NT; ++t) {
+          const float4 o = *reinterpret_cast<const float4*>(xch + ((wc * 5 + t) * 64 + lane) * 4);
+          acc[t][0] += o.x; acc[t][1] += o.y; acc[t][2] += o.z; acc[t][3] += o.w;
+        }
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -289,6 +315,9 @@ __device__ __forceinline__ void dib_small_bwd(const float* g, int pg, int N, con
 // global [rows_valid][width] (leading dimension ld) -> LDS tile [16][pitch]; rows >= rows_valid are zero-filled
 __device__ __forceinline__ void dib_small_load_tile(const float* __restrict__ src, long long ld, int width, int rows_valid,
                                                     float* dst, int pitch) {
+  // (a variant with each thread owning a float4 column of all 16 rows - 16 loads in flight - measured 1.5 % SLOWER on the
+  // set-transformer step in a same-box A/B, profiles/r05n_row_tile_variants_ab.txt: the flat loop below already overlaps its
+  // loads across the 8 waves)
   const int w4 = width >> 2;
   for (int i = threadIdx.x; i < DIB_SMALL_ROWS * w4; i += DIB_SMALL_THREADS) {
     const int row = i / w4, c = (i - row * w4) * 4;

@@ -34,6 +34,17 @@ from ._gemm_plan import DESC, _Gemm, _SkinnyKGemm, _d, _ptr, _ptr8
 from ._lib import check
 
 ACT_NONE, ACT_RELU, ACT_LEAKY01 = 0, 1, _lib.ACT_LEAKY_RELU_01
+
+
+class _BlockDesc(ctypes.Structure):
+    """include/dib_st.h dib_st_block_desc: element offsets of one attention block's token-wise chain in the flat parameter buffer"""
+    _fields_ = [("o_w", ctypes.c_int64), ("o_b", ctypes.c_int64), ("ln1_g", ctypes.c_int64), ("ln1_b", ctypes.c_int64),
+                ("ln2_g", ctypes.c_int64), ("ln2_b", ctypes.c_int64), ("ff_w", ctypes.c_int64 * 3), ("ff_b", ctypes.c_int64 * 3),
+                ("n_ff", ctypes.c_int32), ("ff_width", ctypes.c_int32 * 3), ("D", ctypes.c_int32), ("HK", ctypes.c_int32),
+                ("eps", ctypes.c_float), ("act", ctypes.c_int32)]
+
+
+assert ctypes.sizeof(_BlockDesc) == 128
 LOSS_BCE_LOGITS = 0
 # Test switch: take train_step's collective branch even on a ONE-rank process group, so that the RCCL calls themselves run
 # on the single GPU the test box has (tests/_dp_gpu_st_worker.py).  A 1-rank sum all-reduce is the identity.
@@ -328,6 +339,23 @@ class SetTransformerDIB:
         ln_ws = int(self.lib.dib_add_layernorm_bwd_workspace_bytes(T, D)) // 4
         take("ln_ws", ln_ws)
         take("kl_ws", int(self.lib.dib_token_kl_workspace_bytes(T, D)) // 4 + 4)
+        # the token-wise half of every block as one launch per direction (csrc/dib_st_chain.h) for up to 4096 tokens
+        chain_descs = []
+        if getattr(self, "use_chain", True) and len(ff) <= 3:
+            for b in range(self.number_attention_blocks):
+                pre = f"blk{b}_"
+                dsc = _BlockDesc()
+                dsc.o_w, dsc.o_b = self.offsets[pre + "o_w"], self.offsets[pre + "o_b"]
+                dsc.ln1_g, dsc.ln1_b = self.offsets[pre + "ln1_g"], self.offsets[pre + "ln1_b"]
+                dsc.ln2_g, dsc.ln2_b = self.offsets[pre + "ln2_g"], self.offsets[pre + "ln2_b"]
+                for l, u in enumerate(ff):
+                    dsc.ff_w[l], dsc.ff_b[l], dsc.ff_width[l] = self.offsets[pre + f"ff{l}_w"], self.offsets[pre + f"ff{l}_b"], u
+                dsc.n_ff, dsc.D, dsc.HK, dsc.eps, dsc.act = len(ff), D, HK, self.layer_norm_epsilon, ACT_RELU
+                chain_descs.append(dsc)
+            if not (chain_descs and all(self.lib.dib_st_chain_supported(ctypes.byref(dsc), T) for dsc in chain_descs)):
+                chain_descs = []
+        if chain_descs:
+            take("chain_ws", int(self.lib.dib_st_chain_workspace_bytes(T, D)) // 4)
         take("loss_ws", int(self.lib.dib_loss_rows_workspace_bytes(B)) // 4 + 4)
         ws = torch.zeros(o, dtype=torch.float32, device=self.device)
         # flash attention, stash mode: one score-tile buffer per block, outside the fp32-indexed workspace (its own allocation:
@@ -441,9 +469,24 @@ class SetTransformerDIB:
                 g[f"b{b}_dk"] = _Gemm(2, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_q"] + bi * P * HK + hi * K, HK,
                                            off["g_k"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
                                     nsplit=1, rows_per_split=max(P, 1))
-            g[f"b{b}_qkv_wgrad"] = _Gemm(2, [_d(off[xin], D, off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, D, HK, T,
-                                                bias_off=po[pre + nm + "_b"]) for nm in "qkv"], ws, ws, gt, bias_out=gt,
+            qkv_wgrad_descs = [_d(off[xin], D, off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, D, HK, T, bias_off=po[pre + nm + "_b"])
+                               for nm in "qkv"]
+            g[f"b{b}_qkv_wgrad"] = _Gemm(2, qkv_wgrad_descs, ws, ws, gt, bias_out=gt,
                                          nsplit=nsplit, rows_per_split=rps, split_stride=self.n_alloc)
+            if chain_descs:
+                # the feed-forward layers' weight gradients in one grouped launch (dy = the chain backward's g_ff); the output
+                # projection's (dy = the gradient of LN1's addends = the block-input gradient buffer BEFORE the projections' dgrads
+                # are added) and q / k / v's keep their own launches
+                descs = []
+                for l in range(nff):
+                    kin_l, src_l = (D, f"b{b}_h") if l == 0 else (ff[l - 1], f"b{b}_ff{l - 1}")
+                    dy_l = "g_z" if l == nff - 1 else f"g_ff{l}"
+                    descs.append(_d(off[src_l], kin_l, off[dy_l], ff[l], po[pre + f"ff{l}_w"], ff[l], kin_l, ff[l], T,
+                                    bias_off=po[pre + f"ff{l}_b"]))
+                # (one launch for ALL of them was tried: a grouped launch's grid is max-shape tiles x groups, and [1536, 32] next to
+                # [32, 1536] made it 21 600 mostly empty workgroups - 48 us; the feed-forward layers share a shape class)
+                g[f"b{b}_ff_wgrad"] = _Gemm(2, descs, ws, ws, gt, bias_out=gt, nsplit=nsplit, rows_per_split=rps,
+                                            split_stride=self.n_alloc)
             if ksplit > 1:   # 3 projections x ksplit chunks -> 3 * ksplit slabs, summed straight into g_xq (= g_xq + g_xk + g_xv)
                 ck = HK // ksplit
                 g[f"b{b}_qkv_dgrad"] = _SplitKGemm(
@@ -479,7 +522,8 @@ class SetTransformerDIB:
         for gg in g.values():
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
-                    enc_units=enc_units, stash=stash, stash_block_bytes=stash_block_bytes, stash_denied=None, ksplit=ksplit)
+                    enc_units=enc_units, stash=stash, stash_block_bytes=stash_block_bytes, stash_denied=None, ksplit=ksplit,
+                    chain=chain_descs)
         # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
         # (training batch, validation batch, a ragged tail), evict least recently used beyond that
         step_keys = [k for k in self._plans if k[0] != "enc" and k not in self._graphs]   # a captured graph pins its plan
@@ -583,6 +627,13 @@ class SetTransformerDIB:
                 check(lib.dib_attention_fwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]), B, P, H,
                                             self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
                                             _ptr(pl["stash"][b]) if use_stash else c_void_p(0), st), "dib_attention_fwd")
+            if pl["chain"]:   # output projection -> Add + LN -> feed-forward -> Add + LN: one launch (16-token tiles)
+                ffp = (c_void_p * 3)(*[_ptr(ws, off[f"b{b}_ff{l}"]) for l in range(len(self.ff_arch_per_block))])
+                check(lib.dib_st_chain_fwd(ctypes.byref(pl["chain"][b]), T, _ptr(self.params), _ptr(ws, off[f"b{b}_ctx"]),
+                                           _ptr(ws, off[xin]), _ptr(ws, off[f"b{b}_h"]), _ptr(ws, off[f"b{b}_xhat1"]),
+                                           _ptr(ws, off[f"b{b}_rstd1"]), ffp, _ptr(ws, off[f"b{b}_x"]), _ptr(ws, off[f"b{b}_xhat2"]),
+                                           _ptr(ws, off[f"b{b}_rstd2"]), st), "dib_st_chain_fwd")
+                continue
             g[f"b{b}_o_fwd"].run(lib, st)
             ks = pl["ksplit"]   # split-K output projection: its slabs are the second addend
             check(lib.dib_add_layernorm_fwd(_ptr(ws, off[xin]), _ptr(ws, off["ksplit_ws"] if ks > 1 else off[f"b{b}_mha"]),
@@ -636,6 +687,24 @@ class SetTransformerDIB:
         for b in range(self.number_attention_blocks - 1, -1, -1):
             pre = f"blk{b}_"
             gin, gout = self._block_grad_names(b)
+            if pl["chain"]:
+                # LN2 backward -> feed-forward dgrads -> LN1 backward -> output-projection dgrad in one launch; then the attention
+                # backward, ONE grouped launch for the block's weight gradients, and the projections' dgrads (added to gout)
+                ffp = (c_void_p * 3)(*[_ptr(ws, off[f"b{b}_ff{l}"]) for l in range(nff)])
+                gfp = (c_void_p * 3)(*[_ptr(ws, off["g_z" if l == nff - 1 else f"g_ff{l}"]) for l in range(nff)])
+                check(lib.dib_st_chain_bwd(ctypes.byref(pl["chain"][b]), T, _ptr(self.params), _ptr(ws, off[gin]),
+                                           _ptr(ws, off[f"b{b}_xhat2"]), _ptr(ws, off[f"b{b}_rstd2"]), ffp,
+                                           _ptr(ws, off[f"b{b}_xhat1"]), _ptr(ws, off[f"b{b}_rstd1"]), gfp, _ptr(ws, off[gout]),
+                                           _ptr(ws, off["g_ctx"]), _ptr(gt), _ptr(ws, off["chain_ws"]), st), "dib_st_chain_bwd")
+                g[f"b{b}_ff_wgrad"].run(lib, st)
+                g[f"b{b}_o_wgrad"].run(lib, st)
+                self._attention_backward(pl, b, B, P, H, scale)
+                g[f"b{b}_qkv_wgrad"].run(lib, st)
+                g[f"b{b}_qkv_dgrad"].run(lib, st)
+                if pl["ksplit"] == 1:
+                    for nm in "qkv":
+                        check(lib.dib_add_inplace(_ptr(ws, off[gout]), _ptr(ws, off[f"g_x{nm}"]), T * D, st), "dib_add_inplace")
+                continue
             # x_out = LN2(h + ff): gin -> g_a (gradient of both addends) and, in the same pass, g_z = g_a * relu'(ff output)
             # (the feed-forward branch's pre-activation gradient), d(gamma2, beta2)
             check(lib.dib_add_layernorm_bwd_fused(_ptr(ws, off[gin]), c_void_p(0), _ptr(ws, off[f"b{b}_xhat2"]),
@@ -655,20 +724,7 @@ class SetTransformerDIB:
             # multi-head attention
             g[f"b{b}_o_wgrad"].run(lib, st)
             g[f"b{b}_o_dgrad"].run(lib, st)
-            if pl["impl"] == "gemm":
-                g[f"b{b}_dv"].run(lib, st)
-                g[f"b{b}_dp"].run(lib, st)
-                check(lib.dib_softmax_rows_bwd(_ptr(ws, off[f"b{b}_S"]), _ptr(ws, off["g_S"]), B * H * P, P, pl["ldS"], scale, st),
-                      "dib_softmax_rows_bwd")
-                g[f"b{b}_dq"].run(lib, st)
-                g[f"b{b}_dk"].run(lib, st)
-            else:
-                HK = H * self.key_dim
-                check(lib.dib_attention_bwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
-                                            _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
-                                            _ptr(pl["stash"][b]) if self.last.get("stash") else c_void_p(0),   # as the forward ran
-                                            B, P, H, self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
-                                            _ptr(ws, off["attn_delta"]), st), "dib_attention_bwd")
+            self._attention_backward(pl, b, B, P, H, scale)
             g[f"b{b}_qkv_wgrad"].run(lib, st)
             g[f"b{b}_qkv_dgrad"].run(lib, st)
             # gradient w.r.t. the block's input = residual (already in gout) + the three projection inputs
@@ -694,6 +750,24 @@ class SetTransformerDIB:
         out3 = self._view(pl, "out3", 3)
         self.last["bce"] = out3[0:1] * inv
         self.last["correct"] = out3[1:2]
+
+    def _attention_backward(self, pl, b: int, B: int, P: int, H: int, scale: float) -> None:
+        """g_ctx -> g_q, g_k, g_v of block b (flash kernels, or the grouped-GEMM products with the stashed probabilities)"""
+        lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
+        if pl["impl"] == "gemm":
+            g[f"b{b}_dv"].run(lib, st)
+            g[f"b{b}_dp"].run(lib, st)
+            check(lib.dib_softmax_rows_bwd(_ptr(ws, off[f"b{b}_S"]), _ptr(ws, off["g_S"]), B * H * P, P, pl["ldS"], scale, st),
+                  "dib_softmax_rows_bwd")
+            g[f"b{b}_dq"].run(lib, st)
+            g[f"b{b}_dk"].run(lib, st)
+        else:
+            HK = H * self.key_dim
+            check(lib.dib_attention_bwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
+                                        _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
+                                        _ptr(pl["stash"][b]) if self.last.get("stash") else c_void_p(0),   # as the forward ran
+                                        B, P, H, self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
+                                        _ptr(ws, off["attn_delta"]), st), "dib_attention_bwd")
 
     def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7, fused_reduce: bool = False) -> None:
         if fused_reduce and self.n_alloc % 4 == 0:   # slab reduce + Keras-Adam + step-count bump in one launch

@@ -1098,3 +1098,38 @@ def test_small_batch_row_tile_kernels_equal_the_large_batch_path(arch, linear, B
                 bad[k] = ("norm", rel)
     assert not bad, bad
     assert torch.isfinite(s["grads"]).all()
+
+
+@pytest.mark.parametrize("B", [128, 2048 + 77, 16384])
+def test_workspace_needs_only_dib_workspace_init(B):
+    """include/dib_hip.h workspace contract: whatever a workspace held before, dib_workspace_init makes it usable - it zeroes
+    exactly the regions whose unwritten parts are read (split-batch gradient slabs beyond a launch's chosen split count, the
+    per-step scalars, the tail's arrival counters) and writes the merged weight-gradient table.  A step on a workspace that
+    was filled with NaN and re-initialised must reproduce the step on the fresh one bit for bit (a stale slab, a stale counter
+    or a missing table entry would show as a NaN or a different sum)."""
+    from dib_amd._lib import check
+    spec = orc.DIBSpec([1] * 50, [128, 128], [256, 256], 1, feature_embedding_dimension=32)   # F = 50: ragged split choices
+    eng, _ = _engine(spec, 2)
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, 50)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32)
+    xd, yd = eng.to_device(x), eng.to_device(y)
+    eng.set_beta(0.02)
+    p0 = eng.params.clone()
+    outs = []
+    for poison in (False, True):
+        eng.params.copy_(p0)
+        eng.reset_optimizer()
+        eng.metrics_acc.zero_()
+        ws = eng.workspace(B)
+        if poison:
+            ws.fill_(float("nan"))
+            check(eng.lib.dib_workspace_init(eng.layout, B, _ptr(ws), eng._stream()), "dib_workspace_init")
+        for step in range(2):
+            eng.train_step(xd, yd, None, 0, B, 3, step, "bce_logits", optimizer=("adam", 0.9, 0.999, 1e-7))
+        eng.eval_step(xd, yd, None, 0, B, 3, 50, "bce_logits")
+        torch.cuda.synchronize()
+        outs.append((eng.grads.clone(), eng.params.clone(), eng.metrics_acc.clone(), eng.step_out(B).clone()))
+    for a, b in zip(*outs):
+        assert torch.isfinite(b).all()
+        assert torch.equal(a, b)

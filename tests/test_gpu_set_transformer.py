@@ -507,3 +507,36 @@ def test_score_stash_is_allocated_lazily_and_capped_across_plans():
     torch.cuda.synchronize()
     for k, v in m.get_grads().items():
         assert np.array_equal(v, ga[k]), k
+
+
+@pytest.mark.parametrize("B,P", [(32, 50), (3, 21), (1, 1), (2, 200)])
+def test_token_chain_kernels_equal_the_layer_by_layer_path(B, P):
+    """csrc/dib_st_chain.h (output projection -> Add+LN -> feed-forward -> Add+LN, and its backward, as one launch per
+    direction; one grouped launch for a block's weight gradients) against the layer-by-layer launches on twin models with the
+    notebook's architecture: prediction, KL, every stashed activation the backward needs, every gradient block - to fp32
+    summation-order tolerance (2e-4 of each block's max; a relu unit at a kink may move one token's share)."""
+    spec = sto.SetTransformerSpec()
+    rng = np.random.default_rng(B * 100 + P)
+    x = rng.standard_normal((B, P, spec.particle_feature_dimensions)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32)
+    outs = []
+    for chain in (True, False):
+        m, _ = _model(spec, seed=3)
+        m.use_chain = chain
+        m.beta_dev.fill_(0.01)
+        pred = m.forward(x, step=4).clone()
+        m.loss_and_backward(y)
+        torch.cuda.synchronize()
+        pl = m.last["plan"]
+        assert bool(pl["chain"]) == chain
+        outs.append(dict(pred=pred, kl=m.last["kl"].clone(), grads=m.get_grads(),
+                         x_last=m._view(pl, f"b{spec.number_attention_blocks - 1}_x", B * P, spec.bottleneck_dimension).clone(),
+                         h0=m._view(pl, "b0_h", B * P, spec.bottleneck_dimension).clone()))
+    c, r = outs
+    for k in ("pred", "kl", "x_last", "h0"):
+        assert (c[k] - r[k]).abs().max() <= 2e-5 * (1e-6 + r[k].abs().max()), k
+    gmax = max(np.abs(v).max() for v in r["grads"].values())
+    for name in r["grads"]:
+        ref = r["grads"][name].astype(np.float64)
+        err = np.abs(c["grads"][name].astype(np.float64) - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-7 * gmax, (name, err, np.abs(ref).max())

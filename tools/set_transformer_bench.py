@@ -37,10 +37,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graphs", type=int, default=0, help="1: one hipGraph replay per step (SetTransformerDIB(use_graphs=True))")
+    ap.add_argument("--chain", type=int, default=1, help="0: the layer-by-layer launches instead of the token-chain kernels (A/B)")
     a = ap.parse_args()
     import dib_amd
     m = dib_amd.SetTransformerDIB(particle_feature_dimensions=a.features, attention=os.environ.get("DIB_ST_ATTENTION", "auto"),
                                   use_graphs=bool(a.graphs))
+    m.use_chain = bool(a.chain)
     rng = np.random.default_rng(0)
     x = torch.from_numpy(rng.standard_normal((a.batch, a.particles, a.features)).astype(np.float32)).to(m.device)
     y = torch.from_numpy((rng.random((a.batch, 1)) > 0.5).astype(np.float32)).to(m.device)
