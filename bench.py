@@ -627,6 +627,10 @@ def main():
                          "print it: the command the rocprofv3 passes of profiles/*_config5_* wrap")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=VALUE",
                     help="dib_set_tuning(KEY, VALUE) before any layout is created (include/dib_hip.h lists the keys; A/B runs)")
+    ap.add_argument("--force-dp-extras", action="store_true",
+                    help="run the multi-GPU `extra` measurements (dp_breakdown, other scaling mode) under ONE RCCL rank too "
+                         "(python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --force-dp-extras): exercises the code "
+                         "path the driver's SCALE run takes")
     ap.add_argument("--dry-run-backend", default=None, help=argparse.SUPPRESS)  # CPU test of the launcher path (gloo)
     args = ap.parse_args()
 
@@ -730,7 +734,7 @@ def main():
         if "roofline" not in out:
             out["roofline"] = dict(out["step_roofline"], traffic=None)
     extra = {}
-    if not args.no_extra and world > 1:
+    if not args.no_extra and (world > 1 or (args.force_dp_extras and dist is not None)):
         deadline = _ExtrasDeadline(args.extra_timeout, rank, out, extra)
         deadline.start()
         try:  # exposed communication of the headline configuration
