@@ -423,16 +423,30 @@ def keras_path_default_batch(dev, epochs=200):
     m.fit(d["x_train"], d["y_train"], epochs=3, **kw)
     torch.cuda.synchronize()
     lib = m._engine.lib
-    l0 = int(lib.dib_launch_count())
-    t0 = time.perf_counter()
-    m.fit(d["x_train"], d["y_train"], epochs=epochs, **kw)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / epochs / 8          # per (training step + validation step) pair
-    launches = (int(lib.dib_launch_count()) - l0) / epochs / 8
+
+    def timed():
+        l0 = int(lib.dib_launch_count())
+        t0 = time.perf_counter()
+        m.fit(d["x_train"], d["y_train"], epochs=epochs, **kw)
+        torch.cuda.synchronize()
+        # per (training step + validation step) pair
+        return (time.perf_counter() - t0) / epochs / 8, (int(lib.dib_launch_count()) - l0) / epochs / 8
+
+    dt, launches = timed()
+    # fit evaluates the epoch's 8 validation batches as ONE 1024-row launch set (model.validation_merge_rows: same per-row
+    # numbers, History sums in another order); the same run with them evaluated one by one, for the record
+    merge = m.validation_merge_rows
+    m.validation_merge_rows = 0
+    m.fit(d["x_train"], d["y_train"], epochs=3, **kw)
+    dt1, launches1 = timed()
+    m.validation_merge_rows = merge
     fl = gemm_flops_per_sample(10, 5) * 128                # training step only (the validation forward is ~1/3 more)
     return {"workload": "reference default: Boolean circuit, F = 10, B = 128, 8 train + 8 validation steps per epoch, fit()",
             "us_per_train_plus_validation_step": round(1e6 * dt, 1), "epochs_timed": epochs,
             "library_launches_per_train_plus_validation_step": round(launches, 2),
+            "validation": f"the epoch's 8 validation batches in one launch set of {merge} rows (fit.validation_merge_rows)",
+            "validation_batches_one_by_one": {"us_per_train_plus_validation_step": round(1e6 * dt1, 1),
+                                              "library_launches_per_train_plus_validation_step": round(launches1, 2)},
             "seconds_for_the_reference_11000_epochs": round(dt * 8 * 11000, 1),
             "flops_per_train_step": int(fl), "step_roofline_frac_lower_bound": round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 6)}
 

@@ -129,6 +129,13 @@ SIGNATURES = {
                                     c_void_p]),
     "dib_positional_encoding": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_positional_encoding_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dib_mlp_small_supported": (c_int, [c_void_p, c_int]),
+    "dib_mlp_small_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_mlp_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dib_integration_fwd_and_mlp_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                                c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_backward_and_mlp_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "dib_reduce_adam_step": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "dib_mi_workspace_bytes": (c_int64, [c_int, c_int]),

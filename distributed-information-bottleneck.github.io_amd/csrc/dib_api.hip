@@ -205,6 +205,9 @@ struct Tuning {
   int fused_encoder = 1;     // layouts created from now on may use the fused encoder-bank kernels (0: grouped-GEMM path)
   int fused_head = 1;        // dib_output_head_fused_supported may answer 1
   int small_batch = 1;       // batches <= 1024 rows: row-tile kernels (csrc/dib_small.h) where the layout allows
+  int mlp_row_tiles = 1;     // ... and for a plain MLP (dib_mlp_small_*: the custom loop's output encoder)
+  int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
+  int attn_small_waves = 4;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int num_cus = 256;         // compute units of the device (set from hipDeviceProp by the first dib_layout_upload_tables)
 };
 inline Tuning& tuning() { static Tuning t; return t; }
@@ -545,6 +548,11 @@ static bool use_merged_wgrad(const dib_layout* l, int batch) {
   return use_small_enc(l, batch) && use_small_int(l, batch);
 }
 
+// A second, independent network for the NEXT dib_small_integration_kernel launch of this thread to carry in its grid
+// (dib_integration_fwd_and_mlp_fwd / dib_backward_and_mlp_bwd arm it; whoever armed it launches it alone if nobody took it).
+struct SmallCompanion { DibSmallIntArgs args; size_t lds = 0; bool armed = false; };
+static thread_local SmallCompanion t_companion;
+
 // one launch of dib_small_integration_kernel; `mode` = DIB_SMALL_INT_* bits.  Head arguments may be null / 0 without a head.
 static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params, int mode,
                              int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0, float inv_bg,
@@ -560,6 +568,18 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.pred = w + m.pred; a.g_pred = w + m.g_pred;
   a.loss_kind = loss_kind; a.Y = y; a.ldy = ldy; a.row_idx = (const int*)row_idx; a.row0 = row0; a.inv_bg = inv_bg;
   a.partial_w = w + m.skinny_partial; a.partial_l = w + m.loss_partial;
+  if (t_companion.armed) {
+    t_companion.armed = false;
+    DibSmallIntPair p;
+    p.s[0] = a; p.s[1] = t_companion.args;
+    const size_t lds = std::max((size_t)l->sb_int_lds, t_companion.lds);
+    static int pair_lds_have[64] = {};
+    if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_pair_kernel, lds, pair_lds_have)) return rc;
+    ProfScope ps(kProfOther, st);
+    DIB_LAUNCH(dib_small_integration_pair_kernel, dim3(std::max(small_tiles(batch), small_tiles(p.s[1].batch)), 2),
+               dim3(DIB_SMALL_THREADS), lds, st, p);
+    return (int)hipGetLastError();
+  }
   static int lds_have[64] = {};
   if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_kernel, (size_t)l->sb_int_lds, lds_have)) return rc;
   ProfScope ps(kProfOther, st);
@@ -1400,6 +1420,9 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "fused_encoder")) return &t.fused_encoder;
   if (!std::strcmp(key, "fused_head")) return &t.fused_head;
   if (!std::strcmp(key, "small_batch")) return &t.small_batch;
+  if (!std::strcmp(key, "mlp_row_tiles")) return &t.mlp_row_tiles;
+  if (!std::strcmp(key, "infonce_one_launch")) return &t.infonce_one_launch;
+  if (!std::strcmp(key, "attn_small_waves")) return &t.attn_small_waves;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
   return nullptr;
 }
@@ -1506,6 +1529,22 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
     if (e != hipSuccess) return (int)e;
   }
   ProfScope ps(kProfOther, st);
+  if ((similarity == 0 || similarity == 1 || similarity == 4) && batch <= DIB_INCE1_MAXB && dim <= 64 && knobs().infonce_one_launch) {
+    // the reference's default batch: similarity, log-sum-exps, loss and both gradients in ONE launch (dib_infonce_small_kernel)
+    const bool grads = g_x && g_y;
+    const dim3 grid(grads ? cdiv(batch, 64) : 1, grads ? 2 : 1);
+    const size_t lds = (size_t)DIB_INCE1_LDS_FLOATS * sizeof(float);
+    static int lds_have[3][64] = {};
+#define DIB_INCE_ONE(KD, SLOT)                                                                                                  \
+    do {                                                                                                                        \
+      if (int rc = ensure_dynamic_lds((const void*)dib_infonce_small_kernel<KD>, lds, lds_have[SLOT])) return rc;               \
+      DIB_LAUNCH(dib_infonce_small_kernel<KD>, grid, dim3(DIB_INCE1_THREADS), lds, st, emb_x, emb_y, batch, dim, inv_t, temperature,          \
+                 grads ? g_x : (float*)nullptr, grads ? g_y : (float*)nullptr, loss_out);                                       \
+    } while (0)
+    if (similarity == 0) DIB_INCE_ONE(0, 0); else if (similarity == 1) DIB_INCE_ONE(1, 1); else DIB_INCE_ONE(4, 2);
+#undef DIB_INCE_ONE
+    return (int)hipGetLastError();
+  }
   if (similarity == 0 || similarity == 1 || similarity == 4) {
     // dot-product similarities: S, g_x = C Y, g_y = C^T X as three MFMA products (csrc/dib_infonce_mfma.h)
     const int nb32 = cdiv(batch, 32), t64 = cdiv(batch, 64);
@@ -1581,6 +1620,117 @@ int dib_positional_encoding_rows(const float* x, int64_t ldx, const int32_t* row
   DIB_LAUNCH(dib_posenc_rows_kernel, dim3(grid_for((int64_t)n * d)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx,
                      (const int*)row_idx, n, d, n_blocks, out);
   return (int)hipGetLastError();
+}
+
+// ---- plain MLP on the row-tile kernels (include/dib_hip.h dib_mlp_small_*): dib_small_integration_kernel with its input
+// tile built from the batch's rows of X (DIB_SMALL_INT_POSENC_IN) and the dgrad chain stopped at the first layer ----
+static int64_t mlp_small_lds_floats(const dib_mlp_desc* d) {
+  const int nf = d->n_freq > 1 ? d->n_freq : 1;
+  int64_t fl = (int64_t)DIB_SMALL_ROWS * dib_small_pitch(d->in_dim * nf);
+  for (int i = 0; i < d->n_hidden; ++i) fl += 2ll * DIB_SMALL_ROWS * dib_small_pitch(d->width[i]);
+  return fl + (int64_t)DIB_SMALL_ROWS * dib_small_pitch(d->width[d->n_hidden]) + DIB_SMALL_XCH_FLOATS;
+}
+int dib_mlp_small_supported(const dib_mlp_desc* d, int batch) {
+  if (!d || !knobs().small_batch || !knobs().mlp_row_tiles || batch < 1 || batch > kSmallMaxBatch) return 0;
+  if (d->n_hidden < 1 || d->n_hidden > 3 || d->in_dim < 1 || d->act < 0 || d->act > 2) return 0;
+  const int nf = d->n_freq > 1 ? d->n_freq : 1;
+  if ((int64_t)d->in_dim * nf > 1024) return 0;
+  for (int i = 0; i <= d->n_hidden; ++i)
+    if (d->width[i] < 16 || d->width[i] % 16 != 0 || d->width[i] > 1024) return 0;
+  return mlp_small_lds_floats(d) * 4 <= 150 * 1024 ? 1 : 0;
+}
+static void mlp_small_fill(const dib_mlp_desc* d, DibSmallIntArgs& a, const float* params, int n) {
+  const int nf = d->n_freq > 1 ? d->n_freq : 1;
+  a.batch = n; a.K0 = d->in_dim * nf; a.params = params; a.n_hidden = d->n_hidden;
+  for (int i = 0; i <= d->n_hidden; ++i) { a.width[i] = d->width[i]; a.w_off[i] = d->w_off[i]; a.b_off[i] = d->b_off[i]; }
+  a.act = d->act; a.out_act = 0; a.out_dim = d->width[d->n_hidden];
+  a.in_dim = d->in_dim; a.n_freq = nf;
+}
+static int mlp_small_launch(const dib_mlp_desc* d, const DibSmallIntArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)mlp_small_lds_floats(d) * 4;
+  static int lds_have[64] = {};
+  if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_kernel, lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, st);
+  DIB_LAUNCH(dib_small_integration_kernel, dim3(small_tiles(a.batch)), dim3(DIB_SMALL_THREADS), lds, st, a);
+  return (int)hipGetLastError();
+}
+// argument sets of the two passes (validated); DIB_OK, or the error the stand-alone entry point reports
+static int mlp_small_fwd_args(const dib_mlp_desc* d, const float* params, const float* x, int64_t ldx, const int32_t* row_idx, int n,
+                              float* a0, float* const* h, float* out, DibSmallIntArgs& a) {
+  if (!d || !params || !x || !out || n <= 0) return DIB_E_ARG;
+  if (!dib_mlp_small_supported(d, n)) return DIB_E_UNSUPPORTED;
+  bool stash = a0 != nullptr;
+  for (int i = 0; i < d->n_hidden; ++i) stash = stash && h != nullptr && h[i] != nullptr;
+  if (a0 != nullptr && !stash) return DIB_E_ARG;
+  std::memset(&a, 0, sizeof(a));
+  a.mode = DIB_SMALL_INT_FWD | DIB_SMALL_INT_OUT | DIB_SMALL_INT_POSENC_IN | (stash ? 0 : DIB_SMALL_INT_INFER);
+  a.X = x; a.ldx = ldx; a.row_idx = (const int*)row_idx; a.row0 = 0; a.a0 = a0; a.pred = out;
+  if (stash) for (int i = 0; i < d->n_hidden; ++i) a.h[i] = h[i];
+  mlp_small_fill(d, a, params, n);
+  return DIB_OK;
+}
+static int mlp_small_bwd_args(const dib_mlp_desc* d, const float* params, const float* g_out, float* const* h, float* const* g, int n,
+                              DibSmallIntArgs& a) {
+  if (!d || !params || !g_out || !h || !g || n <= 0) return DIB_E_ARG;
+  if (!dib_mlp_small_supported(d, n)) return DIB_E_UNSUPPORTED;
+  std::memset(&a, 0, sizeof(a));
+  a.mode = DIB_SMALL_INT_LOAD_H | DIB_SMALL_INT_BWD_OUT | DIB_SMALL_INT_BWD | DIB_SMALL_INT_NO_GU;
+  a.g_pred = const_cast<float*>(g_out);
+  for (int i = 0; i < d->n_hidden; ++i) {
+    if (!h[i] || !g[i]) return DIB_E_ARG;
+    a.h[i] = h[i]; a.g[i] = g[i];
+  }
+  mlp_small_fill(d, a, params, n);
+  return DIB_OK;
+}
+int dib_mlp_small_fwd(const dib_mlp_desc* d, const float* params, const float* x, int64_t ldx, const int32_t* row_idx, int n,
+                      float* a0, float* const* h, float* out, dib_stream_t stream) {
+  if (n == 0) return DIB_OK;
+  DibSmallIntArgs a;
+  if (int rc = mlp_small_fwd_args(d, params, x, ldx, row_idx, n, a0, h, out, a)) return rc;
+  return mlp_small_launch(d, a, (hipStream_t)stream);
+}
+int dib_mlp_small_bwd(const dib_mlp_desc* d, const float* params, const float* g_out, float* const* h, float* const* g, int n,
+                      dib_stream_t stream) {
+  if (n == 0) return DIB_OK;
+  DibSmallIntArgs a;
+  if (int rc = mlp_small_bwd_args(d, params, g_out, h, g, n, a)) return rc;
+  return mlp_small_launch(d, a, (hipStream_t)stream);
+}
+// the companion protocol: arm, run the model's entry point, launch alone if the model's path had no row-tile launch to share
+static int with_companion(const dib_mlp_desc* d, const DibSmallIntArgs& c, hipStream_t st, int model_rc_fn(void*), void* ctx) {
+  t_companion.args = c;
+  t_companion.lds = (size_t)mlp_small_lds_floats(d) * 4;
+  t_companion.armed = true;
+  int rc = model_rc_fn(ctx);
+  if (t_companion.armed) {
+    t_companion.armed = false;
+    if (!rc) rc = mlp_small_launch(d, c, st);
+  }
+  return rc;
+}
+int dib_integration_fwd_and_mlp_fwd(dib_layout* l, int batch, const float* params, void* ws, const dib_mlp_desc* d,
+                                    const float* mlp_params, const float* x, int64_t ldx, const int32_t* row_idx, int n, float* a0,
+                                    float* const* h, float* out, dib_stream_t stream) {
+  DibSmallIntArgs c;
+  if (int rc = mlp_small_fwd_args(d, mlp_params, x, ldx, row_idx, n, a0, h, out, c)) return rc;
+  struct Ctx { dib_layout* l; int batch; const float* params; void* ws; dib_stream_t stream; } ctx{l, batch, params, ws, stream};
+  return with_companion(d, c, (hipStream_t)stream, [](void* p) {
+    Ctx* q = (Ctx*)p;
+    return dib_integration_fwd(q->l, q->batch, q->params, q->ws, q->stream);
+  }, &ctx);
+}
+int dib_backward_and_mlp_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                             float inv_global_batch, int flags, void* ws, const dib_mlp_desc* d, const float* mlp_params,
+                             const float* g_out, float* const* h, float* const* g, int n, dib_stream_t stream) {
+  DibSmallIntArgs c;
+  if (int rc = mlp_small_bwd_args(d, mlp_params, g_out, h, g, n, c)) return rc;
+  struct Ctx { dib_layout* l; int batch; const float* params; float* grads; const float* beta_dev; float inv; int flags; void* ws;
+               dib_stream_t stream; } ctx{l, batch, params, grads, beta_dev, inv_global_batch, flags, ws, stream};
+  return with_companion(d, c, (hipStream_t)stream, [](void* p) {
+    Ctx* q = (Ctx*)p;
+    return dib_backward(q->l, q->batch, q->params, q->grads, q->beta_dev, q->inv, q->flags, q->ws, q->stream);
+  }, &ctx);
 }
 
 // grads = sum of the nsplit partial slabs (nsplit == 0: grads as given), Keras-Adam on (params, m, v), step count bumped - ONE
@@ -1948,10 +2098,13 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
     static bool attr_small[64] = {};
     if (dib_attr_needed(attr_small)) {
       hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)dib_attn_small_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
     ProfScope ps(kProfAttnBwd, st);
-    DIB_LAUNCH(dib_attn_small_bwd_kernel, dim3(H, B), dim3(256), lds, st, a);
+    if (knobs().attn_small_waves >= 8) DIB_LAUNCH(dib_attn_small_bwd8_kernel, dim3(H, B), dim3(512), lds, st, a);
+    else DIB_LAUNCH(dib_attn_small_bwd_kernel, dim3(H, B), dim3(256), lds, st, a);
     return (int)hipGetLastError();
   }
   float* delta = (float*)ws;

@@ -319,3 +319,171 @@ dib_attn_small_bwd_kernel(DibAttnArgs a) {
     dib_attn_small_store(dQb, a.ld, wm * 32, col, P, h, dq[n], a.scale);
   }
 }
+
+// =====================================================================================================================
+// The backward with 8 waves (round 5).  With 137 KB of LDS the kernel above is one workgroup per CU = ONE wave per SIMD: nothing
+// overlaps its LDS latencies, its exponentials or its global loads / stores, and it runs at 3 x its MFMA time (57.8 us per
+// launch of 384 workgroups at the notebook's size; the same finding as the first one-launch InfoNCE kernel,
+// profiles/HISTORY.md 13).  Same LDS map, 512 threads, the five products split between the wave groups lo = waves 0-3 and
+// hi = waves 4-7 (tile position (wm, wn) = bits of wave & 3 as above):
+//   lo: S            hi: dP = dO V^T -> handed over through the dS tile's space
+//   lo: P, delta, dS (the 16 exponentials per lane)
+//   lo: dV = P^T dO  hi: dK = dS^T (scale Q)        (the same code on different tiles: two 32 x 32 tiles per wave)
+//   all: dQ = scale dS K, one 32 x 32 tile per wave (query block wave & 1, columns 32 (wave >> 1))
+// 160 MFMAs per wave instead of 320; every sum in the order of the 4-wave kernel (bit-identical results).
+// =====================================================================================================================
+__device__ __forceinline__ void dib_attn_small_load8(float* __restrict__ T, const float* __restrict__ base, long long ld, int P,
+                                                     int tid, float mul) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = (tid >> 5) + 16 * p;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < P) v = *reinterpret_cast<const float4*>(base + (long long)r * ld + (tid & 31) * 4);
+    *reinterpret_cast<float4*>(T + r * kAttnPitch + (tid & 31) * 4) = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
+  }
+}
+
+// grid (H, B), 512 threads, dynamic LDS DibAttnSmallBwdLds floats
+__global__ void __launch_bounds__(512)
+dib_attn_small_bwd8_kernel(DibAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;                               // scaled Q
+  float* Ks = Qs + kAttnSmallP * kAttnPitch;
+  float* Gs = Ks + kAttnSmallP * kAttnPitch;     // dO
+  float* Pt = Gs + kAttnSmallP * kAttnPitch;     // [64 queries][68] probabilities
+  float* dSt = Pt + kAttnSmallP * kAttnSP;       // [64 queries][68] dP, then dS
+  float* Ls = dSt + kAttnSmallP * kAttnSP;       // lse of the 64 queries (+inf beyond P)
+  float* Dp = Ls + kAttnSmallP;                  // [2][64] partial delta (keys 0..31 | 32..63)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int head = blockIdx.x, b = blockIdx.y, P = a.P;
+  const long long tok0 = (long long)b * P;
+  const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
+  const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
+  const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
+  const float* dOb = a.d_o + tok0 * a.ld + head * kAttnD;
+  dib_attn_small_load8(Qs, Qb, a.ld, P, tid, a.scale);
+  dib_attn_small_load8(Ks, Kb, a.ld, P, tid, 1.0f);
+  dib_attn_small_load8(Gs, dOb, a.ld, P, tid, 1.0f);
+  if (tid < kAttnSmallP) Ls[tid] = tid < P ? a.lse[((long long)b * a.H + head) * P + tid] : INFINITY;
+  const int key = wn * 32 + l31;
+  const float kmul = key < P ? 1.0f : 0.0f;
+  // hi waves: the V row of this lane's key (B operand of dP = dO V^T), resident in registers
+  float4 vf[16];
+  if (grp == 1) dib_attn_rowfrag(vf, Vb, a.ld, min(key, P - 1), h, kmul);
+  __syncthreads();
+  // ---- lo: S, hi: dP   [query wm*32.., key wn*32..] ----
+  dib_f32x16 sd;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sd[r] = 0.f;
+  if (grp == 0) {
+    const float* Qw = Qs + wm * 32 * kAttnPitch;
+    const float* Kw = Ks + wn * 32 * kAttnPitch;
+    float4 qq = dib_attn_kc(Qw, 0, l31, h), kk = dib_attn_kc(Kw, 0, l31, h);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int qn_ = q < 15 ? q + 1 : 15;
+      const float4 qn = dib_attn_kc(Qw, qn_, l31, h), kn = dib_attn_kc(Kw, qn_, l31, h);
+      sd = DIB_MFMA(qq.x, kk.x, sd);
+      sd = DIB_MFMA(qq.y, kk.y, sd);
+      sd = DIB_MFMA(qq.z, kk.z, sd);
+      sd = DIB_MFMA(qq.w, kk.w, sd);
+      qq = qn; kk = kn;
+    }
+  } else {
+    const float* Gw = Gs + wm * 32 * kAttnPitch;
+    float4 gg = dib_attn_kc(Gw, 0, l31, h);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float4 gn = dib_attn_kc(Gw, q < 15 ? q + 1 : 15, l31, h);
+      sd = DIB_MFMA(gg.x, vf[q].x, sd);
+      sd = DIB_MFMA(gg.y, vf[q].y, sd);
+      sd = DIB_MFMA(gg.z, vf[q].z, sd);
+      sd = DIB_MFMA(gg.w, vf[q].w, sd);
+      gg = gn;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dSt[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kAttnSP + key] = sd[r];
+  }
+  __syncthreads();
+  // ---- lo: P, delta, dS ----
+  float pv[16], dpv[16];
+  if (grp == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpv[r] = dSt[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kAttnSP + key];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      pv[r] = expf(sd[r] - Ls[qi]) * kmul;          // query beyond P: lse = +inf -> 0
+      const float part = dib_half_sum(pv[r] * dpv[r]);
+      if (l31 == 0) Dp[wn * kAttnSmallP + qi] = part;
+    }
+  }
+  __syncthreads();
+  if (grp == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float delta = Dp[qi] + Dp[kAttnSmallP + qi];
+      Pt[qi * kAttnSP + key] = pv[r];
+      dSt[qi * kAttnSP + key] = pv[r] * (dpv[r] - delta);
+    }
+  }
+  __syncthreads();
+  // ---- lo: dV[key wm*32.., d wn*64..] = P^T dO;  hi: dK = dS^T (scale Q): contraction over the 64 queries ----
+  {
+    const float* At = grp == 0 ? Pt : dSt;
+    const float* Bt = grp == 0 ? Gs : Qs;
+    dib_f32x16 t0, t1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { t0[r] = 0.f; t1[r] = 0.f; }
+    struct Ops { float4 a, b0, b1; };
+    auto fetch = [&](int q) {
+      Ops o;
+      const float* pp = At + (q * 8 + h * 4) * kAttnSP + wm * 32 + l31;
+      o.a = make_float4(pp[0], pp[kAttnSP], pp[2 * kAttnSP], pp[3 * kAttnSP]);
+      o.b0 = dib_attn_mc(Bt, q, wn * 64 + l31, h);
+      o.b1 = dib_attn_mc(Bt, q, wn * 64 + 32 + l31, h);
+      return o;
+    };
+    Ops cur = fetch(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const Ops nxt = fetch(q < 7 ? q + 1 : 7);
+      t0 = DIB_MFMA(cur.a.x, cur.b0.x, t0);
+      t1 = DIB_MFMA(cur.a.x, cur.b1.x, t1);
+      t0 = DIB_MFMA(cur.a.y, cur.b0.y, t0);
+      t1 = DIB_MFMA(cur.a.y, cur.b1.y, t1);
+      t0 = DIB_MFMA(cur.a.z, cur.b0.z, t0);
+      t1 = DIB_MFMA(cur.a.z, cur.b1.z, t1);
+      t0 = DIB_MFMA(cur.a.w, cur.b0.w, t0);
+      t1 = DIB_MFMA(cur.a.w, cur.b1.w, t1);
+      cur = nxt;
+    }
+    float* outb = (grp == 0 ? a.dv : a.dk) + tok0 * a.ld + head * kAttnD;
+    dib_attn_small_store(outb, a.ld, wm * 32, wn * 64 + l31, P, h, t0, 1.0f);
+    dib_attn_small_store(outb, a.ld, wm * 32, wn * 64 + 32 + l31, P, h, t1, 1.0f);
+  }
+  // ---- dQ[query 32 (wave & 1).., d 32 (wave >> 1)..] = scale dS K: contraction over the 64 keys ----
+  {
+    const int qm = wave & 1, cb = wave >> 1;
+    dib_f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+    const float* dsrow = dSt + (qm * 32 + l31) * kAttnSP + h * 4;
+    float4 ds = *reinterpret_cast<const float4*>(dsrow);
+    float4 kc = dib_attn_mc(Ks, 0, cb * 32 + l31, h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int qn_ = q < 7 ? q + 1 : 7;
+      const float4 dsn = *reinterpret_cast<const float4*>(dsrow + qn_ * 8);
+      const float4 kn = dib_attn_mc(Ks, qn_, cb * 32 + l31, h);
+      dq = DIB_MFMA(ds.x, kc.x, dq);
+      dq = DIB_MFMA(ds.y, kc.y, dq);
+      dq = DIB_MFMA(ds.z, kc.z, dq);
+      dq = DIB_MFMA(ds.w, kc.w, dq);
+      ds = dsn; kc = kn;
+    }
+    dib_attn_small_store(a.dq + tok0 * a.ld + head * kAttnD, a.ld, qm * 32, cb * 32 + l31, P, h, dq, a.scale);
+  }
+}

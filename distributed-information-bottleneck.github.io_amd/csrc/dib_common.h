@@ -109,6 +109,16 @@ __device__ __forceinline__ float dib_block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Phase marks of the small-batch kernels (diagnostic build -DDIB_SMALL_TIMING; tools/small_phase_timing.py): thread 0 of
+// workgroup (0, 0) stores the 100 MHz wall clock at each phase boundary of the last launch.  Encoder forward marks at [0, 16),
+// the integration kernel at [16, 40), the encoder backward at [40, 56), the one-launch InfoNCE kernel at [56, 64).
+#ifdef DIB_SMALL_TIMING
+__device__ long long dib_small_dbg[64];
+#define DIB_ST(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dib_small_dbg[i] = wall_clock64(); } while (0)
+#else
+#define DIB_ST(i) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Keras Adam on one element (reference train.py:128-129): m += (1-b1)(g-m); v += (1-b2)(g^2-v);
 // theta -= lr_t m/(sqrt(v)+eps), lr_t = lr sqrt(1-b2^t)/(1-b1^t).  ONE definition with floating-point contraction OFF, used by

@@ -33,6 +33,7 @@
 #pragma once
 #include "dib_common.h"
 #include "dib_gemm.h"   // dib_f32x16, DIB_MFMA
+#include "dib_fused.h"  // dib_f32x4, DIB_MFMA16
 
 #define DIB_INCE_TS 64          // tile edge
 #define DIB_INCE_KP 68          // LDS pitch of a k-contiguous operand tile (b128 fragment reads: conflict-free at BK + 4)
@@ -438,4 +439,275 @@ dib_infonce_grad_final_kernel(const float* __restrict__ X, const float* __restri
   }
   const float self = (side == 0 ? X : Y)[o];
   (side == 0 ? GX : GY)[o] = kind == 4 ? (g - self * r) : (self * r - g);
+}
+
+// =====================================================================================================================
+// One launch for the reference's DEFAULT batch (train.py:34: 128 rows, shared space 64, train.py:60): B <= 128, D <= 64.
+// The three launches above spend 39 us on 2 MFLOP at that size (profiles/r05i_config2_loop_kernel_stats_b128.csv: similarity
+// 12.3, log-sum-exp + loss 6.4, gradients 19.9 us - each a dependent launch of a handful of workgroups).  Here every
+// workgroup keeps BOTH embedding sets and the whole [128][128] similarity matrix in its CU's LDS (136 KB of the 160) and
+// recomputes S and the 2 B log-sum-exps itself - 8192 MFMA cycles per SIMD, cheaper than any exchange between workgroups -
+// then evaluates the gradient of ITS 64 self rows of one side: grid (ceil(B/64) self blocks, 2 sides); without gradients (the
+// validation pass) one workgroup.  512 threads = 2 waves per SIMD: the square roots / exponentials of one wave run under the
+// MFMAs of the other (with 4 waves the phases ran back to back: S 11.6 us of which 3.7 are MFMAs, profiles/r05r_*).  The
+// coefficient matrix overwrites S in place (side 1 reads it transposed: the LDS pitch is odd, so row-wise and column-wise
+// accesses are both conflict-free).  Same expressions as the kernels above except v_sqrt_f32 / v_rsq_f32 (1 ulp) for the
+// IEEE sqrtf / division sequences; every sum in a fixed order.  Workgroup (0, 0) writes the loss.
+// =====================================================================================================================
+#define DIB_INCE1_MAXB 128
+#define DIB_INCE1_THREADS 512
+#define DIB_INCE1_SP 129          // pitch of the similarity / coefficient matrix
+#define DIB_INCE1_LDS_FLOATS (2 * DIB_INCE1_MAXB * DIB_INCE_KP + DIB_INCE1_MAXB * DIB_INCE1_SP + 4 * DIB_INCE1_MAXB + 4 * 256 + 8 * 64 + 64 + 8)
+
+template <int KIND>
+__device__ __forceinline__ float dib_ince1_similarity(float ab, float na, float nb, float inv_t) {
+  if (KIND == 4) return ab * __builtin_amdgcn_rsqf(na) * __builtin_amdgcn_rsqf(nb) * inv_t;
+  const float d2 = fmaxf(na + nb - 2.0f * ab, 0.f);   // utils.py:85-90
+  return ((KIND == 0) ? -d2 : -__builtin_amdgcn_sqrtf(d2 + 1e-9f)) * inv_t;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(DIB_INCE1_THREADS)
+dib_infonce_small_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, float inv_t, float temperature,
+                         float* __restrict__ GX, float* __restrict__ GY, float* __restrict__ loss_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds1[];
+  float* Xs = lds1;                                         // [128][68]  rows >= B and columns >= D are zero
+  float* Ys = Xs + DIB_INCE1_MAXB * DIB_INCE_KP;
+  float* Sm = Ys + DIB_INCE1_MAXB * DIB_INCE_KP;            // [128][129]
+  float* Nx = Sm + DIB_INCE1_MAXB * DIB_INCE1_SP;           // |x_i|^2
+  float* Ny = Nx + DIB_INCE1_MAXB;
+  float* lse_r = Ny + DIB_INCE1_MAXB;
+  float* lse_c = lse_r + DIB_INCE1_MAXB;
+  float* mpart = lse_c + DIB_INCE1_MAXB;                    // [2 halves][256 rows | columns]
+  float* spart = mpart + 2 * 256;
+  float* Rpart = spart + 2 * 256;                           // [8][64]
+  float* Rtot = Rpart + 8 * 64;                             // [64]
+  float* red = Rtot + 64;                                   // [8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int nrow32 = (B + 31) >> 5;                         // 32-row blocks that hold data
+
+  DIB_ST(56);
+  // ---- phase 1: both embedding sets -> LDS (all loads of a thread in flight together), squared row norms ----
+  {
+    const bool vec = (D & 3) == 0 && ((((uintptr_t)X) | ((uintptr_t)Y)) & 15) == 0;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    float4 xa[4], ya[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = lr + 32 * p;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (r < B) {
+        const float* sx = X + (long long)r * D + lc;
+        const float* sy = Y + (long long)r * D + lc;
+        if (vec && lc + 3 < D) { a = *reinterpret_cast<const float4*>(sx); b = *reinterpret_cast<const float4*>(sy); }
+        else {
+          if (lc < D) { a.x = sx[0]; b.x = sy[0]; }
+          if (lc + 1 < D) { a.y = sx[1]; b.y = sy[1]; }
+          if (lc + 2 < D) { a.z = sx[2]; b.z = sy[2]; }
+          if (lc + 3 < D) { a.w = sx[3]; b.w = sy[3]; }
+        }
+      }
+      xa[p] = a; ya[p] = b;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = lr + 32 * p;
+      *reinterpret_cast<float4*>(Xs + r * DIB_INCE_KP + lc) = xa[p];
+      *reinterpret_cast<float4*>(Ys + r * DIB_INCE_KP + lc) = ya[p];
+      const float sx = dib_row16_sum(xa[p].x * xa[p].x + xa[p].y * xa[p].y + xa[p].z * xa[p].z + xa[p].w * xa[p].w);
+      const float sy = dib_row16_sum(ya[p].x * ya[p].x + ya[p].y * ya[p].y + ya[p].z * ya[p].z + ya[p].w * ya[p].w);
+      if ((tid & 15) == 0) { Nx[r] = sx; Ny[r] = sy; }
+    }
+  }
+  __syncthreads();
+  DIB_ST(57);
+
+  // ---- phase 2: S = similarity(X Y^T): wave w owns rows [32 (w & 3), + 32) x column blocks 2 (w >> 2), 2 (w >> 2) + 1 ----
+  {
+    const int rb = wave & 3, kq = (D + 7) >> 3;
+    const float* arow = Xs + (rb * 32 + l31) * DIB_INCE_KP + h * 4;
+#pragma unroll 1
+    for (int nn = 0; nn < 2; ++nn) {
+      const int n = 2 * (wave >> 2) + nn;
+      if (rb >= nrow32 || n >= nrow32) continue;   // wave-uniform
+      dib_f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* brow = Ys + (n * 32 + l31) * DIB_INCE_KP + h * 4;
+#pragma unroll 2
+      for (int q = 0; q < kq; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + q * 8);
+        const float4 b = *reinterpret_cast<const float4*>(brow + q * 8);
+        acc = DIB_MFMA(a.x, b.x, acc);
+        acc = DIB_MFMA(a.y, b.y, acc);
+        acc = DIB_MFMA(a.z, b.z, acc);
+        acc = DIB_MFMA(a.w, b.w, acc);
+      }
+      const int j = n * 32 + l31;
+      const float nb = Ny[j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        Sm[i * DIB_INCE1_SP + j] = (i < B && j < B) ? dib_ince1_similarity<KIND>(acc[r], Nx[i], nb, inv_t) : -INFINITY;
+      }
+    }
+  }
+  __syncthreads();
+  DIB_ST(58);
+
+  // ---- phase 3: log-sum-exp of every row (t < 128) and column (t >= 128), t = tid & 255; the two halves of the workgroup
+  // take entries [0, 64) and [64, 128) and are merged in that order ----
+  {
+    const int t = tid & 255, idx = t & 127, half = tid >> 8;
+    const bool col = t >= 128;
+    const int stride = col ? DIB_INCE1_SP : 1;
+    const float* base = Sm + (col ? idx : idx * DIB_INCE1_SP);
+    const int ubeg = 64 * half, uend = min(B, ubeg + 64);
+    float m = -INFINITY, ssum = 0.f;
+    if (idx < B && ubeg < uend) {
+      // batches of 16 LDS reads in flight (a read per dependent trip would be one LDS latency per entry)
+#pragma unroll 1
+      for (int u0 = ubeg; u0 < uend; u0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = base[min(u0 + k, uend - 1) * stride];   // duplicates of the last entry: harmless for a max
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m = fmaxf(m, v[k]);
+      }
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four interleaved partial sums: a fixed order
+#pragma unroll 1
+      for (int u0 = ubeg; u0 < uend; u0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = base[min(u0 + k, uend - 1) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) {
+          s0 += u0 + k < uend ? __expf(v[k] - m) : 0.f;
+          s1 += u0 + k + 1 < uend ? __expf(v[k + 1] - m) : 0.f;
+          s2 += u0 + k + 2 < uend ? __expf(v[k + 2] - m) : 0.f;
+          s3 += u0 + k + 3 < uend ? __expf(v[k + 3] - m) : 0.f;
+        }
+      }
+      ssum = (s0 + s1) + (s2 + s3);
+    }
+    mpart[half * 256 + t] = m;
+    spart[half * 256 + t] = ssum;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int idx = tid & 127;
+    const float m0 = mpart[tid], m1 = mpart[256 + tid];
+    const float mm = fmaxf(m0, m1);
+    float l = 0.f;
+    if (idx < B) {   // m0 is finite for idx < B (entry 0 exists); m1 = -inf when the second half is empty
+      const float tot = spart[tid] * __expf(m0 - mm) + (m1 == -INFINITY ? 0.f : spart[256 + tid] * __expf(m1 - mm));
+      l = mm + logf(tot);
+    }
+    (tid >= 128 ? lse_c : lse_r)[idx] = l;
+  }
+  __syncthreads();
+  DIB_ST(59);
+  if (blockIdx.x == 0 && blockIdx.y == 0) {   // loss = (1/B) sum_i (lse_r[i] + lse_c[i] - 2 S_ii)   (block-uniform branch)
+    float term = 0.f;
+    if (tid < B) term = (lse_r[tid] - Sm[tid * DIB_INCE1_SP + tid]) + (lse_c[tid] - Sm[tid * DIB_INCE1_SP + tid]);
+    term = dib_wave_sum(term);
+    if (lane == 0) red[wave] = term;
+    __syncthreads();
+    if (tid == 0) loss_out[0] = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / (float)B;
+  }
+  DIB_ST(60);
+  if (GX == nullptr || GY == nullptr) return;
+
+  // ---- phase 4: coefficients of this workgroup's 64 self rows, in place; R[self] = their row sums ----
+  const int side = blockIdx.y, s0 = blockIdx.x * 64;
+  const float sc = inv_t / (float)B;
+  {
+    const int sl = tid & 63, part = tid >> 6, self = s0 + sl;   // part = wave: 16 partners each
+    float rs = 0.f;
+    const float lse_self = side == 0 ? lse_r[self] : lse_c[self];
+    const float rn_self = KIND == 4 ? __builtin_amdgcn_rsqf(side == 0 ? Nx[self] : Ny[self]) : 1.f;
+    const bool self_ok = self < B;
+    const int estride = side == 0 ? 1 : DIB_INCE1_SP;                 // along the partners
+    float* ebase = Sm + (side == 0 ? self * DIB_INCE1_SP : self);
+    const float* lse_p = side == 0 ? lse_c : lse_r;
+    const float* n_p = side == 0 ? Ny : Nx;
+    if (part * 16 < 32 * nrow32) {                                    // partner blocks beyond the batch were never written
+#pragma unroll 1
+      for (int u0 = 0; u0 < 16; u0 += 8) {                            // 8 reads in flight, then 8 evaluations + stores
+        float sv[8], lp[8], np_[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int p = part * 16 + u0 + k;
+          sv[k] = ebase[p * estride];
+          lp[k] = lse_p[p];
+          np_[k] = KIND == 4 ? n_p[p] : 1.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int p = part * 16 + u0 + k;
+          float cf = 0.f, c2 = 0.f;
+          if (self_ok && p < B) {
+            const float sij = sv[k];
+            const float w = (__expf(sij - lse_self) + __expf(sij - lp[k]) - (p == self ? 2.0f : 0.f)) * sc;
+            if (KIND == 0) cf = sij < 0.f ? -2.0f * w : 0.f;
+            else if (KIND == 1) { const float rr = -sij * temperature; cf = (rr * rr > 1.0000005e-9f) ? -w * __builtin_amdgcn_rcpf(rr) : 0.f; }
+            else {
+              const float rn_p = __builtin_amdgcn_rsqf(np_[k]);
+              cf = w * rn_self * rn_p;
+              c2 = w * (sij * temperature) * (rn_self * rn_self);
+            }
+          }
+          ebase[p * estride] = cf;
+          rs += KIND == 4 ? c2 : cf;
+        }
+      }
+    }
+    Rpart[part * 64 + sl] = rs;
+  }
+  __syncthreads();
+  if (tid < 64)
+    Rtot[tid] = ((Rpart[tid] + Rpart[64 + tid]) + (Rpart[128 + tid] + Rpart[192 + tid])) +
+                ((Rpart[256 + tid] + Rpart[320 + tid]) + (Rpart[384 + tid] + Rpart[448 + tid]));
+  __syncthreads();
+  DIB_ST(61);
+
+  // ---- phase 5: G[64 self][64] = C . Other as 16 tiles of 16 x 16 (v_mfma_f32_16x16x4_f32), two per wave: self rows
+  // [16 (w & 3), + 16) x columns [32 (w >> 2), + 32); g = alpha self R + beta G ----
+  {
+    const int ti = wave & 3, tj0 = 2 * (wave >> 2), j = lane & 15, q4 = lane >> 4;
+    const float* Oth = side == 0 ? Ys : Xs;
+    const float* Self = side == 0 ? Xs : Ys;
+    float* Gout = side == 0 ? GX : GY;
+    dib_f32x4 acc0 = dib_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const int srow = s0 + ti * 16 + j;                         // A: lane (i = j, k = q4)
+    const int astride = side == 0 ? 1 : DIB_INCE1_SP;
+    const float* ap = Sm + (side == 0 ? srow * DIB_INCE1_SP : srow) + q4 * astride;
+    const float* bp = Oth + q4 * DIB_INCE_KP + tj0 * 16 + j;   // B: lane (column j, k = q4)
+    const int ksteps = 8 * nrow32;                             // partner index in steps of 4
+#pragma unroll 4
+    for (int ks = 0; ks < ksteps; ++ks) {
+      const float a = ap[4 * ks * astride];
+      const float b0 = bp[4 * ks * DIB_INCE_KP], b1 = bp[4 * ks * DIB_INCE_KP + 16];
+      acc0 = DIB_MFMA16(a, b0, acc0);
+      acc1 = DIB_MFMA16(a, b1, acc1);
+    }
+    DIB_ST(62);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int il = ti * 16 + 4 * q4 + r, i = s0 + il;
+      if (i < B) {
+        const float rt = Rtot[il];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int e = (tj0 + c) * 16 + j;
+          if (e < D) {
+            const float sr = Self[i * DIB_INCE_KP + e] * rt;
+            const float g = c == 0 ? acc0[r] : acc1[r];
+            Gout[(long long)i * D + e] = KIND == 4 ? (g - sr) : (sr - g);
+          }
+        }
+      }
+    }
+    DIB_ST(63);
+  }
 }

@@ -20,15 +20,7 @@
 
 #define DIB_SMALL_ROWS 16
 
-// Phase marks of the row-tile kernels (diagnostic build -DDIB_SMALL_TIMING; tools/small_phase_timing.py): thread 0 of
-// workgroup (0, 0) stores the 100 MHz wall clock at each phase boundary of the last launch.  K1 marks at [0, 16), the
-// integration kernel at [16, 40), the encoder backward at [40, 56).
-#ifdef DIB_SMALL_TIMING
-__device__ long long dib_small_dbg[64];
-#define DIB_ST(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) dib_small_dbg[i] = wall_clock64(); } while (0)
-#else
-#define DIB_ST(i) do { } while (0)
-#endif
+// (phase marks DIB_ST(i) of the diagnostic build -DDIB_SMALL_TIMING: dib_common.h)
 #define DIB_SMALL_THREADS 512   // 8 waves = 2 per SIMD: the contraction of every layer is split between wave w and w + 4, so
                                 // that one of the pair issues MFMAs while the other waits for its weights (each weight is read
                                 // once per workgroup, straight from L2: the kernels are latency-bound, not bandwidth-bound)
@@ -434,6 +426,8 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
 #define DIB_SMALL_INT_INFER 64     // no stashes (validation)
 #define DIB_SMALL_INT_LOAD_H 128   // hidden activations come from the global stashes (a backward launched on its own)
 #define DIB_SMALL_INT_LOAD_G 256   // dL/dh_{n-1} comes from its global stash (written by a separately launched output head)
+#define DIB_SMALL_INT_POSENC_IN 512  // the input tile is gather + PositionalEncoding of X rows (a plain MLP: dib_mlp_small_*)
+#define DIB_SMALL_INT_NO_GU 1024   // the dgrad chain stops at dL/dh_0 (no gradient with respect to the input)
 
 struct DibSmallIntArgs {
   const float* U; float* GU; int batch, K0;
@@ -444,12 +438,15 @@ struct DibSmallIntArgs {
   float* pred; float* g_pred;
   int loss_kind; const float* Y; long long ldy; const int* row_idx; long long row0; float inv_bg;
   float* partial_w; float* partial_l;                         // head: [tile][K + 1], [tile][2]
+  // DIB_SMALL_INT_POSENC_IN (a plain MLP over its own input, e.g. the InfoNCE path's output encoder, train.py:184-192): the
+  // input tile is built from rows row_idx[b] (or row0 + b) of X: [x | sin 2x | sin 4x | ...] (the expressions of
+  // dib_posenc_rows_kernel), K0 = in_dim * n_freq, and stashed in a0 [B][K0] (operand of the first weight gradient)
+  const float* X; long long ldx; int in_dim, n_freq; float* a0;
 };
 
-__global__ void __launch_bounds__(DIB_SMALL_THREADS)
-dib_small_integration_kernel(DibSmallIntArgs a) {
+__device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs& a, const int tile) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = tile * DIB_SMALL_ROWS, rows_valid = min(DIB_SMALL_ROWS, a.batch - r0);
   const int n = a.n_hidden;
   // LDS map: u | h_0 .. h_{n-1} | g_0 .. g_{n-1} | pred / g_pred tile | head scratch.  (n <= 3; every loop over layers is
@@ -491,7 +488,33 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
     }
   }
   if (a.mode & DIB_SMALL_INT_FWD) {
-    dib_small_load_tile(a.U + (long long)r0 * a.K0, a.K0, a.K0, rows_valid, us, pu);
+    if (a.mode & DIB_SMALL_INT_POSENC_IN) {
+      const int d = a.in_dim;
+      for (int i = tid; i < DIB_SMALL_ROWS * d; i += DIB_SMALL_THREADS) {
+        const int row = i / d, c = i - row * d;
+        const bool ok = row < rows_valid;
+        float x = 0.f;
+        if (ok) {
+          const int b = r0 + row;
+          const long long grow = a.row_idx ? (long long)a.row_idx[b] : a.row0 + b;
+          x = a.X[grow * a.ldx + c];
+        }
+        float* dst = us + row * pu + c;
+        const bool keep = ok && a.a0 != nullptr;
+        float* gd = a.a0 + (long long)(r0 + row) * a.K0 + c;
+        dst[0] = x;
+        if (keep) gd[0] = x;
+        float fr = 2.0f;
+        for (int jb = 1; jb < a.n_freq; ++jb) {
+          const float v = ok ? sinf(fr * x) : 0.f;
+          dst[jb * d] = v;
+          if (keep) gd[jb * d] = v;
+          fr *= 2.0f;
+        }
+      }
+    } else {
+      dib_small_load_tile(a.U + (long long)r0 * a.K0, a.K0, a.K0, rows_valid, us, pu);
+    }
     __syncthreads();
     DIB_ST(17);
 #pragma unroll
@@ -617,11 +640,26 @@ dib_small_integration_kernel(DibSmallIntArgs a) {
         DIB_ST(24 + l);
       }
     }
-    // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output)
-    dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
-                  a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
+    // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output; a plain MLP's input needs no gradient)
+    if (!(a.mode & DIB_SMALL_INT_NO_GU))
+      dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
+                    a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
     DIB_ST(28);
   }
+}
+
+__global__ void __launch_bounds__(DIB_SMALL_THREADS)
+dib_small_integration_kernel(DibSmallIntArgs a) { dib_small_integration_body(a, blockIdx.x); }
+
+// Two independent networks in ONE grid (blockIdx.y picks the argument set): the custom InfoNCE loop's X model and its output
+// encoder between the encoder bank and the loss (train.py:203-219) - each is 8 workgroups at the reference's batch of 128, and
+// a launch of its own costs more than its work.  The argument sets stay in the kernarg segment (uniform index: scalar loads).
+struct DibSmallIntPair { DibSmallIntArgs s[2]; };
+__global__ void __launch_bounds__(DIB_SMALL_THREADS)
+dib_small_integration_pair_kernel(DibSmallIntPair p) {
+  const DibSmallIntArgs& a = p.s[blockIdx.y];
+  if ((int)blockIdx.x * DIB_SMALL_ROWS >= a.batch) return;   // the two batches may differ
+  dib_small_integration_body(a, blockIdx.x);
 }
 
 // =====================================================================================================================

@@ -9,6 +9,7 @@ gradients contract over the batch in <= 32 row slabs (one partial parameter buff
 whole batch: 265 us per layer at the chaos notebook's batch of 2048 (profiles/r03m_*)."""
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Dict, Optional, Sequence
 
@@ -17,6 +18,15 @@ import torch
 
 from ._gemm_plan import _Gemm, _d, _ptr
 from ._lib import ACTIVATIONS, SYNC_WORDS as _SYNC_WORDS, check
+
+
+class _MlpDesc(ctypes.Structure):
+    """include/dib_hip.h dib_mlp_desc: where the layers of a plain MLP sit in its flat parameter buffer"""
+    _fields_ = [("w_off", ctypes.c_int64 * 4), ("b_off", ctypes.c_int64 * 4), ("n_hidden", ctypes.c_int32),
+                ("width", ctypes.c_int32 * 4), ("in_dim", ctypes.c_int32), ("n_freq", ctypes.c_int32), ("act", ctypes.c_int32)]
+
+
+assert ctypes.sizeof(_MlpDesc) == 96
 
 
 class DenseStack:
@@ -45,6 +55,14 @@ class DenseStack:
         self.lr_dev = torch.full((1,), 1e-3, dtype=torch.float32, device=self.device)
         self._plans: Dict[int, dict] = {}
         self._last: Optional[dict] = None
+        # batches <= 1024 rows: the whole layer chain of 16 rows in one workgroup (dib_mlp_small_fwd / _bwd, csrc/dib_small.h)
+        self._desc = None
+        if 2 <= len(self.dims) <= 4:
+            d = _MlpDesc()
+            for l in range(len(self.dims)):
+                d.w_off[l], d.b_off[l], d.width[l] = self.w_off[l], self.b_off[l], self.dims[l][1]
+            d.n_hidden, d.in_dim, d.n_freq, d.act = len(self.dims) - 1, self.input_dim, max(self.n_freq, 1), self.act
+            self._desc = d
 
     # views
     def kernel(self, l):
@@ -94,7 +112,11 @@ class DenseStack:
             gg.upload(self.device)
         if len(self._plans) >= 4:                             # train batch, validation batch, their tails
             self._plans.pop(next(iter(self._plans)))
-        pl = self._plans[n] = dict(n=n, ws=ws, off=off, g=g, nsplit=nsplit, slabs=slabs)
+        pl = self._plans[n] = dict(n=n, ws=ws, off=off, g=g, nsplit=nsplit, slabs=slabs, small=False)
+        if self._desc is not None:
+            nh = L - 1
+            ptrs = lambda pre: (ctypes.c_void_p * 3)(*[_ptr(ws, off[f"{pre}{l + 1}"]).value if l < nh else None for l in range(3)])
+            pl.update(h_ptrs=ptrs("a"), g_ptrs=ptrs("g"))
         return pl
 
     def _view(self, pl, name, rows, cols):
@@ -113,6 +135,16 @@ class DenseStack:
         n = y.shape[0] if rows is None else int(rows.shape[0])
         pl = self._plan(n)
         st = self.eng._stream()
+        L = len(self.dims)
+        # (asked per call: "small_batch" is a run-time tuning key; the backward follows the forward's choice)
+        pl["small"] = bool(self._desc is not None and y.dim() == 2 and y.stride(1) == 1
+                           and self.lib.dib_mlp_small_supported(ctypes.byref(self._desc), n))
+        if pl["small"]:   # gather + positional encoding + every layer: one launch
+            check(self.lib.dib_mlp_small_fwd(ctypes.byref(self._desc), _ptr(self.params), _ptr(y), y.stride(0),
+                                             _ptr(rows) if rows is not None else None, n, _ptr(pl["ws"], pl["off"]["a0"]),
+                                             pl["h_ptrs"], _ptr(pl["ws"], pl["off"][f"a{L}"]), st), "dib_mlp_small_fwd")
+            self._last = pl
+            return self._view(pl, f"a{L}", n, self.dims[-1][1])
         if rows is not None:   # gather (+ positional encoding) in one launch, straight into the first layer's operand
             check(self.lib.dib_positional_encoding_rows(_ptr(y), y.stride(0), _ptr(rows), n, self.input_dim, self.n_freq,
                                                         _ptr(pl["ws"], pl["off"]["a0"]), st), "dib_positional_encoding_rows")
@@ -127,6 +159,42 @@ class DenseStack:
         self._last = pl
         return self._view(pl, f"a{len(self.dims)}", n, self.dims[-1][1])
 
+    def companion_forward(self, y: torch.Tensor, rows: Optional[torch.Tensor] = None):
+        """The argument tuple of `dib_integration_fwd_and_mlp_fwd` for forward(y, rows) - the caller hands it to the X model's
+        forward (HipEngine.forward(companion=...)), which runs both networks in one grid; the result is then
+        `companion_output()`.  None when this batch does not take the row-tile kernels (the caller calls forward() itself)."""
+        y = y.to(device=self.device, dtype=torch.float32)
+        n = y.shape[0] if rows is None else int(rows.shape[0])
+        if rows is not None and (rows.dtype != torch.int32 or rows.device != y.device or rows.dim() != 1 or not rows.is_contiguous()):
+            raise ValueError("rows must be a contiguous 1-D int32 tensor on the stack's device")
+        if self._desc is None or y.dim() != 2 or y.stride(1) != 1 or n < 1 \
+                or not self.lib.dib_mlp_small_supported(ctypes.byref(self._desc), n):
+            return None
+        pl = self._plan(n)
+        pl["small"] = True
+        self._last = pl
+        self._keep = (y, rows)   # alive until the launch that reads them has been issued
+        return (ctypes.byref(self._desc), _ptr(self.params), _ptr(y), y.stride(0), _ptr(rows) if rows is not None else None, n,
+                _ptr(pl["ws"], pl["off"]["a0"]), pl["h_ptrs"], _ptr(pl["ws"], pl["off"][f"a{len(self.dims)}"]))
+
+    def companion_output(self) -> torch.Tensor:
+        pl = self._last
+        return self._view(pl, f"a{len(self.dims)}", pl["n"], self.dims[-1][1])
+
+    def companion_backward(self, g_out: torch.Tensor):
+        """The argument tuple of `dib_backward_and_mlp_bwd` for the dgrad chain of backward(g_out) (HipEngine.backward(companion=...));
+        follow with backward(g_out, dgrad_done=True) for the weight gradients.  None if the last forward did not take the
+        row-tile kernels."""
+        pl = self._last
+        assert pl is not None and g_out.shape[0] == pl["n"], "backward follows a forward with the same batch"
+        if not pl["small"]:
+            return None
+        n, L = pl["n"], len(self.dims)
+        dst = self._view(pl, f"g{L}", n, self.dims[-1][1])
+        if not (g_out.data_ptr() == dst.data_ptr() and g_out.shape == dst.shape and g_out.stride() == dst.stride()):
+            dst.copy_(g_out)
+        return (ctypes.byref(self._desc), _ptr(self.params), _ptr(pl["ws"], pl["off"][f"g{L}"]), pl["h_ptrs"], pl["g_ptrs"], n)
+
     def output_grad_buffer(self) -> torch.Tensor:
         """[n, output_dim] view that backward() reads d loss / d output from (of the last forward's plan): a loss kernel can
         write its gradient there directly."""
@@ -134,9 +202,10 @@ class DenseStack:
         assert pl is not None
         return self._view(pl, f"g{len(self.dims)}", pl["n"], self.dims[-1][1])
 
-    def backward(self, g_out: torch.Tensor, reduce: bool = True) -> None:
+    def backward(self, g_out: torch.Tensor, reduce: bool = True, dgrad_done: bool = False) -> None:
         """grads <- d loss / d params given d loss / d output of the last forward (overwrites self.grads).  reduce=False: the
-        batch-slab partials are left for adam_step(fused_reduce=True), which sums them in the optimizer's own launch."""
+        batch-slab partials are left for adam_step(fused_reduce=True), which sums them in the optimizer's own launch.
+        dgrad_done=True: the dgrad chain already ran as the companion of the X model's backward (companion_backward)."""
         pl = self._last
         assert pl is not None and g_out.shape[0] == pl["n"], "backward follows a forward with the same batch"
         n, L, st = pl["n"], len(self.dims), self.eng._stream()
@@ -145,8 +214,14 @@ class DenseStack:
             dst.copy_(g_out)
         if pl["nsplit"] == 1:
             self.grads.zero_()
-        for l in reversed(range(1, L)):
-            pl["g"][f"dgrad{l}"].run(self.lib, st)   # dL/d(pre-activation of layer l-1)
+        if dgrad_done:
+            assert pl["small"]
+        elif pl["small"]:                                # the whole dgrad chain: one launch
+            check(self.lib.dib_mlp_small_bwd(ctypes.byref(self._desc), _ptr(self.params), _ptr(pl["ws"], pl["off"][f"g{L}"]),
+                                             pl["h_ptrs"], pl["g_ptrs"], n, st), "dib_mlp_small_bwd")
+        else:
+            for l in reversed(range(1, L)):
+                pl["g"][f"dgrad{l}"].run(self.lib, st)   # dL/d(pre-activation of layer l-1)
         pl["g"]["wgrad_all"].run(self.lib, st)       # dW_l[i,o] = a_l^T @ g_{l+1}, bias gradients = column sums of g_{l+1}, all l
         self._unreduced = pl if (pl["nsplit"] > 1 and not reduce) else None
         if pl["nsplit"] > 1 and reduce:

@@ -194,13 +194,18 @@ class HipEngine:
     # ---- the step -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, row_idx: Optional[torch.Tensor], row0: int, batch: int, seed: int, step: int,
                 deterministic: bool = False, inference: bool = False, hidden_only: bool = False,
-                defer_sums: bool = False) -> None:
+                defer_sums: bool = False, companion=None) -> None:
         """reference models.py:96-123 -> ws[U], ws[PRED], KL local sums in ws[STEP_OUT].  inference=True: no backward
         follows (validation / predict), the fused forward skips the stashes it would write for it.  defer_sums=True: the KL
-        column sums are left to the step's tail launch (step_tail with TAIL_KL)."""
+        column sums are left to the step's tail launch (step_tail with TAIL_KL).  companion: DenseStack.companion_forward(...)
+        - the custom loop's output encoder runs in the integration network's grid (dib_integration_fwd_and_mlp_fwd)."""
         self.encoder_forward(x, row_idx, row0, batch, seed, step, deterministic, inference, defer_sums)
         ws, st = self.workspace(batch), self._stream()
-        if hidden_only:  # the output layer is evaluated by the fused head together with the loss
+        if companion is not None:
+            assert not hidden_only
+            check(self.lib.dib_integration_fwd_and_mlp_fwd(self.layout, batch, _ptr(self.params), _ptr(ws), *companion, st),
+                  "dib_integration_fwd_and_mlp_fwd")
+        elif hidden_only:  # the output layer is evaluated by the fused head together with the loss
             check(self.lib.dib_integration_fwd_hidden(self.layout, batch, _ptr(self.params), _ptr(ws), st),
                   "dib_integration_fwd_hidden")
         else:
@@ -259,7 +264,7 @@ class HipEngine:
 
     def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float,
                  on_integration_grads_ready=None, hidden_only: bool = False, on_encoder_front_grads_ready=None,
-                 finish_flags: int = 0, optimizer=None, integration_done: bool = False) -> None:
+                 finish_flags: int = 0, optimizer=None, integration_done: bool = False, companion=None) -> None:
         """Backward pass, with the hooks of the data-parallel bucket protocol:
         `on_integration_grads_ready(grads_slice)` is called as soon as the integration network's gradients (bucket 1) are
         final - right after dib_integration_bwd - so their all-reduce runs under the whole encoder-bank backward;
@@ -276,12 +281,18 @@ class HipEngine:
             # no bucket protocol: the rest of the backward pass in one entry - for small batches the dgrad chains are one
             # launch each and ALL weight gradients one grouped launch - then ONE tail launch
             assert on_encoder_front_grads_ready is None
-            check(self.lib.dib_backward(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(self.beta_dev),
-                                        float(inv_global_batch), _lib.BWD_INTEGRATION_DONE if integration_done else 0, _ptr(ws), st),
-                  "dib_backward")
+            bflags = _lib.BWD_INTEGRATION_DONE if integration_done else 0
+            if companion is not None:   # DenseStack.companion_backward(...): the output encoder's dgrad chain in the same grid
+                check(self.lib.dib_backward_and_mlp_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(self.beta_dev),
+                                                        float(inv_global_batch), bflags, _ptr(ws), *companion, st),
+                      "dib_backward_and_mlp_bwd")
+            else:
+                check(self.lib.dib_backward(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(self.beta_dev),
+                                            float(inv_global_batch), bflags, _ptr(ws), st), "dib_backward")
             self.step_tail(batch, -1, FIN | head | finish_flags | (_lib.TAIL_BUMP if optimizer and optimizer[0] == "adam" else 0),
                            inv_global_batch, optimizer=optimizer)
             return
+        assert companion is None, "a companion pass rides on dib_backward (no bucket hooks)"
         if not integration_done:   # (dib_integration_head_step already ran the integration network's backward)
             fn = self.lib.dib_integration_bwd_hidden if hidden_only else self.lib.dib_integration_bwd
             check(fn(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(ws), st), "dib_integration_bwd")
@@ -529,7 +540,8 @@ class HipEngine:
         return loss, gx, gy
 
     def backward_from_pred_grad(self, g_pred: torch.Tensor, row_idx, row0: int, batch: int, seed: int, step: int,
-                                inv_global_batch: Optional[float] = None, finish_flags: int = 0, optimizer=None) -> None:
+                                inv_global_batch: Optional[float] = None, finish_flags: int = 0, optimizer=None,
+                                companion=None) -> None:
         """Backward of the model given dL/d(model output) from a custom loss (reference train.py:216-219): the
         beta*KL term (models.py:118) is added inside the encoder-bank backward.  Gradients land in self.grads.
         finish_flags / optimizer: what the backward's last launch also does (step_tail: e.g. TAIL_KL | TAIL_METRICS after a
@@ -538,7 +550,7 @@ class HipEngine:
         dst = self.g_pred(batch)
         if not (g_pred.data_ptr() == dst.data_ptr() and g_pred.shape == dst.shape and g_pred.stride() == dst.stride()):
             dst.copy_(g_pred)   # (a custom loss may have written its gradient straight into the view)
-        self.backward(row_idx, row0, batch, seed, step, inv, finish_flags=finish_flags, optimizer=optimizer)
+        self.backward(row_idx, row0, batch, seed, step, inv, finish_flags=finish_flags, optimizer=optimizer, companion=companion)
 
     def mi_sandwich_bounds(self, enc_out: torch.Tensor, seed: int, step: int, feature: int):
         """(InfoNCE lower, leave-one-out upper) in nats for one batch enc_out [N, 2E] (reference utils.py:36-62)."""

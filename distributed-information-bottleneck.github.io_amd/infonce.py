@@ -237,15 +237,21 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
             # launches of a training step: encoder bank, integration network, Y encoder (gather + 3 layers), 3 InfoNCE kernels
             # (which write dL/d(embedding) where the two backward passes read it), the two backward chains, and ONE tail each
             # (partials + KL sums + accumulation + Adam + counter bump) - no torch kernel in the loop
-            eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training, defer_sums=True)   # noise always on (train.py:263-265)
-            emb_y = yenc.forward(ys, rows=idx)
+            # (row-tile batches: the Y encoder's forward rides in the integration network's grid, its dgrad chain in the
+            # integration backward's - 9 launches per training step)
+            comp = yenc.companion_forward(ys, rows=idx) if hasattr(yenc, "companion_forward") else None
+            ckw = {} if comp is None else dict(companion=comp)
+            eng.forward(xs, idx, 0, B, model.noise_seed, step, inference=not training, defer_sums=True, **ckw)   # noise always on (train.py:263-265)
+            emb_y = yenc.forward(ys, rows=idx) if comp is None else yenc.companion_output()
             loss, gx, gy = eng.infonce(eng.pred(B), emb_y, similarity, temperature, want_grads=training,
                                        out_gx=eng.g_pred(B) if training else None,
                                        out_gy=yenc.output_grad_buffer() if training else None, loss_out=slots.next())
             if training:
+                compb = yenc.companion_backward(gy) if comp is not None else None
                 eng.backward_from_pred_grad(gx, idx, 0, B, model.noise_seed, step, inv_global_batch=1.0 / batch_size,
-                                            finish_flags=_lib.TAIL_KL | _lib.TAIL_METRICS, optimizer=adam)
-                yenc.backward(gy, reduce=False)
+                                            finish_flags=_lib.TAIL_KL | _lib.TAIL_METRICS, optimizer=adam,
+                                            **({} if compb is None else dict(companion=compb)))
+                yenc.backward(gy, reduce=False, **({} if compb is None else dict(dgrad_done=True)))
                 yenc.adam_step(fused_reduce=True)                  # one Keras Adam over all variables (train.py:196,219)
             else:
                 eng.step_tail(B, -1, _lib.TAIL_KL | _lib.TAIL_METRICS, 1.0 / batch_size, metrics_acc=kl_acc["kl_validation"])

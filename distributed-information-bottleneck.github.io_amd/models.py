@@ -148,6 +148,7 @@ class DistributedIBNet:
         # data-parallel gradient all-reduce buckets (fit under torch.distributed): 3 = integration / encoder front layers /
         # last encoder layer, each issued as soon as it is final (default); 2 = integration / encoder bank; 1 = one all-reduce
         self.dp_small_batch_rows = 1024   # per-rank batches up to this many rows use ONE gradient bucket (see fit)
+        self.validation_merge_rows = 1024  # fit: full validation batches are evaluated together up to this many rows (0: one by one)
         self.dp_buckets = int(os.environ.get("DIB_DP_BUCKETS", "3"))
         if self.dp_buckets not in (1, 2, 3):
             raise ValueError(f"DIB_DP_BUCKETS={self.dp_buckets}: 1, 2 or 3")
@@ -504,14 +505,24 @@ class DistributedIBNet:
                     vsteps = 0
                     if getattr(eng, "step_dev", None) is not None:
                         eng.set_step_counter((1 << 31) + epoch)  # validation noise stream, same key as the eager path
-                    for s0 in range(0, nv, bs):
+                    # Validation batches do not depend on each other - no state changes between them, one noise key per epoch
+                    # (rows keyed by their dataset index) - and every History quantity is linear in per-row sums: k full
+                    # batches are evaluated as ONE launch set of k * bs rows with the per-batch 1 / bs scaling and counted as k
+                    # steps.  Same per-row numbers, sums in another order (fp32 rounding).  At the reference's default (8
+                    # validation batches of 128 rows per epoch, train.py:30-34) that is 3 launches per epoch instead of 24.
+                    kmerge = max(1, self.validation_merge_rows // bs) if world == 1 else 1
+                    s0 = 0
+                    while s0 < nv:
                         gb = min(bs, nv - s0)
-                        lo = (gb * rank) // world
-                        hi = (gb * (rank + 1)) // world
+                        nb = min(kmerge, (nv - s0) // bs) if gb == bs else 1
+                        rows = gb * nb
+                        lo = (rows * rank) // world
+                        hi = (rows * (rank + 1)) // world
                         if hi > lo:
                             eng.eval_step(xvd, yvd, None, s0 + lo, hi - lo, self.noise_seed, (1 << 31) + epoch, kind,
                                           inv_global_batch=1.0 / gb)
-                        vsteps += 1
+                        vsteps += nb
+                        s0 += rows
                     if getattr(eng, "step_dev", None) is not None:
                         eng.set_step_counter(self._step)
                     logs.update(self._epoch_logs(reduce_metrics(eng.read_metrics()), vsteps, "val_"))

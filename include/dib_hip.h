@@ -226,6 +226,9 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "fused_encoder"  (1)    layouts created afterwards may use the fused encoder-bank kernels (0: grouped-GEMM path; A/B, tests)
  *   "fused_head"     (1)    dib_output_head_fused_supported may answer 1
  *   "small_batch"    (1)    batches <= 1024 rows use the row-tile kernels of csrc/dib_small.h where the layout allows
+ *   "mlp_row_tiles"  (1)    ... and dib_mlp_small_supported may answer 1 (the custom loop's output encoder on the row-tile kernels)
+ *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
+ *   "attn_small_waves" (4)  dib_attention_bwd for neighbourhoods of <= 64 particles: 4 waves per workgroup (the round-4 kernel), or 8
  *   "num_cus"        (device) compute units the split rule prices rounds with (set from hipDeviceProp at table upload)
  * Returns DIB_E_ARG for an unknown key or a negative value. */
 int dib_set_tuning(const char* key, int value);
@@ -265,6 +268,44 @@ int dib_positional_encoding(const float* x, int64_t ldx, int n, int d, int n_fre
 /* the same of rows row_idx[0..n) of x (the shuffled batch of the custom loop, train.py:226-227); n_freq <= 1: a plain gather */
 int dib_positional_encoding_rows(const float* x, int64_t ldx, const int32_t* row_idx, int n, int d, int n_freq, float* out,
                                  dib_stream_t stream);
+
+/* The custom loop's output encoder (train.py:184-192: [PositionalEncoding ->] Dense(units, act)* -> Dense(out)) at ITS batch
+ * sizes (128 .. 1024 rows): the whole layer chain of 16 batch rows in one workgroup (csrc/dib_small.h), one launch for the
+ * forward (gather + positional encoding + every layer) and one for the dgrad chain, instead of 1 + L and L - 1 launches.
+ * The weight gradients stay one grouped GEMM on the stashes these write (dib_gemm_grouped, include/dib_st.h).
+ * Layer i: kernel [in_i][width[i]] row-major at params + w_off[i], bias at params + b_off[i]; in_0 = in_dim * max(n_freq, 1);
+ * width[n_hidden] = the output width (linear).  act: DIB_ACT_* of the hidden layers (linear / relu / leaky_relu only). */
+typedef struct dib_mlp_desc {
+  int64_t w_off[4], b_off[4];
+  int32_t n_hidden, width[4];
+  int32_t in_dim, n_freq, act;
+} dib_mlp_desc;   /* 96 bytes */
+/* 1 if (desc, batch) can take the row-tile kernels: 1-3 hidden layers and the output of widths % 16 == 0 (<= 1024), a
+ * piecewise-linear activation, batch <= 1024, "small_batch" and "mlp_row_tiles" tuning on */
+int dib_mlp_small_supported(const dib_mlp_desc* d, int batch);
+/* x: [rows][ldx] device matrix; row_idx (may be NULL: rows 0 .. n-1): the batch's rows.  Writes a0 [n][in_0] (the encoded
+ * input; may be NULL when no backward follows), h[i] [n][width[i]] post-activation stashes, i < n_hidden (NULL entries
+ * allowed together with a0 == NULL), out [n][width[n_hidden]]. */
+int dib_mlp_small_fwd(const dib_mlp_desc* d, const float* params, const float* x, int64_t ldx, const int32_t* row_idx, int n,
+                      float* a0, float* const* h, float* out, dib_stream_t stream);
+/* g_out [n][width[n_hidden]] = dL/d out; h: the forward's stashes; writes g[i] [n][width[i]] = dL/d(pre-activation of hidden
+ * layer i), i < n_hidden - with g_out and a0 / h the operands of every layer's weight gradient. */
+int dib_mlp_small_bwd(const dib_mlp_desc* d, const float* params, const float* g_out, float* const* h, float* const* g, int n,
+                      dib_stream_t stream);
+/* The custom loop runs TWO independent networks between the encoder bank and the loss, and again between the loss and the
+ * encoder bank's backward (train.py:203-219: model(x) and output_encoder(y); tape.gradient of both).  At its batch sizes
+ * each of them is a handful of workgroups, so the two entry points below give the pairs ONE grid each:
+ *   dib_integration_fwd_and_mlp_fwd = dib_integration_fwd(l, batch, params, ws) ; dib_mlp_small_fwd(d, mlp_params, x, ...)
+ *   dib_backward_and_mlp_bwd        = dib_backward(l, batch, params, grads, ...) ; dib_mlp_small_bwd(d, mlp_params, g_out, ...)
+ * with the same results (the same workgroup code runs on the same tiles); where the model's path has no row-tile launch
+ * to share (large batch, "small_batch" tuning off on its side) the MLP pass is launched on its own after it.
+ * DIB_E_UNSUPPORTED (nothing launched) if !dib_mlp_small_supported(d, n). */
+int dib_integration_fwd_and_mlp_fwd(dib_layout* l, int batch, const float* params, void* ws, const dib_mlp_desc* d,
+                                    const float* mlp_params, const float* x, int64_t ldx, const int32_t* row_idx, int n, float* a0,
+                                    float* const* h, float* out, dib_stream_t stream);
+int dib_backward_and_mlp_bwd(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev,
+                             float inv_global_batch, int flags, void* ws, const dib_mlp_desc* d, const float* mlp_params,
+                             const float* g_out, float* const* h, float* const* g, int n, dib_stream_t stream);
 
 /* Mutual-information sandwich bounds (utils.estimate_mi_sandwich_bounds, utils.py:10-73; used by
  * InfoPerFeatureCallback models.py:188-223): per-row InfoNCE-lower / leave-one-out-upper terms (nats, float64,

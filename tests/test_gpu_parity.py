@@ -545,6 +545,43 @@ def test_infonce_edge_shapes(kind, B, D):
     assert np.abs(gy.cpu().numpy() - g2).max() < tol * np.abs(g2).max() + 1e-7
 
 
+@pytest.mark.parametrize("B,D", [(128, 64), (100, 64), (64, 20), (33, 6)])
+@pytest.mark.parametrize("kind", ["l2sq", "l2", "cosine"])
+def test_infonce_one_launch_path(kind, B, D):
+    """dib_infonce_small_kernel (batch <= 128, dim <= 64: the reference's default batch and shared space, train.py:34,60) - the
+    whole symmetric InfoNCE in one launch - against the float64 autograd checker at the tolerances of the three-launch path,
+    against that path itself (dib_set_tuning("infonce_one_launch", 0)), and the loss-only call of the validation pass."""
+    import dib_torch_cpu as tc
+    from dib_amd import _lib
+    eng, _ = _engine(SPECS["no_hidden"])
+    rng = np.random.default_rng(B * 7 + D)
+    a = rng.standard_normal((B, D)).astype(np.float32)
+    b = (a + 0.7 * rng.standard_normal((B, D))).astype(np.float32)
+    temp = 0.7
+    if kind != "cosine":
+        S1 = orc.scaled_similarity(a, b, kind, 1.0)
+        off = S1[~np.eye(len(S1), dtype=bool)]
+        temp = float(max(np.median(np.diag(S1)) - np.median(off), 1.0) / 4.0)
+    ad, bd = eng.to_device(a), eng.to_device(b)
+    assert _lib.get_tuning("infonce_one_launch") == 1
+    n0 = eng.lib.dib_launch_count()
+    loss, gx, gy = eng.infonce(ad, bd, kind, temp)
+    assert eng.lib.dib_launch_count() - n0 == 1
+    loss_only, _, _ = eng.infonce(ad, bd, kind, temp, want_grads=False)
+    try:
+        _lib.set_tuning("infonce_one_launch", 0)
+        loss3, gx3, gy3 = eng.infonce(ad, bd, kind, temp)
+    finally:
+        _lib.set_tuning("infonce_one_launch", 1)
+    ref, g1, g2 = tc.infonce_loss_and_grads(a, b, kind, temp)
+    assert abs(float(loss.item()) - ref) < 2e-5 * (1 + abs(ref)), (float(loss.item()), ref)
+    assert float(loss_only.item()) == float(loss.item())
+    assert abs(float(loss.item()) - float(loss3.item())) < 1e-5 * (1 + abs(ref))
+    for got, got3, want in ((gx, gx3, g1), (gy, gy3, g2)):
+        assert np.abs(got.cpu().numpy() - want).max() < 2e-4 * np.abs(want).max() + 1e-9
+        assert (got - got3).abs().max().item() < 2e-5 * np.abs(want).max() + 1e-9
+
+
 def test_mi_sandwich_bounds_at_the_reference_evaluation_size():
     """utils.py:10-11 evaluates the bounds on batches of 1024 (evaluation_batch_size); embedding dimension 32 (train.py:55).
     Device float64 log-sum-exp kernel vs the literal restatement of utils.py:36-62 on the device's own samples."""
@@ -597,6 +634,108 @@ def test_dense_stack_matches_numpy(n):
         assert np.abs(got_w - gw).max() < 2e-4 * (1 + np.abs(gw).max()) and np.abs(got_b - gb).max() < 2e-4 * (1 + np.abs(gb).max())
         if l > 0:
             gg = (gg @ Ws[l].T) * (hs[l] > 0)
+
+
+@pytest.mark.parametrize("n,units,out,act,pe,gather", [(128, [128, 128], 64, "relu", True, True),
+                                                       (37, [128, 128], 64, "leaky_relu", True, False),
+                                                       (1000, [64, 32, 48], 16, "relu", False, True),
+                                                       (1, [32], 32, None, True, True)])
+def test_dense_stack_row_tile_kernels(n, units, out, act, pe, gather):
+    """The output encoder at the custom loop's batch sizes (train.py:184-192 at B = 128 .. 1024): dib_mlp_small_fwd / _bwd - gather
+    + PositionalEncoding + every layer in one launch, the dgrad chain in another (csrc/dib_small.h) - against float64 numpy, and
+    against the layer-by-layer grouped-GEMM launches of the same DenseStack (dib_set_tuning("small_batch", 0))."""
+    from dib_amd import _lib
+    from dib_amd.dense import DenseStack
+    eng, _ = _engine(SPECS["no_hidden"])
+    nf = 5 if pe else 1
+    ds = DenseStack(eng, 6, units, out, act, pe, nf, seed=4)
+    L = len(units) + 1
+    rng = np.random.default_rng(n)
+    ytab = rng.standard_normal((n + 9, 6)).astype(np.float32)
+    rows = rng.permutation(n + 9)[:n].astype(np.int32) if gather else None
+    for l in range(L):
+        ds.bias(l).copy_(torch.tensor(rng.standard_normal(ds.dims[l][1]) * 0.1, dtype=torch.float32))
+    yd = eng.to_device(ytab if gather else ytab[:n])
+    rd = eng.to_device(rows, dtype=torch.int32) if gather else None
+    assert ds.lib.dib_mlp_small_supported(ctypes.byref(ds._desc), n) == 1
+    g = rng.standard_normal((n, out)).astype(np.float32)
+    res = {}
+    try:
+        for small in (1, 0):
+            _lib.set_tuning("small_batch", small)
+            o = ds.forward(yd, rows=rd)
+            assert ds._last["small"] == bool(small)
+            o = o.clone()
+            ds.backward(eng.to_device(g))
+            torch.cuda.synchronize()
+            res[small] = (o.cpu().numpy(), ds.grads.clone().cpu().numpy())
+    finally:
+        _lib.set_tuning("small_batch", 1)
+    # float64 numpy
+    yb = (ytab[rows] if gather else ytab[:n]).astype(np.float64)
+    h = orc.positional_encoding(yb, [2 ** k for k in range(1, nf)]) if pe else yb
+    slope = {"relu": 0.0, "leaky_relu": 0.2, None: 1.0}[act]
+    Ws = [ds.kernel(l).cpu().numpy().astype(np.float64) for l in range(L)]
+    bs = [ds.bias(l).cpu().numpy().astype(np.float64) for l in range(L)]
+    hs = [h]
+    for l in range(L):
+        z = hs[-1] @ Ws[l] + bs[l]
+        hs.append(np.where(z > 0, z, slope * z) if l < L - 1 else z)
+    ref_g = np.zeros(ds.n_params)
+    gg = g.astype(np.float64)
+    for l in reversed(range(L)):
+        i, o_ = ds.dims[l]
+        ref_g[ds.w_off[l]: ds.w_off[l] + i * o_] = (hs[l].T @ gg).reshape(-1)
+        ref_g[ds.b_off[l]: ds.b_off[l] + o_] = gg.sum(0)
+        if l > 0:
+            gg = (gg @ Ws[l].T) * np.where(hs[l] > 0, 1.0, slope)
+    for small in (1, 0):
+        o, gr = res[small]
+        assert np.abs(o - hs[-1]).max() < 2e-5 * (1 + np.abs(hs[-1]).max()), small
+        assert np.abs(gr - ref_g).max() < 2e-4 * (1 + np.abs(ref_g).max()), small
+    assert np.abs(res[1][0] - res[0][0]).max() < 2e-5 * (1 + np.abs(res[0][0]).max())
+
+
+@pytest.mark.parametrize("arch,B", [("pendulum", 128), ("pendulum", 100), ("plain", 1000), ("no_row_tiles", 128)])
+def test_companion_grids_equal_the_separate_launches(arch, B):
+    """include/dib_hip.h dib_integration_fwd_and_mlp_fwd / dib_backward_and_mlp_bwd: the custom loop's two networks in one grid
+    each (train.py:203-219) against the separate entry points - the same workgroup code on the same tiles, so every output,
+    stash and gradient must be BIT-identical.  "no_row_tiles": an X model whose integration network has no row-tile path
+    (tanh) - the output encoder's pass is then launched on its own by the same entry point."""
+    from dib_amd.dense import DenseStack
+    from dib_amd.engine import HipEngine
+    if arch == "no_row_tiles":
+        spec = orc.DIBSpec([2, 1], [32, 32], [64], 64, feature_embedding_dimension=16, activation_fn="tanh")
+    else:
+        spec = _SMALL_ARCHS[arch][0]
+    eng = HipEngine(**spec_kwargs(spec), init_seed=3)
+    eng.set_beta(0.05)
+    D = spec.output_dimensionality
+    ds = DenseStack(eng, 6, [128, 128], D, "relu", True, 5, seed=9)
+    rng = np.random.default_rng(B)
+    nin = sum(spec.feature_dimensionalities)
+    xd = eng.to_device(rng.standard_normal((B + 5, nin)).astype(np.float32))
+    yd = eng.to_device(rng.standard_normal((B + 5, 6)).astype(np.float32))
+    idx = eng.to_device(rng.permutation(B + 5)[:B].astype(np.int32), dtype=torch.int32)
+    gp = eng.to_device(rng.standard_normal((B, D)).astype(np.float32) / B)
+    gy = eng.to_device(rng.standard_normal((B, D)).astype(np.float32) / B)
+    recs = []
+    for paired in (False, True):
+        eng.grads.zero_(); ds.grads.zero_()
+        comp = ds.companion_forward(yd, rows=idx) if paired else None
+        assert not paired or comp is not None
+        eng.forward(xd, idx, 0, B, 7, 3, companion=comp)
+        emb_y = (ds.companion_output() if paired else ds.forward(yd, rows=idx)).clone()
+        pred = eng.pred(B).clone()
+        compb = ds.companion_backward(gy) if paired else None
+        eng.backward_from_pred_grad(gp, idx, 0, B, 7, 3, inv_global_batch=1.0 / B, companion=compb)
+        ds.backward(gy, dgrad_done=paired)
+        torch.cuda.synchronize()
+        recs.append(dict(emb_y=emb_y, pred=pred, xg=eng.grads.clone(), yg=ds.grads.clone(), gu=eng.g_u(B).clone()))
+    a, b = recs
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert torch.isfinite(b["yg"]).all() and b["yg"].abs().max() > 0 and b["xg"].abs().max() > 0
 
 
 def test_infonce_training_loop_on_pendulum(tmp_path):
@@ -998,7 +1137,7 @@ def test_tuning_switchboard_is_the_only_hidden_input():
     from dib_amd.engine import HipEngine
     lib = _lib.load_library()
     for key in ("fwd_small_wgs", "fwd_narrow_wgs", "stream_rows", "split_policy", "split_overhead", "fused_encoder", "fused_head",
-                "small_batch", "num_cus"):
+                "small_batch", "mlp_row_tiles", "infonce_one_launch", "attn_small_waves", "num_cus"):
         v = _lib.get_tuning(key)
         _lib.set_tuning(key, v + 1)
         assert _lib.get_tuning(key) == v + 1

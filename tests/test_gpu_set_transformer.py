@@ -253,6 +253,43 @@ def test_attention_backward_score_stash_equals_recompute(B, P, H):
         assert (a.double().cpu() - b).abs().max() <= 2e-5 * b.abs().max() + 1e-6, name
 
 
+@pytest.mark.parametrize("B,P,H", [(2, 50, 3), (1, 64, 2), (3, 1, 1), (2, 33, 12)])
+def test_attention_backward_8_waves_equals_4_waves(B, P, H):
+    """csrc/dib_attn_small.h: the 8-wave backward (two waves per SIMD, the five products split between the wave groups) runs
+    every dot product in the order of the 4-wave kernel it replaces - dq / dk / dv must be BIT-identical
+    (dib_set_tuning("attn_small_waves", 4) selects the old kernel)."""
+    import ctypes
+    from dib_amd import _lib
+    from dib_amd._lib import check, load_library
+    lib = load_library()
+    D, dev = 128, torch.device("cuda:0")
+    T, ld = B * P, H * D
+    g = torch.Generator(device="cpu").manual_seed(B * 77 + P)
+    mk = lambda: (torch.randn((T, ld), generator=g) * 0.5).to(dev)
+    q, k, v, do = mk(), mk(), mk(), mk()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale = 1.0 / D ** 0.5
+    o = torch.zeros_like(q)
+    lse = torch.zeros(B * H * P, device=dev)
+    ws = torch.zeros(int(lib.dib_attention_bwd_workspace_bytes(B, P, H)) // 4, device=dev)
+    check(lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, ld, scale, p(o), p(lse), ctypes.c_void_p(0), st), "fwd")
+    res = {}
+    default = _lib.get_tuning("attn_small_waves")
+    try:
+        for waves in (8, 4):
+            _lib.set_tuning("attn_small_waves", waves)
+            dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+            check(lib.dib_attention_bwd(p(q), p(k), p(v), p(o), p(do), p(lse), ctypes.c_void_p(0), B, P, H, D, ld, scale, p(dq),
+                                        p(dk), p(dv), p(ws), st), "bwd")
+            torch.cuda.synchronize()
+            res[waves] = (dq, dk, dv)
+    finally:
+        _lib.set_tuning("attn_small_waves", default)
+    for name, a, b in zip(("dq", "dk", "dv"), res[8], res[4]):
+        assert torch.isfinite(a).all() and torch.equal(a, b), name
+
+
 def test_train_steps_match_oracle_adam():
     """Three notebook train steps (lr warm-up value, per-step beta, Keras Adam) against the oracle."""
     spec = sto.SetTransformerSpec(number_attention_blocks=2)

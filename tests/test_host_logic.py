@@ -51,6 +51,40 @@ def test_fit_history_contract_matches_oracle_fit():
                        atol=1e-6)
 
 
+def test_fit_evaluates_full_validation_batches_together():
+    """fit's validation pass (reference train.py:157-166 validation_data=): full batches are independent and every History
+    quantity is linear in per-row sums, so k of them run as one launch set of k * batch_size rows scaled by 1 / batch_size and
+    counted as k steps (model.validation_merge_rows); a ragged last batch stays on its own.  Same History as the oracle's
+    batch-by-batch pass, fewer engine calls."""
+    import dib_amd
+    spec = orc.DIBSpec([1, 1, 1, 1], [8], [8], 1, feature_embedding_dimension=4)
+    x, y = _si_circuit()
+    hists, calls = [], []
+    for merge in (1024, 0):
+        model = _model(spec, noise_seed=3, shuffle_seed=5, init_seed=1)
+        model.validation_merge_rows = merge
+        opt = dib_amd.optimizers.get("adam")
+        opt.learning_rate = 1e-2
+        model.compile(optimizer=opt, loss=dib_amd.losses.BinaryCrossentropy(from_logits=True), metrics=["accuracy"])
+        eng = model._ensure_engine()
+        seen = []
+        inner = eng.eval_step
+        eng.eval_step = lambda *a, _inner=inner, _seen=seen, **k: (_seen.append((a[3], a[4], k.get("inv_global_batch"))), _inner(*a, **k))[1]
+        hists.append(model.fit(x, y, epochs=2, shuffle=True, batch_size=24, verbose=False, validation_data=(x, y)).history)
+        calls.append(seen)
+    p = orc.glorot_uniform_init(spec, 1)
+    ref = orc.fit(spec, p, x, y, epochs=2, batch_size=24, loss_kind="bce_logits", beta_fn=lambda e: 1.0, lr=1e-2,
+                  validation_data=(x, y), noise_seed=3, shuffle_seed=5, metrics=["accuracy"])
+    assert len(x) == 64
+    assert calls[0] == [(0, 48, 1.0 / 24), (48, 16, 1.0 / 16)] * 2                       # 2 full batches together, then the ragged one
+    assert calls[1] == [(0, 24, 1.0 / 24), (24, 24, 1.0 / 24), (48, 16, 1.0 / 16)] * 2
+    for k in ref:
+        if k in ("beta", "val_beta"):
+            continue
+        assert np.allclose(hists[0][k], ref[k], rtol=1e-9, atol=1e-12), k
+        assert np.allclose(hists[1][k], ref[k], rtol=1e-9, atol=1e-12), k
+
+
 def test_beta_variable_and_annealing_callback():
     import dib_amd
     spec = orc.DIBSpec([1, 1], [4], [4], 1, feature_embedding_dimension=4)

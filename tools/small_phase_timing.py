@@ -43,5 +43,25 @@ def main():
         t[5] - t[0], t[17] - t[16], t[18] - t[17], t[19] - t[18], t[22] - t[19], t[22] - t[16]))
 
 
+def infonce_main():
+    """phase marks [56, 64) of dib_infonce_small_kernel at the reference's default batch (B = 128, shared space 64, l2)"""
+    from dib_amd.engine import HipEngine
+    B, D = 128, 64
+    eng = HipEngine([1, 1], [], [], 1, feature_embedding_dimension=4)
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((B, D)).astype(np.float32)
+    b = (a + 0.7 * rng.standard_normal((B, D))).astype(np.float32)
+    ad, bd = eng.to_device(a), eng.to_device(b)
+    read = eng.lib.dib_small_debug_read
+    out = (ctypes.c_longlong * 64)()
+    names = ["stage X, Y + norms", "S = sim(X Y^T)", "row / column lse", "loss", "coefficients + R", "C . Other (MFMA)", "epilogue"]
+    for it in range(4):
+        junk = torch.randn(1 << 22, device=eng.device).sum()   # other work between the launches, as in a training step
+        eng.infonce(ad, bd, "l2", 4.0)
+        assert read(out) == 0
+        t = np.array(list(out), dtype=np.float64) / 100.0
+        print("dib_infonce_small_kernel (us):", {n: round(t[57 + i] - t[56 + i], 2) for i, n in enumerate(names)}, "total", round(t[63] - t[56], 2))
+
+
 if __name__ == "__main__":
-    main()
+    infonce_main() if "infonce" in sys.argv[1:] else main()
