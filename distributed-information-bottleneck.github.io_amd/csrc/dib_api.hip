@@ -207,7 +207,7 @@ struct Tuning {
   int small_batch = 1;       // batches <= 1024 rows: row-tile kernels (csrc/dib_small.h) where the layout allows
   int mlp_row_tiles = 1;     // ... and for a plain MLP (dib_mlp_small_*: the custom loop's output encoder)
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
-  int attn_small_waves = 4;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
+  int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int num_cus = 256;         // compute units of the device (set from hipDeviceProp by the first dib_layout_upload_tables)
 };
 inline Tuning& tuning() { static Tuning t; return t; }
@@ -1422,7 +1422,7 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "small_batch")) return &t.small_batch;
   if (!std::strcmp(key, "mlp_row_tiles")) return &t.mlp_row_tiles;
   if (!std::strcmp(key, "infonce_one_launch")) return &t.infonce_one_launch;
-  if (!std::strcmp(key, "attn_small_waves")) return &t.attn_small_waves;
+  if (!std::strcmp(key, "attn_small_bwd_waves")) return &t.attn_small_bwd_waves;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
   return nullptr;
 }
@@ -2103,7 +2103,7 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
       if (e != hipSuccess) return (int)e;
     }
     ProfScope ps(kProfAttnBwd, st);
-    if (knobs().attn_small_waves >= 8) DIB_LAUNCH(dib_attn_small_bwd8_kernel, dim3(H, B), dim3(512), lds, st, a);
+    if (knobs().attn_small_bwd_waves >= 8) DIB_LAUNCH(dib_attn_small_bwd8_kernel, dim3(H, B), dim3(512), lds, st, a);
     else DIB_LAUNCH(dib_attn_small_bwd_kernel, dim3(H, B), dim3(256), lds, st, a);
     return (int)hipGetLastError();
   }

@@ -330,7 +330,10 @@ dib_attn_small_bwd_kernel(DibAttnArgs a) {
 //   lo: P, delta, dS (the 16 exponentials per lane)
 //   lo: dV = P^T dO  hi: dK = dS^T (scale Q)        (the same code on different tiles: two 32 x 32 tiles per wave)
 //   all: dQ = scale dS K, one 32 x 32 tile per wave (query block wave & 1, columns 32 (wave >> 1))
-// 160 MFMAs per wave instead of 320; every sum in the order of the 4-wave kernel (bit-identical results).
+// 160 MFMAs per wave instead of 320; every sum in the order of the 4-wave kernel (bit-identical results).  Same-box A/B of the
+// notebook-size step: 1.488 -> 1.446 ms (57.8 -> 49.5 us per launch; the launch moves 69 MB, ~ 17 us at HBM speed, in 1.5
+// rounds of workgroups).  The same split of the FORWARD kernel measured 1.5 % SLOWER on the step (its exchange tile and the
+// idle half of the softmax cost more than the overlap buys) and was not kept (profiles/r05t_attention_8_waves_ab.txt).
 // =====================================================================================================================
 __device__ __forceinline__ void dib_attn_small_load8(float* __restrict__ T, const float* __restrict__ base, long long ld, int P,
                                                      int tid, float mul) {

@@ -307,15 +307,26 @@ __device__ __forceinline__ void dib_small_bwd(const float* g, int pg, int N, con
 // global [rows_valid][width] (leading dimension ld) -> LDS tile [16][pitch]; rows >= rows_valid are zero-filled
 __device__ __forceinline__ void dib_small_load_tile(const float* __restrict__ src, long long ld, int width, int rows_valid,
                                                     float* dst, int pitch) {
-  // (a variant with each thread owning a float4 column of all 16 rows - 16 loads in flight - measured 1.5 % SLOWER on the
-  // set-transformer step in a same-box A/B, profiles/r05n_row_tile_variants_ab.txt: the flat loop below already overlaps its
-  // loads across the 8 waves)
-  const int w4 = width >> 2;
-  for (int i = threadIdx.x; i < DIB_SMALL_ROWS * w4; i += DIB_SMALL_THREADS) {
-    const int row = i / w4, c = (i - row * w4) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < rows_valid) v = *reinterpret_cast<const float4*>(src + (long long)row * ld + c);
-    *reinterpret_cast<float4*>(dst + row * pitch + c) = v;
+  // Four loads per thread in flight per trip (the rolled loop the compiler makes of the plain form issues ONE load per trip
+  // and waits for it: the set-transformer chain's 16 x 1536 context tile was 12 dependent L2 round trips, ~9 us of a 45 us
+  // kernel).  A variant with each thread owning a float4 column of all 16 rows - 16 loads in flight - measured 1.5 % SLOWER
+  // on the set-transformer step (profiles/r05n_row_tile_variants_ab.txt): on the many 32-wide tiles only 8 threads had work.
+  const int w4 = width >> 2, total = DIB_SMALL_ROWS * w4;
+#pragma unroll 1
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * DIB_SMALL_THREADS) {
+    float4 v[4];
+    int off[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * DIB_SMALL_THREADS;
+      const int row = i / w4, c = (i - row * w4) * 4;
+      off[u] = row * pitch + c;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < total && row < rows_valid) v[u] = *reinterpret_cast<const float4*>(src + (long long)row * ld + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * DIB_SMALL_THREADS < total) *reinterpret_cast<float4*>(dst + off[u]) = v[u];
   }
 }
 

@@ -228,7 +228,8 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "small_batch"    (1)    batches <= 1024 rows use the row-tile kernels of csrc/dib_small.h where the layout allows
  *   "mlp_row_tiles"  (1)    ... and dib_mlp_small_supported may answer 1 (the custom loop's output encoder on the row-tile kernels)
  *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
- *   "attn_small_waves" (4)  dib_attention_bwd for neighbourhoods of <= 64 particles: 4 waves per workgroup (the round-4 kernel), or 8
+ *   "attn_small_bwd_waves" (8) dib_attention_bwd for neighbourhoods of <= 64 particles: 8 waves per workgroup (two per SIMD), or 4
+ *                           (the round-4 kernel; bit-identical results)
  *   "num_cus"        (device) compute units the split rule prices rounds with (set from hipDeviceProp at table upload)
  * Returns DIB_E_ARG for an unknown key or a negative value. */
 int dib_set_tuning(const char* key, int value);

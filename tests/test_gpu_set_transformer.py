@@ -257,7 +257,7 @@ def test_attention_backward_score_stash_equals_recompute(B, P, H):
 def test_attention_backward_8_waves_equals_4_waves(B, P, H):
     """csrc/dib_attn_small.h: the 8-wave backward (two waves per SIMD, the five products split between the wave groups) runs
     every dot product in the order of the 4-wave kernel it replaces - dq / dk / dv must be BIT-identical
-    (dib_set_tuning("attn_small_waves", 4) selects the old kernel)."""
+    (dib_set_tuning("attn_small_bwd_waves", 4) selects the old kernel)."""
     import ctypes
     from dib_amd import _lib
     from dib_amd._lib import check, load_library
@@ -270,23 +270,25 @@ def test_attention_backward_8_waves_equals_4_waves(B, P, H):
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     scale = 1.0 / D ** 0.5
-    o = torch.zeros_like(q)
-    lse = torch.zeros(B * H * P, device=dev)
     ws = torch.zeros(int(lib.dib_attention_bwd_workspace_bytes(B, P, H)) // 4, device=dev)
-    check(lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, ld, scale, p(o), p(lse), ctypes.c_void_p(0), st), "fwd")
     res = {}
-    default = _lib.get_tuning("attn_small_waves")
+    keys = ("attn_small_bwd_waves",)
+    default = [_lib.get_tuning(k_) for k_ in keys]
     try:
         for waves in (8, 4):
-            _lib.set_tuning("attn_small_waves", waves)
-            dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+            for k_ in keys:
+                _lib.set_tuning(k_, waves)
+            o, dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(4))
+            lse = torch.full((B * H * P,), float("nan"), device=dev)
+            check(lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, ld, scale, p(o), p(lse), ctypes.c_void_p(0), st), "fwd")
             check(lib.dib_attention_bwd(p(q), p(k), p(v), p(o), p(do), p(lse), ctypes.c_void_p(0), B, P, H, D, ld, scale, p(dq),
                                         p(dk), p(dv), p(ws), st), "bwd")
             torch.cuda.synchronize()
-            res[waves] = (dq, dk, dv)
+            res[waves] = (o, lse, dq, dk, dv)
     finally:
-        _lib.set_tuning("attn_small_waves", default)
-    for name, a, b in zip(("dq", "dk", "dv"), res[8], res[4]):
+        for k_, d_ in zip(keys, default):
+            _lib.set_tuning(k_, d_)
+    for name, a, b in zip(("o", "lse", "dq", "dk", "dv"), res[8], res[4]):
         assert torch.isfinite(a).all() and torch.equal(a, b), name
 
 

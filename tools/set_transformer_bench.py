@@ -38,8 +38,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graphs", type=int, default=0, help="1: one hipGraph replay per step (SetTransformerDIB(use_graphs=True))")
     ap.add_argument("--chain", type=int, default=1, help="0: the layer-by-layer launches instead of the token-chain kernels (A/B)")
+    ap.add_argument("--tuning", default="", help="dib_set_tuning keys, e.g. attn_small_waves=8 (A/B)")
     a = ap.parse_args()
     import dib_amd
+    from dib_amd import _lib
+    for kv in filter(None, a.tuning.split(",")):
+        k, v = kv.split("=")
+        _lib.set_tuning(k.strip(), int(v))
     m = dib_amd.SetTransformerDIB(particle_feature_dimensions=a.features, attention=os.environ.get("DIB_ST_ATTENTION", "auto"),
                                   use_graphs=bool(a.graphs))
     m.use_chain = bool(a.chain)
@@ -60,7 +65,7 @@ def main():
     print(json.dumps({"workload": f"set-transformer DIB, {a.batch} neighbourhoods x {a.particles} particles x {a.features} features",
                       "ms_per_step": round(1e3 * dt, 3), "neighbourhoods_per_s": round(a.batch / dt, 1),
                       "algorithmic_TFLOPs": round(fl / dt / 1e12, 2), "params": m.n_params,
-                      "attention": m.attention_impl, "graph_replay": bool(a.graphs)}))
+                      "attention": m.attention_impl, "graph_replay": bool(a.graphs), "tuning": a.tuning}))
 
 
 if __name__ == "__main__":
