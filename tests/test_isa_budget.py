@@ -103,3 +103,18 @@ def test_no_kernel_of_the_library_uses_scratch_except_the_fused_backward(kernels
     assert len(kernels) >= 80
     offenders = {k: v["ScratchSize"] for k, v in kernels.items() if v["ScratchSize"] > 0}
     assert all("dib_fused_encoder_bwd_kernelILi128ELi128ELi32E" in k and v <= 32 for k, v in offenders.items()), offenders
+
+
+def test_round5_small_batch_kernels_keep_two_waves_per_simd(kernels):
+    """The kernels round 5 added for batches of <= 1024 rows / <= 64 particles run ONE workgroup per CU and rest on its 8 waves
+    being two per SIMD (profiles/HISTORY.md 13): 512-thread workgroups need <= 256 registers per wave.  The paired
+    integration kernel (argument set picked by blockIdx.y from the kernarg segment) must cost what the single one costs."""
+    single = _one(kernels, "dib_small_integration_kernel")
+    pair = _one(kernels, "dib_small_integration_pair_kernel")
+    assert pair["NumVgprs"] == single["NumVgprs"] and pair["ScratchSize"] == 0 and pair["mfma"] == single["mfma"]
+    for kind in (0, 1, 4):
+        k = _one(kernels, f"dib_infonce_small_kernelILi{kind}E")
+        assert k["NumVgprs"] + k["NumAgprs"] <= 128 and k["ScratchSize"] == 0   # (<= 128: four waves per SIMD would fit too)
+    b8, b4 = _one(kernels, "dib_attn_small_bwd8_kernel"), _one(kernels, "dib_attn_small_bwd_kernel")
+    assert b8["NumVgprs"] + b8["NumAgprs"] <= 256 and b8["ScratchSize"] == 0
+    assert b4["mfma"] == 320 and b8["mfma"] == 64 + 64 + 64 + 32   # S | dP (one per wave group), dV | dK (shared code), dQ tile
