@@ -30,7 +30,9 @@ namespace {
 
 constexpr int64_t kAlign = 64;  // floats (256 B)
 constexpr int kMaxSplits = 32;   // partial slabs of a split-batch weight gradient
-constexpr int kSmallMaxBatch = 1024;   // batches up to this many rows may take the row-tile kernels of dib_small.h
+// Row-tile kernels of dib_small.h: hard limits (they size workspace regions); WHICH batches take them is the "small_wgs" rule
+constexpr int kSmallMaxBatch = 2048;     // rows
+constexpr int kSmallMaxEncWgs = 1024;    // row tiles x features (d(W1|b1) partials: one [16][H1] block per encoder workgroup)
 constexpr int kSplitRows = 512;  // minimum batch rows per wgrad split: 8 K-tiles of 64 (measured: 2048 left mid-size batches with 16-256 workgroups)
 inline int64_t align_up(int64_t v, int64_t a = kAlign) { return (v + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -117,9 +119,10 @@ struct dib_layout {
     m.rows_per_split = rps;
     m.wgrad_partial = take(ns > 1 ? (int64_t)ns * align_up(n_params, 4) : 0);
     // fused backward: per-wave partials of d(W1|b1), [<= ceil(256/F) workgroups x 8 waves][F][16][H1]
-    // (small-batch path: one partial per 16-row tile, [<= kSmallMaxBatch / 16 tiles][F][16][H1])
+    // (small-batch path: one partial per 16-row tile, [<= kSmallMaxEncWgs (tile, feature) pairs][16][H1])
     m.dw1_partial = take(std::max<int64_t>(fused_id >= 0 && n_enc == 2 ? (int64_t)cdiv(256, F) * 8 * F * 16 * enc_units[0] : 0,
-                                           sb_enc && B <= kSmallMaxBatch ? (int64_t)cdiv(B, DIB_SMALL_ROWS) * F * 16 * enc_units[0] : 0));
+                                           sb_enc && B <= kSmallMaxBatch && (int64_t)cdiv(B, DIB_SMALL_ROWS) * F <= kSmallMaxEncWgs
+                                               ? (int64_t)cdiv(B, DIB_SMALL_ROWS) * F * 16 * enc_units[0] : 0));
     // [F][B][2] x 64-bit act' masks (fused fwd -> fused bwd), one bit per hidden unit
     m.h2mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
     m.h1mask = take(fused_id >= 0 ? (int64_t)F * B * 4 : 0);
@@ -204,7 +207,8 @@ struct Tuning {
   int split_overhead = 128;  // ... with this per-workgroup fixed cost, in batch rows (prologue + partial-tile store)
   int fused_encoder = 1;     // layouts created from now on may use the fused encoder-bank kernels (0: grouped-GEMM path)
   int fused_head = 1;        // dib_output_head_fused_supported may answer 1
-  int small_batch = 1;       // batches <= 1024 rows: row-tile kernels (csrc/dib_small.h) where the layout allows
+  int small_batch = 1;       // row-tile kernels (csrc/dib_small.h) where the layout allows, while ...
+  int small_wgs = 512;       // ... (row tiles of 16) x (features) <= this (and batch <= 2048)
   int mlp_row_tiles = 1;     // ... and for a plain MLP (dib_mlp_small_*: the custom loop's output encoder)
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
@@ -456,10 +460,17 @@ static int ensure_dynamic_lds(const void* fn, size_t bytes, int (&have)[64]) {
   return DIB_OK;
 }
 static int small_tiles(int batch) { return cdiv(batch, DIB_SMALL_ROWS); }
-static bool use_small_enc(const dib_layout* l, int batch) {
-  return knobs().small_batch && l->sb_enc && batch <= kSmallMaxBatch && (long long)small_tiles(batch) * l->F <= 8192;
+// The row-tile regime: while (row tiles x features) - the encoder kernels' workgroup count - is at most "small_wgs" (512: two
+// rounds of the 256 CUs).  Measured crossover of the Keras-path training step against the large-batch kernels, F = 2 .. 64 x
+// B = 128 .. 2048 (profiles/r05x_small_batch_crossover.txt): row tiles win at <= 512 (0.47 - 0.93 of the large path's time), lose
+// from 640 up (1.05 - 2.4 x); a fixed row limit of 1024 had F = 64 at B = 1024 at 1.8 x and left F = 4 at B = 2048 (the chaos
+// notebook's loop) on the large path at 1 / 0.8.
+static bool small_regime(const dib_layout* l, int batch) {
+  return knobs().small_batch && batch <= kSmallMaxBatch &&
+         (long long)small_tiles(batch) * l->F <= std::min(knobs().small_wgs, kSmallMaxEncWgs);
 }
-static bool use_small_int(const dib_layout* l, int batch) { return knobs().small_batch && l->sb_int && batch <= kSmallMaxBatch; }
+static bool use_small_enc(const dib_layout* l, int batch) { return l->sb_enc && small_regime(l, batch); }
+static bool use_small_int(const dib_layout* l, int batch) { return l->sb_int && small_regime(l, batch); }
 // the backward's d(W1|b1) comes as per-workgroup partials (fused backward or small-batch backward): how many
 static int enc_dw1_parts(const dib_layout* l, int batch) {
   if (use_small_enc(l, batch)) return small_tiles(batch);
@@ -1420,6 +1431,7 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "fused_encoder")) return &t.fused_encoder;
   if (!std::strcmp(key, "fused_head")) return &t.fused_head;
   if (!std::strcmp(key, "small_batch")) return &t.small_batch;
+  if (!std::strcmp(key, "small_wgs")) return &t.small_wgs;
   if (!std::strcmp(key, "mlp_row_tiles")) return &t.mlp_row_tiles;
   if (!std::strcmp(key, "infonce_one_launch")) return &t.infonce_one_launch;
   if (!std::strcmp(key, "attn_small_bwd_waves")) return &t.attn_small_bwd_waves;

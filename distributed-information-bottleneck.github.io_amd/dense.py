@@ -55,7 +55,7 @@ class DenseStack:
         self.lr_dev = torch.full((1,), 1e-3, dtype=torch.float32, device=self.device)
         self._plans: Dict[int, dict] = {}
         self._last: Optional[dict] = None
-        # batches <= 1024 rows: the whole layer chain of 16 rows in one workgroup (dib_mlp_small_fwd / _bwd, csrc/dib_small.h)
+        # batches <= 2048 rows: the whole layer chain of 16 rows in one workgroup (dib_mlp_small_fwd / _bwd, csrc/dib_small.h)
         self._desc = None
         if 2 <= len(self.dims) <= 4:
             d = _MlpDesc()

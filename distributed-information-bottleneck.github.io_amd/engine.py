@@ -347,7 +347,7 @@ class HipEngine:
         finish = _lib.TAIL_KL | (_lib.TAIL_LOSS_HEAD if fused_head else _lib.TAIL_LOSS) | (_lib.TAIL_METRICS if accumulate else 0)
         if fused_head:
             # encoder bank, then the integration network's whole share in one entry: hidden layers, output Dense(1) + loss and
-            # their backward down to dL/du (one launch of 16-row tiles for batches <= 1024 rows), hidden weight gradients
+            # their backward down to dL/du (one launch of 16-row tiles in the row-tile regime), hidden weight gradients
             self.encoder_forward(x, row_idx, row0, batch, seed, step, defer_sums=True)
             single = on_integration_grads_ready is None   # no bucket protocol: every weight gradient of the step in dib_backward
             check(self.lib.dib_integration_head_step(self.layout, kind, _ptr(y), y.stride(0), _ptr(row_idx), int(row0), batch,

@@ -157,7 +157,7 @@ int dib_integration_bwd_hidden(dib_layout* l, int batch, const float* params, fl
                                dib_stream_t stream);
 /* The three calls above as ONE entry (what a training / validation step with the fused head uses):
  *   dib_integration_head_step = dib_integration_fwd_hidden + dib_output_head_fused(flags) [+ dib_integration_bwd_hidden unless
- *   DIB_HEAD_NO_GRAD].  For batches <= 1024 rows the hidden layers, the head, the loss and the dgrad chain back to ws[G_U] run
+ *   DIB_HEAD_NO_GRAD].  For batches in the row-tile regime ("small_wgs" tuning key) the hidden layers, the head, the loss and the dgrad chain back to ws[G_U] run
  *   as one launch of 16-row tiles (csrc/dib_small.h; "small_batch" tuning key) instead of five GEMM launches. */
 int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
                               int batch, float inv_global_batch, int flags, const float* params, float* grads, void* ws,
@@ -165,7 +165,7 @@ int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int6
 /* dib_backward: everything of a step's backward pass that follows the loss, for single-GPU callers (the data-parallel bucket
  * protocol uses the separate entries below): dib_integration_bwd (skipped with DIB_BWD_INTEGRATION_DONE: the step ran
  * dib_integration_head_step(DIB_HEAD_DEFER_WGRAD), only its hidden-layer weight gradients are outstanding) + dib_encoder_bank_bwd.
- * For batches <= 1024 rows all weight gradients of the step are ONE grouped launch over the descriptor table that
+ * In the row-tile regime ("small_wgs") all weight gradients of the step are ONE grouped launch over the descriptor table that
  * dib_workspace_init wrote for this batch size.  Follow with dib_grads_finalize / dib_step_tail. */
 #define DIB_BWD_INTEGRATION_DONE 1
 int dib_backward(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev, float inv_global_batch,
@@ -225,7 +225,8 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "split_overhead" (128)  per-workgroup fixed cost, in batch rows, of that rule's cost model
  *   "fused_encoder"  (1)    layouts created afterwards may use the fused encoder-bank kernels (0: grouped-GEMM path; A/B, tests)
  *   "fused_head"     (1)    dib_output_head_fused_supported may answer 1
- *   "small_batch"    (1)    batches <= 1024 rows use the row-tile kernels of csrc/dib_small.h where the layout allows
+ *   "small_batch"    (1)    small batches use the row-tile kernels of csrc/dib_small.h where the layout allows, namely while
+ *   "small_wgs"      (512)  ceil(batch / 16) x number_features <= this (the measured crossover, profiles/r05x_*) and batch <= 2048
  *   "mlp_row_tiles"  (1)    ... and dib_mlp_small_supported may answer 1 (the custom loop's output encoder on the row-tile kernels)
  *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
  *   "attn_small_bwd_waves" (8) dib_attention_bwd for neighbourhoods of <= 64 particles: 8 waves per workgroup (two per SIMD), or 4
@@ -271,7 +272,7 @@ int dib_positional_encoding_rows(const float* x, int64_t ldx, const int32_t* row
                                  dib_stream_t stream);
 
 /* The custom loop's output encoder (train.py:184-192: [PositionalEncoding ->] Dense(units, act)* -> Dense(out)) at ITS batch
- * sizes (128 .. 1024 rows): the whole layer chain of 16 batch rows in one workgroup (csrc/dib_small.h), one launch for the
+ * sizes (128 .. 2048 rows): the whole layer chain of 16 batch rows in one workgroup (csrc/dib_small.h), one launch for the
  * forward (gather + positional encoding + every layer) and one for the dgrad chain, instead of 1 + L and L - 1 launches.
  * The weight gradients stay one grouped GEMM on the stashes these write (dib_gemm_grouped, include/dib_st.h).
  * Layer i: kernel [in_i][width[i]] row-major at params + w_off[i], bias at params + b_off[i]; in_0 = in_dim * max(n_freq, 1);
@@ -282,7 +283,7 @@ typedef struct dib_mlp_desc {
   int32_t in_dim, n_freq, act;
 } dib_mlp_desc;   /* 96 bytes */
 /* 1 if (desc, batch) can take the row-tile kernels: 1-3 hidden layers and the output of widths % 16 == 0 (<= 1024), a
- * piecewise-linear activation, batch <= 1024, "small_batch" and "mlp_row_tiles" tuning on */
+ * piecewise-linear activation, batch <= 2048, "small_batch" and "mlp_row_tiles" tuning on */
 int dib_mlp_small_supported(const dib_mlp_desc* d, int batch);
 /* x: [rows][ldx] device matrix; row_idx (may be NULL: rows 0 .. n-1): the batch's rows.  Writes a0 [n][in_0] (the encoded
  * input; may be NULL when no backward follows), h[i] [n][width[i]] post-activation stashes, i < n_hidden (NULL entries

@@ -1137,7 +1137,7 @@ def test_tuning_switchboard_is_the_only_hidden_input():
     from dib_amd.engine import HipEngine
     lib = _lib.load_library()
     for key in ("fwd_small_wgs", "fwd_narrow_wgs", "stream_rows", "split_policy", "split_overhead", "fused_encoder", "fused_head",
-                "small_batch", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "num_cus"):
+                "small_batch", "small_wgs", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "num_cus"):
         v = _lib.get_tuning(key)
         _lib.set_tuning(key, v + 1)
         assert _lib.get_tuning(key) == v + 1
@@ -1166,11 +1166,13 @@ _SMALL_ARCHS = {
 }
 
 
-@pytest.mark.parametrize("B", [1, 16, 37, 128, 1000])
+@pytest.mark.parametrize("B", [1, 16, 37, 128, 1000, 2048])
 @pytest.mark.parametrize("linear", [True, False])
 @pytest.mark.parametrize("arch", sorted(_SMALL_ARCHS))
 def test_small_batch_row_tile_kernels_equal_the_large_batch_path(arch, linear, B):
-    """csrc/dib_small.h (16-row tiles, batches <= 1024) against the large-batch kernels on the SAME engine, switched with
+    """csrc/dib_small.h (16-row tiles; the regime is (row tiles x features) <= "small_wgs" = 512 and <= 2048 rows: "north" with its 10
+    features leaves it between B = 128 and 1000 - both runs then take the large-batch kernels - the others stay in it up to
+    2048) against the large-batch kernels on the SAME engine, switched with
     dib_set_tuning("small_batch", .): forward stashes, KL / loss sums, prediction, every gradient, the validation step and the
     custom-loss contract, to fp32 summation-order tolerance.  linear=True (no activation): every quantity elementwise - the
     whole plumbing with no kinks.  linear=False (the architecture's own relu / leaky_relu): forward quantities elementwise;
