@@ -1071,14 +1071,14 @@ def test_step_tail_equals_the_separate_launches(arch, B, small, opt):
     """dib_step_tail (one launch: bucket reduce + fused-head reduce + KL / loss sums + metrics + optimizer + counter bump)
     against the separate entry points it replaces, three steps in a row on twin engines: gradients, the per-step scalars,
     the History accumulators and Adam's step count bit for bit (same fixed summation orders); parameters and moments to one
-    ulp-level tolerance.  small = 0: the large-batch kernels on both sides.  small = 1 (batches <= 1024): train_step runs the
+    ulp-level tolerance.  small = 0: the large-batch kernels on both sides.  small = 1 (batches in the row-tile regime): train_step runs the
     integration network's forward + head + dgrad chain as ONE row-tile launch (dib_integration_head_step), the separate entry
     points run it in pieces (hidden forward / fused head kernel / dgrad chain from the stashes): same values, different
     summation order in the head - compared to fp32 tolerance instead."""
     from dib_amd import _lib
     from dib_amd.engine import HipEngine
     if small and B > 1024:
-        pytest.skip("the row-tile kernels take batches <= 1024")
+        pytest.skip("beyond the row-tile regime for these layouts (dib_set_tuning small_wgs)")
     _lib.set_tuning("small_batch", small)
     try:
         _step_tail_case(arch, B, small, opt, HipEngine)
