@@ -557,10 +557,14 @@ class DistributedIBNet:
         n, bs = xd.shape[0], int(batch_size or 32)
         eng.read_metrics()
         steps = 0
-        for s0 in range(0, n, bs):
+        # full batches are evaluated together like fit's validation pass (same per-row numbers; see validation_merge_rows)
+        kmerge, s0 = max(1, self.validation_merge_rows // bs), 0
+        while s0 < n:
             b = min(bs, n - s0)
-            eng.eval_step(xd, yd, None, s0, b, self.noise_seed, (1 << 31) - 1, self.loss.kind)
-            steps += 1
+            nb = min(kmerge, (n - s0) // bs) if b == bs else 1
+            eng.eval_step(xd, yd, None, s0, b * nb, self.noise_seed, (1 << 31) - 1, self.loss.kind, inv_global_batch=1.0 / b)
+            steps += nb
+            s0 += b * nb
         return self._epoch_logs(eng.read_metrics(), steps, "")
 
 

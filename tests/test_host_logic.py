@@ -85,6 +85,30 @@ def test_fit_evaluates_full_validation_batches_together():
         assert np.allclose(hists[1][k], ref[k], rtol=1e-9, atol=1e-12), k
 
 
+def test_evaluate_merges_full_batches_like_fit():
+    """model.evaluate (Keras surface of the reference's `model.evaluate`-style checks): the same batching rule as fit's validation
+    pass - identical logs with validation_merge_rows = 0 and 1024, fewer engine calls."""
+    import dib_amd
+    spec = orc.DIBSpec([1, 1, 1, 1], [8], [8], 1, feature_embedding_dimension=4)
+    x, y = _si_circuit()
+    logs, calls = [], []
+    for merge in (1024, 0):
+        model = _model(spec, noise_seed=3, shuffle_seed=5, init_seed=1)
+        model.validation_merge_rows = merge
+        model.compile(optimizer=dib_amd.optimizers.get("adam"), loss=dib_amd.losses.BinaryCrossentropy(from_logits=True),
+                      metrics=["accuracy"])
+        eng = model._ensure_engine()
+        seen = []
+        inner = eng.eval_step
+        eng.eval_step = lambda *a, _inner=inner, _seen=seen, **k: (_seen.append((a[3], a[4])), _inner(*a, **k))[1]
+        logs.append(model.evaluate(x, y, batch_size=24))
+        calls.append(seen)
+    assert calls[0] == [(0, 48), (48, 16)] and calls[1] == [(0, 24), (24, 24), (48, 16)]
+    assert set(logs[0]) == set(logs[1])
+    for k in logs[0]:
+        assert np.isclose(logs[0][k], logs[1][k], rtol=1e-9, atol=1e-12), k
+
+
 def test_beta_variable_and_annealing_callback():
     import dib_amd
     spec = orc.DIBSpec([1, 1], [4], [4], 1, feature_embedding_dimension=4)
