@@ -1142,7 +1142,7 @@ static int encoder_bank_bwd_stages(dib_layout* l, int batch, const float* params
 
 // The integration network's whole share of a step with the fused 1-unit head: hidden layers forward, output Dense(1) + loss,
 // and (training) the head's backward, the dgrad chain back to dL/du and the hidden layers' weight gradients.
-// = dib_integration_fwd_hidden + dib_output_head_fused(flags) + dib_integration_bwd_hidden; for batches <= 1024 rows the
+// = dib_integration_fwd_hidden + dib_output_head_fused(flags) + dib_integration_bwd_hidden; in the row-tile regime (small_regime) the
 // forward, the head and the dgrad chain are ONE launch of dib_small_integration_kernel (16-row tiles, csrc/dib_small.h).
 int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0,
                               int batch, float inv_global_batch, int flags, const float* params, float* grads, void* ws,
@@ -1190,7 +1190,7 @@ int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int6
 // Everything of a step's backward pass that follows the loss, in one entry (single-GPU callers; the data-parallel bucket
 // protocol keeps the separate entries): [dib_integration_bwd unless DIB_BWD_INTEGRATION_DONE] + dib_encoder_bank_bwd, with
 // the weight gradients of the integration network's hidden layers that dib_integration_head_step(DIB_HEAD_DEFER_WGRAD) left
-// (DIB_BWD_INTEGRATION_DONE).  For batches <= 1024 rows ALL weight gradients of the step - encoder layers 2.., integration
+// (DIB_BWD_INTEGRATION_DONE).  In the row-tile regime ALL weight gradients of the step - encoder layers 2.., integration
 // layers - are ONE grouped launch over the per-batch descriptor table dib_workspace_init wrote into the workspace.
 int dib_backward(dib_layout* l, int batch, const float* params, float* grads, const float* beta_dev, float inv_global_batch,
                  int flags, void* ws, dib_stream_t stream) {

@@ -3,7 +3,8 @@
 // The reference's own runs are small-batch (train.py:30-34: B = 128, 11 000 epochs; chaos notebook: B = 2048).  There the
 // fused kernels of dib_fused.h put ONE workgroup on each feature - 10 workgroups on 256 CUs at the Boolean-circuit default,
 // 31 us of which 11 us are the MFMAs of one CU - and the integration network ran as five GEMM launches of 8 workgroups
-// each.  Below ~1024 rows the right decomposition is the other one: a workgroup owns 16 batch ROWS (the smallest MFMA tile,
+// each.  While (row tiles x features) stays within two rounds of the CUs (dib_api.hip small_regime; measured crossover
+// profiles/r05x_small_batch_crossover.txt) the right decomposition is the other one: a workgroup owns 16 batch ROWS (the smallest MFMA tile,
 // v_mfma_f32_16x16x4_f32, exact fp32), keeps those rows' activations in LDS through the whole layer chain and streams the
 // weights from L2 straight into the MFMA B operand (each weight is used once per workgroup: nothing to stage).
 //   dib_small_encoder_fwd_kernel  grid (row tiles, F): gather + PositionalEncoding (models.py:22-23) + Dense chain

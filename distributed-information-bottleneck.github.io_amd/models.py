@@ -444,7 +444,7 @@ class DistributedIBNet:
                     pending = []
                     nb = self.dp_buckets if (dist is not None and hasattr(eng, "part_range")) else 1
                     if nb > 1 and gb // world <= self.dp_small_batch_rows:
-                        # small per-rank batches (<= 1024 rows: the row-tile kernels, one grouped launch for every weight
+                        # small per-rank batches (<= 1024 rows: a handful of kernels per step, one grouped launch for every weight
                         # gradient): the backward is a handful of launches with nothing to hide an all-reduce under - one
                         # bucket after it, and the launches (hence the bits) of the single-process step.  Decided from the
                         # GLOBAL batch: identical on every rank.

@@ -106,7 +106,7 @@ def test_no_kernel_of_the_library_uses_scratch_except_the_fused_backward(kernels
 
 
 def test_round5_small_batch_kernels_keep_two_waves_per_simd(kernels):
-    """The kernels round 5 added for batches of <= 1024 rows / <= 64 particles run ONE workgroup per CU and rest on its 8 waves
+    """The kernels round 5 added for small batches / <= 64 particles run ONE workgroup per CU and rest on its 8 waves
     being two per SIMD (profiles/HISTORY.md 13): 512-thread workgroups need <= 256 registers per wave.  The paired
     integration kernel (argument set picked by blockIdx.y from the kernarg segment) must cost what the single one costs."""
     single = _one(kernels, "dib_small_integration_kernel")
