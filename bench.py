@@ -454,11 +454,16 @@ def keras_path_default_batch(dev, epochs=200):
 class Workload:
     """One engine + resident dataset + the step of the benchmark for a (feature count, scaling mode)."""
 
-    def __init__(self, n_features, dev, rank, world, dist, scaling, global_batch, dp_buckets):
-        from dib_amd.engine import HipEngine
+    def __init__(self, n_features, dev, rank, world, dist, scaling, global_batch, dp_buckets, engine=None, n_rows=N_ROWS):
+        """engine / n_rows: the CPU test of this class's data-parallel step (tests/test_bench_launcher.py) passes the
+        test-only float64 engine and a small dataset and runs the SAME step / dp_breakdown code over gloo."""
         self.F, self.rank, self.world, self.dist = n_features, rank, world, dist
-        self.eng = HipEngine([1] * n_features, ENC, INTEG, 1, device=dev, init_seed=0)
-        x, y = synthetic(N_ROWS, n_features)
+        if engine is None:
+            from dib_amd.engine import HipEngine
+            engine = HipEngine([1] * n_features, ENC, INTEG, 1, device=dev, init_seed=0)
+        self.eng, self.n_rows = engine, int(n_rows)
+        self._sync = torch.cuda.synchronize if str(dev).startswith("cuda") else (lambda: None)
+        x, y = synthetic(self.n_rows, n_features)
         self.xd, self.yd = self.eng.to_device(x), self.eng.to_device(y)
         self.eng.set_beta(1e-3)
         self.eng.set_lr(3e-4)
@@ -476,7 +481,7 @@ class Workload:
         else:                     # weak: every GPU steps through its own 65536-row batches
             self.gb = global_batch * self.world
             self.lo, self.B = 0, global_batch
-        self.n_batches = max(1, N_ROWS // global_batch)
+        self.n_batches = max(1, self.n_rows // global_batch)
         self.stride = global_batch
 
     def row0(self, i):
@@ -526,11 +531,11 @@ class Workload:
         out = {"per_gpu_batch": self.B, "global_batch": self.gb, "steps": steps}
 
         def timed(fn, n):
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            self._sync(); dist.barrier(); self._sync()
             t0 = time.perf_counter()
             for i in range(n):
                 fn(i)
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            self._sync(); dist.barrier(); self._sync()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return 1e3 * float(t.item()) / n
@@ -562,17 +567,17 @@ class Workload:
 
     def timed_block(self, first_step, steps, dev):
         dist = self.dist
-        torch.cuda.synchronize()
+        self._sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        self._sync()
         t0 = time.perf_counter()
         for i in range(steps):
             self.step(first_step + i)
-        torch.cuda.synchronize()
+        self._sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        self._sync()
         elapsed = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

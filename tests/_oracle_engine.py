@@ -108,7 +108,7 @@ class OracleEngine:
 
     def optimizer_step_part(self, batch, part, optimizer, bump):
         """the optimizer on ONE gradient bucket; every call of a step sees the same Adam step count, `bump` advances it"""
-        off, cnt = self.part_range(part)
+        off, cnt = (0, self.n_params) if part == -1 else self.part_range(part)   # -1: the whole buffer (one-bucket protocol)
         keep = np.ones(self.n_params, dtype=bool)
         keep[off: off + cnt] = False
         flat = lambda q: params_to_flat(self.blocks, q, self.n_params, np.float64)

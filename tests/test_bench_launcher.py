@@ -67,3 +67,69 @@ def test_multi_gpu_extras_deadline_cancelled_in_time_is_silent():
     d.cancel()
     time.sleep(0.8)
     assert "extra" not in out
+
+
+def _bench_dp_worker(rank, world, port, out_dir, buckets, scaling):
+    """one rank of the CPU run of bench.Workload's own data-parallel step (the code the driver's SCALE run executes), gloo"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (ROOT, os.path.join(ROOT, "oracle"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    d = None
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+    import bench
+    import dib_oracle as orc
+    from _helpers import spec_kwargs
+    from _oracle_engine import OracleEngine
+    F, gb = 8, 24      # (bench.synthetic's label uses the first 8 features)
+    spec = orc.DIBSpec([1] * F, [8], [8], 1, feature_embedding_dimension=4)
+    eng = OracleEngine(**spec_kwargs(spec), init_seed=0)
+    wl = bench.Workload(F, "cpu", rank, world, d, scaling, gb if scaling == "strong" else gb // world, buckets, engine=eng,
+                        n_rows=4 * gb)
+    for i in range(4):
+        wl.step(i)
+    np.save(os.path.join(out_dir, f"p_{scaling}_w{world}_b{buckets}_r{rank}.npy"), eng.get_flat_params())
+    if world > 1:
+        # the scaling record's own breakdown: collective-free steps, every bucket's all-reduce alone, the three protocols -
+        # every rank must get through it (same collectives in the same order on every rank) and report the same keys
+        out = wl.dp_breakdown(2, "cpu")
+        assert set(out["step_ms_by_protocol"]) == {"buckets_1", "buckets_2", "buckets_3"}
+        assert set(out["all_reduce_alone"]) == {"integration", "encoder_front", "encoder_last", "encoder_bank", "all"}
+        m, _ = wl.measure(1, 2, 2, "cpu")      # barrier + max-over-ranks timing blocks
+        assert m > 0
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_data_parallel_step_equals_single_process(tmp_path, world):
+    """bench.Workload.step under 1 / 2 / 3 gradient buckets over gloo (world 2 and 3; strong scaling: rank r takes rows
+    [r B / N, (r + 1) B / N) of each global batch - uneven shards at N = 3) leaves every rank with the parameters of the
+    single-process step on the whole batch; dp_breakdown and the timed blocks complete on every rank.  Float64 test engine."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    def port():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+        return p
+
+    _bench_dp_worker(0, 1, port(), str(tmp_path), 3, "strong")
+    ref = np.load(tmp_path / "p_strong_w1_b3_r0.npy")
+    for buckets in (1, 2, 3):
+        mp.spawn(_bench_dp_worker, args=(world, port(), str(tmp_path), buckets, "strong"), nprocs=world, join=True)
+        got = [np.load(tmp_path / f"p_strong_w{world}_b{buckets}_r{r}.npy") for r in range(world)]
+        for g in got[1:]:
+            assert np.array_equal(g, got[0])                      # every rank applied the same update
+        assert np.abs(got[0] - ref).max() < 1e-9 * (1 + np.abs(ref).max()), buckets
+    # weak scaling (every rank steps through its own batches): the ranks still end with one set of parameters
+    mp.spawn(_bench_dp_worker, args=(world, port(), str(tmp_path), 3, "weak"), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"p_weak_w{world}_b3_r{r}.npy") for r in range(world)]
+    assert all(np.array_equal(g, got[0]) for g in got[1:]) and np.isfinite(got[0]).all()
