@@ -1,7 +1,10 @@
 """fit on the reference's default run (Boolean circuit, F = 10, B = 128, 8 validation batches per epoch) for several values of
 model.validation_merge_rows (how many rows of full validation batches one launch set evaluates; 0 = batch by batch):
 microseconds per (training + validation) step pair.  profiles/r05zz_validation_merge_rows_sweep.txt."""
-import json, time, torch, sys
+import sys
+import time
+
+import torch
 sys.path.insert(0, '.')
 import bench, dib_amd
 d = dib_amd.data.fetch_boolean_circuit()
