@@ -650,6 +650,9 @@ def main():
                     help="run the multi-GPU `extra` measurements (dp_breakdown, other scaling mode) under ONE RCCL rank too "
                          "(python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --force-dp-extras): exercises the code "
                          "path the driver's SCALE run takes")
+    ap.add_argument("--only-dp-breakdown", action="store_true",
+                    help="with --force-dp-extras: the data-parallel breakdown is the only extra (the per-GPU operating point, "
+                         "e.g. --batch 8192 under one RCCL rank)")
     ap.add_argument("--dry-run-backend", default=None, help=argparse.SUPPRESS)  # CPU test of the launcher path (gloo)
     args = ap.parse_args()
 
@@ -761,6 +764,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             extra["dp_breakdown"] = {"error": f"{type(e).__name__}: {e}"}
         try:  # the other scaling mode, same engine
+            if args.only_dp_breakdown:
+                raise StopIteration
             other = "weak" if args.scaling == "strong" else "strong"
             wl.set_scaling(other, args.batch)
             m2, t2 = wl.measure(2, args.steps, 1, dev)
@@ -768,17 +773,22 @@ def main():
                                          "ms_per_step": round(1e3 * m2 / args.steps, 4), "per_gpu_batch": wl.B,
                                          "global_batch": wl.gb}
             wl.set_scaling(args.scaling, args.batch)
+        except StopIteration:
+            pass
         except Exception as e:  # noqa: BLE001
             extra["other_scaling"] = {"error": f"{type(e).__name__}: {e}"}
         # BASELINE config 5 under data parallelism (neighbourhoods sharded over the ranks, gradient all-reduce over RCCL inside
         # SetTransformerDIB.train_step): one neighbourhood of 4096 particles per GPU, i.e. never fewer neighbourhoods than ranks
         try:
-            extra["config5_set_transformer"] = dict(config5_set_transformer(dev, nb=max(4, world), steps=3),
-                                                    parallelism=f"dp{world} over neighbourhoods")
+            if not args.only_dp_breakdown:
+                extra["config5_set_transformer"] = dict(config5_set_transformer(dev, nb=max(4, world), steps=3),
+                                                        parallelism=f"dp{world} over neighbourhoods")
         except Exception as e:  # noqa: BLE001
             extra["config5_set_transformer"] = {"error": f"{type(e).__name__}: {e}"}
         deadline.cancel()
 
+    if args.only_dp_breakdown:
+        args.no_extra = True
     if rank == 0:
         if world == 1 and not args.no_extra:
             # BASELINE config 4 (amorphous-plasticity radial density, 50 shell features; the notebook and its data are a

@@ -217,24 +217,6 @@ def load_library(build_if_missing: bool = True):
     return _attach(ctypes.CDLL(LIB_PATH))
 
 
-# entry points with the same signature, argument meaning and workspace sizes in every ABI revision since 3
-_ABI_STABLE = {"dib_version", "dib_abi_version", "dib_error_string", "dib_layout_create", "dib_layout_destroy",
-               "dib_layout_param_count", "dib_layout_param_block", "dib_layout_table_bytes", "dib_layout_upload_tables",
-               "dib_layout_set_step_counter", "dib_workspace_bytes", "dib_workspace_init", "dib_workspace_offset",
-               "dib_layout_wgrad_splits", "dib_encoder_bank_fwd", "dib_integration_fwd", "dib_integration_bwd",
-               "dib_output_head_fused_supported", "dib_integration_fwd_hidden", "dib_integration_bwd_hidden",
-               "dib_encoder_bank_bwd", "dib_encoder_bank_bwd_stage", "dib_grads_finalize", "dib_grads_finalize_part",
-               "dib_layout_part_range", "dib_metrics_accumulate", "dib_adam_step", "dib_sgd_step", "dib_profile_enable",
-               "dib_profile_summary", "dib_philox_normal_fill", "dib_philox_normal_ref"}
-
-
-def _refuse(name, have):
-    def fn(*_a, **_k):
-        raise RuntimeError(f"{name}: not ABI-stable between library version {have} and binding version {ABI_VERSION} "
-                           "(DIB_LIB_ABI_CHECK=0 binds only the unchanged entry points)")
-    return fn
-
-
 def _attach(lib):
     global _lib
     try:
@@ -242,21 +224,14 @@ def _attach(lib):
         have = int(lib.dib_abi_version())
     except AttributeError:
         have = None
-    # DIB_LIB_ABI_CHECK=0 (a same-box A/B against a library built from an older round, tools/runs/r04g.sh; never set outside
-    # such an experiment): only the entry points whose signature and meaning have not changed since ABI 3 are bound - the
-    # config-3 step of bench.py as round 3 drove it; every other name raises on use instead of misbinding its arguments.
-    lenient = os.environ.get("DIB_LIB_ABI_CHECK", "1") == "0"
-    if have != ABI_VERSION and not lenient:
+    # A library of another ABI revision is refused outright: a stale variant build called with shifted arguments would corrupt
+    # memory silently.  (Rounds 4-5 had a lenient mode, DIB_LIB_ABI_CHECK=0, that bound only the entry points unchanged since
+    # ABI 3 for same-box A/Bs against an older round's library; since ABI 5 every step goes through entry points that
+    # did not exist then, so the mode could no longer run a step and was removed - tools/runs/r04g.sh is a historical record.)
+    if have != ABI_VERSION:
         raise RuntimeError(f"libdib_hip ABI version {have} != {ABI_VERSION} expected by this binding ({getattr(lib, '_name', '?')}): "
                            "rebuild it (python -c 'import __graft_entry__ as g; g.build()' / tools/build_variant.sh)")
-    if lenient and have != ABI_VERSION:
-        import warnings
-        warnings.warn(f"DIB_LIB_ABI_CHECK=0: binding ONLY the ABI-stable entry points of a version-{have} library "
-                      f"(this binding is version {ABI_VERSION}); everything else raises", RuntimeWarning)
     for name, (res, args) in list(SIGNATURES.items()) + list(SIGNATURES_ST.items()):
-        if lenient and have != ABI_VERSION and name not in _ABI_STABLE:
-            setattr(lib, name, _refuse(name, have))
-            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -1,11 +1,13 @@
 // dib_api.hip - C ABI (include/dib_hip.h) of the MI355X Distributed-IB hot path: layout, workspace
 // carving and the launch sequences of the forward / backward / optimizer steps.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -22,9 +24,10 @@
 #include "dib_st_chain.h"
 #include "../../include/dib_st.h"
 
-// every kernel launch of the library goes through this macro: dib_launch_count() reports how many a step issues (bench.py)
-static unsigned long long g_dib_launches = 0;
-#define DIB_LAUNCH(...) do { ++g_dib_launches; hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+// every kernel launch of the library goes through this macro: dib_launch_count() reports how many a step issues (bench.py).
+// Relaxed atomic: entry points may run on several host threads at once (include/dib_hip.h "Threads").
+static std::atomic<unsigned long long> g_dib_launches{0};
+#define DIB_LAUNCH(...) do { g_dib_launches.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 namespace {
 
@@ -75,6 +78,7 @@ struct dib_layout {
   // groups [0, n_enc F): encoder layers 1 .. n_enc (feature-major), then the integration layers 0 .. n_int
   int wg_groups() const { return n_enc * F + n_int + 1; }
   mutable std::map<int, std::vector<DibGemmGroup>> wg_tables;
+  mutable std::mutex wg_mu;            // two threads may initialise workspaces of one layout (include/dib_hip.h "Threads")
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
@@ -151,8 +155,9 @@ namespace {
 // 13 fused encoder bwd; 14 every other (HBM-bound) kernel; 15 dib_attn_fwd_kernel; 16 dib_attn_bwd_kernel
 constexpr int kProfCats = 17;
 constexpr int kProfFusedFwd = 12, kProfFusedBwd = 13, kProfOther = 14, kProfAttnFwd = 15, kProfAttnBwd = 16;
-struct Prof {
-  bool on = false;
+struct Prof {   // diagnostics (bench.py roofline): the tables are guarded, so a second thread's launches are recorded, not racy
+  std::atomic<bool> on{false};
+  std::mutex mu;
   std::vector<hipEvent_t> pool;                     // recycled events
   std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[kProfCats];
   hipEvent_t get() {
@@ -168,10 +173,13 @@ struct ProfScope {
   ProfScope(int c, hipStream_t s) : cat(c), st(s) {
     // the small HBM-bound kernels are not bracketed (event pairs serialise kernel boundaries: ~10 us each); rocprofv3
     // reports them (profiles/*_kernel_stats.csv)
-    if (g_prof.on && cat != 14) { a = g_prof.get(); b = g_prof.get(); (void)hipEventRecord(a, st); }
+    if (g_prof.on.load(std::memory_order_relaxed) && cat != 14) {
+      { std::lock_guard<std::mutex> lk(g_prof.mu); a = g_prof.get(); b = g_prof.get(); }
+      (void)hipEventRecord(a, st);
+    }
   }
   ~ProfScope() {
-    if (a) { (void)hipEventRecord(b, st); g_prof.spans[cat].push_back({a, b}); }
+    if (a) { (void)hipEventRecord(b, st); std::lock_guard<std::mutex> lk(g_prof.mu); g_prof.spans[cat].push_back({a, b}); }
   }
 };
 
@@ -212,10 +220,25 @@ struct Tuning {
   int mlp_row_tiles = 1;     // ... and for a plain MLP (dib_mlp_small_*: the custom loop's output encoder)
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
-  int num_cus = 256;         // compute units of the device (set from hipDeviceProp by the first dib_layout_upload_tables)
+  int num_cus = 0;           // compute units the split rule prices rounds with; 0 = the current device's own count (device_cus)
 };
+// Process-wide and written ONLY by dib_set_tuning, which the header documents as a configuration call made while no other
+// entry point is running; every other entry point only reads it.
 inline Tuning& tuning() { static Tuning t; return t; }
 inline const Tuning& knobs() { return tuning(); }
+// compute units of the CURRENT device, queried once per device ordinal (no process-wide "the device": one process may drive
+// several GPUs from several threads)
+inline int device_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+  cus[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+inline int split_rule_cus() { return knobs().num_cus > 0 ? knobs().num_cus : device_cus(); }
 
 template <int MODE, int NI, int NJ>
 int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int N, const float* A, const float* B, float* C,
@@ -315,7 +338,7 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
     // co-resident workgroups per CU of each tile shape (LDS / register budget of dib_gemm_kernel<2, NI, NJ, BK>)
     const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
     const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
-    pick_wgrad_splits(tiles, knobs().num_cus * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
+    pick_wgrad_splits(tiles, split_rule_cus() * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
@@ -346,20 +369,31 @@ inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: track it per device ordinal (two engines on two
 // GPUs in one process are allowed).
-static bool dib_attr_needed(bool (&done)[64]) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-  if (done[dev]) return false;
-  done[dev] = true;
-  return true;
-}
+// Two host threads may reach the same first launch together (include/dib_hip.h "Threads"): the flag is published only AFTER the
+// attribute call (release in the destructor), the slow path is serialised, the steady state is one acquire load.
+static std::mutex g_attr_mu;
+struct AttrOnce {
+  std::atomic<bool>* slot = nullptr;
+  bool need = false;
+  std::unique_lock<std::mutex> lk;
+  explicit AttrOnce(std::atomic<bool> (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { need = true; return; }
+    slot = &done[dev];
+    if (slot->load(std::memory_order_acquire)) return;
+    lk = std::unique_lock<std::mutex>(g_attr_mu);
+    need = !slot->load(std::memory_order_relaxed);
+  }
+  explicit operator bool() const { return need; }
+  ~AttrOnce() { if (need && slot) slot->store(true, std::memory_order_release); }
+};
 
 template <int H1, int H2, int E, bool RELU>
 static int launch_fused_fwd(const DibFusedFwdArgs& a, int gx, int F, hipStream_t st) {
   using C = DibFusedCfg<H1, H2, E>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set[64] = {};
-  if (dib_attr_needed(attr_set)) {
+  static std::atomic<bool> attr_set[64];
+  if (AttrOnce once(attr_set); once) {
     hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_fwd_kernel<H1, H2, E, RELU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -409,8 +443,8 @@ template <int H1, int H2, int E, bool RELU>
 static int launch_fused_bwd(const DibFusedBwdArgs& a, int gx, int F, hipStream_t st) {
   using C = DibFusedBwdCfg<H1, H2, E>;
   const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-  static bool attr_set[64] = {};
-  if (dib_attr_needed(attr_set)) {
+  static std::atomic<bool> attr_set[64];
+  if (AttrOnce once(attr_set); once) {
     hipError_t e = hipFuncSetAttribute((const void*)dib_fused_encoder_bwd_kernel<H1, H2, E, RELU>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -451,6 +485,8 @@ static int fused_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
 // ---- small-batch row-tile path (dib_small.h) ---------------------------------------------------------------------
 // dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize (per device): raised to what a launch needs
 static int ensure_dynamic_lds(const void* fn, size_t bytes, int (&have)[64]) {
+  if (bytes <= 64 * 1024) return DIB_OK;
+  std::lock_guard<std::mutex> lk(g_attr_mu);   // `have` is shared by every host thread (include/dib_hip.h "Threads")
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if ((int)bytes <= have[dev] || bytes <= 64 * 1024) return DIB_OK;
@@ -523,6 +559,7 @@ static int small_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
 // Descriptors with absolute workspace offsets for this batch size (the activation buffers' offsets are not linear in the batch:
 // every buffer is 256-byte aligned), A and B both relative to the workspace base, C / bias_out relative to the gradient target.
 static const std::vector<DibGemmGroup>& wg_table_host(const dib_layout* l, const dib_layout::WsMap& m, int batch) {
+  std::lock_guard<std::mutex> lk(l->wg_mu);   // std::map nodes are stable: the reference outlives the lock
   auto it = l->wg_tables.find(batch);
   if (it != l->wg_tables.end()) return it->second;
   std::vector<DibGemmGroup> t;
@@ -827,12 +864,6 @@ int dib_layout_upload_tables(dib_layout* l, void* dev_tables, dib_stream_t strea
   char* fmp = fo + align_up((int64_t)l->fused_offs.size() * sizeof(long long), 256);
   e = hipMemcpyAsync(fmp, l->featmap.data(), l->featmap.size() * sizeof(int4), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return (int)e;
-  {  // the split rule prices rounds of the chip's workgroup slots: take the CU count from the device, not from a constant
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      tuning().num_cus = prop.multiProcessorCount;
-  }
   l->dev_groups = (const DibGemmGroup*)base;
   l->dev_colmap = (const int4*)cm;
   l->dev_fused_offs = (const long long*)fo;
@@ -1534,8 +1565,8 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
   float* norms = lse + 2ll * batch;
   const float inv_t = 1.0f / temperature;
   const int tiles = cdiv(batch, 32);
-  static bool attr_set[64] = {};
-  if (dib_attr_needed(attr_set)) {   // two 32-row tiles of up to 256 (+1) floats: 65 792 bytes at the widest
+  static std::atomic<bool> attr_set[64];
+  if (AttrOnce once(attr_set); once) {   // two 32-row tiles of up to 256 (+1) floats: 65 792 bytes at the widest
     hipError_t e = hipFuncSetAttribute((const void*)dib_infonce_sim_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        2 * 32 * 257 * (int)sizeof(float));
     if (e != hipSuccess) return (int)e;
@@ -1570,8 +1601,8 @@ int dib_infonce_fwd_bwd(const float* emb_x, const float* emb_y, int batch, int d
     float* Rp = Gp + 2ll * nsplit * batch * dim;
     const int nacc = cdiv(dim, 64);
     const size_t os_bytes = (size_t)64 * (64 * nacc + 4) * sizeof(float);
-    static bool attr_mfma[64] = {};
-    if (dib_attr_needed(attr_mfma)) {
+    static std::atomic<bool> attr_mfma[64];
+    if (AttrOnce once(attr_mfma); once) {
 #define DIB_INCE_ATTR(NA, KD)                                                                                          \
       if (hipFuncSetAttribute((const void*)dib_infonce_grad_mfma_kernel<NA, KD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               64 * (64 * NA + 4) * (int)sizeof(float)) != hipSuccess) return DIB_E_ARG;
@@ -1797,9 +1828,10 @@ int dib_philox_normal_fill(float* eps, const int32_t* row_idx, int64_t row0, int
   return (int)hipGetLastError();
 }
 
-int64_t dib_launch_count(void) { return (int64_t)g_dib_launches; }
+int64_t dib_launch_count(void) { return (int64_t)g_dib_launches.load(std::memory_order_relaxed); }
 
 int dib_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   for (int c = 0; c < kProfCats; ++c) {
     for (auto& sp : g_prof.spans[c]) { g_prof.pool.push_back(sp.first); g_prof.pool.push_back(sp.second); }
     g_prof.spans[c].clear();
@@ -1810,6 +1842,7 @@ int dib_profile_enable(int on) {
 
 int dib_profile_summary(double* ms_by_category, int* launches_by_category) {
   if (!ms_by_category || !launches_by_category) return DIB_E_ARG;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   for (int c = 0; c < kProfCats; ++c) {
     double tot = 0.0;
     for (auto& sp : g_prof.spans[c]) {
@@ -2073,8 +2106,8 @@ int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int
   ProfScope ps(kProfAttnFwd, (hipStream_t)stream);
   if (P <= kAttnSmallP) {   // the whole head in LDS, one workgroup per (neighbourhood, head): csrc/dib_attn_small.h (no stash)
     const size_t lds = (size_t)DibAttnSmallFwdLds * sizeof(float);
-    static bool attr_small[64] = {};
-    if (dib_attr_needed(attr_small)) {
+    static std::atomic<bool> attr_small[64];
+    if (AttrOnce once(attr_small); once) {
       hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
@@ -2107,8 +2140,8 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
     a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
     a.P = P; a.H = H; a.ld = ld; a.scale = scale;
     const size_t lds = (size_t)DibAttnSmallBwdLds * sizeof(float);
-    static bool attr_small[64] = {};
-    if (dib_attr_needed(attr_small)) {
+    static std::atomic<bool> attr_small[64];
+    if (AttrOnce once(attr_small); once) {
       hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)dib_attn_small_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2129,8 +2162,8 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
   a.s_stash = const_cast<float*>(s_stash);
   a.P = P; a.H = H; a.ld = ld; a.scale = scale;
   const size_t lds = (size_t)DibAttnBwdLds * sizeof(float);
-  static bool attr_set[64] = {};
-  if (dib_attr_needed(attr_set)) {
+  static std::atomic<bool> attr_set[64];
+  if (AttrOnce once(attr_set); once) {
     hipError_t e = hipFuncSetAttribute((const void*)dib_attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void*)dib_attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

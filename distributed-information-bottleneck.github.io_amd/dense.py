@@ -128,8 +128,10 @@ class DenseStack:
         with the same batch size.  rows (int32 / int64 device tensor): encode y[rows] - gathered straight into the workspace."""
         y = y.to(device=self.device, dtype=torch.float32)
         if rows is not None:
-            if rows.dtype != torch.int32 or rows.device != y.device or rows.dim() != 1 or not rows.is_contiguous():
-                raise ValueError("rows must be a contiguous 1-D int32 tensor on the stack's device")
+            if rows.dim() != 1:
+                raise ValueError("rows must be a 1-D index tensor")
+            # the kernels read contiguous int32 indices; int64 / strided / host index tensors are converted, not refused
+            rows = rows.to(device=y.device, dtype=torch.int32).contiguous()
             if y.stride(1) != 1:
                 y = y.contiguous()
         n = y.shape[0] if rows is None else int(rows.shape[0])

@@ -264,7 +264,8 @@ class HipEngine:
 
     def backward(self, row_idx, row0: int, batch: int, seed: int, step: int, inv_global_batch: float,
                  on_integration_grads_ready=None, hidden_only: bool = False, on_encoder_front_grads_ready=None,
-                 finish_flags: int = 0, optimizer=None, integration_done: bool = False, companion=None) -> None:
+                 finish_flags: int = 0, optimizer=None, integration_done: bool = False, companion=None,
+                 metrics_acc: Optional[torch.Tensor] = None) -> None:
         """Backward pass, with the hooks of the data-parallel bucket protocol:
         `on_integration_grads_ready(grads_slice)` is called as soon as the integration network's gradients (bucket 1) are
         final - right after dib_integration_bwd - so their all-reduce runs under the whole encoder-bank backward;
@@ -272,7 +273,8 @@ class HipEngine:
         gradients of the encoder layers before the last (bucket 2) are final; the last layer's weight gradient (bucket 3)
         is computed after it, under that all-reduce, and is the only part left for the caller to reduce afterwards.
         Every bucket is finalised by ONE dib_step_tail launch; the LAST of them also carries `finish_flags` (the step's
-        deferred KL / loss sums, the metric accumulation) and, without hooks, the optimizer (`optimizer`, see step_tail)."""
+        deferred KL / loss sums, the metric accumulation - into `metrics_acc`, default the model's History accumulator) and,
+        without hooks, the optimizer (`optimizer`, see step_tail)."""
         ws = self.workspace(batch)
         st = self._stream()
         FIN = _lib.TAIL_FINALIZE
@@ -290,7 +292,7 @@ class HipEngine:
                 check(self.lib.dib_backward(self.layout, batch, _ptr(self.params), _ptr(self.grads), _ptr(self.beta_dev),
                                             float(inv_global_batch), bflags, _ptr(ws), st), "dib_backward")
             self.step_tail(batch, -1, FIN | head | finish_flags | (_lib.TAIL_BUMP if optimizer and optimizer[0] == "adam" else 0),
-                           inv_global_batch, optimizer=optimizer)
+                           inv_global_batch, optimizer=optimizer, metrics_acc=metrics_acc)
             return
         assert companion is None, "a companion pass rides on dib_backward (no bucket hooks)"
         if not integration_done:   # (dib_integration_head_step already ran the integration network's backward)
@@ -308,7 +310,7 @@ class HipEngine:
                 check(self.lib.dib_encoder_bank_bwd_stage(self.layout, batch, _ptr(self.params), _ptr(self.grads),
                                                           _ptr(self.beta_dev), float(inv_global_batch), stage, _ptr(ws), st),
                       "dib_encoder_bank_bwd_stage")
-                self.step_tail(batch, part, FIN | (finish_flags if stage == 2 else 0), inv_global_batch)
+                self.step_tail(batch, part, FIN | (finish_flags if stage == 2 else 0), inv_global_batch, metrics_acc=metrics_acc)
                 if stage == 1:
                     off, cnt = self.part_range(2)
                     on_encoder_front_grads_ready(self.grads[off: off + cnt])
@@ -316,10 +318,10 @@ class HipEngine:
         check(self.lib.dib_encoder_bank_bwd(self.layout, batch, _ptr(self.params), _ptr(self.grads),
                                             _ptr(self.beta_dev), float(inv_global_batch), _ptr(ws), st), "dib_encoder_bank_bwd")
         if on_integration_grads_ready is not None:
-            self.step_tail(batch, 0, FIN | finish_flags, inv_global_batch)
+            self.step_tail(batch, 0, FIN | finish_flags, inv_global_batch, metrics_acc=metrics_acc)
         else:
             self.step_tail(batch, -1, FIN | head | finish_flags | (_lib.TAIL_BUMP if optimizer and optimizer[0] == "adam" else 0),
-                           inv_global_batch, optimizer=optimizer)
+                           inv_global_batch, optimizer=optimizer, metrics_acc=metrics_acc)
 
     def accumulate_metrics(self, batch: int, inv_global_batch: float) -> None:
         check(self.lib.dib_metrics_accumulate(self.layout, batch, _ptr(self.beta_dev), float(inv_global_batch),
@@ -541,16 +543,18 @@ class HipEngine:
 
     def backward_from_pred_grad(self, g_pred: torch.Tensor, row_idx, row0: int, batch: int, seed: int, step: int,
                                 inv_global_batch: Optional[float] = None, finish_flags: int = 0, optimizer=None,
-                                companion=None) -> None:
+                                companion=None, metrics_acc: Optional[torch.Tensor] = None) -> None:
         """Backward of the model given dL/d(model output) from a custom loss (reference train.py:216-219): the
         beta*KL term (models.py:118) is added inside the encoder-bank backward.  Gradients land in self.grads.
         finish_flags / optimizer: what the backward's last launch also does (step_tail: e.g. TAIL_KL | TAIL_METRICS after a
-        forward(defer_sums=True), and the optimizer update of a single-process loop)."""
+        forward(defer_sums=True), and the optimizer update of a single-process loop); TAIL_METRICS accumulates into `metrics_acc`
+        (a custom loop passes its OWN accumulator: the default is the one model.fit's History is read from)."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         dst = self.g_pred(batch)
         if not (g_pred.data_ptr() == dst.data_ptr() and g_pred.shape == dst.shape and g_pred.stride() == dst.stride()):
             dst.copy_(g_pred)   # (a custom loss may have written its gradient straight into the view)
-        self.backward(row_idx, row0, batch, seed, step, inv, finish_flags=finish_flags, optimizer=optimizer, companion=companion)
+        self.backward(row_idx, row0, batch, seed, step, inv, finish_flags=finish_flags, optimizer=optimizer, companion=companion,
+                      metrics_acc=metrics_acc)
 
     def mi_sandwich_bounds(self, enc_out: torch.Tensor, seed: int, step: int, feature: int):
         """(InfoNCE lower, leave-one-out upper) in nats for one batch enc_out [N, 2E] (reference utils.py:36-62)."""

@@ -57,7 +57,10 @@ class _BatchStream:
         again = np.flatnonzero(ss[1:] == ss[:-1]) + 1
         out = self.buf[slots]
         out[order[again]] = incoming[order[again - 1]]
-        self.buf[slots] = incoming            # duplicates: numpy keeps the last assignment = the last refill
+        # one write per slot: its LAST refill of this call (numpy leaves the result of an advanced-index assignment with repeated
+        # indices unspecified)
+        last = np.r_[ss[1:] != ss[:-1], True] if m else np.zeros(0, dtype=bool)
+        self.buf[ss[last]] = incoming[order[last]]
         return out
 
     def next(self) -> np.ndarray:
@@ -228,9 +231,10 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
     adam = ("adam", 0.9, 0.999, 1e-7)                             # tf.keras.optimizers.Adam defaults (train.py:128-129)
     slots = _LossSlots(eng.device, eng.metrics_acc.dtype)
     # single process: the per-feature KL of every step is accumulated on the device by the step's LAST launch (metrics_acc[f] +=
-    # KL_f sum / B, dib_step_tail) - training and validation into separate accumulators, read once per epoch boundary
-    kl_acc = dict(kl=eng.metrics_acc, kl_validation=torch.zeros_like(eng.metrics_acc))
-    eng.metrics_acc.zero_()
+    # KL_f sum / B, dib_step_tail) - training and validation into accumulators of THIS loop, read once per epoch boundary.
+    # (Not eng.metrics_acc: that is the accumulator model.fit's History is read from, and the loop ends one step short of the
+    # last boundary - the steps after the last recorded epoch would stay in it and pollute the first epoch of a later fit.)
+    kl_acc = dict(kl=torch.zeros_like(eng.metrics_acc), kl_validation=torch.zeros_like(eng.metrics_acc))
 
     def eval_batch(xs, ys, idx, training, step):
         if dist is None:
@@ -249,7 +253,7 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
             if training:
                 compb = yenc.companion_backward(gy) if comp is not None else None
                 eng.backward_from_pred_grad(gx, idx, 0, B, model.noise_seed, step, inv_global_batch=1.0 / batch_size,
-                                            finish_flags=_lib.TAIL_KL | _lib.TAIL_METRICS, optimizer=adam,
+                                            finish_flags=_lib.TAIL_KL | _lib.TAIL_METRICS, optimizer=adam, metrics_acc=kl_acc["kl"],
                                             **({} if compb is None else dict(companion=compb)))
                 yenc.backward(gy, reduce=False, **({} if compb is None else dict(dgrad_done=True)))
                 yenc.adam_step(fused_reduce=True)                  # one Keras Adam over all variables (train.py:196,219)
@@ -282,15 +286,17 @@ def fit_infonce(model, x_train, y_train, x_valid, y_valid, *, batch_size: int, n
         return _epoch_mean(values, scalar=name.startswith('loss'))
 
     eng.set_beta(float(model.beta.value()))                        # the first step runs at the constructor's beta (models.py:86)
-    out = run_custom_loop(
-        dataset_length=n, validation_set_length=nv, batch_size=batch_size, number_pretraining_epochs=number_pretraining_epochs,
-        number_annealing_epochs=number_annealing_epochs, beta_start=beta_start, beta_end=beta_end,
-        train_step=lambda step_num: eval_batch(xd, yd, train_rows(step_num), True, step_num),
-        validation_step=lambda epoch_num, vb: eval_batch(xvd, yvd, validation_rows(epoch_num, vb), False,
-                                                         (1 << 31) + epoch_num * 1024 + vb),
-        assign_beta=model.beta.assign,
-        epoch_callback=(lambda e: epoch_callback(e, model)) if epoch_callback is not None else None, epoch_mean=epoch_mean)
-    train_idx["next"].cancel()
-    pool.shutdown(wait=True)
+    try:
+        out = run_custom_loop(
+            dataset_length=n, validation_set_length=nv, batch_size=batch_size, number_pretraining_epochs=number_pretraining_epochs,
+            number_annealing_epochs=number_annealing_epochs, beta_start=beta_start, beta_end=beta_end,
+            train_step=lambda step_num: eval_batch(xd, yd, train_rows(step_num), True, step_num),
+            validation_step=lambda epoch_num, vb: eval_batch(xvd, yvd, validation_rows(epoch_num, vb), False,
+                                                             (1 << 31) + epoch_num * 1024 + vb),
+            assign_beta=model.beta.assign,
+            epoch_callback=(lambda e: epoch_callback(e, model)) if epoch_callback is not None else None, epoch_mean=epoch_mean)
+    finally:   # also when a step or the caller's epoch_callback raises: no worker thread / pending draw left behind
+        train_idx["next"].cancel()
+        pool.shutdown(wait=True, cancel_futures=True)
     out['kl_total'], out['kl_total_validation'] = out['kl'].sum(-1), out['kl_validation'].sum(-1)
     return out

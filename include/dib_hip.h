@@ -20,6 +20,23 @@
  *     is also the RCCL all-reduce bucket.
  *   - beta, learning-rate and the Adam step counter are DEVICE scalars (mirrors tf.Variable,
  *     models.py:86) so a captured step can be replayed while the host anneals beta.
+ *
+ * Threads ("thread-safe across distinct (device, stream, workspace) triples")
+ *   - Every entry point that enqueues work may be called from several host threads at the same time as long as no two
+ *     concurrent calls share a stream or write the same caller-owned buffer (workspace, gradient / parameter / Adam buffers,
+ *     sync words, outputs).  The device a call runs on is the calling thread's current HIP device.  The results are the bits
+ *     of the same calls made one after the other (tests/test_gpu_concurrency.py: two threads x two streams x two layouts).
+ *   - A dib_layout is immutable after dib_layout_upload_tables / dib_layout_set_step_counter; from then on several threads
+ *     may use ONE layout with distinct workspaces (dib_workspace_init takes the layout's internal lock for its per-batch
+ *     descriptor cache).  dib_layout_create / _upload_tables / _set_step_counter / _destroy of one layout are not
+ *     concurrent with anything else that uses it.
+ *   - The library keeps no other per-call state in globals: the first-launch kernel attributes (dynamic LDS limits, per device
+ *     ordinal) are set under a lock and published before the launch that needs them; the compute-unit count of the split rule
+ *     is read from the calling thread's current device; dib_launch_count is a relaxed atomic sum over all threads.
+ *   - dib_set_tuning is CONFIGURATION, not a per-call argument: it writes process-wide integers that every other entry
+ *     point only reads.  Call it while no other entry point is running (start-up, or between steps of a single-threaded A/B);
+ *     dib_get_tuning is always safe.  dib_profile_enable / dib_profile_summary are diagnostics with their own lock: spans
+ *     from all threads land in one table.
  */
 #ifndef DIB_HIP_H
 #define DIB_HIP_H
@@ -231,7 +248,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
  *   "attn_small_bwd_waves" (8) dib_attention_bwd for neighbourhoods of <= 64 particles: 8 waves per workgroup (two per SIMD), or 4
  *                           (the round-4 kernel; bit-identical results)
- *   "num_cus"        (device) compute units the split rule prices rounds with (set from hipDeviceProp at table upload)
+ *   "num_cus"        (0)    compute units the split rule prices rounds with; 0 = the calling thread's current device's own count
  * Returns DIB_E_ARG for an unknown key or a negative value. */
 int dib_set_tuning(const char* key, int value);
 int dib_get_tuning(const char* key, int* value);

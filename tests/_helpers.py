@@ -1,4 +1,6 @@
-"""Test helpers: oracle <-> flat-buffer mapping, spec zoo."""
+"""Test helpers: oracle <-> flat-buffer mapping, spec zoo, the dispatch switches of the library."""
+import contextlib
+
 import numpy as np
 
 import dib_oracle as orc
@@ -81,4 +83,41 @@ SPECS = {
     "fused_fwd_in16_gemm_bwd": orc.DIBSpec([4, 2], [32, 32], [16], 1, number_positional_encoding_frequencies=4,
                                            feature_embedding_dimension=32),
     "fused_fwd_only_e16": orc.DIBSpec([1, 1, 2], [64, 64], [32], 1, feature_embedding_dimension=16),
+    "fused_fwd_only_e8": orc.DIBSpec([1, 1, 1, 1], [32, 32], [64], 1, feature_embedding_dimension=8),   # smoke()'s architecture
+    # the non-relu template variants of the remaining fused instantiations (the Boolean notebook's networks are leaky_relu:
+    # complex_systems/InfoDecomp_Boolean_circuits.ipynb:266-268; train.py:37 makes the activation a flag)
+    "fused_128_leaky": orc.DIBSpec([1, 2, 1], [128, 128], [32], 1, activation_fn="leaky_relu", feature_embedding_dimension=32),
+    "fused_fwd_only_e8_leaky": orc.DIBSpec([1, 1], [32, 32], [16], 1, activation_fn="leaky_relu", feature_embedding_dimension=8),
+    "fused_fwd_only_e16_linear": orc.DIBSpec([2, 1], [64, 64], [16], 1, activation_fn=None, feature_embedding_dimension=16),
 }
+# zoo entries one of the fused large-batch instantiations covers (csrc/dib_api.hip kFused: encoder = two hidden layers of
+# (128,128,32) / (32,32,32) / forward-only (32,32,8), (64,64,16); inputs <= 16 wide; relu / leaky_relu / linear)
+FUSED_ELIGIBLE = ("boolean4_32x32", "pendulum_ragged", "tabular8_default", "fused_leaky", "fused_linear_act", "fused_no_posenc",
+                  "fused_in15", "fused_fwd_in16_gemm_bwd", "fused_fwd_only_e16", "fused_fwd_only_e8", "fused_128_leaky",
+                  "fused_fwd_only_e8_leaky", "fused_fwd_only_e16_linear")
+
+# The library picks its kernels by batch size and architecture (csrc/dib_api.hip: small_regime, fused_id).  Every test that
+# compares with the float64 oracle runs on BOTH sides of every switch:
+#   "default"      what a caller gets: row-tile kernels (csrc/dib_small.h) while ceil(B / 16) x F <= 512 and B <= 2048,
+#                  otherwise the fused encoder-bank kernels where the architecture has an instantiation, otherwise grouped GEMMs
+#   "large_batch"  dib_set_tuning("small_batch", 0): the large-batch kernels at every batch size
+#   "grouped_gemm" ... and dib_set_tuning("fused_encoder", 0) for layouts created inside: the general grouped-GEMM path
+DISPATCH_PATHS = ("default", "large_batch", "grouped_gemm")
+
+
+@contextlib.contextmanager
+def dispatch_path(path):
+    """Engines must be CREATED inside the context ("fused_encoder" is read by dib_layout_create)."""
+    from dib_amd import _lib
+    assert path in DISPATCH_PATHS, path
+    old = {k: _lib.get_tuning(k) for k in ("small_batch", "fused_encoder")}
+    try:
+        if path != "default":
+            _lib.set_tuning("small_batch", 0)
+        if path == "grouped_gemm":
+            _lib.set_tuning("fused_encoder", 0)
+        yield
+    finally:
+        for k, v in old.items():
+            _lib.set_tuning(k, v)
+

@@ -109,13 +109,14 @@ class CheckerXEngine(_FlatAdam):
         acc[: self.F] += self._kl.detach() * batch * inv_global_batch
 
     def backward_from_pred_grad(self, g_pred, row_idx, row0, batch, seed, step, inv_global_batch=None, finish_flags=0,
-                                optimizer=None):
+                                optimizer=None, metrics_acc=None):
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         # d/dtheta [ sum_rows <emb_x, dL/d emb_x> + beta * sum_rows sum_f KL / global batch ]; _kl is the LOCAL row mean
         obj = (self._ex * g_pred).sum() + self.beta * self._kl.sum() * batch * inv
         self._store_grads(torch.autograd.grad(obj, self.vars))
         if finish_flags & 32:
-            self.metrics_acc[: self.F] += self._kl.detach() * batch * inv
+            acc = self.metrics_acc if metrics_acc is None else metrics_acc
+            acc[: self.F] += self._kl.detach() * batch * inv
         if optimizer is not None:
             assert optimizer[0] == "adam"
             self.adam_step(None, *optimizer[1:4])

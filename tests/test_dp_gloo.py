@@ -169,6 +169,9 @@ def _run_infonce_loop(rank, world, port, out_dir):
     yenc = CheckerYEncoder(yk, yb, "relu", True, 3)
     out = fit_infonce(model, *data, learning_rate=2e-3, shared_dimensionality=6, similarity="l2", temperature=0.7, seed=4,
                       output_encoder=yenc, **kw)
+    # the custom loop keeps its KL sums in accumulators of its own - the model's History accumulator (what a later
+    # model.fit reads its first epoch from) is never touched, although the loop ends one step short of the last boundary
+    assert float(model._engine.metrics_acc.abs().max()) == 0.0
     np.savez(os.path.join(out_dir, f"loop_w{world}_r{rank}.npz"), x_params=model._engine.flat_params(),
              y_params=yenc.flat_params(), **out)
     if world > 1:

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import dib_oracle as orc
-from _helpers import SPECS, flat_to_params, params_to_flat, random_params, spec_kwargs
+from _helpers import DISPATCH_PATHS, FUSED_ELIGIBLE, SPECS, dispatch_path, flat_to_params, params_to_flat, random_params, spec_kwargs
 
 pytestmark = pytest.mark.gpu
 
@@ -164,9 +164,20 @@ def test_eps_matches_oracle_and_host_ref():
     assert np.abs(got2 - ref2).max() < 1e-5
 
 
+@pytest.mark.parametrize("path", DISPATCH_PATHS)
 @pytest.mark.parametrize("name", list(SPECS))
-@pytest.mark.parametrize("B", [1, 37, 300])
-def test_forward_backward_parity(name, B):
+@pytest.mark.parametrize("B", [1, 37, 300, 2100])
+def test_forward_backward_parity(name, B, path):
+    """The architecture zoo x batch sizes x BOTH SIDES OF EVERY DISPATCH SWITCH (tests/_helpers.py dispatch_path) against the
+    float64 oracle.  B = 2100 is beyond the row-tile regime for every layout (> 2048 rows): the fused-eligible entries then
+    run the persistent fused kernels over several 256-row tiles per workgroup on the default path too."""
+    if B == 2100 and (name not in FUSED_ELIGIBLE or path == "large_batch"):
+        pytest.skip("B = 2100 is the large-batch case of the fused-eligible entries (default == large_batch there)")
+    with dispatch_path(path):
+        _forward_backward_parity(name, B)
+
+
+def _forward_backward_parity(name, B):
     spec = SPECS[name]
     # (zlib.crc32, not hash(): str hashes are salted per process, and with a different parameter seed every run the odd run hit
     # a ReLU unit within round-off of 0 - one flipped unit moves a gradient column by ~1/sqrt(B) of its scale)
@@ -221,8 +232,14 @@ def test_forward_backward_parity(name, B):
         assert err <= 3e-4 * (np.abs(ref).max() + 1e-3), (b, err, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("path", DISPATCH_PATHS)
 @pytest.mark.parametrize("name", ["tabular8_default", "no_posenc_leaky"])   # fused kernels / general (elementwise) path
-def test_late_annealing_regime_small_sigma_large_mu(name):
+def test_late_annealing_regime_small_sigma_large_mu(name, path):
+    with dispatch_path(path):
+        _late_annealing_regime(name)
+
+
+def _late_annealing_regime(name):
     """the backward recovers eps * sigma as u - mu instead of regenerating eps.  That difference cancels once
     sigma << |mu| - the late-annealing state of an informative feature (logvar ~ -16, |mu| ~ 4: sigma = 3e-4, ulp(u) = 5e-7,
     so eps * sigma carries ~1e-3 relative error per element).  What it feeds is only the NOISE term of d loss / d logvar,
@@ -328,9 +345,16 @@ def test_encode_deterministic_and_bhattacharyya():
         assert np.abs(bh - bref).max() < 1e-3 * (1 + np.abs(bref).max())
 
 
-def test_fit_trajectory_matches_oracle_fit():
+@pytest.mark.parametrize("path", DISPATCH_PATHS)
+def test_fit_trajectory_matches_oracle_fit(path):
     """BASELINE metric 2: per-epoch KL{f} within 1e-3 nats of the oracle over a full fit()
-    (same init, same batch order, same counter-based eps), incl. validation and accuracy."""
+    (same init, same batch order, same counter-based eps), incl. validation and accuracy - on the row-tile kernels (default at
+    these batch sizes), on the fused <32,32,8> forward + grouped-GEMM backward (large_batch) and on the grouped-GEMM path."""
+    with dispatch_path(path):
+        _fit_trajectory()
+
+
+def _fit_trajectory():
     import dib_amd
     spec = orc.DIBSpec([1, 1, 1, 1], [32, 32], [64, 64], 1, feature_embedding_dimension=8)
     x, y = orc.boolean_circuit_truth_table([0, 1, 2, 3, [0, 2, 0], [2, 4, 3], [0, 5, 1]], 4)  # SI circuit (c)
@@ -907,7 +931,19 @@ def test_north_star_architecture_multi_step_trajectory():
         assert np.abs(a - b).max() < 5e-5, "parameters after 3 Adam steps"
 
 
-def _random_spec(rng):
+def _random_spec(rng, row_tiles=False):
+    if row_tiles:   # architectures the row-tile kernels cover (csrc/dib_api.hip sb_enc / sb_int): widths % 16 == 0, inputs <= 15 wide
+        F = int(rng.integers(1, 6))
+        pe = bool(rng.integers(0, 2))
+        nf = int(rng.integers(1, 6)) if pe else 1
+        dims = [int(v) for v in rng.integers(1, 15 // nf + 1, F)]
+        w = [16, 32, 48, 64, 96, 128]
+        E = int(rng.choice([8, 16, 24, 32]))
+        while (F * E) % 16:
+            E += 8
+        return orc.DIBSpec(dims, [int(rng.choice(w)), int(rng.choice(w))], [int(rng.choice(w)) for _ in range(int(rng.integers(1, 4)))],
+                           int(rng.integers(1, 6)), use_positional_encoding=pe, number_positional_encoding_frequencies=nf,
+                           activation_fn=[None, "relu", "leaky_relu"][int(rng.integers(0, 3))], feature_embedding_dimension=E)
     F = int(rng.integers(1, 6))
     dims = [int(v) for v in rng.integers(1, 7, F)]
     enc = [int(v) for v in rng.integers(1, 70, int(rng.integers(0, 4)))]
@@ -918,13 +954,19 @@ def _random_spec(rng):
                        feature_embedding_dimension=int(rng.integers(1, 41)))
 
 
-@pytest.mark.parametrize("case", range(12))
-def test_random_architectures_forward_backward(case):
+@pytest.mark.parametrize("path", DISPATCH_PATHS)
+@pytest.mark.parametrize("case", range(20))
+def test_random_architectures_forward_backward(case, path):
+    with dispatch_path(path):
+        _random_architecture(case)
+
+
+def _random_architecture(case):
     """Seeded random architectures (ragged feature widths, 0-3 encoder layers, arbitrary unit counts / embedding widths /
     activations / output widths, with and without positional encoding, arbitrary batch) through the general grouped-GEMM
     path (or the fused kernels when they apply): predictions, per-feature KL and every gradient vs the oracle."""
     rng = np.random.default_rng(1000 + case)
-    spec = _random_spec(rng)
+    spec = _random_spec(rng, row_tiles=case >= 12)   # cases 12+: inside the row-tile kernels' coverage (default path runs them)
     eng, p = _engine(spec, seed=case)
     F, E = spec.number_features, spec.feature_embedding_dimension
     B = int(rng.integers(1, 200))
@@ -1143,7 +1185,7 @@ def test_tuning_switchboard_is_the_only_hidden_input():
         assert _lib.get_tuning(key) == v + 1
         _lib.set_tuning(key, v)
     assert lib.dib_set_tuning(b"no_such_key", 1) == -1 and lib.dib_set_tuning(b"fused_head", -3) == -1
-    assert _lib.get_tuning("num_cus") == torch.cuda.get_device_properties(0).multi_processor_count or True
+    assert _lib.get_tuning("num_cus") == 0   # 0 = the current device's own compute-unit count (no process-wide "the device")
     spec = orc.DIBSpec([1] * 4, [128, 128], [256], 1, feature_embedding_dimension=32)
     try:
         _lib.set_tuning("fused_head", 0)

@@ -105,6 +105,9 @@ def test_infonce_loop_trajectory_matches_float64_oracle(tmp_path, batch_size, ro
                               epoch_callback=lambda e, m: snaps.__setitem__(e, state()))
     final = state()
     assert sorted(snaps) == list(range(13)) and final[3] == 104
+    # the loop accumulates KL in accumulators of its own; the model's History accumulator (read by a later
+    # model.fit for its first epoch) stays untouched although 7 training steps follow the last recorded boundary
+    assert float(eng.metrics_acc.abs().max().item()) == 0.0
 
     def oracle(dt, sync):
         ye = ilo.YEncoder(y0[0], y0[1], "relu", True, 5, dtype=dt)

@@ -342,3 +342,41 @@ def test_subset_informations_match_the_notebook_statements_executed():
         assert abs(table[int((c.astype(np.int64) << np.arange(10)).sum())] - w) < 1e-12
     # monotone in the subset (more gates never carry less) and the full set carries all of H(Y)
     assert abs(want[-1] - float(fx["entropy_y_bits"])) < 1e-12 and want[0] == 0
+
+
+# The numbers the reference's own run PRINTED for the six SI circuits (InfoDecomp_Boolean_circuits.ipynb, outputs of cell 10:
+# "H(Y)=..., Sum of Shapley values = ...", "Shapley values: [...]", "Logistic regression accuracy: ..."; raw-JSON lines 987-992
+# for circuit (c), 1058-1063 for (d)) - deterministic functions of the truth tables, so they are known answers.
+_SI_PRINTED = [
+    (1.000, [0.3333333333333333, 0.3333333333333333, 0.3333333333333333], 0.500),
+    (1.000, [0.21854635407652215, 0.21854635407652215, 0.5629072918469556], 0.750),
+    (0.811, [0.0962198571076538, 0.37685891933722027, 0.0962198571076538, 0.24197949090660467], 0.875),
+    (1.000, [0.3425060887628776, 0.09250608876287761, 0.47248173371136726, 0.09250608876287761], 0.625),
+    (0.954, [0.6361993267150806, 0.04121479843161109, 0.13619932671508067, 0.09960575263158164, 0.041214798431611056], 0.938),
+    (1.000, [0.20314536459234778, 0.0937092708153044, 0.0937092708153044, 0.2031453645923478, 0.2031453645923478,
+             0.2031453645923478], 0.500),
+]
+
+
+@pytest.mark.parametrize("circuit", range(6))
+def test_si_circuit_printed_known_answers(circuit):
+    """H(Y), the Shapley values (to the 16 digits the notebook printed) and the logistic-regression accuracy of every SI circuit,
+    from the oracle's restatements on the PRODUCT's truth table (dib_amd.data.truth_table, the data path `train.py --dataset
+    boolean_circuit` uses)."""
+    import dib_amd
+    spec = orc.SI_CIRCUITS[circuit]
+    n = sum(1 for v in spec if isinstance(v, int))
+    table = dib_amd.data.truth_table(spec, n)
+    xo, yo = orc.boolean_circuit_truth_table(spec, n)
+    x, y = 2 * table[:, :n] - 1, table[:, -1].astype(np.int64)
+    assert np.array_equal(x, xo) and np.array_equal(y, yo)
+    hy, shap, acc = _SI_PRINTED[circuit]
+    entropy_y = orc.entropy_bits(np.bincount(y, minlength=2) / len(y))
+    assert f"{entropy_y:.3f}" == f"{hy:.3f}"
+    got = orc.shapley_values_bits(x, y)
+    assert np.abs(got - np.array(shap)).max() < 1e-14, (got, shap)
+    assert abs(got.sum() - entropy_y) < 1e-12                     # efficiency: the values share out all of H(Y)
+    # "Logistic regression accuracy" (the notebook: LogisticRegression(random_state=0, penalty='none') on the 0/1 truth table)
+    from sklearn.linear_model import LogisticRegression
+    clf = LogisticRegression(random_state=0, penalty=None, max_iter=10000).fit(table[:, :n], y)
+    assert f"{np.average(clf.predict(table[:, :n]) == y):.3f}" == f"{acc:.3f}"
