@@ -25,7 +25,7 @@ SOURCES = ["dib_api.hip", "dib_gemm.h", "dib_elementwise.h", "dib_common.h", "di
 
 # error codes (include/dib_hip.h)
 DIB_OK = 0
-ABI_VERSION = 5   # include/dib_hip.h DIB_ABI_VERSION this binding's SIGNATURES were written against
+ABI_VERSION = 6   # include/dib_hip.h DIB_ABI_VERSION this binding's SIGNATURES were written against
 ACTIVATIONS = {None: 0, "linear": 0, "None": 0, "relu": 1, "leaky_relu": 2, "tanh": 3, "sigmoid": 4, "elu": 5,
                "softplus": 6}
 ACT_LEAKY_RELU_01 = 7  # tf.keras.layers.LeakyReLU(0.1) (include/dib_st.h)

@@ -261,7 +261,6 @@ __global__ void dib_metrics_accumulate_kernel(const float* __restrict__ step_out
   if (i == F + 2) acc[F + 2] += step_out[F + 2];
 }
 
-__global__ void dib_set_scalar_kernel(float* p, float v) { p[0] = v; }
 
 // out[i] = (acc ? acc[i] : 0) + sum_s partial[s*stride + i], i < n   (fixed order => deterministic; acc may be out itself)
 __global__ void __launch_bounds__(256)
@@ -533,16 +532,6 @@ dib_mi_probe_rows_kernel(const float* __restrict__ enc_probe, const double* __re
 // (Round 3: the first version recomputed the norms and the dot product inside the gradient loop - O(B^2 D^2), 9.0 ms per
 // call at B = 2048, D = 64 against 0.35 ms for the whole encoder step; tools/infonce_bench.py, profiles/r03i_*, r03j_*.)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-dib_infonce_norms_kernel(const float* __restrict__ X, const float* __restrict__ Y, int B, int D, float* __restrict__ norms) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= 2 * B) return;
-  const float* r = idx < B ? X + (long long)idx * D : Y + (long long)(idx - B) * D;
-  float s = 0.f;
-  for (int e = 0; e < D; ++e) s += r[e] * r[e];
-  norms[idx] = s;
-}
-
 // grid (ceil(B/32) column tiles, ceil(B/32) row tiles), 256 threads, dynamic LDS 2 * 32 * (D + 1) floats.
 // Writes S AND its transpose ST (and the arg-max table and its transpose): every later pass over columns - column
 // log-sum-exp, g_y - then reads rows of the transposed copy, coalesced (the first version walked S with stride B).

@@ -356,6 +356,23 @@ class SetTransformerDIB:
                 chain_descs = []
         if chain_descs:
             take("chain_ws", int(self.lib.dib_st_chain_workspace_bytes(T, D)) // 4)
+        # Deferred weight gradients (round 6): on the chain path every block keeps the operands of its weight gradients in
+        # buffers of its own - dL/d(feed-forward pre-activations), dL/dq|k|v, and the gradient of LN1's addends (slot 0 of
+        # b{b}_dx; slots 1.. are the split-K slabs of the q/k/v input gradient, so that ONE fixed-order sum over the slots is
+        # the gradient handed to the next block and slot 0 stays what the output projection's weight gradient contracts
+        # with) - and ALL blocks' weight gradients run at the end of the backward as one grouped launch per shape class
+        # (q/k/v: 3 x blocks groups of [D, HK]; output projection: [HK, D]; feed-forward) instead of 3 launches per block:
+        # at the notebook's size 18 launches of 7-18 us on a few dozen workgroups each become 3 that fill the chip.
+        defer = bool(chain_descs) and ksplit > 1 and bool(getattr(self, "defer_wgrads", True))
+        if defer:
+            for b in range(self.number_attention_blocks):
+                take(f"b{b}_g_z", T * D)
+                for l, u in enumerate(ff[:-1]):
+                    take(f"b{b}_g_ff{l}", T * u)
+                for nm in "qkv":
+                    take(f"b{b}_g_{nm}", T * HK)
+                take(f"b{b}_dx", (1 + 3 * ksplit) * T * D)
+        gn = (lambda b, nm: f"b{b}_{nm}") if defer else (lambda b, nm: nm)   # per-block / shared gradient buffer names
         take("loss_ws", int(self.lib.dib_loss_rows_workspace_bytes(B)) // 4 + 4)
         ws = torch.zeros(o, dtype=torch.float32, device=self.device)
         # flash attention, stash mode: one score-tile buffer per block, outside the fp32-indexed workspace (its own allocation:
@@ -403,6 +420,7 @@ class SetTransformerDIB:
                                                  act=ACT_LEAKY01)
             kin, src = u, f"enc_h{l}"
         bh = [(b_, h_) for b_ in range(B) for h_ in range(H)]
+        dw_qkv, dw_o, dw_ff = [], [], []   # deferred weight gradients: descriptors of all blocks by shape class
         for b in range(self.number_attention_blocks):
             xin = "x0" if b == 0 else f"b{b - 1}_x"
             pre = f"blk{b}_"
@@ -451,28 +469,33 @@ class SetTransformerDIB:
                     g[f"b{b}_ff0_dgrad"] = dense_dgrad(gy, ky, pre + "ff0_w", "g_h", D, T)
             # attention output projection
             gout = self._block_grad_names(b)[1]   # gradient w.r.t. the block's input x (= gradient of LN1's two addends)
-            g[f"b{b}_o_wgrad"] = dense_wgrad(f"b{b}_ctx", HK, gout, D, pre + "o_w", pre + "o_b", T)
+            if defer:
+                off[f"b{b}_gln1"] = off[f"b{b}_dx"]   # slot 0 of the block's dx region (alias)
+            g[f"b{b}_o_wgrad"] = dense_wgrad(f"b{b}_ctx", HK, f"b{b}_gln1" if defer else gout, D, pre + "o_w", pre + "o_b", T)
             o_dgrad_descs = [_d(off[gout], D, po[pre + "o_w"], D, off["g_ctx"], HK, T, HK, D)]
             mk = _SkinnyKGemm if skinny and _SkinnyKGemm.fits(1, o_dgrad_descs) else _Gemm
             g[f"b{b}_o_dgrad"] = mk(1, o_dgrad_descs, ws, self.params, ws)
             if gemm_attn:
                 g[f"b{b}_dv"] = _Gemm(2, [_d(off[f"b{b}_S"] + (bi * H + hi) * P * ldS, ldS, off["g_ctx"] + bi * P * HK + hi * K, HK,
-                                           off["g_v"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
+                                           off[gn(b, "g_v")] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
                                     nsplit=1, rows_per_split=max(P, 1))
             if gemm_attn:
                 g[f"b{b}_dp"] = _Gemm(1, [_d(off["g_ctx"] + bi * P * HK + hi * K, HK, off[f"b{b}_v"] + bi * P * HK + hi * K, HK,
                                            off["g_S"] + (bi * H + hi) * P * ldS, ldS, P, P, K) for bi, hi in bh], ws, ws, ws)
             if gemm_attn:
                 g[f"b{b}_dq"] = _Gemm(0, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_k"] + bi * P * HK + hi * K, HK,
-                                           off["g_q"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
+                                           off[gn(b, "g_q")] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws)
             if gemm_attn:
                 g[f"b{b}_dk"] = _Gemm(2, [_d(off["g_S"] + (bi * H + hi) * P * ldS, ldS, off[f"b{b}_q"] + bi * P * HK + hi * K, HK,
-                                           off["g_k"] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
+                                           off[gn(b, "g_k")] + bi * P * HK + hi * K, HK, P, K, P) for bi, hi in bh], ws, ws, ws,
                                     nsplit=1, rows_per_split=max(P, 1))
-            qkv_wgrad_descs = [_d(off[xin], D, off[f"g_{nm}"], HK, po[pre + nm + "_w"], HK, D, HK, T, bias_off=po[pre + nm + "_b"])
+            qkv_wgrad_descs = [_d(off[xin], D, off[gn(b, f"g_{nm}")], HK, po[pre + nm + "_w"], HK, D, HK, T, bias_off=po[pre + nm + "_b"])
                                for nm in "qkv"]
             g[f"b{b}_qkv_wgrad"] = _Gemm(2, qkv_wgrad_descs, ws, ws, gt, bias_out=gt,
                                          nsplit=nsplit, rows_per_split=rps, split_stride=self.n_alloc)
+            if defer:
+                dw_qkv += qkv_wgrad_descs
+                dw_o.append(_d(off[f"b{b}_ctx"], HK, off[f"b{b}_gln1"], D, po[pre + "o_w"], D, HK, D, T, bias_off=po[pre + "o_b"]))
             if chain_descs:
                 # the feed-forward layers' weight gradients in one grouped launch (dy = the chain backward's g_ff); the output
                 # projection's (dy = the gradient of LN1's addends = the block-input gradient buffer BEFORE the projections' dgrads
@@ -480,14 +503,23 @@ class SetTransformerDIB:
                 descs = []
                 for l in range(nff):
                     kin_l, src_l = (D, f"b{b}_h") if l == 0 else (ff[l - 1], f"b{b}_ff{l - 1}")
-                    dy_l = "g_z" if l == nff - 1 else f"g_ff{l}"
+                    dy_l = gn(b, "g_z" if l == nff - 1 else f"g_ff{l}")
                     descs.append(_d(off[src_l], kin_l, off[dy_l], ff[l], po[pre + f"ff{l}_w"], ff[l], kin_l, ff[l], T,
                                     bias_off=po[pre + f"ff{l}_b"]))
                 # (one launch for ALL of them was tried: a grouped launch's grid is max-shape tiles x groups, and [1536, 32] next to
                 # [32, 1536] made it 21 600 mostly empty workgroups - 48 us; the feed-forward layers share a shape class)
                 g[f"b{b}_ff_wgrad"] = _Gemm(2, descs, ws, ws, gt, bias_out=gt, nsplit=nsplit, rows_per_split=rps,
                                             split_stride=self.n_alloc)
-            if ksplit > 1:   # 3 projections x ksplit chunks -> 3 * ksplit slabs, summed straight into g_xq (= g_xq + g_xk + g_xv)
+                if defer:
+                    dw_ff += descs
+            if defer:   # the slabs land behind the LN1-addend gradient in the block's own region; one sum over all slots -> gout
+                ck = HK // ksplit
+                g[f"b{b}_qkv_dgrad"] = _SplitKGemm(
+                    _Gemm(1, [_d(off[f"b{b}_g_{nm}"] + s_ * ck, HK, po[pre + nm + "_w"] + s_ * ck, HK,
+                                 off[f"b{b}_dx"] + (1 + i_ * ksplit + s_) * T * D, D, T, D, ck)
+                              for i_, nm in enumerate("qkv") for s_ in range(ksplit)], ws, self.params, ws),
+                    ws, off[f"b{b}_dx"], T * D, 1 + 3 * ksplit, ws, off[gout], mode="store")
+            elif ksplit > 1:   # 3 projections x ksplit chunks -> 3 * ksplit slabs, summed straight into g_xq (= g_xq + g_xk + g_xv)
                 ck = HK // ksplit
                 g[f"b{b}_qkv_dgrad"] = _SplitKGemm(
                     _Gemm(1, [_d(off[f"g_{nm}"] + s_ * ck, HK, po[pre + nm + "_w"] + s_ * ck, HK,
@@ -519,11 +551,35 @@ class SetTransformerDIB:
                 g[f"fin{l}_dgrad"] = dense_dgrad(f"g_fin{l}", u, f"fin{l}_w", f"g_fin{l - 1}", kin_l, B, aux=src_l, act=ACT_LEAKY01)
             else:
                 g["fin0_dgrad"] = dense_dgrad(f"g_fin{l}", u, "fin0_w", "g_pool", D, B)
+        deferred = []
+        if defer:
+            # the particle encoder's weight gradients contract over the same T tokens and fit the feed-forward class's tiles:
+            # three more groups of that launch instead of three launches; the head's (contraction over the B neighbourhoods)
+            # become one grouped launch
+            dw_ff += [dict(zip(DESC.names, g[f"enc{l}_wgrad"].host[0])) for l in range(len(enc_units))]
+            g["head_wgrads"] = _Gemm(2, [dict(zip(DESC.names, g[k].host[0])) for k in
+                                         ["out_wgrad"] + [f"fin{l}_wgrad" for l in range(nfin)]], ws, ws, gt, bias_out=gt,
+                                     nsplit=1, rows_per_split=max(B, 1), split_stride=self.n_alloc)
+            # one grouped launch per shape class.  A grouped launch's grid is (splits, tiles of the LARGEST group shape, groups):
+            # the split count of each class is chosen so that its workgroups make about `deferred_wgrad_target_wgs` - many
+            # groups need few, long splits (1536: the best of 384 / 512 / 768 / 1024 / 1536 at the notebook's size, 1.335 ...
+            # 1.319 ms per step, profiles/r06b_set_transformer_deferred_wgrads_ab.txt; 2048 and 3072 no better, r06c); slabs
+            # beyond a launch's count are never written and stay zero (the slab buffer is zero-initialised and every launch
+            # always writes the same slabs)
+            target = int(getattr(self, "deferred_wgrad_target_wgs", 1536))
+            for name, descs, (tm, tn) in (("dw_qkv", dw_qkv, (64, 128)), ("dw_o", dw_o, (128, 64)), ("dw_ff", dw_ff, (128, 128))):
+                mm, nn = max(d["M"] for d in descs), max(d["N"] for d in descs)
+                tiles = len(descs) * ((mm + tm - 1) // tm) * ((nn + tn - 1) // tn)
+                ns = max(1, min(nsplit, int(round(target / tiles))))
+                r = ((T + ns - 1) // ns + 63) // 64 * 64
+                ns = (T + r - 1) // r
+                g[name] = _Gemm(2, descs, ws, ws, gt, bias_out=gt, nsplit=ns, rows_per_split=r, split_stride=self.n_alloc)
+                deferred.append(name)
         for gg in g.values():
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
                     enc_units=enc_units, stash=stash, stash_block_bytes=stash_block_bytes, stash_denied=None, ksplit=ksplit,
-                    chain=chain_descs)
+                    chain=chain_descs, deferred_wgrads=deferred)
         # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
         # (training batch, validation batch, a ragged tail), evict least recently used beyond that
         step_keys = [k for k in self._plans if k[0] != "enc" and k not in self._graphs]   # a captured graph pins its plan
@@ -675,12 +731,17 @@ class SetTransformerDIB:
             self.grads.zero_()  # blocks are overwritten; alignment gaps stay zero
         check(lib.dib_loss_rows(LOSS_BCE_LOGITS, _ptr(ws, off["pred"]), self.output_dimensionality, _ptr(y), y.stride(0), B, inv,
                                 _ptr(ws, off["g_pred"]), _ptr(ws, off["out3"]), _ptr(ws, off["loss_ws"]), st), "dib_loss_rows")
-        # head
-        g["out_wgrad"].run(lib, st)
+        # head (deferred weight gradients: the dgrad chain first, then ONE grouped launch for the head's weight gradients)
+        dw = bool(pl["deferred_wgrads"])
+        if not dw:
+            g["out_wgrad"].run(lib, st)
         g["out_dgrad"].run(lib, st)
         for l in range(len(self.final_processing_arch) - 1, -1, -1):
-            g[f"fin{l}_wgrad"].run(lib, st)
+            if not dw:
+                g[f"fin{l}_wgrad"].run(lib, st)
             g[f"fin{l}_dgrad"].run(lib, st)
+        if dw:
+            g["head_wgrads"].run(lib, st)
         check(lib.dib_mean_pool_bwd(_ptr(ws, off["g_pool"]), B, P, D, _ptr(ws, off["g_x"]), st), "dib_mean_pool_bwd")
         scale = 1.0 / math.sqrt(self.key_dim)
         nff = len(self.ff_arch_per_block)
@@ -690,16 +751,21 @@ class SetTransformerDIB:
             if pl["chain"]:
                 # LN2 backward -> feed-forward dgrads -> LN1 backward -> output-projection dgrad in one launch; then the attention
                 # backward, ONE grouped launch for the block's weight gradients, and the projections' dgrads (added to gout)
+                defer = bool(pl["deferred_wgrads"])   # the block's weight-gradient operands stay in buffers of its own
+                gb = (lambda nm: f"b{b}_{nm}") if defer else (lambda nm: nm)
                 ffp = (c_void_p * 3)(*[_ptr(ws, off[f"b{b}_ff{l}"]) for l in range(nff)])
-                gfp = (c_void_p * 3)(*[_ptr(ws, off["g_z" if l == nff - 1 else f"g_ff{l}"]) for l in range(nff)])
+                gfp = (c_void_p * 3)(*[_ptr(ws, off[gb("g_z" if l == nff - 1 else f"g_ff{l}")]) for l in range(nff)])
                 check(lib.dib_st_chain_bwd(ctypes.byref(pl["chain"][b]), T, _ptr(self.params), _ptr(ws, off[gin]),
                                            _ptr(ws, off[f"b{b}_xhat2"]), _ptr(ws, off[f"b{b}_rstd2"]), ffp,
-                                           _ptr(ws, off[f"b{b}_xhat1"]), _ptr(ws, off[f"b{b}_rstd1"]), gfp, _ptr(ws, off[gout]),
+                                           _ptr(ws, off[f"b{b}_xhat1"]), _ptr(ws, off[f"b{b}_rstd1"]), gfp,
+                                           _ptr(ws, off[f"b{b}_gln1" if defer else gout]),
                                            _ptr(ws, off["g_ctx"]), _ptr(gt), _ptr(ws, off["chain_ws"]), st), "dib_st_chain_bwd")
-                g[f"b{b}_ff_wgrad"].run(lib, st)
-                g[f"b{b}_o_wgrad"].run(lib, st)
-                self._attention_backward(pl, b, B, P, H, scale)
-                g[f"b{b}_qkv_wgrad"].run(lib, st)
+                if not defer:
+                    g[f"b{b}_ff_wgrad"].run(lib, st)
+                    g[f"b{b}_o_wgrad"].run(lib, st)
+                self._attention_backward(pl, b, B, P, H, scale, *(gb(f"g_{nm}") for nm in "qkv"))
+                if not defer:
+                    g[f"b{b}_qkv_wgrad"].run(lib, st)
                 g[f"b{b}_qkv_dgrad"].run(lib, st)
                 if pl["ksplit"] == 1:
                     for nm in "qkv":
@@ -740,9 +806,12 @@ class SetTransformerDIB:
                                            self.logvar_initialization, _ptr(self.beta_dev), inv,
                                            _ptr(ws, off[f"g_enc_h{ne - 1}"]), st), "dib_token_reparam_kl_bwd")
         for l in range(ne - 1, -1, -1):
-            g[f"enc{l}_wgrad"].run(lib, st)
+            if not dw:   # (deferred: three more groups of the feed-forward class's launch below)
+                g[f"enc{l}_wgrad"].run(lib, st)
             if l > 0:
                 g[f"enc{l}_dgrad"].run(lib, st)
+        for name in pl["deferred_wgrads"]:   # every block's weight gradients, one grouped launch per shape class
+            g[name].run(lib, st)
         self._unreduced = pl if (pl["nsplit"] > 1 and not reduce) else None
         if pl["nsplit"] > 1 and reduce:
             check(lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_alloc, pl["nsplit"], self.n_alloc, _ptr(self.grads), st),
@@ -751,8 +820,10 @@ class SetTransformerDIB:
         self.last["bce"] = out3[0:1] * inv
         self.last["correct"] = out3[1:2]
 
-    def _attention_backward(self, pl, b: int, B: int, P: int, H: int, scale: float) -> None:
-        """g_ctx -> g_q, g_k, g_v of block b (flash kernels, or the grouped-GEMM products with the stashed probabilities)"""
+    def _attention_backward(self, pl, b: int, B: int, P: int, H: int, scale: float, gq: str = "g_q", gk: str = "g_k",
+                            gv: str = "g_v") -> None:
+        """g_ctx -> g_q, g_k, g_v of block b (flash kernels, or the grouped-GEMM products with the stashed probabilities);
+        gq / gk / gv name the workspace buffers that receive them (flash path)."""
         lib, st, ws, off, g = self.lib, self._stream(), pl["ws"], pl["off"], pl["g"]
         if pl["impl"] == "gemm":
             g[f"b{b}_dv"].run(lib, st)
@@ -766,7 +837,7 @@ class SetTransformerDIB:
             check(lib.dib_attention_bwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
                                         _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
                                         _ptr(pl["stash"][b]) if self.last.get("stash") else c_void_p(0),   # as the forward ran
-                                        B, P, H, self.key_dim, HK, scale, _ptr(ws, off["g_q"]), _ptr(ws, off["g_k"]), _ptr(ws, off["g_v"]),
+                                        B, P, H, self.key_dim, HK, scale, _ptr(ws, off[gq]), _ptr(ws, off[gk]), _ptr(ws, off[gv]),
                                         _ptr(ws, off["attn_delta"]), st), "dib_attention_bwd")
 
     def adam_step(self, beta_1=0.9, beta_2=0.999, epsilon=1e-7, fused_reduce: bool = False) -> None:

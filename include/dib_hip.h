@@ -83,8 +83,9 @@ const char* dib_version(void);
  * memory silently.  History: 3 = round 3 (attention stash arguments, 17 profile categories); 4 = round 4; 5 = round 5
  * (`flags` argument of dib_loss_fwd_bwd / dib_output_head_fused, dib_step_tail, dib_set_tuning; the workspace grew by the
  * tail's arrival counters, which dib_workspace_init zeroes - re-run it on workspaces kept from an older library; the
- * experimental bf16x6 GEMM entry points left the library). */
-#define DIB_ABI_VERSION 5
+ * experimental bf16x6 GEMM entry points left the library); 6 = round 6 (the tuning key "num_cus" = 0 now
+ * means "the calling thread's current device's own count"; the library no longer writes it; no signature changed). */
+#define DIB_ABI_VERSION 6
 int dib_abi_version(void);
 const char* dib_error_string(int code);
 

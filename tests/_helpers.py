@@ -89,12 +89,15 @@ SPECS = {
     "fused_128_leaky": orc.DIBSpec([1, 2, 1], [128, 128], [32], 1, activation_fn="leaky_relu", feature_embedding_dimension=32),
     "fused_fwd_only_e8_leaky": orc.DIBSpec([1, 1], [32, 32], [16], 1, activation_fn="leaky_relu", feature_embedding_dimension=8),
     "fused_fwd_only_e16_linear": orc.DIBSpec([2, 1], [64, 64], [16], 1, activation_fn=None, feature_embedding_dimension=16),
+    # the fused 1-unit output head's wider variants (last integration layer of 257-512 / more than 512 units)
+    "head_wide_384": orc.DIBSpec([1, 1], [32, 32], [384], 1, feature_embedding_dimension=32),
+    "head_wide_640": orc.DIBSpec([1, 1], [32, 32], [64, 640], 1, feature_embedding_dimension=32),
 }
 # zoo entries one of the fused large-batch instantiations covers (csrc/dib_api.hip kFused: encoder = two hidden layers of
 # (128,128,32) / (32,32,32) / forward-only (32,32,8), (64,64,16); inputs <= 16 wide; relu / leaky_relu / linear)
 FUSED_ELIGIBLE = ("boolean4_32x32", "pendulum_ragged", "tabular8_default", "fused_leaky", "fused_linear_act", "fused_no_posenc",
                   "fused_in15", "fused_fwd_in16_gemm_bwd", "fused_fwd_only_e16", "fused_fwd_only_e8", "fused_128_leaky",
-                  "fused_fwd_only_e8_leaky", "fused_fwd_only_e16_linear")
+                  "fused_fwd_only_e8_leaky", "fused_fwd_only_e16_linear", "head_wide_384", "head_wide_640")
 
 # The library picks its kernels by batch size and architecture (csrc/dib_api.hip: small_regime, fused_id).  Every test that
 # compares with the float64 oracle runs on BOTH sides of every switch:

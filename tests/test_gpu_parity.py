@@ -551,7 +551,7 @@ def test_infonce_at_working_batch_sizes(kind, B, D):
     assert ey < tol * np.abs(g2).max() + 1e-9, ("d/dy", ey, np.abs(g2).max(), temp)
 
 
-@pytest.mark.parametrize("B,D", [(33, 256), (70, 5), (1, 7)])
+@pytest.mark.parametrize("B,D", [(33, 256), (70, 5), (1, 7), (150, 100), (70, 160)])   # D = 100 / 160: the 2- / 3-accumulator gradient kernels
 @pytest.mark.parametrize("kind", ["l2sq", "l2", "l1", "linf", "cosine"])
 def test_infonce_edge_shapes(kind, B, D):
     """ragged 32 x 32 pair tiles, the widest supported embedding (256: the similarity kernel's LDS tiles need the raised

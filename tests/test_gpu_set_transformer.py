@@ -579,3 +579,48 @@ def test_token_chain_kernels_equal_the_layer_by_layer_path(B, P):
         ref = r["grads"][name].astype(np.float64)
         err = np.abs(c["grads"][name].astype(np.float64) - ref).max()
         assert err <= 2e-4 * np.abs(ref).max() + 1e-7 * gmax, (name, err, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("attention", ["auto", "gemm"])
+@pytest.mark.parametrize("B,P", [(32, 50), (3, 21), (2, 200), (1, 1)])
+def test_deferred_grouped_weight_gradients_equal_the_per_block_launches(B, P, attention):
+    """Round 6: on the chain path all blocks' weight gradients run at the end of the backward as one grouped launch per shape
+    class (q/k/v, output projection, feed-forward + particle encoder) on per-block operand buffers, with a split count of
+    their own, the head's as one more grouped launch, and the gradient handed from block to block is ONE fixed-order sum over
+    [LN1-addend gradient | split-K slabs of the q/k/v input gradient] - with the flash kernels and with the grouped-GEMM
+    attention (whose dq / dk / dv products must land in the per-block buffers too).  Against the per-block launches (`defer_wgrads = False`) on a twin
+    model: prediction, KL, the last block's q and every gradient block to fp32 summation-order tolerance; a second step on the
+    same plan reproduces the first bit for bit (slabs beyond a class's split count stay zero)."""
+    spec = sto.SetTransformerSpec()
+    rng = np.random.default_rng(B * 7 + P)
+    x = rng.standard_normal((B, P, spec.particle_feature_dimensions)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32)
+    outs = []
+    nb = spec.number_attention_blocks
+    HK = spec.number_heads_per_mha * spec.key_dim
+    for defer in (True, False):
+        m, _ = _model(spec, seed=5, attention=attention)
+        m.defer_wgrads = defer
+        m.beta_dev.fill_(0.02)
+        pred = m.forward(x, step=2).clone()
+        m.loss_and_backward(y)
+        torch.cuda.synchronize()
+        pl = m.last["plan"]
+        assert bool(pl["deferred_wgrads"]) == defer and bool(pl["chain"])
+        g1 = m.get_grads()
+        q_last = m._view(pl, f"b{nb - 1}_q", B * P, HK).clone()
+        if defer:
+            m.forward(x, step=2)
+            m.loss_and_backward(y)
+            torch.cuda.synchronize()
+            for k, v in m.get_grads().items():
+                assert np.array_equal(v, g1[k]), k
+        outs.append(dict(pred=pred, kl=m.last["kl"].clone(), q_last=q_last, grads=g1))
+    d, r = outs
+    for k in ("pred", "kl", "q_last"):
+        assert (d[k] - r[k]).abs().max() <= 2e-5 * (1e-6 + r[k].abs().max()), k
+    gmax = max(np.abs(v).max() for v in r["grads"].values())
+    for name in r["grads"]:
+        ref = r["grads"][name].astype(np.float64)
+        err = np.abs(d["grads"][name].astype(np.float64) - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-7 * gmax, (name, err, np.abs(ref).max())

@@ -25,18 +25,61 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "distributed-information-bottleneck.github.io_amd", "libdib_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
-# test FUNCTIONS whose assertions compare device results with an independent CPU checker (oracle/dib_oracle.py float64,
-# oracle/dib_torch_cpu.py float64 autograd, the float64 loop / set-transformer oracles, NumPy products)
+# tests (file::function) whose assertions compare device results with an INDEPENDENT CPU checker: oracle/dib_oracle.py (float64
+# NumPy), oracle/dib_torch_cpu.py (float64 autograd), the float64 loop / set-transformer oracles, plain NumPy float64 formulas
 ORACLE_TESTS = {
-    "test_gemm_vs_numpy", "test_skinny_k_gemm_vs_numpy", "test_gemm_is_transpose_detecting", "test_eps_matches_oracle_and_host_ref",
-    "test_forward_backward_parity", "test_late_annealing_regime_small_sigma_large_mu", "test_split_batch_wgrad_and_dp_equivalence",
-    "test_adam_matches_keras_form", "test_encode_deterministic_and_bhattacharyya", "test_fit_trajectory_matches_oracle_fit",
-    "test_north_star_shape_properties", "test_mi_sandwich_bounds_match_oracle", "test_infonce_loss_and_grads_match_oracle",
-    "test_infonce_at_working_batch_sizes", "test_infonce_edge_shapes", "test_infonce_one_launch_path",
-    "test_mi_sandwich_bounds_at_the_reference_evaluation_size", "test_dense_stack_matches_numpy", "test_dense_stack_row_tile_kernels",
-    "test_autograd_bridge_matches_oracle_gradients", "test_hipgraph_fit_is_bit_identical_to_eager_and_matches_oracle",
-    "test_north_star_architecture_multi_step_trajectory", "test_random_architectures_forward_backward",
+    "test_gpu_parity.py": {
+        "test_gemm_vs_numpy", "test_skinny_k_gemm_vs_numpy", "test_eps_matches_oracle_and_host_ref", "test_forward_backward_parity",
+        "test_late_annealing_regime_small_sigma_large_mu", "test_split_batch_wgrad_and_dp_equivalence", "test_adam_matches_keras_form",
+        "test_encode_deterministic_and_bhattacharyya", "test_fit_trajectory_matches_oracle_fit", "test_north_star_shape_properties",
+        "test_mi_sandwich_bounds_match_oracle", "test_ib_flag_one_wide_feature_on_the_boolean_circuit",
+        "test_infonce_loss_and_grads_match_oracle", "test_infonce_at_working_batch_sizes", "test_infonce_edge_shapes",
+        "test_infonce_one_launch_path", "test_mi_sandwich_bounds_at_the_reference_evaluation_size", "test_dense_stack_matches_numpy",
+        "test_dense_stack_row_tile_kernels", "test_autograd_bridge_matches_oracle_gradients",
+        "test_hipgraph_fit_is_bit_identical_to_eager_and_matches_oracle", "test_north_star_architecture_multi_step_trajectory",
+        "test_random_architectures_forward_backward"},
+    "test_gpu_fullsize.py": {
+        "test_config3_full_batch_step_all_gradients", "test_config4_f50_full_batch_step_all_gradients",
+        "test_config4_f50_ragged_batch_general_and_fused_paths_agree", "test_config3_fit_trajectory_beta_ramp_full_batch"},
+    "test_gpu_set_transformer.py": {
+        "test_forward_replays_the_notebook_fixture", "test_forward_backward_parity", "test_config5_size_4096_particles_flash_all_gradients",
+        "test_config5_full_depth_six_blocks_at_4096_particles", "test_attention_backward_score_stash_equals_recompute",
+        "test_train_steps_match_oracle_adam", "test_probe_grid_information_bounds_match_oracle",
+        "test_backward_follows_the_forward_that_ran"},
+    "test_gpu_trajectories.py": {
+        "test_infonce_loop_trajectory_matches_float64_oracle", "test_keras_path_trajectory_160_steps_through_the_ramp"},
+    "test_gpu_building_blocks.py": {
+        "test_softmax_rows_forward_backward_vs_float64", "test_add_layernorm_forward_backward_vs_float64", "test_act_grad_mul_vs_numpy",
+        "test_sgd_step_vs_numpy", "test_gemm_tile_shapes_the_default_rules_rarely_pick"},
 }
+# tests that demand the bits (or fp32 summation-order tolerance) of a path the tests above check against an oracle
+EQUIVALENCE_TESTS = {
+    "test_gpu_parity.py": {
+        "test_companion_grids_equal_the_separate_launches", "test_fused_output_head_equals_the_unfused_sequence",
+        "test_step_tail_equals_the_separate_launches", "test_small_batch_row_tile_kernels_equal_the_large_batch_path",
+        "test_workspace_needs_only_dib_workspace_init", "test_inference_forward_skips_stashes_but_not_results"},
+    "test_gpu_set_transformer.py": {
+        "test_attention_backward_8_waves_equals_4_waves", "test_token_chain_kernels_equal_the_layer_by_layer_path",
+        "test_deferred_grouped_weight_gradients_equal_the_per_block_launches",
+        "test_graph_replay_of_the_train_step_is_bit_identical_to_eager",
+        "test_evaluation_forward_skips_the_score_stash_and_backward_still_agrees",
+        "test_data_parallel_shards_reproduce_the_full_batch_gradient", "test_large_token_count_uses_split_weight_gradients"},
+    "test_gpu_dp_and_cache.py": {
+        "test_fit_under_rccl_one_rank_equals_single_process", "test_three_bucket_backward_hooks_equal_the_plain_backward",
+        "test_set_transformer_train_step_under_rccl_one_rank_equals_single_process"},
+    "test_gpu_concurrency.py": {"test_two_threads_two_streams_equal_the_serial_run"},
+}
+
+
+def _kind(nodeid):
+    """'*' oracle-comparing, '=' equivalence with an oracle-checked path, ' ' other"""
+    parts = nodeid.split("::")
+    f, fn = os.path.basename(parts[0]), parts[-1].split("[")[0]
+    if fn in ORACLE_TESTS.get(f, ()):
+        return "*"
+    if fn in EQUIVALENCE_TESTS.get(f, ()):
+        return "="
+    return " "
 
 
 def library_kernels(lib=LIB):
@@ -123,19 +166,20 @@ def build(trace_dir, tests_tsv, out_path):
     dm = demangle(lib_kernels)
     lines = ["# kernel coverage of `python -m pytest tests -m gpu` under rocprofv3 --kernel-trace --marker-trace -M",
              f"# test ranges from: {how}; {len(disp)} dispatches, {unassigned} outside every test range (session set-up)",
-             f"# {len(lib_kernels)} kernel symbols in libdib_hip.so (gfx950 code object); '*' = the test compares with the float64 / NumPy oracle",
-             "# format: KERNEL <mangled>  |  <demangled>  |  launches  |  tests  |  oracle-comparing tests ; then one line per test (at most 12, oracle tests first)"]
+             f"# {len(lib_kernels)} kernel symbols in libdib_hip.so (gfx950 code object); '*' = the test compares with the float64 / NumPy oracle,",
+             "# '=' = the test demands equality (bits or fp32 summation-order tolerance) with a path that '*' tests check",
+             "# format: KERNEL <mangled>  |  <demangled>  |  launches  |  tests  |  '*' tests  |  '=' tests ; then one line per test (at most 12, '*' first)"]
     missing = []
     for k in lib_kernels:
         tests = by_kernel.get(k, {})
-        fn = lambda nodeid: nodeid.split("::")[-1].split("[")[0]
-        oracle = [t for t in tests if fn(t) in ORACLE_TESTS]
-        lines.append(f"KERNEL {k}  |  {dm[k]}  |  {sum(tests.values())}  |  {len(tests)}  |  {len(oracle)}")
+        oracle = [t for t in tests if _kind(t) == "*"]
+        equiv = [t for t in tests if _kind(t) == "="]
+        lines.append(f"KERNEL {k}  |  {dm[k]}  |  {sum(tests.values())}  |  {len(tests)}  |  {len(oracle)}  |  {len(equiv)}")
         if not tests:
             missing.append(k)
-        order = sorted(tests, key=lambda t: (fn(t) not in ORACLE_TESTS, t))
+        order = sorted(tests, key=lambda t: ("*= ".index(_kind(t)), t))
         for t in order[:12]:
-            lines.append(f"    {'*' if fn(t) in ORACLE_TESTS else ' '} {t}  ({tests[t]})")
+            lines.append(f"    {_kind(t)} {t}  ({tests[t]})")
         if len(order) > 12:
             lines.append(f"      ... and {len(order) - 12} more tests")
     other = sorted(k for k in by_kernel if k not in set(lib_kernels))
@@ -150,18 +194,18 @@ def build(trace_dir, tests_tsv, out_path):
 
 
 def read_record(path):
-    """{mangled kernel: (launches, number of tests, number of oracle-comparing tests)}"""
+    """{mangled kernel: (launches, number of tests, number of oracle-comparing tests, number of equivalence tests)}"""
     rec = {}
     for line in open(path):
         if line.startswith("KERNEL "):
             parts = [p.strip() for p in line[len("KERNEL "):].split("  |  ")]
-            rec[parts[0]] = (int(parts[2]), int(parts[3]), int(parts[4]))
+            rec[parts[0]] = (int(parts[2]), int(parts[3]), int(parts[4]), int(parts[5]) if len(parts) > 5 else 0)
     return rec
 
 
 def check(path):
     rec = read_record(path)
-    bad = [k for k in library_kernels() if rec.get(k, (0, 0, 0))[1] == 0]
+    bad = [k for k in library_kernels() if rec.get(k, (0, 0, 0, 0))[1] == 0]
     for k in bad:
         print("not covered:", k)
     return 1 if bad else 0

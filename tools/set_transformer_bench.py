@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--graphs", type=int, default=0, help="1: one hipGraph replay per step (SetTransformerDIB(use_graphs=True))")
     ap.add_argument("--chain", type=int, default=1, help="0: the layer-by-layer launches instead of the token-chain kernels (A/B)")
+    ap.add_argument("--defer", type=int, default=1, help="0: per-block weight-gradient launches instead of the deferred grouped ones (A/B)")
+    ap.add_argument("--defer-target", type=int, default=0, help="workgroups per deferred weight-gradient launch (0: the default)")
     ap.add_argument("--tuning", default="", help="dib_set_tuning keys, e.g. attn_small_waves=8 (A/B)")
     a = ap.parse_args()
     import dib_amd
@@ -48,6 +50,9 @@ def main():
     m = dib_amd.SetTransformerDIB(particle_feature_dimensions=a.features, attention=os.environ.get("DIB_ST_ATTENTION", "auto"),
                                   use_graphs=bool(a.graphs))
     m.use_chain = bool(a.chain)
+    m.defer_wgrads = bool(a.defer)
+    if a.defer_target:
+        m.deferred_wgrad_target_wgs = a.defer_target
     rng = np.random.default_rng(0)
     x = torch.from_numpy(rng.standard_normal((a.batch, a.particles, a.features)).astype(np.float32)).to(m.device)
     y = torch.from_numpy((rng.random((a.batch, 1)) > 0.5).astype(np.float32)).to(m.device)
@@ -56,16 +61,20 @@ def main():
     for _ in range(a.warmup):
         m.train_step(x, y)
     torch.cuda.synchronize()
+    n0 = _lib.load_library().dib_launch_count()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         m.train_step(x, y)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    launches = (_lib.load_library().dib_launch_count() - n0) / a.steps
     fl = 3 * fwd_flops(m, a.particles) * a.batch
     print(json.dumps({"workload": f"set-transformer DIB, {a.batch} neighbourhoods x {a.particles} particles x {a.features} features",
                       "ms_per_step": round(1e3 * dt, 3), "neighbourhoods_per_s": round(a.batch / dt, 1),
                       "algorithmic_TFLOPs": round(fl / dt / 1e12, 2), "params": m.n_params,
-                      "attention": m.attention_impl, "graph_replay": bool(a.graphs), "tuning": a.tuning}))
+                      "attention": m.attention_impl, "graph_replay": bool(a.graphs), "tuning": a.tuning,
+                      "library_launches_per_step": round(launches, 1), "defer_wgrads": bool(a.defer),
+                      "defer_target_wgs": a.defer_target or None}))
 
 
 if __name__ == "__main__":
