@@ -177,8 +177,8 @@ SIGNATURES_ST = {
     "dib_st_chain_workspace_bytes": (c_int64, [c_int64, c_int]),
     "dib_st_chain_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
-    "dib_st_chain_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_st_chain_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_mean_pool_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_mean_pool_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dib_add_inplace": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),

@@ -1675,7 +1675,8 @@ static int64_t mlp_small_lds_floats(const dib_mlp_desc* d) {
 }
 int dib_mlp_small_supported(const dib_mlp_desc* d, int batch) {
   if (!d || !knobs().small_batch || !knobs().mlp_row_tiles || batch < 1 || batch > kSmallMaxBatch) return 0;
-  if (d->n_hidden < 1 || d->n_hidden > 3 || d->in_dim < 1 || d->act < 0 || d->act > 2) return 0;
+  if (d->n_hidden < 1 || d->n_hidden > 3 || d->in_dim < 1) return 0;
+  if (!(d->act >= 0 && d->act <= 2) && d->act != DIB_ACT_LEAKY_RELU_01) return 0;   // piecewise-linear activations only
   const int nf = d->n_freq > 1 ? d->n_freq : 1;
   if ((int64_t)d->in_dim * nf > 1024) return 0;
   for (int i = 0; i <= d->n_hidden; ++i)
@@ -2048,16 +2049,18 @@ int dib_st_chain_fwd(const dib_st_block_desc* d, int64_t T, const float* params,
   return (int)hipGetLastError();
 }
 
-int dib_st_chain_bwd(const dib_st_block_desc* d, int64_t T, const float* params, const float* g_out, const float* xhat2,
-                     const float* rstd2, const float* const* ff, const float* xhat1, const float* rstd1, float* const* g_ff,
-                     float* g_in, float* g_ctx, float* grads, void* ws, dib_stream_t stream) {
+int dib_st_chain_bwd(const dib_st_block_desc* d, int64_t T, const float* params, const float* g_out, int g_out_slabs,
+                     int64_t g_out_stride, const float* xhat2, const float* rstd2, const float* const* ff, const float* xhat1,
+                     const float* rstd1, float* const* g_ff, float* g_in, float* g_ctx, float* grads, void* ws, dib_stream_t stream) {
   if (!d || !params || !g_out || !xhat2 || !rstd2 || !ff || !xhat1 || !rstd1 || !g_ff || !g_in || !g_ctx || !grads || !ws)
     return DIB_E_ARG;
+  if (g_out_slabs < 1 || (g_out_slabs > 1 && (g_out_stride < T * d->D || (g_out_stride & 3))) || ((uintptr_t)g_out & 15)) return DIB_E_ARG;
   if (!dib_st_chain_supported(d, T)) return DIB_E_UNSUPPORTED;
   DibStChainBwdArgs a;
   std::memset(&a, 0, sizeof(a));
   std::memcpy(&a.d, d, sizeof(a.d));
-  a.T = T; a.params = params; a.g_out = g_out; a.xhat2 = xhat2; a.rstd2 = rstd2; a.xhat1 = xhat1; a.rstd1 = rstd1;
+  a.T = T; a.params = params; a.g_out = g_out; a.g_slabs = g_out_slabs; a.g_stride = g_out_stride;
+  a.xhat2 = xhat2; a.rstd2 = rstd2; a.xhat1 = xhat1; a.rstd1 = rstd1;
   for (int l = 0; l < d->n_ff; ++l) { if (!ff[l] || !g_ff[l]) return DIB_E_ARG; a.ff[l] = ff[l]; a.g_ff[l] = g_ff[l]; }
   a.g_in = g_in; a.g_ctx = g_ctx; a.grads = grads;
   const long long tiles = (T + DIB_SMALL_ROWS - 1) / DIB_SMALL_ROWS;

@@ -65,7 +65,8 @@ __device__ __forceinline__ float dib_sigma(float lv) {
 
 // Piecewise-linear activations only on the fused path (linear / relu / leaky_relu): act(v) = max(v,0) + slope*min(v,0)
 // is branch-free, so the hot loop stays straight-line code.  Other activations use the general GEMM path.
-__device__ __forceinline__ float dib_neg_slope(int act) { return act == 1 ? 0.f : (act == 2 ? 0.2f : 1.f); }
+// slope of the negative branch: relu 0, Keras 'leaky_relu' 0.2, tf.keras.layers.LeakyReLU(0.1) (DIB_ACT_LEAKY_RELU_01 = 7) 0.1, linear 1
+__device__ __forceinline__ float dib_neg_slope(int act) { return act == 1 ? 0.f : (act == 2 ? 0.2f : (act == 7 ? 0.1f : 1.f)); }
 // RELU (the reference default, train.py:37) is a compile-time specialisation: one v_max per element instead of three ops.
 template <bool RELU>
 __device__ __forceinline__ void dib_act_tile(float slope, dib_f32x16& v) {

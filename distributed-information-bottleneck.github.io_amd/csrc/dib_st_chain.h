@@ -32,7 +32,8 @@ struct DibStChainFwdArgs {
 
 struct DibStChainBwdArgs {
   DibStChainDesc d; long long T; const float* params;
-  const float* g_out; const float* xhat2; const float* rstd2; const float* ff[DIB_ST_CHAIN_MAX_FF]; const float* xhat1;
+  const float* g_out; int g_slabs; long long g_stride;   // dL/dx' = sum of g_slabs buffers g_stride floats apart, in slab order
+  const float* xhat2; const float* rstd2; const float* ff[DIB_ST_CHAIN_MAX_FF]; const float* xhat1;
   const float* rstd1;
   float* g_ff[DIB_ST_CHAIN_MAX_FF]; float* g_in; float* g_ctx;
   float* grads;          // LayerNorm gamma / beta gradients go to grads + ln{1,2}_{g,b}
@@ -232,7 +233,33 @@ dib_st_chain_bwd_kernel(DibStChainBwdArgs a) {
   const float slope = dib_neg_slope(d.act);
   float* part = a.ln_partial + (long long)tile * 4 * D;
 
-  dib_small_load_tile(a.g_out + r0 * D, D, D, rows_valid, gs, pD);
+  if (a.g_slabs <= 1) {
+    dib_small_load_tile(a.g_out + r0 * D, D, D, rows_valid, gs, pD);
+  } else {
+    // the gradient arrives as partial slabs (round 6: [the next block's LN1-addend gradient | the split-K slabs of its
+    // q / k / v input gradient]): summed here in slab order, 4 loads in flight per thread - instead of a reduce launch per block
+    const int w4 = D >> 2, total = DIB_SMALL_ROWS * w4;
+    for (int i = tid; i < total; i += DIB_SMALL_THREADS) {
+      const int row = i / w4, c = (i - row * w4) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows_valid) {
+        const float* src = a.g_out + (r0 + row) * D + c;
+        int sl = 0;
+        for (; sl + 4 <= a.g_slabs; sl += 4) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long long)(sl + u) * a.g_stride);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; sl < a.g_slabs; ++sl) {
+          const float4 v = *reinterpret_cast<const float4*>(src + (long long)sl * a.g_stride);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+      *reinterpret_cast<float4*>(gs + row * pD + c) = acc;
+    }
+  }
 #pragma unroll
   for (int l = 0; l < DIB_ST_CHAIN_MAX_FF; ++l)
     if (l < nff) dib_small_load_tile(a.ff[l] + r0 * d.ff_width[l], d.ff_width[l], d.ff_width[l], rows_valid, fs[l], pf[l]);

@@ -387,7 +387,10 @@ class SetTransformerDIB:
         # 12-36 workgroups looping over all rows - 110-137 us each, the top entries of the first profile)
         # (64-row slabs up to 2048 tokens: at 1600 tokens the 6 slabs of the T // 256 rule left the feed-forward wgrads on 6
         # workgroups walking 9 dependent k-tiles each - 24 us per launch, 28 such launches per step)
-        nsplit = max(1, min(32, T // 64))
+        # (deferred weight gradients: many groups per launch fill the chip with FEW splits, and every slab costs the optimizer's
+        # launch a pass over the whole gradient buffer - 25 slabs x 5.2 MB were 130 MB, 33 us of a 1.29 ms step at the notebook's
+        # size; `deferred_max_slabs`)
+        nsplit = max(1, min(int(getattr(self, "deferred_max_slabs", 8)) if defer else 32, T // 64))
         rps = ((T + nsplit - 1) // nsplit + 31) // 32 * 32
         nsplit = (T + rps - 1) // rps
         slabs = torch.zeros(nsplit * self.n_alloc, dtype=torch.float32, device=self.device) if nsplit > 1 else None
@@ -512,13 +515,16 @@ class SetTransformerDIB:
                                             split_stride=self.n_alloc)
                 if defer:
                     dw_ff += descs
-            if defer:   # the slabs land behind the LN1-addend gradient in the block's own region; one sum over all slots -> gout
+            if defer:
+                # the slabs land behind the LN1-addend gradient in the block's own region; the sum over all slots is taken by
+                # the consumer: the previous block's chain launch sums them as it loads its tile (dib_st_chain_bwd g_out_slabs),
+                # block 0's go through one reduce launch into the buffer the bottleneck's backward reads
                 ck = HK // ksplit
                 g[f"b{b}_qkv_dgrad"] = _SplitKGemm(
                     _Gemm(1, [_d(off[f"b{b}_g_{nm}"] + s_ * ck, HK, po[pre + nm + "_w"] + s_ * ck, HK,
                                  off[f"b{b}_dx"] + (1 + i_ * ksplit + s_) * T * D, D, T, D, ck)
                               for i_, nm in enumerate("qkv") for s_ in range(ksplit)], ws, self.params, ws),
-                    ws, off[f"b{b}_dx"], T * D, 1 + 3 * ksplit, ws, off[gout], mode="store")
+                    ws, off[f"b{b}_dx"], T * D, 1 + 3 * ksplit, ws, off[gout], mode="store" if b == 0 else "defer")
             elif ksplit > 1:   # 3 projections x ksplit chunks -> 3 * ksplit slabs, summed straight into g_xq (= g_xq + g_xk + g_xv)
                 ck = HK // ksplit
                 g[f"b{b}_qkv_dgrad"] = _SplitKGemm(
@@ -551,6 +557,19 @@ class SetTransformerDIB:
                 g[f"fin{l}_dgrad"] = dense_dgrad(f"g_fin{l}", u, f"fin{l}_w", f"g_fin{l - 1}", kin_l, B, aux=src_l, act=ACT_LEAKY01)
             else:
                 g["fin0_dgrad"] = dense_dgrad(f"g_fin{l}", u, "fin0_w", "g_pool", D, B)
+        # the particle encoder (PositionalEncoding -> Dense(LeakyReLU(0.1))* -> Dense) on the row-tile MLP kernels for up to 2048
+        # tokens: one launch forward (encoding included), one for the dgrad chain, instead of 4 + 2
+        enc_mlp = None
+        if getattr(self, "encoder_row_tiles", True) and 2 <= len(enc_units) <= 4:
+            from .dense import _MlpDesc
+            dsc = _MlpDesc()
+            for l, u in enumerate(enc_units):
+                dsc.w_off[l], dsc.b_off[l], dsc.width[l] = po[f"enc{l}_w"], po[f"enc{l}_b"], u
+            dsc.n_hidden, dsc.in_dim, dsc.n_freq, dsc.act = len(enc_units) - 1, F0, self.number_positional_encoding_frequencies, ACT_LEAKY01
+            if self.lib.dib_mlp_small_supported(ctypes.byref(dsc), T):
+                nh = len(enc_units) - 1
+                hp = lambda pre: (c_void_p * 3)(*[_ptr(ws, off[f"{pre}{l}"]).value if l < nh else None for l in range(3)])
+                enc_mlp = dict(desc=dsc, h=hp("enc_h"), g=hp("g_enc_h"))
         deferred = []
         if defer:
             # the particle encoder's weight gradients contract over the same T tokens and fit the feed-forward class's tiles:
@@ -579,7 +598,7 @@ class SetTransformerDIB:
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
                     enc_units=enc_units, stash=stash, stash_block_bytes=stash_block_bytes, stash_denied=None, ksplit=ksplit,
-                    chain=chain_descs, deferred_wgrads=deferred)
+                    chain=chain_descs, deferred_wgrads=deferred, enc_mlp=enc_mlp)
         # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
         # (training batch, validation batch, a ragged tail), evict least recently used beyond that
         step_keys = [k for k in self._plans if k[0] != "enc" and k not in self._graphs]   # a captured graph pins its plan
@@ -656,11 +675,16 @@ class SetTransformerDIB:
         T, D = pl["T"], self.bottleneck_dimension
         step = self._step if step is None else int(step)
         self._view(pl, "feats", T, F0).copy_(x.view(T, F0))
-        check(lib.dib_positional_encoding(_ptr(ws, off["feats"]), F0, T, F0, self.number_positional_encoding_frequencies,
-                                          _ptr(ws, off["pe"]), st), "dib_positional_encoding")
         ne = len(pl["enc_units"])
-        for l in range(ne):
-            g[f"enc{l}_fwd"].run(lib, st)
+        em = pl["enc_mlp"]
+        if em is not None:
+            check(lib.dib_mlp_small_fwd(ctypes.byref(em["desc"]), _ptr(self.params), _ptr(ws, off["feats"]), F0, None, T,
+                                        _ptr(ws, off["pe"]), em["h"], _ptr(ws, off[f"enc_h{ne - 1}"]), st), "dib_mlp_small_fwd")
+        else:
+            check(lib.dib_positional_encoding(_ptr(ws, off["feats"]), F0, T, F0, self.number_positional_encoding_frequencies,
+                                              _ptr(ws, off["pe"]), st), "dib_positional_encoding")
+            for l in range(ne):
+                g[f"enc{l}_fwd"].run(lib, st)
         check(lib.dib_token_reparam_kl_fwd(_ptr(ws, off[f"enc_h{ne - 1}"]), T, D, self.logvar_initialization, self.noise_seed,
                                            step & 0xFFFFFFFF, _ptr(self.step_dev) if _step_from_device else c_void_p(0),
                                            int(row0), 1 if deterministic else 0, _ptr(ws, off["x0"]),
@@ -755,7 +779,12 @@ class SetTransformerDIB:
                 gb = (lambda nm: f"b{b}_{nm}") if defer else (lambda nm: nm)
                 ffp = (c_void_p * 3)(*[_ptr(ws, off[f"b{b}_ff{l}"]) for l in range(nff)])
                 gfp = (c_void_p * 3)(*[_ptr(ws, off[gb("g_z" if l == nff - 1 else f"g_ff{l}")]) for l in range(nff)])
-                check(lib.dib_st_chain_bwd(ctypes.byref(pl["chain"][b]), T, _ptr(self.params), _ptr(ws, off[gin]),
+                # deferred: the gradient of this block's output is [LN1-addend gradient | q/k/v input-gradient slabs] of the
+                # NEXT block, summed by the kernel as it loads its tile; the last block's comes from the pooling backward
+                from_slabs = defer and b + 1 < self.number_attention_blocks
+                check(lib.dib_st_chain_bwd(ctypes.byref(pl["chain"][b]), T, _ptr(self.params),
+                                           _ptr(ws, off[f"b{b + 1}_dx"] if from_slabs else off[gin]),
+                                           1 + 3 * pl["ksplit"] if from_slabs else 1, T * D if from_slabs else 0,
                                            _ptr(ws, off[f"b{b}_xhat2"]), _ptr(ws, off[f"b{b}_rstd2"]), ffp,
                                            _ptr(ws, off[f"b{b}_xhat1"]), _ptr(ws, off[f"b{b}_rstd1"]), gfp,
                                            _ptr(ws, off[f"b{b}_gln1" if defer else gout]),
@@ -805,10 +834,14 @@ class SetTransformerDIB:
         check(lib.dib_token_reparam_kl_bwd(_ptr(ws, off[f"enc_h{ne - 1}"]), _ptr(ws, off[g_u]), _ptr(ws, off["x0"]), T, D,
                                            self.logvar_initialization, _ptr(self.beta_dev), inv,
                                            _ptr(ws, off[f"g_enc_h{ne - 1}"]), st), "dib_token_reparam_kl_bwd")
+        em = pl["enc_mlp"]
+        if em is not None:   # the encoder's dgrad chain in one launch (its weight gradients: grouped, on the stashes)
+            check(lib.dib_mlp_small_bwd(ctypes.byref(em["desc"]), _ptr(self.params), _ptr(ws, off[f"g_enc_h{ne - 1}"]), em["h"], em["g"],
+                                        T, st), "dib_mlp_small_bwd")
         for l in range(ne - 1, -1, -1):
             if not dw:   # (deferred: three more groups of the feed-forward class's launch below)
                 g[f"enc{l}_wgrad"].run(lib, st)
-            if l > 0:
+            if l > 0 and em is None:
                 g[f"enc{l}_dgrad"].run(lib, st)
         for name in pl["deferred_wgrads"]:   # every block's weight gradients, one grouped launch per shape class
             g[name].run(lib, st)

@@ -83,8 +83,9 @@ const char* dib_version(void);
  * memory silently.  History: 3 = round 3 (attention stash arguments, 17 profile categories); 4 = round 4; 5 = round 5
  * (`flags` argument of dib_loss_fwd_bwd / dib_output_head_fused, dib_step_tail, dib_set_tuning; the workspace grew by the
  * tail's arrival counters, which dib_workspace_init zeroes - re-run it on workspaces kept from an older library; the
- * experimental bf16x6 GEMM entry points left the library); 6 = round 6 (the tuning key "num_cus" = 0 now
- * means "the calling thread's current device's own count"; the library no longer writes it; no signature changed). */
+ * experimental bf16x6 GEMM entry points left the library); 6 = round 6 (dib_st_chain_bwd takes its incoming
+ * gradient as g_out_slabs partial buffers; the tuning key "num_cus" = 0 now means "the calling thread's current device's own
+ * count" and the library no longer writes it). */
 #define DIB_ABI_VERSION 6
 int dib_abi_version(void);
 const char* dib_error_string(int code);
@@ -294,7 +295,8 @@ int dib_positional_encoding_rows(const float* x, int64_t ldx, const int32_t* row
  * forward (gather + positional encoding + every layer) and one for the dgrad chain, instead of 1 + L and L - 1 launches.
  * The weight gradients stay one grouped GEMM on the stashes these write (dib_gemm_grouped, include/dib_st.h).
  * Layer i: kernel [in_i][width[i]] row-major at params + w_off[i], bias at params + b_off[i]; in_0 = in_dim * max(n_freq, 1);
- * width[n_hidden] = the output width (linear).  act: DIB_ACT_* of the hidden layers (linear / relu / leaky_relu only). */
+ * width[n_hidden] = the output width (linear).  act: DIB_ACT_* of the hidden layers (linear / relu / leaky_relu, and dib_st.h's
+ * DIB_ACT_LEAKY_RELU_01 = LeakyReLU(0.1), the set transformer's particle encoder). */
 typedef struct dib_mlp_desc {
   int64_t w_off[4], b_off[4];
   int32_t n_hidden, width[4];

@@ -98,7 +98,9 @@ int dib_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd,
  * workgroup owns 16 tokens).  Offsets are ELEMENT offsets into `params` (Keras orientation: o_w [heads*key_dim, D], ff_w[l]
  * [in, width]); D % 32 == 0, D <= 256; widths and HK % 16 == 0; ff_width[n_ff - 1] == D; act in {linear, relu, leaky_relu}.
  *   fwd: mha = ctx @ o_w + o_b; h = LN1(x_in + mha) (+ xhat1, rstd1); f_l = act(f_{l-1} ff_w[l] + ff_b[l]); x_out = LN2(h + f_last)
- *   bwd: from g_out = dL/dx_out: g_ff[l] = dL/d(pre-activation of layer l) (the dy operands of the ff weight gradients),
+ *   bwd: from g_out = dL/dx_out (ABI 6: given as g_out_slabs >= 1 partial buffers g_out_stride floats apart, summed by the
+ *        kernel in slab order - the next block's LN1-addend gradient and the split-K slabs of its q / k / v input gradient
+ *        arrive that way, without a reduce launch per block): g_ff[l] = dL/d(pre-activation of layer l) (the dy operands of the ff weight gradients),
  *        g_in = dL/d(x_in + mha) (the residual share of the block input's gradient AND the dy of the o_w gradient),
  *        g_ctx = g_in @ o_w^T, and the four LayerNorm parameter gradients written to grads + ln{1,2}_{g,b}.
  * ws: dib_st_chain_workspace_bytes, zero-filled once by the caller (per-tile partials + one arrival counter). */
@@ -113,9 +115,9 @@ int dib_st_chain_supported(const dib_st_block_desc* d, int64_t T);
 int64_t dib_st_chain_workspace_bytes(int64_t T, int D);
 int dib_st_chain_fwd(const dib_st_block_desc* d, int64_t T, const float* params, const float* ctx, const float* x_in, float* h,
                      float* xhat1, float* rstd1, float* const* ff, float* x_out, float* xhat2, float* rstd2, dib_stream_t stream);
-int dib_st_chain_bwd(const dib_st_block_desc* d, int64_t T, const float* params, const float* g_out, const float* xhat2,
-                     const float* rstd2, const float* const* ff, const float* xhat1, const float* rstd1, float* const* g_ff,
-                     float* g_in, float* g_ctx, float* grads, void* ws, dib_stream_t stream);
+int dib_st_chain_bwd(const dib_st_block_desc* d, int64_t T, const float* params, const float* g_out, int g_out_slabs,
+                     int64_t g_out_stride, const float* xhat2, const float* rstd2, const float* const* ff, const float* xhat1,
+                     const float* rstd1, float* const* g_ff, float* g_in, float* g_ctx, float* grads, void* ws, dib_stream_t stream);
 
 int dib_add_layernorm_bwd_fused(const float* dy, const float* dy2, const float* xhat, const float* rstd, const float* gamma,
                                 int64_t T, int D, float* ds, const float* act_src, int act, float* dz, float* dgamma_dbeta,
