@@ -132,6 +132,10 @@ SIGNATURES = {
     "dib_mlp_small_supported": (c_int, [c_void_p, c_int]),
     "dib_mlp_small_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_mlp_small_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dib_mlp_small_head_supported": (c_int, [c_void_p, c_int]),
+    "dib_mlp_small_head_workspace_bytes": (c_int64, [c_void_p, c_int]),
+    "dib_mlp_small_head_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_integration_fwd_and_mlp_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_backward_and_mlp_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,
@@ -163,6 +167,9 @@ SIGNATURES_ST = {
     "dib_attention_stash_bytes": (c_int64, [c_int, c_int, c_int]),
     "dib_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
+    "dib_attention_fwd_proj_supported": (c_int, [c_int, c_int, c_int]),
+    "dib_attention_fwd_proj": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dib_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dib_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

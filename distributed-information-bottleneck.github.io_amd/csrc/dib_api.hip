@@ -220,6 +220,7 @@ struct Tuning {
   int mlp_row_tiles = 1;     // ... and for a plain MLP (dib_mlp_small_*: the custom loop's output encoder)
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
+  int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
   int num_cus = 0;           // compute units the split rule prices rounds with; 0 = the current device's own count (device_cus)
 };
 // Process-wide and written ONLY by dib_set_tuning, which the header documents as a configuration call made while no other
@@ -240,11 +241,11 @@ inline int device_cus() {
 }
 inline int split_rule_cus() { return knobs().num_cus > 0 ? knobs().num_cus : device_cus(); }
 
-template <int MODE, int NI, int NJ>
+template <int MODE, int NI, int NJ, bool FLAT = false>
 int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int N, const float* A, const float* B, float* C,
                   const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit,
                   int rows_per_split, long long split_stride, hipStream_t st) {
-  const int tm = cdiv(M, 64 * NI), tn = cdiv(N, 64 * NJ);
+  const int tm = cdiv(M, FLAT ? 32 : 64 * NI), tn = cdiv(N, FLAT ? 256 : 64 * NJ);
   // grid.y / grid.z are limited to 65535: a clean return code instead of a launch error
   if (c.count > 65535 || (MODE == 2 && (long long)tm * tn > 65535)) return DIB_E_UNSUPPORTED;
   dim3 grid;
@@ -253,7 +254,8 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
   // K-tile depth per tile shape (each a same-box A/B, profiles/HISTORY.md): 64 for the 128 x 128 tile of every mode - one
   // prefetch + barrier pair per 64-deep MFMA phase hides the HBM latency a 32-deep phase exposes (+18 %) - and for the 64 x 128
   // weight-gradient tile of the 256 x 256 integration layer (0.136 -> 0.124 ms); 32 for the other narrow tiles.
-  constexpr int BK = (NI == 2 && NJ == 2) ? 64 : ((MODE == 2 && NI == 1 && NJ == 2) ? 64 : 32);
+  // (the flat 32 x 256 weight-gradient tile: 32 - its 256-column operand tile at 64 deep would need 76 KB of static LDS)
+  constexpr int BK = FLAT ? 32 : ((NI == 2 && NJ == 2) ? 64 : ((MODE == 2 && NI == 1 && NJ == 2) ? 64 : 32));
   // cache policy of the streamed operands / outputs (dib_gemm.h: stream_flags): non-temporal from 8192 streamed rows up
   // (DIB_GEMM_STREAM_ROWS; M for forward / dgrad, the contracted rows for a weight gradient)
   const long long streamed_rows = MODE == 2 ? (long long)nsplit * rows_per_split : (long long)M;
@@ -261,7 +263,7 @@ int launch_gemm_t(const DibGemmGroup* dev_groups, const GemmCall& c, int M, int 
   // hidden activation of the integration network, stored non-temporally, cost the fused head that reads it next 19 us)
   const bool big_out = MODE != 2 && (long long)M * N * (long long)sizeof(float) * c.count >= (256ll << 20);
   const int stream_flags = streamed_rows >= knobs().stream_rows ? (big_out ? 3 : 1) : 0;
-  DIB_LAUNCH((dib_gemm_kernel<MODE, NI, NJ, BK>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
+  DIB_LAUNCH((dib_gemm_kernel<MODE, NI, NJ, BK, FLAT>), grid, dim3(256), 0, st, dev_groups + c.first, A, B, C,
                      bias, aux, bias_out, batch, act, tm, tn, rows_per_split, split_stride, stream_flags);
   return (int)hipGetLastError();
 }
@@ -341,6 +343,12 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
     pick_wgrad_splits(tiles, split_rule_cus() * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
+  if constexpr (MODE == 2) {
+    // a 32-row operand against a wide one (q / k / v weight gradients of the set transformer): the flat 32 x 256 tile
+    if (M <= 32 && N >= 256 && knobs().wgrad_flat_tile)
+      return launch_gemm_t<2, 1, 2, true>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, rows_per_split,
+                                          split_stride, st);
+  }
 #define DIB_GO(NI, NJ) launch_gemm_t<MODE, NI, NJ>(dev_groups, c, M, N, A, B, C, bias, aux, bias_out, batch, act, nsplit, \
                                                    rows_per_split, split_stride, st)
   if (ni1) return nj1 ? DIB_GO(1, 1) : DIB_GO(1, 2);
@@ -1466,6 +1474,7 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "mlp_row_tiles")) return &t.mlp_row_tiles;
   if (!std::strcmp(key, "infonce_one_launch")) return &t.infonce_one_launch;
   if (!std::strcmp(key, "attn_small_bwd_waves")) return &t.attn_small_bwd_waves;
+  if (!std::strcmp(key, "wgrad_flat_tile")) return &t.wgrad_flat_tile;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
   return nullptr;
 }
@@ -1741,6 +1750,58 @@ int dib_mlp_small_bwd(const dib_mlp_desc* d, const float* params, const float* g
   if (int rc = mlp_small_bwd_args(d, params, g_out, h, g, n, a)) return rc;
   return mlp_small_launch(d, a, (hipStream_t)stream);
 }
+// ---- plain MLP with a 1-unit head: the whole training step of the head network in ONE launch (include/dib_hip.h) ----
+static int64_t mlp_head_lds_floats(const dib_mlp_desc* d) {
+  int64_t fl = (int64_t)DIB_SMALL_ROWS * dib_small_pitch(d->in_dim);
+  for (int i = 0; i < d->n_hidden; ++i) fl += 2ll * DIB_SMALL_ROWS * dib_small_pitch(d->width[i]);
+  return fl + (int64_t)DIB_SMALL_ROWS * dib_small_pitch(1) + DIB_SMALL_XCH_FLOATS + 9 * (d->width[d->n_hidden - 1] + 1) + 32;
+}
+int dib_mlp_small_head_supported(const dib_mlp_desc* d, int n) {
+  if (!d || !knobs().small_batch || !knobs().mlp_row_tiles || n < 1 || n > kSmallMaxBatch) return 0;
+  if (d->n_hidden < 1 || d->n_hidden > 3 || d->in_dim < 16 || d->in_dim % 16 || d->in_dim > 1024 || d->n_freq > 1) return 0;
+  if (!(d->act >= 0 && d->act <= 2) && d->act != DIB_ACT_LEAKY_RELU_01) return 0;
+  for (int i = 0; i < d->n_hidden; ++i)
+    if (d->width[i] < 16 || d->width[i] % 16 != 0 || d->width[i] > 1024) return 0;
+  if (d->width[d->n_hidden] != 1) return 0;
+  return mlp_head_lds_floats(d) * 4 <= 150 * 1024 ? 1 : 0;
+}
+int64_t dib_mlp_small_head_workspace_bytes(const dib_mlp_desc* d, int n) {
+  if (!d || n < 1 || d->n_hidden < 1 || d->n_hidden > 3) return DIB_E_ARG;
+  return ((int64_t)small_tiles(n) * (d->width[d->n_hidden - 1] + 1 + 2) + 16) * (int64_t)sizeof(float);
+}
+int dib_mlp_small_head_step(const dib_mlp_desc* d, const float* params, const float* x, int n, const float* y, int64_t ldy,
+                            int loss_kind, float inv_global_batch, float* const* h, float* const* g, float* pred, float* g_pred,
+                            float* g_x, float* grads, float* sums3, void* ws, dib_stream_t stream) {
+  if (!d || !params || !x || !y || !h || !g || !pred || !g_pred || !grads || !sums3 || !ws || n <= 0) return DIB_E_ARG;
+  if (loss_kind != DIB_LOSS_BCE_LOGITS && loss_kind != DIB_LOSS_MSE) return DIB_E_UNSUPPORTED;
+  if (!dib_mlp_small_head_supported(d, n)) return DIB_E_UNSUPPORTED;
+  DibSmallIntArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.mode = DIB_SMALL_INT_FWD | DIB_SMALL_INT_HEAD | DIB_SMALL_INT_HEAD_GRAD | DIB_SMALL_INT_BWD | DIB_SMALL_INT_HEAD_REDUCE |
+           (g_x ? 0 : DIB_SMALL_INT_NO_GU);
+  a.U = x; a.GU = g_x; a.batch = n; a.K0 = d->in_dim; a.params = params; a.n_hidden = d->n_hidden;
+  for (int i = 0; i <= d->n_hidden; ++i) { a.width[i] = d->width[i]; a.w_off[i] = d->w_off[i]; a.b_off[i] = d->b_off[i]; }
+  for (int i = 0; i < d->n_hidden; ++i) {
+    if (!h[i] || !g[i]) return DIB_E_ARG;
+    a.h[i] = h[i]; a.g[i] = g[i];
+  }
+  a.act = d->act; a.out_act = 0; a.out_dim = 1;
+  a.pred = pred; a.g_pred = g_pred; a.loss_kind = loss_kind; a.Y = y; a.ldy = ldy; a.row_idx = nullptr; a.row0 = 0;
+  a.inv_bg = inv_global_batch;
+  const int tiles = small_tiles(n), KL = d->width[d->n_hidden - 1];
+  float* w = (float*)ws;
+  a.partial_w = w; a.partial_l = w + (int64_t)tiles * (KL + 1);
+  a.sync = (unsigned*)(a.partial_l + 2 * tiles);   // zero at first use (the caller zero-fills the workspace once)
+  a.head_gw = grads + d->w_off[d->n_hidden]; a.head_gb = grads + d->b_off[d->n_hidden];
+  a.sums3 = sums3; a.loss_scale = inv_global_batch;
+  const size_t lds = (size_t)mlp_head_lds_floats(d) * 4;
+  static int lds_have[64] = {};
+  if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_kernel, lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, (hipStream_t)stream);
+  DIB_LAUNCH(dib_small_integration_kernel, dim3(tiles), dim3(DIB_SMALL_THREADS), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 // the companion protocol: arm, run the model's entry point, launch alone if the model's path had no row-tile launch to share
 static int with_companion(const dib_mlp_desc* d, const DibSmallIntArgs& c, hipStream_t st, int model_rc_fn(void*), void* ctx) {
   t_companion.args = c;
@@ -2111,13 +2172,40 @@ int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int
     const size_t lds = (size_t)DibAttnSmallFwdLds * sizeof(float);
     static std::atomic<bool> attr_small[64];
     if (AttrOnce once(attr_small); once) {
-      hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    DIB_LAUNCH(dib_attn_small_fwd_kernel, dim3(H, B), dim3(256), lds, (hipStream_t)stream, a);
+    DIB_LAUNCH(dib_attn_small_fwd_kernel<false>, dim3(H, B), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
   DIB_LAUNCH(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int dib_attention_fwd_proj_supported(int P, int key_dim, int model_dim) {
+  return P >= 1 && P <= kAttnSmallP && key_dim == kAttnD && model_dim == 32;
+}
+
+int dib_attention_fwd_proj(const float* x, int64_t ldx, const float* params, const int64_t* w_off, const int64_t* b_off, int B, int P,
+                           int H, int key_dim, int model_dim, int64_t ld, float scale, float* q, float* k, float* v, float* o,
+                           float* lse, dib_stream_t stream) {
+  if (!x || !params || !w_off || !b_off || !q || !k || !v || !o || !lse || B <= 0 || P <= 0 || H <= 0 || ldx < model_dim || (ldx & 3))
+    return DIB_E_ARG;
+  if (!dib_attention_fwd_proj_supported(P, key_dim, model_dim)) return DIB_E_UNSUPPORTED;
+  if (ld != (int64_t)H * key_dim) return DIB_E_ARG;   // the projection kernels [model_dim][H * key_dim] share the outputs' leading dimension
+  if ((((uintptr_t)x | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) != 0) return DIB_E_ARG;
+  DibAttnArgs a{};
+  a.o = o; a.lse = lse; a.P = P; a.H = H; a.ld = ld; a.scale = scale;
+  a.px = x; a.pldx = ldx; a.pparams = params; a.pq = q; a.pk = k; a.pv = v;
+  for (int i = 0; i < 3; ++i) { a.pw[i] = w_off[i]; a.pb[i] = b_off[i]; }
+  ProfScope ps(kProfAttnFwd, (hipStream_t)stream);
+  const size_t lds = (size_t)DibAttnSmallFwdLds * sizeof(float);
+  static std::atomic<bool> attr_small[64];
+  if (AttrOnce once(attr_small); once) {
+    hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  DIB_LAUNCH(dib_attn_small_fwd_kernel<true>, dim3(H, B), dim3(256), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -55,6 +55,9 @@ struct DibAttnArgs {
   float* dq; float* dk; float* dv;                  // bwd out [T, ld]
   float* s_stash;                                   // fwd out / bwd in (NULL: recompute), see dib_attn_stash_tile
   int P, H; long long ld; float scale;
+  // round 6, dib_attn_small_fwd_kernel<true> only: q, k, v are OUTPUTS - the head's slices of the three input projections
+  // x [T, 32] @ W_i [32, H * 128] + b_i are computed in the kernel's prologue (and written for the backward)
+  const float* px; long long pldx; const float* pparams; long long pw[3], pb[3]; float* pq; float* pk; float* pv;
 };
 
 // first element of the 32 x 32 score tile (key tile kt, query tile qt) of (neighbourhood b, head): row-major [query][key]

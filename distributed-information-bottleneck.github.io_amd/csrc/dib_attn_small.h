@@ -47,6 +47,12 @@ __device__ __forceinline__ void dib_attn_small_store(float* __restrict__ base, l
 }
 
 // grid (H, B), 256 threads, dynamic LDS DibAttnSmallFwdLds floats
+// PROJ (round 6): the head's q, k, v are not read but COMPUTED here - MultiHeadAttention's three input Dense layers on the
+// neighbourhood's tokens, x [P, 32] @ W_i[:, head's 128 columns] + b_i - and written out for the backward: the projection launch
+// in front of every attention block (14 us of 57 per block at the notebook's size) disappears.  Wave (wm, wn) owns rows
+// [32 wm, +32) x columns [64 wn, +64) of each of the three tiles; its A operand (the tokens' 32 values, 16 registers) and the
+// weight fragments (4-byte loads, 128-byte runs per k) come straight from global memory / L2 - no extra LDS, same occupancy.
+template <bool PROJ>
 __global__ void __launch_bounds__(256)
 dib_attn_small_fwd_kernel(DibAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -56,16 +62,67 @@ dib_attn_small_fwd_kernel(DibAttnArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int head = blockIdx.x, b = blockIdx.y, P = a.P;
   const long long tok0 = (long long)b * P;
-  const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
-  const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
-  const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
-  dib_attn_small_load(Qs, Qb, a.ld, P, tid, a.scale);
-  dib_attn_small_load(Ks, Kb, a.ld, P, tid, 1.0f);
   float4 vr[8];                                  // V rows: in flight during the S product, into Q's space after it
+  dib_f32x16 vacc[2];                            // PROJ: the wave's 32 x 64 piece of V in accumulator layout instead
+  if constexpr (!PROJ) {
+    const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
+    const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
+    const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
+    dib_attn_small_load(Qs, Qb, a.ld, P, tid, a.scale);
+    dib_attn_small_load(Ks, Kb, a.ld, P, tid, 1.0f);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int r = (tid >> 5) + 8 * p;
-    vr[p] = r < P ? *reinterpret_cast<const float4*>(Vb + (long long)r * a.ld + (tid & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < 8; ++p) {
+      const int r = (tid >> 5) + 8 * p;
+      vr[p] = r < P ? *reinterpret_cast<const float4*>(Vb + (long long)r * a.ld + (tid & 31) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    // A fragments: x[row 32 wm + l31][k = 8 q + 4 h + t], q = 0..3 (rows >= P: zero)
+    const int xrow = wm * 32 + l31;
+    float4 xa[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      xa[q] = xrow < P ? *reinterpret_cast<const float4*>(a.px + (tok0 + xrow) * a.pldx + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int col0 = head * kAttnD + wn * 64 + l31;          // this lane's column of tile j = 0 (tile 1: + 32)
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
+      const float* W = a.pparams + a.pw[pi];
+      float bw[2][16];                                        // W[k = 8 q + 4 h + t][col0 + 32 j], index 4 q + t
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bw[j][4 * q + t] = W[(long long)(8 * q + 4 * h + t) * a.ld + col0 + 32 * j];
+      const float b0 = a.pparams[a.pb[pi] + col0], b1 = a.pparams[a.pb[pi] + col0 + 32];
+      dib_f32x16 acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][r] = b0; acc[1][r] = b1; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[j] = DIB_MFMA(xa[q].x, bw[j][4 * q + 0], acc[j]);
+          acc[j] = DIB_MFMA(xa[q].y, bw[j][4 * q + 1], acc[j]);
+          acc[j] = DIB_MFMA(xa[q].z, bw[j][4 * q + 2], acc[j]);
+          acc[j] = DIB_MFMA(xa[q].w, bw[j][4 * q + 3], acc[j]);
+        }
+      }
+      // C fragment: column l31 of tile j, rows (r & 3) + 8 (r >> 2) + 4 h of the wave's 32: to global (rows < P) and to LDS
+      float* Gout = (pi == 0 ? a.pq : (pi == 1 ? a.pk : a.pv)) + tok0 * a.ld;
+      float* Ts = pi == 0 ? Qs : Ks;
+      const float mul = pi == 0 ? a.scale : 1.0f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const bool ok = row < P;
+          if (ok) Gout[(long long)row * a.ld + col0 + 32 * j] = acc[j][r];
+          if (pi < 2) Ts[row * kAttnPitch + wn * 64 + 32 * j + l31] = ok ? acc[j][r] * mul : 0.f;
+        }
+        if (pi == 2) vacc[j] = acc[j];
+      }
+    }
   }
   __syncthreads();
   // ---- S[query wm*32.., key wn*32..] ----
@@ -105,8 +162,18 @@ dib_attn_small_fwd_kernel(DibAttnArgs a) {
   float* St = Ks;
 #pragma unroll
   for (int r = 0; r < 16; ++r) St[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kAttnSP + wn * 32 + l31] = s[r];
+  if constexpr (!PROJ) {
 #pragma unroll
-  for (int p = 0; p < 8; ++p) *reinterpret_cast<float4*>(Qs + ((tid >> 5) + 8 * p) * kAttnPitch + (tid & 31) * 4) = vr[p];
+    for (int p = 0; p < 8; ++p) *reinterpret_cast<float4*>(Qs + ((tid >> 5) + 8 * p) * kAttnPitch + (tid & 31) * 4) = vr[p];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        Qs[row * kAttnPitch + wn * 64 + 32 * j + l31] = row < P ? vacc[j][r] : 0.f;
+      }
+  }
   __syncthreads();
   // ---- row softmax in place: thread = (query tid >> 2, keys 16 (tid & 3) ..) ----
   {

@@ -119,15 +119,19 @@ struct DibStage {
 
 #define DIB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-template <int MODE, int NI, int NJ, int BK>
+// FLAT (round 6, weight gradients of a 32-row operand only - the set transformer's q / k / v kernels [32, heads x key_dim]): the
+// four waves side by side, a 32 x 256 tile of 32 x 64 wave tiles.  On the 64 x 128 tile two of the four waves owned rows that
+// do not exist (M = 32): 18 such groups per step at the notebook's size ran at 41 TFLOP/s.
+template <int MODE, int NI, int NJ, int BK, bool FLAT = false>
 __global__ void __launch_bounds__(256, 2)
 dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict__ Abase,
                 const float* __restrict__ Bbase, float* __restrict__ Cbase, const float* __restrict__ bias,
                 const float* __restrict__ aux, float* __restrict__ bias_out, int batch, int act, int tiles_m,
                 int tiles_n, int rows_per_split, long long split_stride, int stream_flags = 0) {
+  static_assert(!FLAT || (MODE == 2 && NI == 1 && NJ == 2), "the flat wave layout is a weight-gradient tile of 32 x (4 x 64)");
   constexpr bool A_KC = (MODE != 2);
   constexpr bool B_KC = (MODE == 1);
-  constexpr int BM = 64 * NI, BN = 64 * NJ;
+  constexpr int BM = FLAT ? 32 : 64 * NI, BN = FLAT ? 256 : 64 * NJ;
   using SA = DibStage<A_KC, BM, BK>;
   using SB = DibStage<B_KC, BN, BK>;
   __shared__ __attribute__((aligned(16))) float smem[SA::FLOATS + SB::FLOATS];
@@ -169,7 +173,7 @@ dib_gemm_kernel(const DibGemmGroup* __restrict__ groups, const float* __restrict
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = FLAT ? 0 : wave >> 1, wn = FLAT ? wave : wave & 1;
   const long long aoff = g.a_off + g.a_boff * batch, boff = g.b_off + g.b_boff * batch;
   const bool vecA = ((aoff | (long long)g.lda) & 3) == 0, vecB = ((boff | (long long)g.ldb) & 3) == 0;
   const float* Ag = Abase + aoff;

@@ -440,6 +440,8 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
 #define DIB_SMALL_INT_LOAD_G 256   // dL/dh_{n-1} comes from its global stash (written by a separately launched output head)
 #define DIB_SMALL_INT_POSENC_IN 512  // the input tile is gather + PositionalEncoding of X rows (a plain MLP: dib_mlp_small_*)
 #define DIB_SMALL_INT_NO_GU 1024   // the dgrad chain stops at dL/dh_0 (no gradient with respect to the input)
+#define DIB_SMALL_INT_HEAD_REDUCE 2048  // the last workgroup to arrive sums the head's per-tile partials itself (a plain MLP with
+                                        // a 1-unit head, dib_mlp_small_head_step: no step tail follows to do it)
 
 struct DibSmallIntArgs {
   const float* U; float* GU; int batch, K0;
@@ -454,6 +456,9 @@ struct DibSmallIntArgs {
   // input tile is built from rows row_idx[b] (or row0 + b) of X: [x | sin 2x | sin 4x | ...] (the expressions of
   // dib_posenc_rows_kernel), K0 = in_dim * n_freq, and stashed in a0 [B][K0] (operand of the first weight gradient)
   const float* X; long long ldx; int in_dim, n_freq; float* a0;
+  // DIB_SMALL_INT_HEAD_REDUCE: d(W_out | b_out) -> head_gw [K], head_gb [1]; {loss sum, #correct, loss sum * loss_scale} -> sums3;
+  // sync: one zero-initialised word (self-cleaning)
+  float* head_gw; float* head_gb; float* sums3; float loss_scale; unsigned* sync;
 };
 
 __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs& a, const int tile) {
@@ -657,6 +662,34 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
       dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
                     a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
     DIB_ST(28);
+  }
+
+  if (a.mode & DIB_SMALL_INT_HEAD_REDUCE) {   // block-uniform
+    // the per-tile partials of the output layer's gradient and of the loss sums, summed in tile order by the last workgroup
+    // to arrive (deterministic; the release / acquire pair of csrc/dib_st_chain.h)
+    __shared__ bool s_last;
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const bool last = __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      if (last) __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int ntl = (int)gridDim.x;
+    for (int i = tid; i <= KL; i += DIB_SMALL_THREADS) {
+      float t = 0.f;
+      for (int tl = 0; tl < ntl; ++tl) t += a.partial_w[(long long)tl * (KL + 1) + i];
+      if (i < KL) a.head_gw[i] = t; else a.head_gb[0] = t;
+    }
+    if (tid < 2) {
+      float t = 0.f;
+      for (int tl = 0; tl < ntl; ++tl) t += a.partial_l[2 * tl + tid];
+      a.sums3[tid] = t;
+      if (tid == 0) a.sums3[2] = t * a.loss_scale;
+    }
   }
 }
 

@@ -570,6 +570,21 @@ class SetTransformerDIB:
                 nh = len(enc_units) - 1
                 hp = lambda pre: (c_void_p * 3)(*[_ptr(ws, off[f"{pre}{l}"]).value if l < nh else None for l in range(3)])
                 enc_mlp = dict(desc=dsc, h=hp("enc_h"), g=hp("g_enc_h"))
+        # the head (pooled neighbourhood -> Dense(LeakyReLU(0.1))* -> Dense(1) -> BCE) as ONE launch for its whole share of a training
+        # step (dib_mlp_small_head_step): forward, loss, gradient of the logit, dgrad chain, the output layer's gradient
+        head_mlp = None
+        if getattr(self, "head_row_tiles", True) and self.output_dimensionality == 1 and 1 <= nfin <= 3:
+            from .dense import _MlpDesc
+            dsc = _MlpDesc()
+            for l, u in enumerate(self.final_processing_arch):
+                dsc.w_off[l], dsc.b_off[l], dsc.width[l] = po[f"fin{l}_w"], po[f"fin{l}_b"], u
+            dsc.w_off[nfin], dsc.b_off[nfin], dsc.width[nfin] = po["out_w"], po["out_b"], 1
+            dsc.n_hidden, dsc.in_dim, dsc.n_freq, dsc.act = nfin, D, 1, ACT_LEAKY01
+            if self.lib.dib_mlp_small_head_supported(ctypes.byref(dsc), B):
+                hp = lambda pre: (c_void_p * 3)(*[_ptr(ws, off[f"{pre}{l}"]).value if l < nfin else None for l in range(3)])
+                head_ws = torch.zeros(int(self.lib.dib_mlp_small_head_workspace_bytes(ctypes.byref(dsc), B)) // 4 + 4,
+                                      dtype=torch.float32, device=self.device)
+                head_mlp = dict(desc=dsc, h=hp("fin"), g=hp("g_fin"), ws=head_ws)
         deferred = []
         if defer:
             # the particle encoder's weight gradients contract over the same T tokens and fit the feed-forward class's tiles:
@@ -577,8 +592,8 @@ class SetTransformerDIB:
             # become one grouped launch
             dw_ff += [dict(zip(DESC.names, g[f"enc{l}_wgrad"].host[0])) for l in range(len(enc_units))]
             g["head_wgrads"] = _Gemm(2, [dict(zip(DESC.names, g[k].host[0])) for k in
-                                         ["out_wgrad"] + [f"fin{l}_wgrad" for l in range(nfin)]], ws, ws, gt, bias_out=gt,
-                                     nsplit=1, rows_per_split=max(B, 1), split_stride=self.n_alloc)
+                                         ([] if head_mlp is not None else ["out_wgrad"]) + [f"fin{l}_wgrad" for l in range(nfin)]],
+                                     ws, ws, gt, bias_out=gt, nsplit=1, rows_per_split=max(B, 1), split_stride=self.n_alloc)
             # one grouped launch per shape class.  A grouped launch's grid is (splits, tiles of the LARGEST group shape, groups):
             # the split count of each class is chosen so that its workgroups make about `deferred_wgrad_target_wgs` - many
             # groups need few, long splits (1536: the best of 384 / 512 / 768 / 1024 / 1536 at the notebook's size, 1.335 ...
@@ -598,7 +613,13 @@ class SetTransformerDIB:
             gg.upload(self.device)
         plan = dict(impl=impl, B=B, P=P, T=T, ldS=ldS, off=off, ws=ws, g=g, nsplit=nsplit, slabs=slabs, gt=gt, pe_w=pe_w,
                     enc_units=enc_units, stash=stash, stash_block_bytes=stash_block_bytes, stash_denied=None, ksplit=ksplit,
-                    chain=chain_descs, deferred_wgrads=deferred, enc_mlp=enc_mlp)
+                    chain=chain_descs, deferred_wgrads=deferred, enc_mlp=enc_mlp, head_mlp=head_mlp,
+                    # <= 64 particles: the q / k / v projections inside the attention forward (dib_attention_fwd_proj)
+                    attn_proj=bool(impl == "flash" and getattr(self, "attention_proj", True)
+                                   and self.lib.dib_attention_fwd_proj_supported(P, K, D)),
+                    qkv_off=[((ctypes.c_int64 * 3)(*[po[f"blk{b}_{nm}_w"] for nm in "qkv"]),
+                              (ctypes.c_int64 * 3)(*[po[f"blk{b}_{nm}_b"] for nm in "qkv"]))
+                             for b in range(self.number_attention_blocks)])
         # a plan holds the whole step workspace + the gradient slabs (166 MB at 4 x 4096): keep the few most recent shapes
         # (training batch, validation batch, a ragged tail), evict least recently used beyond that
         step_keys = [k for k in self._plans if k[0] != "enc" and k not in self._graphs]   # a captured graph pins its plan
@@ -652,7 +673,8 @@ class SetTransformerDIB:
 
     # ---- forward (notebook train_step, forward part) -------------------------------------------------------------------
     def forward(self, batch_inp, step: Optional[int] = None, deterministic: bool = False, row0: int = 0,
-                embs_reparam=None, _step_from_device: bool = False, for_backward: bool = True) -> torch.Tensor:
+                embs_reparam=None, _step_from_device: bool = False, for_backward: bool = True,
+                _skip_head: bool = False) -> torch.Tensor:
         """embs = particle_encoder(batch_inp); logvar - 3; reparameterised sample; kl; loci_prediction = set_transformer(u).
         batch_inp [B, P, particle_feature_dimensions].  Returns the logits [B, out]; self.last holds kl (device scalar).
         embs_reparam [B, P, bottleneck] (optional): use these sampled embeddings instead of the library's counter-based
@@ -697,16 +719,23 @@ class SetTransformerDIB:
         for b in range(self.number_attention_blocks):
             xin = "x0" if b == 0 else f"b{b - 1}_x"
             pre = f"blk{b}_"
-            g[f"b{b}_qkv_fwd"].run(lib, st)
+            if not pl["attn_proj"]:
+                g[f"b{b}_qkv_fwd"].run(lib, st)
             if pl["impl"] == "gemm":
                 g[f"b{b}_qk"].run(lib, st)
                 check(lib.dib_softmax_rows_fwd(_ptr(ws, off[f"b{b}_S"]), B * H * P, P, pl["ldS"], scale, st), "dib_softmax_rows_fwd")
                 g[f"b{b}_pv"].run(lib, st)
             else:
                 HK = H * self.key_dim
-                check(lib.dib_attention_fwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]), B, P, H,
-                                            self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
-                                            _ptr(pl["stash"][b]) if use_stash else c_void_p(0), st), "dib_attention_fwd")
+                if pl["attn_proj"]:   # q, k, v = the block input's projections, computed (and written) by the attention launch
+                    wo, bo = pl["qkv_off"][b]
+                    check(lib.dib_attention_fwd_proj(_ptr(ws, off[xin]), D, _ptr(self.params), wo, bo, B, P, H, self.key_dim, D, HK, scale,
+                                                     _ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
+                                                     _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]), st), "dib_attention_fwd_proj")
+                else:
+                    check(lib.dib_attention_fwd(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]), B, P, H,
+                                                self.key_dim, HK, scale, _ptr(ws, off[f"b{b}_ctx"]), _ptr(ws, off[f"b{b}_lse"]),
+                                                _ptr(pl["stash"][b]) if use_stash else c_void_p(0), st), "dib_attention_fwd")
             if pl["chain"]:   # output projection -> Add + LN -> feed-forward -> Add + LN: one launch (16-token tiles)
                 ffp = (c_void_p * 3)(*[_ptr(ws, off[f"b{b}_ff{l}"]) for l in range(len(self.ff_arch_per_block))])
                 check(lib.dib_st_chain_fwd(ctypes.byref(pl["chain"][b]), T, _ptr(self.params), _ptr(ws, off[f"b{b}_ctx"]),
@@ -730,9 +759,12 @@ class SetTransformerDIB:
                                             _ptr(ws, off[f"b{b}_rstd2"]), st), "dib_add_layernorm_fwd")
         xl = "x0" if self.number_attention_blocks == 0 else f"b{self.number_attention_blocks - 1}_x"
         check(lib.dib_mean_pool_fwd(_ptr(ws, off[xl]), B, P, D, _ptr(ws, off["pool"]), st), "dib_mean_pool_fwd")
-        for l in range(len(self.final_processing_arch)):
-            g[f"fin{l}_fwd"].run(lib, st)
-        g["out_fwd"].run(lib, st)
+        # (_skip_head: a training step whose loss_and_backward runs the head's forward itself, in its one-launch head step -
+        # the returned logits are then those of the PREVIOUS call until loss_and_backward has run)
+        if not (_skip_head and pl["head_mlp"] is not None):
+            for l in range(len(self.final_processing_arch)):
+                g[f"fin{l}_fwd"].run(lib, st)
+            g["out_fwd"].run(lib, st)
         self.attention_impl = pl["impl"]   # what this batch shape ran on (reporting)
         self.last = dict(plan=pl, step=step, row0=int(row0), B=B, P=P, stash=use_stash,
                          kl=self._view(pl, "kl_sum", 1) / B)   # "sum over dimension and particles, avg over batch"
@@ -753,19 +785,33 @@ class SetTransformerDIB:
         gt = pl["gt"]
         if pl["nsplit"] == 1:
             self.grads.zero_()  # blocks are overwritten; alignment gaps stay zero
-        check(lib.dib_loss_rows(LOSS_BCE_LOGITS, _ptr(ws, off["pred"]), self.output_dimensionality, _ptr(y), y.stride(0), B, inv,
-                                _ptr(ws, off["g_pred"]), _ptr(ws, off["out3"]), _ptr(ws, off["loss_ws"]), st), "dib_loss_rows")
-        # head (deferred weight gradients: the dgrad chain first, then ONE grouped launch for the head's weight gradients)
         dw = bool(pl["deferred_wgrads"])
-        if not dw:
-            g["out_wgrad"].run(lib, st)
-        g["out_dgrad"].run(lib, st)
-        for l in range(len(self.final_processing_arch) - 1, -1, -1):
+        hm = pl["head_mlp"]
+        if hm is not None:
+            # the head's whole share of the step in one launch: hidden layers, logit, BCE, dL/dlogit, dgrad chain down to the
+            # pooled embedding, the output layer's gradient and {loss sum, #correct, loss sum * inv} (csrc/dib_small.h)
+            check(lib.dib_mlp_small_head_step(ctypes.byref(hm["desc"]), _ptr(self.params), _ptr(ws, off["pool"]), B, _ptr(y), y.stride(0),
+                                              LOSS_BCE_LOGITS, inv, hm["h"], hm["g"], _ptr(ws, off["pred"]), _ptr(ws, off["g_pred"]),
+                                              _ptr(ws, off["g_pool"]), _ptr(gt), _ptr(ws, off["out3"]), _ptr(hm["ws"]), st),
+                  "dib_mlp_small_head_step")
+            if dw:
+                g["head_wgrads"].run(lib, st)
+            else:
+                for l in range(len(self.final_processing_arch) - 1, -1, -1):
+                    g[f"fin{l}_wgrad"].run(lib, st)
+        else:
+            check(lib.dib_loss_rows(LOSS_BCE_LOGITS, _ptr(ws, off["pred"]), self.output_dimensionality, _ptr(y), y.stride(0), B, inv,
+                                    _ptr(ws, off["g_pred"]), _ptr(ws, off["out3"]), _ptr(ws, off["loss_ws"]), st), "dib_loss_rows")
+            # head (deferred weight gradients: the dgrad chain first, then ONE grouped launch for the head's weight gradients)
             if not dw:
-                g[f"fin{l}_wgrad"].run(lib, st)
-            g[f"fin{l}_dgrad"].run(lib, st)
-        if dw:
-            g["head_wgrads"].run(lib, st)
+                g["out_wgrad"].run(lib, st)
+            g["out_dgrad"].run(lib, st)
+            for l in range(len(self.final_processing_arch) - 1, -1, -1):
+                if not dw:
+                    g[f"fin{l}_wgrad"].run(lib, st)
+                g[f"fin{l}_dgrad"].run(lib, st)
+            if dw:
+                g["head_wgrads"].run(lib, st)
         check(lib.dib_mean_pool_bwd(_ptr(ws, off["g_pool"]), B, P, D, _ptr(ws, off["g_x"]), st), "dib_mean_pool_bwd")
         scale = 1.0 / math.sqrt(self.key_dim)
         nff = len(self.ff_arch_per_block)
@@ -850,7 +896,7 @@ class SetTransformerDIB:
             check(lib.dib_reduce_splits(_ptr(pl["slabs"]), self.n_alloc, pl["nsplit"], self.n_alloc, _ptr(self.grads), st),
                   "dib_reduce_splits")
         out3 = self._view(pl, "out3", 3)
-        self.last["bce"] = out3[0:1] * inv
+        self.last["bce"] = out3[2:3] if hm is not None else out3[0:1] * inv   # (the head step writes loss sum * inv itself)
         self.last["correct"] = out3[1:2]
 
     def _attention_backward(self, pl, b: int, B: int, P: int, H: int, scale: float, gq: str = "g_q", gk: str = "g_k",
@@ -904,7 +950,7 @@ class SetTransformerDIB:
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _FORCE_DP_BRANCH):
             if training and self.use_graphs:
                 return self._train_step_graph(batch_inp, is_loci)
-            self.forward(batch_inp, for_backward=training)
+            self.forward(batch_inp, for_backward=training, _skip_head=training)
             self.loss_and_backward(is_loci, reduce=False) if training else self._loss_only(is_loci)
             if training:
                 self.adam_step(fused_reduce=True)
@@ -915,7 +961,7 @@ class SetTransformerDIB:
         lo, hi = (B * rank) // world, (B * (rank + 1)) // world
         stats = torch.zeros(2, dtype=self.params.dtype, device=self.device)   # [bce sum / B, kl sum / B] of the local rows
         if hi > lo:
-            self.forward(batch_inp[lo:hi], row0=lo * P, for_backward=training)
+            self.forward(batch_inp[lo:hi], row0=lo * P, for_backward=training, _skip_head=training)
             if training:
                 self.loss_and_backward(is_loci[lo:hi], inv_global_batch=1.0 / B)
             else:
@@ -961,7 +1007,7 @@ class SetTransformerDIB:
                 saved = [t.clone() for t in state]
 
                 def body():
-                    self.forward(xs, step=0, _step_from_device=True)
+                    self.forward(xs, step=0, _step_from_device=True, _skip_head=True)
                     self.loss_and_backward(ys, reduce=False)
                     self.adam_step(fused_reduce=True)
 

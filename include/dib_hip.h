@@ -84,7 +84,8 @@ const char* dib_version(void);
  * (`flags` argument of dib_loss_fwd_bwd / dib_output_head_fused, dib_step_tail, dib_set_tuning; the workspace grew by the
  * tail's arrival counters, which dib_workspace_init zeroes - re-run it on workspaces kept from an older library; the
  * experimental bf16x6 GEMM entry points left the library); 6 = round 6 (dib_st_chain_bwd takes its incoming
- * gradient as g_out_slabs partial buffers; the tuning key "num_cus" = 0 now means "the calling thread's current device's own
+ * gradient as g_out_slabs partial buffers; dib_mlp_small_head_{supported,workspace_bytes,step} and dib_attention_fwd_proj{,_supported} added; dib_mlp_desc.act accepts
+ * DIB_ACT_LEAKY_RELU_01; the tuning key "num_cus" = 0 now means "the calling thread's current device's own
  * count" and the library no longer writes it). */
 #define DIB_ABI_VERSION 6
 int dib_abi_version(void);
@@ -250,6 +251,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
  *   "attn_small_bwd_waves" (8) dib_attention_bwd for neighbourhoods of <= 64 particles: 8 waves per workgroup (two per SIMD), or 4
  *                           (the round-4 kernel; bit-identical results)
+ *   "wgrad_flat_tile" (1)   weight gradients of a <= 32-row operand against >= 256 columns use the 32 x 256 tile (0: 64 x 128)
  *   "num_cus"        (0)    compute units the split rule prices rounds with; 0 = the calling thread's current device's own count
  * Returns DIB_E_ARG for an unknown key or a negative value. */
 int dib_set_tuning(const char* key, int value);
@@ -314,6 +316,19 @@ int dib_mlp_small_fwd(const dib_mlp_desc* d, const float* params, const float* x
  * layer i), i < n_hidden - with g_out and a0 / h the operands of every layer's weight gradient. */
 int dib_mlp_small_bwd(const dib_mlp_desc* d, const float* params, const float* g_out, float* const* h, float* const* g, int n,
                       dib_stream_t stream);
+/* A plain MLP with a 1-unit linear output and a BCE-from-logits / 'mse' loss - the set transformer's head,
+ * Dense(256, LeakyReLU(0.1)) -> Dense(1) on the pooled neighbourhood (...set_transformer.ipynb:378-389, train_step :419-445) -
+ * as ONE launch for its whole share of a training step (round 6): hidden layers (stashed in h), z = h_last . w + b -> pred, the
+ * loss, g_pred = dL/dz * inv_global_batch, the dgrad chain g[i] = dL/d(pre-activation of hidden layer i) and g_x = dL/dx
+ * [n][in_dim] (may be NULL), and - summed in tile order by the last workgroup to arrive - the output layer's gradient into
+ * grads + w_off[n_hidden] / b_off[n_hidden] and sums3 = {loss sum, #correct (z > 0.5 == y), loss sum * inv_global_batch}.
+ * The hidden layers' weight gradients stay grouped GEMMs on (x, h, g).  d: width[n_hidden] == 1, n_freq <= 1, in_dim and hidden
+ * widths % 16 == 0; x [n][in_dim] contiguous; ws: dib_mlp_small_head_workspace_bytes, zero-filled once by the caller. */
+int dib_mlp_small_head_supported(const dib_mlp_desc* d, int n);
+int64_t dib_mlp_small_head_workspace_bytes(const dib_mlp_desc* d, int n);
+int dib_mlp_small_head_step(const dib_mlp_desc* d, const float* params, const float* x, int n, const float* y, int64_t ldy,
+                            int loss_kind, float inv_global_batch, float* const* h, float* const* g, float* pred, float* g_pred,
+                            float* g_x, float* grads, float* sums3, void* ws, dib_stream_t stream);
 /* The custom loop runs TWO independent networks between the encoder bank and the loss, and again between the loss and the
  * encoder bank's backward (train.py:203-219: model(x) and output_encoder(y); tape.gradient of both).  At its batch sizes
  * each of them is a handful of workgroups, so the two entry points below give the pairs ONE grid each:

@@ -76,6 +76,14 @@ int64_t dib_attention_stash_bytes(int B, int P, int H);
 int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int P, int H, int key_dim, int64_t ld,
                       float scale, float* o, float* lse, float* s_stash, dib_stream_t stream);
 int64_t dib_attention_bwd_workspace_bytes(int B, int P, int H);
+/* Round 6, neighbourhoods of at most 64 particles (the notebook's 50), model width 32: MultiHeadAttention's three input Dense
+ * layers inside the attention forward - q / k / v [T, ld] are OUTPUTS (written for dib_attention_bwd), computed per
+ * (neighbourhood, head) as x [P, 32] @ (params + w_off[i]) [32, H * key_dim] + (params + b_off[i]), i = q, k, v; ld == H * key_dim.
+ * One launch instead of projection + attention.  dib_attention_fwd_proj_supported: P <= 64, key_dim == 128, model_dim == 32. */
+int dib_attention_fwd_proj_supported(int P, int key_dim, int model_dim);
+int dib_attention_fwd_proj(const float* x, int64_t ldx, const float* params, const int64_t* w_off, const int64_t* b_off, int B, int P,
+                           int H, int key_dim, int model_dim, int64_t ld, float scale, float* q, float* k, float* v, float* o,
+                           float* lse, dib_stream_t stream);
 int dib_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                       const float* s_stash, int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk,
                       float* dv, void* ws, dib_stream_t stream);

@@ -146,3 +146,88 @@ def test_gemm_tile_shapes_the_default_rules_rarely_pick(mode, M, N, K, tuning):
             L.set_tuning(tuning[0], old)
     assert lib.dib_launch_count() == n0 + 1
     assert np.abs(Cd.cpu().numpy() - ref).max() < 2e-5 * (1 + np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M,N,K,groups,nsplit", [(32, 1536, 1600, 3, 4), (32, 256, 100, 1, 1), (20, 300, 777, 2, 3)])
+def test_weight_gradient_flat_tile_vs_numpy(M, N, K, groups, nsplit):
+    """dib_gemm_grouped mode 2 (C = A^T @ B over the rows, + column sums of B) for a <= 32-row operand against a wide one - the set
+    transformer's q / k / v kernels [32, heads x key_dim] - on the 32 x 256 tile (dib_gemm_kernel<2,1,2,32,true>) and, with
+    dib_set_tuning("wgrad_flat_tile", 0), on the 64 x 128 tile: split slabs summed in order vs NumPy float64."""
+    from dib_amd._gemm_plan import _Gemm, _d
+    lib, L = _lib()
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((groups, K, M)).astype(np.float32)
+    Bm = rng.standard_normal((groups, K, N)).astype(np.float32)
+    ref = np.einsum("gkm,gkn->gmn", A.astype(np.float64), Bm.astype(np.float64))
+    ref_b = Bm.astype(np.float64).sum(1)
+    Ad, Bd = torch.from_numpy(A).cuda(), torch.from_numpy(Bm).cuda()
+    per = (M * N + N + 3) // 4 * 4                      # one group's [kernel | bias] block
+    stride = groups * per
+    rps = ((K + nsplit - 1) // nsplit + 31) // 32 * 32
+    descs = [_d(g * K * M, M, g * K * N, N, g * per, N, M, N, K, bias_off=g * per + M * N) for g in range(groups)]
+    outs = []
+    try:
+        for flat in (1, 0):
+            L.set_tuning("wgrad_flat_tile", flat)
+            slabs = torch.full((nsplit * stride,), float("nan"), device="cuda")
+            gm = _Gemm(2, descs, Ad, Bd, slabs, bias_out=slabs, nsplit=nsplit, rows_per_split=rps, split_stride=stride)
+            gm.upload(torch.device("cuda"))
+            gm.run(lib, _stream())
+            torch.cuda.synchronize()
+            tot = slabs.view(nsplit, stride).double().sum(0).cpu().numpy()
+            outs.append(tot)
+            for g in range(groups):
+                got = tot[g * per: g * per + M * N].reshape(M, N)
+                assert np.abs(got - ref[g]).max() < 2e-5 * (1 + np.abs(ref[g]).max()), (flat, g)
+                got_b = tot[g * per + M * N: g * per + M * N + N]
+                assert np.abs(got_b - ref_b[g]).max() < 2e-5 * (1 + np.abs(ref_b[g]).max()), (flat, g, "column sums")
+    finally:
+        L.set_tuning("wgrad_flat_tile", 1)
+
+
+@pytest.mark.parametrize("B,P,H", [(2, 50, 3), (1, 64, 2), (3, 1, 1), (2, 33, 12)])
+def test_attention_forward_with_projections_vs_float64(B, P, H):
+    """dib_attention_fwd_proj (<= 64 particles): tf.keras.layers.MultiHeadAttention(H, 128)(x, x, x) up to the output projection -
+    q / k / v = x @ W_i + b_i per head computed INSIDE the attention launch and written for the backward, softmax(q k^T / sqrt(128)) v,
+    the per-query log-sum-exp - against NumPy float64, and against the two-launch path (projection GEMM + dib_attention_fwd)."""
+    lib, L = _lib()
+    rng = np.random.default_rng(B * 100 + P + H)
+    D, K = 32, 128
+    HK, T = H * K, B * P
+    assert lib.dib_attention_fwd_proj_supported(P, K, D) == 1 and lib.dib_attention_fwd_proj_supported(65, K, D) == 0
+    x = rng.standard_normal((T, D)).astype(np.float32)
+    # one flat parameter buffer: [W_q | b_q | W_k | b_k | W_v | b_v], 16-byte aligned blocks
+    w = [(rng.standard_normal((D, HK)) / np.sqrt(D)).astype(np.float32) for _ in range(3)]
+    bvec = [(0.1 * rng.standard_normal(HK)).astype(np.float32) for _ in range(3)]
+    flat, w_off, b_off = [], [], []
+    for wi, bi in zip(w, bvec):
+        w_off.append(sum(len(f) for f in flat)); flat.append(wi.reshape(-1))
+        b_off.append(sum(len(f) for f in flat)); flat.append(bi)
+    params = torch.from_numpy(np.concatenate(flat)).cuda()
+    xd = torch.from_numpy(x).cuda()
+    q, k, v, o = (torch.full((T, HK), float("nan"), device="cuda") for _ in range(4))
+    lse = torch.empty(B * H * P, device="cuda")
+    scale = 1.0 / np.sqrt(K)
+    L.check(lib.dib_attention_fwd_proj(_ptr(xd), D, _ptr(params), (ctypes.c_int64 * 3)(*w_off), (ctypes.c_int64 * 3)(*b_off), B, P, H, K, D,
+                                       HK, scale, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _stream()), "dib_attention_fwd_proj")
+    torch.cuda.synchronize()
+    x64 = x.astype(np.float64)
+    qr, kr, vr = (x64 @ wi.astype(np.float64) + bi for wi, bi in zip(w, bvec))
+    for got, ref, name in ((q, qr, "q"), (k, kr, "k"), (v, vr, "v")):
+        assert np.abs(got.cpu().numpy() - ref).max() < 2e-5 * (1 + np.abs(ref).max()), name
+    o_ref, lse_ref = np.zeros((T, HK)), np.zeros((B, H, P))
+    for b in range(B):
+        for hh in range(H):
+            sl, cs = slice(b * P, (b + 1) * P), slice(hh * K, (hh + 1) * K)
+            s = scale * qr[sl, cs] @ kr[sl, cs].T
+            m = s.max(1, keepdims=True)
+            e = np.exp(s - m)
+            o_ref[sl, cs] = (e / e.sum(1, keepdims=True)) @ vr[sl, cs]
+            lse_ref[b, hh] = (m + np.log(e.sum(1, keepdims=True)))[:, 0]
+    assert np.abs(o.cpu().numpy() - o_ref).max() < 3e-5 * (1 + np.abs(o_ref).max())
+    assert np.abs(lse.cpu().numpy().reshape(B, H, P) - lse_ref).max() < 3e-5 * (1 + np.abs(lse_ref).max())
+    # the two-launch path on the kernel's own q / k / v: same attention
+    o2, lse2 = torch.empty_like(o), torch.empty_like(lse)
+    L.check(lib.dib_attention_fwd(_ptr(q), _ptr(k), _ptr(v), B, P, H, K, HK, scale, _ptr(o2), _ptr(lse2), None, _stream()), "dib_attention_fwd")
+    torch.cuda.synchronize()
+    assert (o2 - o).abs().max().item() < 1e-5 * (1 + o.abs().max().item()) and (lse2 - lse).abs().max().item() < 1e-5
