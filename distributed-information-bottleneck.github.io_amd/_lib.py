@@ -170,6 +170,8 @@ SIGNATURES_ST = {
     "dib_attention_fwd_proj_supported": (c_int, [c_int, c_int, c_int]),
     "dib_attention_fwd_proj": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dib_attention_bwd_proj": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "dib_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dib_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

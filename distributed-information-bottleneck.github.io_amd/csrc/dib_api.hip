@@ -2209,6 +2209,32 @@ int dib_attention_fwd_proj(const float* x, int64_t ldx, const float* params, con
   return (int)hipGetLastError();
 }
 
+int dib_attention_bwd_proj(const float* q, const float* k, const float* v, const float* d_o, const float* lse, int B, int P, int H,
+                           int key_dim, int model_dim, int64_t ld, float scale, float* dq, float* dk, float* dv, const float* params,
+                           const int64_t* w_off, float* dx_slabs, int64_t slab_stride, dib_stream_t stream) {
+  if (!q || !k || !v || !d_o || !lse || !dq || !dk || !dv || !params || !w_off || !dx_slabs || B <= 0 || P <= 0 || H <= 0)
+    return DIB_E_ARG;
+  if (!dib_attention_fwd_proj_supported(P, key_dim, model_dim)) return DIB_E_UNSUPPORTED;
+  if (ld != (int64_t)H * key_dim || slab_stride < (int64_t)B * P * model_dim || (slab_stride & 3)) return DIB_E_ARG;
+  if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv |
+        (uintptr_t)dx_slabs) & 15) != 0)
+    return DIB_E_ARG;
+  DibAttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.lse = const_cast<float*>(lse); a.d_o = d_o; a.dq = dq; a.dk = dk; a.dv = dv;
+  a.P = P; a.H = H; a.ld = ld; a.scale = scale;
+  a.pparams = params; a.pdx = dx_slabs; a.pdx_stride = slab_stride;
+  for (int i = 0; i < 3; ++i) { if (w_off[i] & 3) return DIB_E_ARG; a.pw[i] = w_off[i]; }
+  const size_t lds = (size_t)DibAttnSmallBwdLds * sizeof(float);
+  static std::atomic<bool> attr_small[64];
+  if (AttrOnce once(attr_small); once) {
+    hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_bwd8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  ProfScope ps(kProfAttnBwd, (hipStream_t)stream);
+  DIB_LAUNCH(dib_attn_small_bwd8_kernel<true>, dim3(H, B), dim3(512), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
 int64_t dib_attention_bwd_workspace_bytes(int B, int P, int H) {
   if (B <= 0 || P <= 0 || H <= 0) return DIB_E_ARG;
   const int64_t nkb = cdiv(P, 128);
@@ -2235,11 +2261,11 @@ int dib_attention_bwd(const float* q, const float* k, const float* v, const floa
     if (AttrOnce once(attr_small); once) {
       hipError_t e = hipFuncSetAttribute((const void*)dib_attn_small_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)dib_attn_small_bwd8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = hipFuncSetAttribute((const void*)dib_attn_small_bwd8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
     ProfScope ps(kProfAttnBwd, st);
-    if (knobs().attn_small_bwd_waves >= 8) DIB_LAUNCH(dib_attn_small_bwd8_kernel, dim3(H, B), dim3(512), lds, st, a);
+    if (knobs().attn_small_bwd_waves >= 8) DIB_LAUNCH(dib_attn_small_bwd8_kernel<false>, dim3(H, B), dim3(512), lds, st, a);
     else DIB_LAUNCH(dib_attn_small_bwd_kernel, dim3(H, B), dim3(256), lds, st, a);
     return (int)hipGetLastError();
   }

@@ -58,6 +58,9 @@ struct DibAttnArgs {
   // round 6, dib_attn_small_fwd_kernel<true> only: q, k, v are OUTPUTS - the head's slices of the three input projections
   // x [T, 32] @ W_i [32, H * 128] + b_i are computed in the kernel's prologue (and written for the backward)
   const float* px; long long pldx; const float* pparams; long long pw[3], pb[3]; float* pq; float* pk; float* pv;
+  // round 6, dib_attn_small_bwd8_kernel<true> only: the head's share of the projections' INPUT gradient,
+  // dq_h W_q[:, head]^T + dk_h W_k[:, head]^T + dv_h W_v[:, head]^T [P, 32], written to slab (1 + head) of pdx (pdx_stride floats apart)
+  float* pdx; long long pdx_stride;
 };
 
 // first element of the 32 x 32 score tile (key tile kt, query tile qt) of (neighbourhood b, head): row-major [query][key]

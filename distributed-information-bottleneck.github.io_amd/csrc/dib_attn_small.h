@@ -83,28 +83,35 @@ dib_attn_small_fwd_kernel(DibAttnArgs a) {
     for (int q = 0; q < 4; ++q)
       xa[q] = xrow < P ? *reinterpret_cast<const float4*>(a.px + (tok0 + xrow) * a.pldx + 8 * q + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int col0 = head * kAttnD + wn * 64 + l31;          // this lane's column of tile j = 0 (tile 1: + 32)
+    // ALL weight fragments of the three projections are requested before the first MFMA (96 registers; the workgroup is
+    // LDS-limited to two per CU anyway): one L2 round trip in front of the prologue instead of three
+    float bw[3][2][16];                                       // W_i[k = 8 q + 4 h + t][col0 + 32 j], index 4 q + t
+    float bb[3][2];
 #pragma unroll
     for (int pi = 0; pi < 3; ++pi) {
       const float* W = a.pparams + a.pw[pi];
-      float bw[2][16];                                        // W[k = 8 q + 4 h + t][col0 + 32 j], index 4 q + t
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bw[j][4 * q + t] = W[(long long)(8 * q + 4 * h + t) * a.ld + col0 + 32 * j];
-      const float b0 = a.pparams[a.pb[pi] + col0], b1 = a.pparams[a.pb[pi] + col0 + 32];
+          for (int t = 0; t < 4; ++t) bw[pi][j][4 * q + t] = W[(long long)(8 * q + 4 * h + t) * a.ld + col0 + 32 * j];
+        bb[pi][j] = a.pparams[a.pb[pi] + col0 + 32 * j];
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < 3; ++pi) {
       dib_f32x16 acc[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[0][r] = b0; acc[1][r] = b1; }
+      for (int r = 0; r < 16; ++r) { acc[0][r] = bb[pi][0]; acc[1][r] = bb[pi][1]; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[j] = DIB_MFMA(xa[q].x, bw[j][4 * q + 0], acc[j]);
-          acc[j] = DIB_MFMA(xa[q].y, bw[j][4 * q + 1], acc[j]);
-          acc[j] = DIB_MFMA(xa[q].z, bw[j][4 * q + 2], acc[j]);
-          acc[j] = DIB_MFMA(xa[q].w, bw[j][4 * q + 3], acc[j]);
+          acc[j] = DIB_MFMA(xa[q].x, bw[pi][j][4 * q + 0], acc[j]);
+          acc[j] = DIB_MFMA(xa[q].y, bw[pi][j][4 * q + 1], acc[j]);
+          acc[j] = DIB_MFMA(xa[q].z, bw[pi][j][4 * q + 2], acc[j]);
+          acc[j] = DIB_MFMA(xa[q].w, bw[pi][j][4 * q + 3], acc[j]);
         }
       }
       // C fragment: column l31 of tile j, rows (r & 3) + 8 (r >> 2) + 4 h of the wave's 32: to global (rows < P) and to LDS
@@ -414,6 +421,11 @@ __device__ __forceinline__ void dib_attn_small_load8(float* __restrict__ T, cons
 }
 
 // grid (H, B), 512 threads, dynamic LDS DibAttnSmallBwdLds floats
+// PROJ (round 6): the kernel ends with the head's share of the q / k / v projections' input gradient - dq_h, dk_h, dv_h go
+// through the (now dead) Q / K / dO tiles and are contracted with the head's 128 columns of the three kernels; the 12 heads'
+// shares land in 12 slabs that the consumer sums in order (the previous block's chain launch, dib_st_chain_bwd g_out_slabs):
+// the split-K dgrad GEMM + its slab reduce per block (16 + 8 us at the notebook's size) disappear.
+template <bool PROJ>
 __global__ void __launch_bounds__(512)
 dib_attn_small_bwd8_kernel(DibAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -500,6 +512,7 @@ dib_attn_small_bwd8_kernel(DibAttnArgs a) {
     }
   }
   __syncthreads();
+  dib_f32x16 pj0, pj1;   // PROJ: the wave's two dV (lo) / dK (hi) tiles, kept for the epilogue
   // ---- lo: dV[key wm*32.., d wn*64..] = P^T dO;  hi: dK = dS^T (scale Q): contraction over the 64 queries ----
   {
     const float* At = grp == 0 ? Pt : dSt;
@@ -533,6 +546,7 @@ dib_attn_small_bwd8_kernel(DibAttnArgs a) {
     float* outb = (grp == 0 ? a.dv : a.dk) + tok0 * a.ld + head * kAttnD;
     dib_attn_small_store(outb, a.ld, wm * 32, wn * 64 + l31, P, h, t0, 1.0f);
     dib_attn_small_store(outb, a.ld, wm * 32, wn * 64 + 32 + l31, P, h, t1, 1.0f);
+    if constexpr (PROJ) { pj0 = t0; pj1 = t1; }
   }
   // ---- dQ[query 32 (wave & 1).., d 32 (wave >> 1)..] = scale dS K: contraction over the 64 keys ----
   {
@@ -555,5 +569,57 @@ dib_attn_small_bwd8_kernel(DibAttnArgs a) {
       ds = dsn; kc = kn;
     }
     dib_attn_small_store(a.dq + tok0 * a.ld + head * kAttnD, a.ld, qm * 32, cb * 32 + l31, P, h, dq, a.scale);
+    if constexpr (PROJ) {
+      // ---- dx_h [64 tokens][32] = dq_h Wq_h^T + dk_h Wk_h^T + dv_h Wv_h^T ----
+      __syncthreads();                                   // every wave is done reading Q, K, dO, P, dS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {                     // C fragments -> row-major tiles: dq -> Qs, dk -> Ks, dv -> Gs
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        Qs[(qm * 32 + rr) * kAttnPitch + cb * 32 + l31] = dq[r] * a.scale;
+        float* T = grp == 0 ? Gs : Ks;
+        T[(wm * 32 + rr) * kAttnPitch + wn * 64 + l31] = pj0[r];
+        T[(wm * 32 + rr) * kAttnPitch + wn * 64 + 32 + l31] = pj1[r];
+      }
+      __syncthreads();
+      // wave w: token block rt = w & 1, quarter kq = w >> 1 of each projection's 128-long contraction
+      const int rt = wave & 1, kq = wave >> 1;
+      dib_f32x16 dx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dx[r] = 0.f;
+#pragma unroll
+      for (int pi = 0; pi < 3; ++pi) {
+        const float* T = (pi == 0 ? Qs : (pi == 1 ? Ks : Gs)) + rt * 32 * kAttnPitch;
+        const float* Wr = a.pparams + a.pw[pi] + (long long)l31 * a.ld + head * kAttnD + 32 * kq + 4 * h;   // W_i[c = l31][head's k]
+        float4 wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wv[q] = *reinterpret_cast<const float4*>(Wr + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 av = dib_attn_kc(T, 4 * kq + q, l31, h);
+          dx = DIB_MFMA(av.x, wv[q].x, dx);
+          dx = DIB_MFMA(av.y, wv[q].y, dx);
+          dx = DIB_MFMA(av.z, wv[q].z, dx);
+          dx = DIB_MFMA(av.w, wv[q].w, dx);
+        }
+      }
+      float* xq = Pt;                                    // exchange: [3 quarters][2 token blocks][16][64] floats (24 KB of the P | dS space)
+      if (kq >= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xq[(((kq - 1) * 2 + rt) * 16 + r) * 64 + lane] = dx[r];
+      }
+      __syncthreads();
+      if (kq == 0) {
+#pragma unroll
+        for (int pq_ = 0; pq_ < 3; ++pq_)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dx[r] += xq[((pq_ * 2 + rt) * 16 + r) * 64 + lane];
+        float* dst = a.pdx + (long long)(1 + head) * a.pdx_stride + tok0 * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (row < P) dst[(long long)row * 32 + l31] = dx[r];
+        }
+      }
+    }
   }
 }

@@ -371,7 +371,7 @@ class SetTransformerDIB:
                     take(f"b{b}_g_ff{l}", T * u)
                 for nm in "qkv":
                     take(f"b{b}_g_{nm}", T * HK)
-                take(f"b{b}_dx", (1 + 3 * ksplit) * T * D)
+                take(f"b{b}_dx", (1 + max(3 * ksplit, H)) * T * D)   # slot 0 + split-K slabs, or + one slab per head (attn_bwd_proj)
         gn = (lambda b, nm: f"b{b}_{nm}") if defer else (lambda b, nm: nm)   # per-block / shared gradient buffer names
         take("loss_ws", int(self.lib.dib_loss_rows_workspace_bytes(B)) // 4 + 4)
         ws = torch.zeros(o, dtype=torch.float32, device=self.device)
@@ -617,6 +617,11 @@ class SetTransformerDIB:
                     # <= 64 particles: the q / k / v projections inside the attention forward (dib_attention_fwd_proj)
                     attn_proj=bool(impl == "flash" and getattr(self, "attention_proj", True)
                                    and self.lib.dib_attention_fwd_proj_supported(P, K, D)),
+                    # ... and their input gradient inside the attention backward (one slab per head behind the LN1-addend
+                    # gradient; needs the per-block dx regions of the deferred mode and the 8-wave kernel)
+                    attn_bwd_proj=bool(defer and impl == "flash" and getattr(self, "attention_bwd_proj", True)
+                                       and self.lib.dib_attention_fwd_proj_supported(P, K, D)
+                                       and _lib.get_tuning("attn_small_bwd_waves") >= 8),
                     qkv_off=[((ctypes.c_int64 * 3)(*[po[f"blk{b}_{nm}_w"] for nm in "qkv"]),
                               (ctypes.c_int64 * 3)(*[po[f"blk{b}_{nm}_b"] for nm in "qkv"]))
                              for b in range(self.number_attention_blocks)])
@@ -830,7 +835,8 @@ class SetTransformerDIB:
                 from_slabs = defer and b + 1 < self.number_attention_blocks
                 check(lib.dib_st_chain_bwd(ctypes.byref(pl["chain"][b]), T, _ptr(self.params),
                                            _ptr(ws, off[f"b{b + 1}_dx"] if from_slabs else off[gin]),
-                                           1 + 3 * pl["ksplit"] if from_slabs else 1, T * D if from_slabs else 0,
+                                           (1 + (H if pl["attn_bwd_proj"] else 3 * pl["ksplit"])) if from_slabs else 1,
+                                           T * D if from_slabs else 0,
                                            _ptr(ws, off[f"b{b}_xhat2"]), _ptr(ws, off[f"b{b}_rstd2"]), ffp,
                                            _ptr(ws, off[f"b{b}_xhat1"]), _ptr(ws, off[f"b{b}_rstd1"]), gfp,
                                            _ptr(ws, off[f"b{b}_gln1" if defer else gout]),
@@ -838,6 +844,18 @@ class SetTransformerDIB:
                 if not defer:
                     g[f"b{b}_ff_wgrad"].run(lib, st)
                     g[f"b{b}_o_wgrad"].run(lib, st)
+                if pl["attn_bwd_proj"]:
+                    # dq, dk, dv AND the head's share of the projections' input gradient (slab 1 + head of the block's dx region)
+                    HK = H * self.key_dim
+                    check(lib.dib_attention_bwd_proj(_ptr(ws, off[f"b{b}_q"]), _ptr(ws, off[f"b{b}_k"]), _ptr(ws, off[f"b{b}_v"]),
+                                                     _ptr(ws, off["g_ctx"]), _ptr(ws, off[f"b{b}_lse"]), B, P, H, self.key_dim, D, HK, scale,
+                                                     _ptr(ws, off[gb("g_q")]), _ptr(ws, off[gb("g_k")]), _ptr(ws, off[gb("g_v")]),
+                                                     _ptr(self.params), pl["qkv_off"][b][0], _ptr(ws, off[f"b{b}_dx"]), T * D, st),
+                          "dib_attention_bwd_proj")
+                    if b == 0:   # block 0's total goes to the buffer the bottleneck's backward reads
+                        check(lib.dib_reduce_splits(_ptr(ws, off["b0_dx"]), T * D, 1 + H, T * D, _ptr(ws, off[gout]), st),
+                              "dib_reduce_splits")
+                    continue
                 self._attention_backward(pl, b, B, P, H, scale, *(gb(f"g_{nm}") for nm in "qkv"))
                 if not defer:
                     g[f"b{b}_qkv_wgrad"].run(lib, st)

@@ -84,7 +84,7 @@ const char* dib_version(void);
  * (`flags` argument of dib_loss_fwd_bwd / dib_output_head_fused, dib_step_tail, dib_set_tuning; the workspace grew by the
  * tail's arrival counters, which dib_workspace_init zeroes - re-run it on workspaces kept from an older library; the
  * experimental bf16x6 GEMM entry points left the library); 6 = round 6 (dib_st_chain_bwd takes its incoming
- * gradient as g_out_slabs partial buffers; dib_mlp_small_head_{supported,workspace_bytes,step} and dib_attention_fwd_proj{,_supported} added; dib_mlp_desc.act accepts
+ * gradient as g_out_slabs partial buffers; dib_mlp_small_head_{supported,workspace_bytes,step} and dib_attention_fwd_proj{,_supported}, dib_attention_bwd_proj added; dib_mlp_desc.act accepts
  * DIB_ACT_LEAKY_RELU_01; the tuning key "num_cus" = 0 now means "the calling thread's current device's own
  * count" and the library no longer writes it). */
 #define DIB_ABI_VERSION 6

@@ -84,6 +84,14 @@ int dib_attention_fwd_proj_supported(int P, int key_dim, int model_dim);
 int dib_attention_fwd_proj(const float* x, int64_t ldx, const float* params, const int64_t* w_off, const int64_t* b_off, int B, int P,
                            int H, int key_dim, int model_dim, int64_t ld, float scale, float* q, float* k, float* v, float* o,
                            float* lse, dib_stream_t stream);
+/* ... and their INPUT gradient inside the attention backward (8-wave kernel of csrc/dib_attn_small.h): besides dq / dk / dv
+ * [T, ld] (still written: operands of the projections' weight gradients) every (neighbourhood, head) workgroup writes
+ * dq_h W_q[:, head]^T + dk_h W_k[:, head]^T + dv_h W_v[:, head]^T [P, model_dim] into slab 1 + head of dx_slabs (slabs
+ * slab_stride floats apart; slab 0 is the caller's: the residual share of the block input's gradient).  The consumer sums
+ * slabs 0 .. H in order (dib_st_chain_bwd g_out_slabs = 1 + H, or dib_reduce_splits).  Same support rule as the forward. */
+int dib_attention_bwd_proj(const float* q, const float* k, const float* v, const float* d_o, const float* lse, int B, int P, int H,
+                           int key_dim, int model_dim, int64_t ld, float scale, float* dq, float* dk, float* dv, const float* params,
+                           const int64_t* w_off, float* dx_slabs, int64_t slab_stride, dib_stream_t stream);
 int dib_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                       const float* s_stash, int B, int P, int H, int key_dim, int64_t ld, float scale, float* dq, float* dk,
                       float* dv, void* ws, dib_stream_t stream);

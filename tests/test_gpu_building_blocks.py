@@ -231,3 +231,40 @@ def test_attention_forward_with_projections_vs_float64(B, P, H):
     L.check(lib.dib_attention_fwd(_ptr(q), _ptr(k), _ptr(v), B, P, H, K, HK, scale, _ptr(o2), _ptr(lse2), None, _stream()), "dib_attention_fwd")
     torch.cuda.synchronize()
     assert (o2 - o).abs().max().item() < 1e-5 * (1 + o.abs().max().item()) and (lse2 - lse).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B,P,H", [(2, 50, 3), (1, 64, 2), (3, 1, 1), (2, 33, 12)])
+def test_attention_backward_with_projection_gradient_vs_float64(B, P, H):
+    """dib_attention_bwd_proj (<= 64 particles): dq / dk / dv bit-identical to dib_attention_bwd's 8-wave kernel, and slab 1 + head
+    of dx = dq_h W_q[:, head]^T + dk_h W_k[:, head]^T + dv_h W_v[:, head]^T against NumPy float64 on the kernel's own dq / dk / dv;
+    slab 0 is left alone."""
+    lib, L = _lib()
+    rng = np.random.default_rng(B * 10 + P + H)
+    D, K = 32, 128
+    HK, T = H * K, B * P
+    q, k, v, d_o = (torch.from_numpy(rng.standard_normal((T, HK)).astype(np.float32)).cuda() for _ in range(4))
+    w = [(rng.standard_normal((D, HK)) / np.sqrt(D)).astype(np.float32) for _ in range(3)]
+    params = torch.from_numpy(np.concatenate([wi.reshape(-1) for wi in w])).cuda()
+    w_off = (ctypes.c_int64 * 3)(0, D * HK, 2 * D * HK)
+    scale = 1.0 / np.sqrt(K)
+    o, lse = torch.empty(T, HK, device="cuda"), torch.empty(B * H * P, device="cuda")
+    L.check(lib.dib_attention_fwd(_ptr(q), _ptr(k), _ptr(v), B, P, H, K, HK, scale, _ptr(o), _ptr(lse), None, _stream()), "dib_attention_fwd")
+    ws = torch.zeros(int(lib.dib_attention_bwd_workspace_bytes(B, P, H)) // 4 + 4, device="cuda")
+    ref = [torch.empty(T, HK, device="cuda") for _ in range(3)]
+    L.check(lib.dib_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(d_o), _ptr(lse), None, B, P, H, K, HK, scale, _ptr(ref[0]),
+                                  _ptr(ref[1]), _ptr(ref[2]), _ptr(ws), _stream()), "dib_attention_bwd")
+    got = [torch.full((T, HK), float("nan"), device="cuda") for _ in range(3)]
+    stride = T * D + 8
+    dx = torch.full(((1 + H) * stride,), 7.0, device="cuda")
+    L.check(lib.dib_attention_bwd_proj(_ptr(q), _ptr(k), _ptr(v), _ptr(d_o), _ptr(lse), B, P, H, K, D, HK, scale, _ptr(got[0]), _ptr(got[1]),
+                                       _ptr(got[2]), _ptr(params), w_off, _ptr(dx), stride, _stream()), "dib_attention_bwd_proj")
+    torch.cuda.synchronize()
+    for a_, b_, nm in zip(got, ref, "qkv"):
+        assert torch.equal(a_, b_), f"d{nm}"
+    dxn = dx.view(1 + H, stride)[:, :T * D].reshape(1 + H, T, D).cpu().numpy()
+    assert (dxn[0] == 7.0).all()
+    g64 = [g.cpu().numpy().astype(np.float64) for g in got]
+    for hh in range(H):
+        cs = slice(hh * K, (hh + 1) * K)
+        want = sum(g64[i][:, cs] @ w[i].astype(np.float64)[:, cs].T for i in range(3))
+        assert np.abs(dxn[1 + hh] - want).max() < 3e-5 * (1 + np.abs(want).max()), hh

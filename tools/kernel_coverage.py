@@ -50,7 +50,7 @@ ORACLE_TESTS = {
         "test_infonce_loop_trajectory_matches_float64_oracle", "test_keras_path_trajectory_160_steps_through_the_ramp"},
     "test_gpu_building_blocks.py": {
         "test_softmax_rows_forward_backward_vs_float64", "test_add_layernorm_forward_backward_vs_float64", "test_act_grad_mul_vs_numpy",
-        "test_sgd_step_vs_numpy", "test_gemm_tile_shapes_the_default_rules_rarely_pick", "test_weight_gradient_flat_tile_vs_numpy", "test_attention_forward_with_projections_vs_float64"},
+        "test_sgd_step_vs_numpy", "test_gemm_tile_shapes_the_default_rules_rarely_pick", "test_weight_gradient_flat_tile_vs_numpy", "test_attention_forward_with_projections_vs_float64", "test_attention_backward_with_projection_gradient_vs_float64"},
 }
 # tests that demand the bits (or fp32 summation-order tolerance) of a path the tests above check against an oracle
 EQUIVALENCE_TESTS = {

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--chain", type=int, default=1, help="0: the layer-by-layer launches instead of the token-chain kernels (A/B)")
     ap.add_argument("--defer", type=int, default=1, help="0: per-block weight-gradient launches instead of the deferred grouped ones (A/B)")
     ap.add_argument("--attn-proj", type=int, default=1, help="0: q / k / v projections as a launch of their own in front of the attention (A/B)")
+    ap.add_argument("--attn-bwd-proj", type=int, default=1, help="0: the projections' input gradient as a split-K GEMM per block (A/B)")
     ap.add_argument("--max-slabs", type=int, default=0, help="cap of the weight-gradient slab count in deferred mode (0: the default)")
     ap.add_argument("--defer-target", type=int, default=0, help="workgroups per deferred weight-gradient launch (0: the default)")
     ap.add_argument("--tuning", default="", help="dib_set_tuning keys, e.g. attn_small_waves=8 (A/B)")
@@ -54,6 +55,7 @@ def main():
     m.use_chain = bool(a.chain)
     m.defer_wgrads = bool(a.defer)
     m.attention_proj = bool(a.attn_proj)
+    m.attention_bwd_proj = bool(a.attn_bwd_proj)
     if a.max_slabs:
         m.deferred_max_slabs = a.max_slabs
     if a.defer_target:
@@ -79,7 +81,7 @@ def main():
                       "algorithmic_TFLOPs": round(fl / dt / 1e12, 2), "params": m.n_params,
                       "attention": m.attention_impl, "graph_replay": bool(a.graphs), "tuning": a.tuning,
                       "library_launches_per_step": round(launches, 1), "defer_wgrads": bool(a.defer),
-                      "defer_target_wgs": a.defer_target or None, "max_slabs": a.max_slabs or None, "attention_proj": bool(a.attn_proj)}))
+                      "defer_target_wgs": a.defer_target or None, "max_slabs": a.max_slabs or None, "attention_proj": bool(a.attn_proj), "attention_bwd_proj": bool(a.attn_bwd_proj)}))
 
 
 if __name__ == "__main__":
