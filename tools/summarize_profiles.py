@@ -18,7 +18,7 @@ def load(path, cname):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != cname:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(", false>", ">")   # (round 6: the FLAT template flag)
         agg[k] += float(r["Counter_Value"])
         cnt[k] += 1
     return agg, cnt
@@ -51,7 +51,7 @@ def main(base, tag, suffix=""):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt, dur, seen = collections.Counter(), collections.defaultdict(float), set()
     for r in rows:
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "") + " grid=" + r["Grid_Size"]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace(", false>", ">")   # (round 6: the FLAT template flag) + " grid=" + r["Grid_Size"]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
