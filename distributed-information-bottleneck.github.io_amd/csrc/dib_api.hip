@@ -36,7 +36,6 @@ constexpr int kMaxSplits = 32;   // partial slabs of a split-batch weight gradie
 // Row-tile kernels of dib_small.h: hard limits (they size workspace regions); WHICH batches take them is the "small_wgs" rule
 constexpr int kSmallMaxBatch = 2048;     // rows
 constexpr int kSmallMaxEncWgs = 1024;    // row tiles x features (d(W1|b1) partials: one [16][H1] block per encoder workgroup)
-constexpr int kSmall4MaxBatch = 1024;    // 4-row tiles of the integration network: the head's per-tile partials are sized for it
 constexpr int kSplitRows = 512;  // minimum batch rows per wgrad split: 8 K-tiles of 64 (measured: 2048 left mid-size batches with 16-256 workgroups)
 inline int64_t align_up(int64_t v, int64_t a = kAlign) { return (v + a - 1) / a * a; }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
@@ -138,9 +137,7 @@ struct dib_layout {
     m.skinny_chunks = cdiv(B, m.skinny_rows);
     {
       const int win = n_int == 0 ? F * E : int_units[n_int - 1];
-      // (4-row tiles of the integration network, B <= kSmall4MaxBatch: one partial per 4 rows - sized for it whatever the tuning says)
-      const int64_t chunks_cap = std::max<int64_t>(m.skinny_chunks, B <= kSmall4MaxBatch ? cdiv(B, 4) : 0);
-      m.skinny_partial = take(out_dim <= 8 ? chunks_cap * ((int64_t)win * out_dim + out_dim) : 0);
+      m.skinny_partial = take(out_dim <= 8 ? (int64_t)m.skinny_chunks * ((int64_t)win * out_dim + out_dim) : 0);
     }
     m.sync = take(DIB_TAIL_SYNC_WORDS);   // arrival counters of dib_step_tail (zeroed by dib_workspace_init, self-cleaning)
     // descriptors of ALL weight gradients of a step with absolute workspace offsets for THIS batch size (written by
@@ -224,9 +221,6 @@ struct Tuning {
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
-  int small_rows4 = 1;       // integration network / plain MLP of the row-tile regime on 4-row tiles (v_mfma_f32_4x4x1) ...
-  int small4_max_rows = 256; // ... for batches of at most this many rows (every workgroup streams all weights: beyond, the copies
-                             // saturate the L2); hard limit kSmall4MaxBatch
   int num_cus = 0;           // compute units the split rule prices rounds with; 0 = the current device's own count (device_cus)
 };
 // Process-wide and written ONLY by dib_set_tuning, which the header documents as a configuration call made while no other
@@ -520,11 +514,6 @@ static bool small_regime(const dib_layout* l, int batch) {
          (long long)small_tiles(batch) * l->F <= std::min(knobs().small_wgs, kSmallMaxEncWgs);
 }
 static bool use_small_enc(const dib_layout* l, int batch) { return l->sb_enc && small_regime(l, batch); }
-// 4-row tiles (csrc/dib_small.h dib_small4_*) for the integration network / a plain MLP of a small batch
-static bool use_small4(int batch) {
-  return knobs().small_rows4 && batch <= std::min(knobs().small4_max_rows, kSmall4MaxBatch);
-}
-static int small_tiles4(int batch) { return cdiv(batch, DIB_SMALL4_ROWS); }
 static bool use_small_int(const dib_layout* l, int batch) { return l->sb_int && small_regime(l, batch); }
 // the backward's d(W1|b1) comes as per-workgroup partials (fused backward or small-batch backward): how many
 static int enc_dw1_parts(const dib_layout* l, int batch) {
@@ -635,42 +624,23 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.pred = w + m.pred; a.g_pred = w + m.g_pred;
   a.loss_kind = loss_kind; a.Y = y; a.ldy = ldy; a.row_idx = (const int*)row_idx; a.row0 = row0; a.inv_bg = inv_bg;
   a.partial_w = w + m.skinny_partial; a.partial_l = w + m.loss_partial;
-  // (the LDS sizes are those of the 16-row layout: an upper bound for the 4-row kernels)
   if (t_companion.armed) {
     t_companion.armed = false;
     DibSmallIntPair p;
     p.s[0] = a; p.s[1] = t_companion.args;
     const size_t lds = std::max((size_t)l->sb_int_lds, t_companion.lds);
-    ProfScope ps(kProfOther, st);
-    if (use_small4(batch) && use_small4(p.s[1].batch)) {
-      static int pair4_lds_have[64] = {};
-      if (int rc = ensure_dynamic_lds((const void*)dib_small4_integration_pair_kernel, lds, pair4_lds_have)) return rc;
-      DIB_LAUNCH(dib_small4_integration_pair_kernel, dim3(std::max(small_tiles4(batch), small_tiles4(p.s[1].batch)), 2),
-                 dim3(DIB_SMALL_THREADS), lds, st, p);
-      return (int)hipGetLastError();
-    }
     static int pair_lds_have[64] = {};
     if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_pair_kernel, lds, pair_lds_have)) return rc;
+    ProfScope ps(kProfOther, st);
     DIB_LAUNCH(dib_small_integration_pair_kernel, dim3(std::max(small_tiles(batch), small_tiles(p.s[1].batch)), 2),
                dim3(DIB_SMALL_THREADS), lds, st, p);
     return (int)hipGetLastError();
   }
-  ProfScope ps(kProfOther, st);
-  if (use_small4(batch)) {
-    static int lds4_have[64] = {};
-    if (int rc = ensure_dynamic_lds((const void*)dib_small4_integration_kernel, (size_t)l->sb_int_lds, lds4_have)) return rc;
-    DIB_LAUNCH(dib_small4_integration_kernel, dim3(small_tiles4(batch)), dim3(DIB_SMALL_THREADS), (size_t)l->sb_int_lds, st, a);
-    return (int)hipGetLastError();
-  }
   static int lds_have[64] = {};
   if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_kernel, (size_t)l->sb_int_lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, st);
   DIB_LAUNCH(dib_small_integration_kernel, dim3(small_tiles(batch)), dim3(DIB_SMALL_THREADS), (size_t)l->sb_int_lds, st, a);
   return (int)hipGetLastError();
-}
-// how many per-tile partials the head of a step left behind (the producer: the row-tile integration kernel on 16- or 4-row
-// tiles, or the large-batch fused head on skinny_chunks row chunks)
-static int head_blocks(const dib_layout* l, const dib_layout::WsMap& m, int batch) {
-  return use_small_int(l, batch) && use_small4(batch) ? small_tiles4(batch) : m.skinny_chunks;
 }
 
 extern "C" {
@@ -1240,9 +1210,9 @@ int dib_integration_head_step(dib_layout* l, int loss_kind, const float* y, int6
     if (!no_grad) {
       float* gt = wgrad_target(m, w, grads);
       DIB_LAUNCH(dib_skinny_wgrad_reduce_kernel, dim3(K + 1), dim3(256), 0, st, (const float*)(w + m.skinny_partial),
-                         head_blocks(l, m, batch), K, 1, gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
+                         m.skinny_chunks, K, 1, gt + l->int_w_off[ly], gt + l->int_b_off[ly]);
     }
-    DIB_LAUNCH(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), head_blocks(l, m, batch),
+    DIB_LAUNCH(dib_loss_finalize_kernel, dim3(2), dim3(256), 0, st, (const float*)(w + m.loss_partial), m.skinny_chunks,
                        (float)batch, w + m.step_out + l->F);
     return (int)hipGetLastError();
   }
@@ -1465,7 +1435,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
     a.nb_dw1 = l->F * 16;
   }
   if (head_seg) {
-    a.head_partial = w + m.skinny_partial; a.head_chunks = head_blocks(l, m, batch); a.head_K = l->int_width[l->n_int - 1];
+    a.head_partial = w + m.skinny_partial; a.head_chunks = m.skinny_chunks; a.head_K = l->int_width[l->n_int - 1];
     a.head_w_off = l->int_w_off[l->n_int]; a.head_b_off = l->int_b_off[l->n_int];
     a.nb_head = a.head_K + 1;
   }
@@ -1476,7 +1446,7 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
   }
   if (flags & (DIB_TAIL_LOSS | DIB_TAIL_LOSS_HEAD)) {
     a.loss_partial = w + m.loss_partial; a.nb_loss = 2; a.rows = (float)batch;
-    a.loss_blocks = (flags & DIB_TAIL_LOSS_HEAD) ? head_blocks(l, m, batch) : m.loss_blocks;
+    a.loss_blocks = (flags & DIB_TAIL_LOSS_HEAD) ? m.skinny_chunks : m.loss_blocks;
   }
   a.beta_dev = beta_dev; a.inv_bg = inv_global_batch; a.metrics_acc = metrics_acc;
   a.sync = (unsigned*)(w + m.sync);
@@ -1505,8 +1475,6 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "infonce_one_launch")) return &t.infonce_one_launch;
   if (!std::strcmp(key, "attn_small_bwd_waves")) return &t.attn_small_bwd_waves;
   if (!std::strcmp(key, "wgrad_flat_tile")) return &t.wgrad_flat_tile;
-  if (!std::strcmp(key, "small_rows4")) return &t.small_rows4;
-  if (!std::strcmp(key, "small4_max_rows")) return &t.small4_max_rows;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
   return nullptr;
 }
@@ -1733,15 +1701,9 @@ static void mlp_small_fill(const dib_mlp_desc* d, DibSmallIntArgs& a, const floa
 }
 static int mlp_small_launch(const dib_mlp_desc* d, const DibSmallIntArgs& a, hipStream_t st) {
   const size_t lds = (size_t)mlp_small_lds_floats(d) * 4;
-  ProfScope ps(kProfOther, st);
-  if (use_small4(a.batch)) {
-    static int lds4_have[64] = {};
-    if (int rc = ensure_dynamic_lds((const void*)dib_small4_integration_kernel, lds, lds4_have)) return rc;
-    DIB_LAUNCH(dib_small4_integration_kernel, dim3(small_tiles4(a.batch)), dim3(DIB_SMALL_THREADS), lds, st, a);
-    return (int)hipGetLastError();
-  }
   static int lds_have[64] = {};
   if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_kernel, lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, st);
   DIB_LAUNCH(dib_small_integration_kernel, dim3(small_tiles(a.batch)), dim3(DIB_SMALL_THREADS), lds, st, a);
   return (int)hipGetLastError();
 }
@@ -1805,7 +1767,7 @@ int dib_mlp_small_head_supported(const dib_mlp_desc* d, int n) {
 }
 int64_t dib_mlp_small_head_workspace_bytes(const dib_mlp_desc* d, int n) {
   if (!d || n < 1 || d->n_hidden < 1 || d->n_hidden > 3) return DIB_E_ARG;
-  return ((int64_t)small_tiles4(n) * (d->width[d->n_hidden - 1] + 1 + 2) + 16) * (int64_t)sizeof(float);   // (sized for 4-row tiles)
+  return ((int64_t)small_tiles(n) * (d->width[d->n_hidden - 1] + 1 + 2) + 16) * (int64_t)sizeof(float);
 }
 int dib_mlp_small_head_step(const dib_mlp_desc* d, const float* params, const float* x, int n, const float* y, int64_t ldy,
                             int loss_kind, float inv_global_batch, float* const* h, float* const* g, float* pred, float* g_pred,
@@ -1826,23 +1788,16 @@ int dib_mlp_small_head_step(const dib_mlp_desc* d, const float* params, const fl
   a.act = d->act; a.out_act = 0; a.out_dim = 1;
   a.pred = pred; a.g_pred = g_pred; a.loss_kind = loss_kind; a.Y = y; a.ldy = ldy; a.row_idx = nullptr; a.row0 = 0;
   a.inv_bg = inv_global_batch;
-  const bool rows4 = use_small4(n);
-  const int tiles = rows4 ? small_tiles4(n) : small_tiles(n), KL = d->width[d->n_hidden - 1];
+  const int tiles = small_tiles(n), KL = d->width[d->n_hidden - 1];
   float* w = (float*)ws;
   a.partial_w = w; a.partial_l = w + (int64_t)tiles * (KL + 1);
   a.sync = (unsigned*)(a.partial_l + 2 * tiles);   // zero at first use (the caller zero-fills the workspace once)
   a.head_gw = grads + d->w_off[d->n_hidden]; a.head_gb = grads + d->b_off[d->n_hidden];
   a.sums3 = sums3; a.loss_scale = inv_global_batch;
   const size_t lds = (size_t)mlp_head_lds_floats(d) * 4;
-  ProfScope ps(kProfOther, (hipStream_t)stream);
-  if (rows4) {
-    static int lds4_have[64] = {};
-    if (int rc = ensure_dynamic_lds((const void*)dib_small4_integration_kernel, lds, lds4_have)) return rc;
-    DIB_LAUNCH(dib_small4_integration_kernel, dim3(tiles), dim3(DIB_SMALL_THREADS), lds, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
-  }
   static int lds_have[64] = {};
   if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_kernel, lds, lds_have)) return rc;
+  ProfScope ps(kProfOther, (hipStream_t)stream);
   DIB_LAUNCH(dib_small_integration_kernel, dim3(tiles), dim3(DIB_SMALL_THREADS), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }

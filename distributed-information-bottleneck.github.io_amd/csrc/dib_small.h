@@ -305,15 +305,14 @@ __device__ __forceinline__ void dib_small_bwd(const float* g, int pg, int N, con
   }
 }
 
-// global [rows_valid][width] (leading dimension ld) -> LDS tile [ROWS][pitch]; rows >= rows_valid are zero-filled
-template <int ROWS = DIB_SMALL_ROWS>
+// global [rows_valid][width] (leading dimension ld) -> LDS tile [16][pitch]; rows >= rows_valid are zero-filled
 __device__ __forceinline__ void dib_small_load_tile(const float* __restrict__ src, long long ld, int width, int rows_valid,
                                                     float* dst, int pitch) {
   // Four loads per thread in flight per trip (the rolled loop the compiler makes of the plain form issues ONE load per trip
   // and waits for it: the set-transformer chain's 16 x 1536 context tile was 12 dependent L2 round trips, ~9 us of a 45 us
   // kernel).  A variant with each thread owning a float4 column of all 16 rows - 16 loads in flight - measured 1.5 % SLOWER
   // on the set-transformer step (profiles/r05n_row_tile_variants_ab.txt): on the many 32-wide tiles only 8 threads had work.
-  const int w4 = width >> 2, total = ROWS * w4;
+  const int w4 = width >> 2, total = DIB_SMALL_ROWS * w4;
 #pragma unroll 1
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * DIB_SMALL_THREADS) {
     float4 v[4];
@@ -332,170 +331,6 @@ __device__ __forceinline__ void dib_small_load_tile(const float* __restrict__ sr
   }
 }
 
-
-// =====================================================================================================================
-// 4-ROW tiles (round 6) for the smallest batches: v_mfma_f32_4x4x1_16B_f32 - 16 independent 4 x 4 outer products per
-// instruction; lane l supplies A = in[row l & 3][k] (the same four rows for every block) and B = W[k][n0 + l], so one
-// instruction is the rank-1 update out[4][64 columns] += in[4][k] W[k][64] and leaves out[row i][n0 + l] in register i of lane l.
-// At the reference's default batch (train.py:34: B = 128) the 16-row kernels are 8 workgroups, each bound by ONE CU's MFMA pipe
-// (8-10 us per 256-wide layer against 3.9 us of MFMA issue, profiles/HISTORY.md 13); 4-row tiles make 32 workgroups with a
-// quarter of the MFMA work each.  Every workgroup streams the whole weight matrix, so the regime ends where the copies of the
-// weights saturate the L2 ("small4_max_rows").  Same sums in a fixed order (bit-exact replay), different order than 16-row tiles.
-// =====================================================================================================================
-typedef float dib_f32x4v __attribute__((ext_vector_type(4)));
-#define DIB_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
-#define DIB_SMALL4_ROWS 4
-
-// out[4][N] = act(in[4][K] @ W[K][N] + bias), N % 16 == 0.  Column groups of 64 go to min(8, groups) wave slots, the other
-// waves share the contraction in contiguous chunks; UB weight rows in flight per wave (register double buffer).
-__device__ __forceinline__ void dib_small4_fwd(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
-                                               const float* __restrict__ bias, float slope, float* out, int pout,
-                                               float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int UB = 32;
-  const int ngroups = (N + 63) / 64;
-  const int nslots = ngroups >= 8 ? 8 : (ngroups >= 4 ? 4 : (ngroups >= 2 ? 2 : 1)), kways = 8 / nslots;
-  const int wc = wave % nslots, kh = wave / nslots;
-  const int kc = ((K + kways - 1) / kways + 3) & ~3;            // contraction chunk of a wave (a multiple of 4)
-  const int kb = kh * kc, ke = min(K, kb + kc);
-  const float* ap = in + (lane & 3) * pin;
-  for (int g0 = 0; g0 < ngroups; g0 += nslots) {                // block-uniform trip count
-    const int n0 = (g0 + wc) * 64;
-    const bool active = g0 + wc < ngroups;
-    const bool col_ok = active && n0 + lane < N;
-    const float* wp = W + (col_ok ? n0 + lane : 0);
-    dib_f32x4v acc = dib_f32x4v{0.f, 0.f, 0.f, 0.f};
-    if (active && kb < ke) {
-      float bcur[UB], bnxt[UB];
-      auto load = [&](int k0, float (&bv)[UB]) {
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int k = k0 + u;
-          bv[u] = (col_ok && k < ke && k < kvalid) ? wp[(long long)k * N] : 0.f;
-        }
-      };
-      load(kb, bcur);
-      for (int k0 = kb; k0 < ke; k0 += UB) {
-        load(k0 + UB, bnxt);
-#pragma unroll
-        for (int u4 = 0; u4 < UB / 4; ++u4) {
-          if (k0 + 4 * u4 >= ke) break;                          // wave-uniform (chunks are multiples of 4; the tile is zero beyond K)
-          float4 av = *reinterpret_cast<const float4*>(ap + k0 + 4 * u4);
-          {   // a ragged contraction (K % 4 != 0): the tile's columns beyond K are not initialised
-            const int kk = k0 + 4 * u4;
-            av.y = kk + 1 < ke ? av.y : 0.f; av.z = kk + 2 < ke ? av.z : 0.f; av.w = kk + 3 < ke ? av.w : 0.f;
-          }
-          acc = DIB_MFMA4(av.x, bcur[4 * u4 + 0], acc);
-          acc = DIB_MFMA4(av.y, bcur[4 * u4 + 1], acc);
-          acc = DIB_MFMA4(av.z, bcur[4 * u4 + 2], acc);
-          acc = DIB_MFMA4(av.w, bcur[4 * u4 + 3], acc);
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) bcur[u] = bnxt[u];
-      }
-    }
-    if (kh >= 1 && active) *reinterpret_cast<float4*>(xch + (((kh - 1) * nslots + wc) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    __syncthreads();
-    if (kh == 0 && active) {
-      for (int p = 1; p < kways; ++p) {
-        const float4 o = *reinterpret_cast<const float4*>(xch + (((p - 1) * nslots + wc) * 64 + lane) * 4);
-        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
-      }
-      if (col_ok) {
-        const float bv = bias[n0 + lane];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = dib_small_act(slope, acc[i] + bv);
-          if (out != nullptr) out[i * pout + n0 + lane] = v;
-          if (gdst != nullptr && i < rows_valid) gdst[(long long)i * gld + n0 + lane] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// gin[4][Kin] = (g[4][N] @ W[Kin][N]^T) (.) act'(h[4][Kin]), Kin % 16 == 0, N % 4 == 0.  Lane l of a 64-wide group owns input
-// unit k0 + l: its weight ROW streams in 16-byte pieces along the contraction (UB float4 in flight).
-__device__ __forceinline__ void dib_small4_bwd(const float* g, int pg, int N, const float* __restrict__ W, int Kin,
-                                               const float* h, int ph, float slope, float* gin, int pgi,
-                                               float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int UB = 8;                                           // float4 pieces (32 contraction indices) per batch
-  const int ngroups = (Kin + 63) / 64;
-  const int nslots = ngroups >= 8 ? 8 : (ngroups >= 4 ? 4 : (ngroups >= 2 ? 2 : 1)), kways = 8 / nslots;
-  const int wc = wave % nslots, kh = wave / nslots;
-  const int nc = ((N + kways - 1) / kways + 3) & ~3;
-  const int nb = kh * nc, ne = min(N, nb + nc);
-  const float* ap = g + (lane & 3) * pg;
-  for (int g0 = 0; g0 < ngroups; g0 += nslots) {
-    const int k0 = (g0 + wc) * 64;
-    const bool active = g0 + wc < ngroups;
-    const bool col_ok = active && k0 + lane < Kin;
-    const float* wp = W + (long long)(col_ok ? k0 + lane : 0) * N;
-    dib_f32x4v acc = dib_f32x4v{0.f, 0.f, 0.f, 0.f};
-    if (active && nb < ne) {
-      float4 bcur[UB], bnxt[UB];
-      auto load = [&](int s0, float4 (&bv)[UB]) {
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int n = s0 + 4 * u;
-          bv[u] = (col_ok && n < ne) ? *reinterpret_cast<const float4*>(wp + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      };
-      load(nb, bcur);
-      for (int s0 = nb; s0 < ne; s0 += 4 * UB) {
-        load(s0 + 4 * UB, bnxt);
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          if (s0 + 4 * u >= ne) break;                            // wave-uniform
-          const float4 av = *reinterpret_cast<const float4*>(ap + s0 + 4 * u);
-          acc = DIB_MFMA4(av.x, bcur[u].x, acc);
-          acc = DIB_MFMA4(av.y, bcur[u].y, acc);
-          acc = DIB_MFMA4(av.z, bcur[u].z, acc);
-          acc = DIB_MFMA4(av.w, bcur[u].w, acc);
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) bcur[u] = bnxt[u];
-      }
-    }
-    if (kh >= 1 && active) *reinterpret_cast<float4*>(xch + (((kh - 1) * nslots + wc) * 64 + lane) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    __syncthreads();
-    if (kh == 0 && active) {
-      for (int p = 1; p < kways; ++p) {
-        const float4 o = *reinterpret_cast<const float4*>(xch + (((p - 1) * nslots + wc) * 64 + lane) * 4);
-        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
-      }
-      if (col_ok) {
-        const int k = k0 + lane;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = acc[i];
-          if (h != nullptr) v *= dib_small_act_grad(slope, h[i * ph + k]);
-          if (gin != nullptr) gin[i * pgi + k] = v;
-          if (gdst != nullptr && i < rows_valid) gdst[(long long)i * gld + k] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// one entry for both tile heights (block-uniform compile-time choice)
-template <int ROWS>
-__device__ __forceinline__ void dib_small_fwd_r(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
-                                                const float* __restrict__ bias, float slope, float* out, int pout,
-                                                float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
-  if constexpr (ROWS == 4) dib_small4_fwd(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch);
-  else dib_small_fwd(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch);
-}
-template <int ROWS>
-__device__ __forceinline__ void dib_small_bwd_r(const float* g, int pg, int N, const float* __restrict__ W, int Kin,
-                                                const float* h, int ph, float slope, float* gin, int pgi,
-                                                float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
-  if constexpr (ROWS == 4) dib_small4_bwd(g, pg, N, W, Kin, h, ph, slope, gin, pgi, gdst, gld, rows_valid, xch);
-  else dib_small_bwd(g, pg, N, W, Kin, h, ph, slope, gin, pgi, gdst, gld, rows_valid, xch);
-}
 
 __host__ __device__ inline int dib_small_pitch(int width) { return (width + 63) / 64 * 64 + 4; }   // pitch % 64 == 4
 
@@ -627,8 +462,8 @@ struct DibSmallIntArgs {
   float* head_gw; float* head_gb; float* sums3; float loss_scale; unsigned* sync;
 };
 
-template <int ROWS>
 __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs& a, const int tile) {
+  constexpr int ROWS = DIB_SMALL_ROWS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = tile * ROWS, rows_valid = min(ROWS, a.batch - r0);
@@ -697,7 +532,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
         }
       }
     } else {
-      dib_small_load_tile<ROWS>(a.U + (long long)r0 * a.K0, a.K0, a.K0, rows_valid, us, pu);
+      dib_small_load_tile(a.U + (long long)r0 * a.K0, a.K0, a.K0, rows_valid, us, pu);
     }
     __syncthreads();
     DIB_ST(17);
@@ -706,7 +541,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
       if (l < n) {
         const float* in = l == 0 ? us : hs[l > 0 ? l - 1 : 0];
         const int K = l == 0 ? a.K0 : a.width[l > 0 ? l - 1 : 0], pin = l == 0 ? pu : ph[l > 0 ? l - 1 : 0];
-        dib_small_fwd_r<ROWS>(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], slope, hs[l], ph[l],
+        dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], slope, hs[l], ph[l],
                       stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid, xch);
         DIB_ST(18 + l);
       }
@@ -714,13 +549,13 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
   } else if (a.mode & DIB_SMALL_INT_LOAD_H) {
 #pragma unroll
     for (int l = 0; l < 3; ++l)
-      if (l < n) dib_small_load_tile<ROWS>(a.h[l] + (long long)r0 * a.width[l], a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
-    if (a.mode & DIB_SMALL_INT_LOAD_G) dib_small_load_tile<ROWS>(g_last + (long long)r0 * KL, KL, KL, rows_valid, gl, pl);
+      if (l < n) dib_small_load_tile(a.h[l] + (long long)r0 * a.width[l], a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
+    if (a.mode & DIB_SMALL_INT_LOAD_G) dib_small_load_tile(g_last + (long long)r0 * KL, KL, KL, rows_valid, gl, pl);
     __syncthreads();
   }
 
   if (a.mode & DIB_SMALL_INT_OUT) {   // general output layer (reference models.py:83)
-    dib_small_fwd_r<ROWS>(hl, pl, KL, KL, a.params + wo_off, a.out_dim, a.params + bo_off, dib_neg_slope(a.out_act), nullptr, 0,
+    dib_small_fwd(hl, pl, KL, KL, a.params + wo_off, a.out_dim, a.params + bo_off, dib_neg_slope(a.out_act), nullptr, 0,
                   a.pred + (long long)r0 * a.out_dim, a.out_dim, rows_valid, xch);
   }
 
@@ -736,7 +571,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
     float pw[16];                        // KL <= 1024: 16 lane-strided columns
 #pragma unroll
     for (int c = 0; c < 16; ++c) pw[c] = 0.f;
-    for (int row = wave; row < ROWS; row += 8) {   // (16-row tiles: rows w, w + 8; 4-row tiles: waves 0-3)
+    for (int row = wave; row < ROWS; row += 8) {   // rows w, w + 8
       if (row >= rows_valid) continue;   // wave-uniform
       const int b = r0 + row;
       float dot = 0.f;
@@ -808,9 +643,9 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
 
   DIB_ST(22);
   if (a.mode & DIB_SMALL_INT_BWD_OUT) {   // dL/dh_{n-1} from a given dL/dpred (custom loss: InfoNCE, train.py:216-219)
-    dib_small_load_tile<ROWS>(a.g_pred + (long long)r0 * a.out_dim, a.out_dim, a.out_dim, rows_valid, ps, po);
+    dib_small_load_tile(a.g_pred + (long long)r0 * a.out_dim, a.out_dim, a.out_dim, rows_valid, ps, po);
     __syncthreads();
-    dib_small_bwd_r<ROWS>(ps, po, a.out_dim, a.params + wo_off, KL, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, KL, rows_valid, xch);
+    dib_small_bwd(ps, po, a.out_dim, a.params + wo_off, KL, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, KL, rows_valid, xch);
   }
 
   if (a.mode & DIB_SMALL_INT_BWD) {
@@ -818,14 +653,14 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
 #pragma unroll
     for (int l = 2; l >= 1; --l) {   // dL/dh_{l-1} = (dL/dh_l @ W_l^T) (.) act'(h_{l-1})
       if (l < n) {
-        dib_small_bwd_r<ROWS>(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], slope, gs[l - 1],
+        dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], slope, gs[l - 1],
                       ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid, xch);
         DIB_ST(24 + l);
       }
     }
     // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output; a plain MLP's input needs no gradient)
     if (!(a.mode & DIB_SMALL_INT_NO_GU))
-      dib_small_bwd_r<ROWS>(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
+      dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
                     a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
     DIB_ST(28);
   }
@@ -860,10 +695,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
 }
 
 __global__ void __launch_bounds__(DIB_SMALL_THREADS)
-dib_small_integration_kernel(DibSmallIntArgs a) { dib_small_integration_body<DIB_SMALL_ROWS>(a, blockIdx.x); }
-// the same network on 4-row tiles (grid = ceil(batch / 4)): see the 4-row primitives above
-__global__ void __launch_bounds__(DIB_SMALL_THREADS)
-dib_small4_integration_kernel(DibSmallIntArgs a) { dib_small_integration_body<DIB_SMALL4_ROWS>(a, blockIdx.x); }
+dib_small_integration_kernel(DibSmallIntArgs a) { dib_small_integration_body(a, blockIdx.x); }
 
 // Two independent networks in ONE grid (blockIdx.y picks the argument set): the custom InfoNCE loop's X model and its output
 // encoder between the encoder bank and the loss (train.py:203-219) - each is 8 workgroups at the reference's batch of 128, and
@@ -873,13 +705,7 @@ __global__ void __launch_bounds__(DIB_SMALL_THREADS)
 dib_small_integration_pair_kernel(DibSmallIntPair p) {
   const DibSmallIntArgs& a = p.s[blockIdx.y];
   if ((int)blockIdx.x * DIB_SMALL_ROWS >= a.batch) return;   // the two batches may differ
-  dib_small_integration_body<DIB_SMALL_ROWS>(a, blockIdx.x);
-}
-__global__ void __launch_bounds__(DIB_SMALL_THREADS)
-dib_small4_integration_pair_kernel(DibSmallIntPair p) {
-  const DibSmallIntArgs& a = p.s[blockIdx.y];
-  if ((int)blockIdx.x * DIB_SMALL4_ROWS >= a.batch) return;
-  dib_small_integration_body<DIB_SMALL4_ROWS>(a, blockIdx.x);
+  dib_small_integration_body(a, blockIdx.x);
 }
 
 // =====================================================================================================================

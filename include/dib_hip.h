@@ -251,8 +251,6 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
  *   "attn_small_bwd_waves" (8) dib_attention_bwd for neighbourhoods of <= 64 particles: 8 waves per workgroup (two per SIMD), or 4
  *                           (the round-4 kernel; bit-identical results)
- *   "small_rows4"    (1)    the integration network / a plain MLP of a small batch run on 4-row tiles (v_mfma_f32_4x4x1: 4 x the workgroups,
- *   "small4_max_rows" (256) a quarter of the MFMA work each) while the batch has at most this many rows (<= 1024)
  *   "wgrad_flat_tile" (1)   weight gradients of a <= 32-row operand against >= 256 columns use the 32 x 256 tile (0: 64 x 128)
  *   "num_cus"        (0)    compute units the split rule prices rounds with; 0 = the calling thread's current device's own count
  * Returns DIB_E_ARG for an unknown key or a negative value. */

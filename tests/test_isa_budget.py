@@ -115,6 +115,21 @@ def test_round5_small_batch_kernels_keep_two_waves_per_simd(kernels):
     for kind in (0, 1, 4):
         k = _one(kernels, f"dib_infonce_small_kernelILi{kind}E")
         assert k["NumVgprs"] + k["NumAgprs"] <= 128 and k["ScratchSize"] == 0   # (<= 128: four waves per SIMD would fit too)
-    b8, b4 = _one(kernels, "dib_attn_small_bwd8_kernel"), _one(kernels, "dib_attn_small_bwd_kernel")
+    b8, b4 = _one(kernels, "dib_attn_small_bwd8_kernelILb0E"), _one(kernels, "dib_attn_small_bwd_kernel")
     assert b8["NumVgprs"] + b8["NumAgprs"] <= 256 and b8["ScratchSize"] == 0
     assert b4["mfma"] == 320 and b8["mfma"] == 64 + 64 + 64 + 32   # S | dP (one per wave group), dV | dK (shared code), dQ tile
+
+
+def test_round6_kernels_keep_their_budgets(kernels):
+    """Round 6: the <= 64-particle attention kernels with MultiHeadAttention's input projections inside (forward: + 96 MFMAs for
+    the head's q, k, v with all 96 weight values in flight - still two workgroups per CU; backward: + 48 MFMAs per wave for the
+    projections' input gradient, two waves per SIMD), and the 32 x 256 weight-gradient tile."""
+    f0, f1 = _one(kernels, "dib_attn_small_fwd_kernelILb0E"), _one(kernels, "dib_attn_small_fwd_kernelILb1E")
+    assert f0["ScratchSize"] == 0 and f1["ScratchSize"] == 0 and f0["mfma"] == 128 and f1["mfma"] == 128 + 96
+    assert f1["NumVgprs"] + f1["NumAgprs"] <= 256 and f1["Occupancy"] >= 2
+    b8p = _one(kernels, "dib_attn_small_bwd8_kernelILb1E")
+    assert b8p["ScratchSize"] == 0 and b8p["NumVgprs"] + b8p["NumAgprs"] <= 256 and b8p["mfma"] == 64 + 64 + 64 + 32 + 48
+    flat = _one(kernels, "dib_gemm_kernelILi2ELi1ELi2ELi32ELb1E")
+    assert flat["ScratchSize"] == 0 and flat["Occupancy"] >= 2 and flat["LDSByteSize"] <= 40 * 1024 and flat["mfma"] == 32
+    single = _one(kernels, "dib_small_integration_kernel")
+    assert single["ScratchSize"] == 0 and single["NumVgprs"] <= 256       # + the head-step reduce (dib_mlp_small_head_step)
