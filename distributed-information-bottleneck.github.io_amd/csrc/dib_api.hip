@@ -47,6 +47,8 @@ struct GemmCall {  // one grouped launch: slice [first, first+count) of the desc
 
 }  // namespace
 
+static int wgrad_max_splits();   // dib_set_tuning("wgrad_max_splits"): defined with the tuning table below
+
 struct dib_layout {
   int F = 0, n_enc = 0, E = 0, n_int = 0, out_dim = 0, use_pe = 0, n_freq = 0, act = 0, out_act = 0;
   std::vector<int> dims, enc_units, int_units;
@@ -111,12 +113,12 @@ struct dib_layout {
     m.loss_blocks = cdiv(B, 256);
     m.loss_partial = take((int64_t)std::max(m.loss_blocks, 512) * 2);  // also the fused output head's per-workgroup partials (<= 512)
     // split-batch wgrad: rows_per_split multiple of 32, <= 32 splits, >= kSplitRows rows per split ...
-    int ns = std::min(kMaxSplits, std::max(1, B / kSplitRows));
+    int ns = std::min(std::min(kMaxSplits, wgrad_max_splits()), std::max(1, B / kSplitRows));
     // ... unless the layout is so narrow that even its largest weight gradient stays under one workgroup per CU with that
     // many splits (BASELINE config 2, the pendulum layout [2,1,2,1]: 16 tiles x 4 splits of 512 rows at B = 2048 - five
     // launches of 18-24 us, each a workgroup walking 16 dependent K-tiles, 100 of the 510 us step,
     // profiles/r04i_config2_loop_kernel_stats_b2048.csv): then slabs of >= 128 rows
-    if (B >= 256 && max_wgrad_tiles64 * ns < 256) ns = std::min(kMaxSplits, std::max(ns, B / 128));
+    if (B >= 256 && max_wgrad_tiles64 * ns < 256) ns = std::min(std::min(kMaxSplits, wgrad_max_splits()), std::max(ns, B / 128));
     int rps = cdiv(cdiv(B, ns), 32) * 32;
     ns = cdiv(B, rps);
     m.nsplit = ns;
@@ -221,12 +223,16 @@ struct Tuning {
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
+  int wgrad_max_splits = 32; // most batch slabs of a layout's weight gradients (<= 32; read when a workspace is sized: set it first)
   int num_cus = 0;           // compute units the split rule prices rounds with; 0 = the current device's own count (device_cus)
 };
 // Process-wide and written ONLY by dib_set_tuning, which the header documents as a configuration call made while no other
 // entry point is running; every other entry point only reads it.
 inline Tuning& tuning() { static Tuning t; return t; }
 inline const Tuning& knobs() { return tuning(); }
+}  // namespace
+static int wgrad_max_splits() { return std::max(1, std::min(32, knobs().wgrad_max_splits)); }
+namespace {
 // compute units of the CURRENT device, queried once per device ordinal (no process-wide "the device": one process may drive
 // several GPUs from several threads)
 inline int device_cus() {
@@ -1475,6 +1481,7 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "infonce_one_launch")) return &t.infonce_one_launch;
   if (!std::strcmp(key, "attn_small_bwd_waves")) return &t.attn_small_bwd_waves;
   if (!std::strcmp(key, "wgrad_flat_tile")) return &t.wgrad_flat_tile;
+  if (!std::strcmp(key, "wgrad_max_splits")) return &t.wgrad_max_splits;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
   return nullptr;
 }

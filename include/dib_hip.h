@@ -251,6 +251,9 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
  *   "attn_small_bwd_waves" (8) dib_attention_bwd for neighbourhoods of <= 64 particles: 8 waves per workgroup (two per SIMD), or 4
  *                           (the round-4 kernel; bit-identical results)
+ *   "wgrad_max_splits" (32) most batch slabs of a layout's weight gradients (1 .. 32; read when a workspace is SIZED: set it before the
+ *                           first dib_workspace_bytes of a layout).  Fewer slabs shrink the tail's reduce but starve the small
+ *                           weight gradients: 32 / 24 / 16 / 8 -> 8.20 / 8.27 / 8.38 / 8.57 ms per config-3 step (profiles/r06j_*)
  *   "wgrad_flat_tile" (1)   weight gradients of a <= 32-row operand against >= 256 columns use the 32 x 256 tile (0: 64 x 128)
  *   "num_cus"        (0)    compute units the split rule prices rounds with; 0 = the calling thread's current device's own count
  * Returns DIB_E_ARG for an unknown key or a negative value. */

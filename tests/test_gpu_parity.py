@@ -1179,7 +1179,7 @@ def test_tuning_switchboard_is_the_only_hidden_input():
     from dib_amd.engine import HipEngine
     lib = _lib.load_library()
     for key in ("fwd_small_wgs", "fwd_narrow_wgs", "stream_rows", "split_policy", "split_overhead", "fused_encoder", "fused_head",
-                "small_batch", "small_wgs", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "wgrad_flat_tile", "num_cus"):
+                "small_batch", "small_wgs", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "wgrad_flat_tile", "wgrad_max_splits", "num_cus"):
         v = _lib.get_tuning(key)
         _lib.set_tuning(key, v + 1)
         assert _lib.get_tuning(key) == v + 1
