@@ -356,6 +356,23 @@ def config2_infonce_loop(dev, batch):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (4 * 16 + 4 * 2)
     launches = int(lib.dib_launch_count()) - l0   # library kernels of 64 training + 8 validation steps (the loop runs no torch kernel per step)
+    # The 72-step call above carries the call's ONE-TIME work (a fresh output encoder: parameter init, uploads, its launch plans;
+    # dataset upload; the batch stream) - ~ 25 us per step at this length, nothing at the reference's (1 875 steps per epoch,
+    # train.py:222-236).  Second figure: the same loop over 16 x as many steps per epoch with the encoder built beforehand
+    # (the kernel timeline of the step: profiles/r06l_config2_loop_b128_timeline.txt).
+    from dib_amd.dense import DenseStack
+    nl = batch * 256
+    xl = rng.standard_normal((nl, 6)).astype(np.float32)
+    yl = (xl + 0.3 * rng.standard_normal((nl, 6))).astype(np.float32)
+    yenc = DenseStack(model._engine, 6, [128, 128], 64, "relu", True, 5, seed=1)
+    kw.update(number_pretraining_epochs=1, number_annealing_epochs=1)
+    infonce.fit_infonce(model, xl[:batch * 16], yl[:batch * 16], xl[:batch], yl[:batch], output_encoder=yenc, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kw.update(number_pretraining_epochs=1, number_annealing_epochs=2)
+    infonce.fit_infonce(model, xl, yl, xl[:batch], yl[:batch], output_encoder=yenc, **kw)   # 2 x 256 train + 2 x 2 validation steps
+    torch.cuda.synchronize()
+    dt_long = (time.perf_counter() - t0) / (2 * 256 + 2 * 2)
     # algorithmic GEMM FLOPs of one TRAINING step (SURVEY 8a conventions: fwd + dgrad + wgrad, first-layer dgrads excluded):
     # X model on the pendulum layout, Y encoder 30 -> 128 -> 128 -> 64, and the InfoNCE products S = X Y^T, C Y, C^T X
     x_enc = [[(5 * d, ENC[0]), (ENC[0], ENC[1]), (ENC[1], 2 * E)] for d in (2, 1, 2, 1)]
@@ -369,6 +386,7 @@ def config2_infonce_loop(dev, batch):
     # prices every timed step as a training step's FLOPs x 64/72 - a slight overstatement of the work, stated here
     tf = flops * (4 * 16) / (4 * 16 + 4 * 2) / dt / 1e12
     return {"batch": batch, "ms_per_step": round(1e3 * dt, 3), "samples_per_s": round(batch / dt, 1),
+            "ms_per_step_256_steps_per_epoch": round(1e3 * dt_long, 3),
             "library_launches_per_step": round(launches / (4 * 16 + 4 * 2), 2),
             "flops_per_train_step": int(flops), "algorithmic_TFLOPs": round(tf, 3),
             "step_roofline_frac": round(tf / PEAK_F32_MFMA_TFLOPS, 5)}
@@ -764,17 +782,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             extra["dp_breakdown"] = {"error": f"{type(e).__name__}: {e}"}
         try:  # the other scaling mode, same engine
-            if args.only_dp_breakdown:
-                raise StopIteration
-            other = "weak" if args.scaling == "strong" else "strong"
-            wl.set_scaling(other, args.batch)
-            m2, t2 = wl.measure(2, args.steps, 1, dev)
-            extra[f"{other}_scaling"] = {"value": round(args.steps * wl.gb / m2, 1), "unit": "samples/s",
-                                         "ms_per_step": round(1e3 * m2 / args.steps, 4), "per_gpu_batch": wl.B,
-                                         "global_batch": wl.gb}
-            wl.set_scaling(args.scaling, args.batch)
-        except StopIteration:
-            pass
+            if not args.only_dp_breakdown:
+                other = "weak" if args.scaling == "strong" else "strong"
+                wl.set_scaling(other, args.batch)
+                m2, t2 = wl.measure(2, args.steps, 1, dev)
+                extra[f"{other}_scaling"] = {"value": round(args.steps * wl.gb / m2, 1), "unit": "samples/s",
+                                             "ms_per_step": round(1e3 * m2 / args.steps, 4), "per_gpu_batch": wl.B,
+                                             "global_batch": wl.gb}
+                wl.set_scaling(args.scaling, args.batch)
         except Exception as e:  # noqa: BLE001
             extra["other_scaling"] = {"error": f"{type(e).__name__}: {e}"}
         # BASELINE config 5 under data parallelism (neighbourhoods sharded over the ranks, gradient all-reduce over RCCL inside

@@ -88,7 +88,7 @@ def make_model(spec: sto.SetTransformerSpec, **kw):
             self.lib, self.device = None, torch.device("cpu")
 
         def forward(self, batch_inp, step=None, deterministic=False, row0=0, embs_reparam=None, _step_from_device=False,
-                    for_backward=True):
+                    for_backward=True, _skip_head=False):
             return backend.forward(self, batch_inp, step, deterministic, row0, embs_reparam)
 
         def loss_and_backward(self, is_loci, inv_global_batch=None, reduce=True):
