@@ -66,7 +66,12 @@ class HipEngine:
             self.lr_dev = torch.full((1,), 1e-3, dtype=torch.float32, device=self.device)
             self._lr_host: Optional[float] = 1e-3
             self.t_dev = z(1, torch.int64)
-            self.metrics_acc = z(self.F + 3)
+            # History accumulators: training | validation, one tensor (one device-to-host copy reads both: fit synchronises
+            # once per epoch - the validation pass is enqueued behind the training steps without reading anything back)
+            self._metrics_stride = (self.F + 3 + 3) // 4 * 4
+            self._metrics2 = z(2 * self._metrics_stride)
+            self.metrics_acc = self._metrics2[: self.F + 3]
+            self.metrics_acc_val = self._metrics2[self._metrics_stride: self._metrics_stride + self.F + 3]
             tb = int(self.lib.dib_layout_table_bytes(self.layout))
             self._tables = torch.zeros(tb, dtype=torch.uint8, device=self.device)
             check(self.lib.dib_layout_upload_tables(self.layout, _ptr(self._tables), self._stream()),
@@ -366,8 +371,9 @@ class HipEngine:
                       on_encoder_front_grads_ready=on_encoder_front_grads_ready, finish_flags=finish, optimizer=optimizer)
 
     def eval_step(self, x, y, row_idx, row0: int, batch: int, seed: int, step: int, loss_kind: str,
-                  inv_global_batch: Optional[float] = None) -> None:
-        """validation: noise stays ON and the KL term is included (reference train.py:263-265)."""
+                  inv_global_batch: Optional[float] = None, metrics_acc: Optional[torch.Tensor] = None) -> None:
+        """validation: noise stays ON and the KL term is included (reference train.py:263-265).  metrics_acc: where the step's
+        History sums go (default: the training accumulator; fit passes `metrics_acc_val`)."""
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         kind = LOSS_KINDS[loss_kind]
         fused_head = self._head_fused(kind)
@@ -379,7 +385,8 @@ class HipEngine:
         else:
             self.forward(x, row_idx, row0, batch, seed, step, inference=True, defer_sums=True)
             self.loss(loss_kind, y, row_idx, row0, batch, inv, defer_sums=True)
-        self.step_tail(batch, -1, _lib.TAIL_KL | (_lib.TAIL_LOSS_HEAD if fused_head else _lib.TAIL_LOSS) | _lib.TAIL_METRICS, inv)
+        self.step_tail(batch, -1, _lib.TAIL_KL | (_lib.TAIL_LOSS_HEAD if fused_head else _lib.TAIL_LOSS) | _lib.TAIL_METRICS, inv,
+                       metrics_acc=metrics_acc)
 
     # ---- hipGraph capture of a whole step (launch-bound small-batch regime) -----------------------
     def enable_step_counter(self, value: int = 0) -> None:
@@ -454,6 +461,14 @@ class HipEngine:
         if reset:
             self.metrics_acc.zero_()
         return m
+
+    def read_metrics_pair(self, reset: bool = True):
+        """(training sums, validation sums) with ONE device-to-host copy (= one synchronisation) and one reset."""
+        both = self._metrics2.detach().cpu().numpy().astype(np.float64)
+        if reset:
+            self._metrics2.zero_()
+        n, st = self.F + 3, self._metrics_stride
+        return both[:n].copy(), both[st: st + n].copy()
 
     def profile_enable(self, on: bool) -> None:
         check(self.lib.dib_profile_enable(1 if on else 0), "dib_profile_enable")

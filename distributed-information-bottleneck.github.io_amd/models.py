@@ -499,10 +499,12 @@ class DistributedIBNet:
                 # done while this epoch's steps are still executing; the read-back below is the epoch's only synchronisation
                 if epoch + 1 < epochs and not self.stop_training:
                     next_order = epoch_order(epoch + 1)
-                logs = self._epoch_logs(reduce_metrics(eng.read_metrics()), nsteps, "")
+                # ONE synchronisation per epoch: the validation pass is enqueued right behind the training steps - its History
+                # sums go to an accumulator of their own - and both are read back together (round 5 read the training sums
+                # first: the device idled through that round trip and the host work behind it, every epoch)
+                vsteps = 0
                 if validation_data is not None:
                     nv = xvd.shape[0]
-                    vsteps = 0
                     if getattr(eng, "step_dev", None) is not None:
                         eng.set_step_counter((1 << 31) + epoch)  # validation noise stream, same key as the eager path
                     # Validation batches do not depend on each other - no state changes between them, one noise key per epoch
@@ -520,12 +522,15 @@ class DistributedIBNet:
                         hi = (rows * (rank + 1)) // world
                         if hi > lo:
                             eng.eval_step(xvd, yvd, None, s0 + lo, hi - lo, self.noise_seed, (1 << 31) + epoch, kind,
-                                          inv_global_batch=1.0 / gb)
+                                          inv_global_batch=1.0 / gb, metrics_acc=eng.metrics_acc_val)
                         vsteps += nb
                         s0 += rows
                     if getattr(eng, "step_dev", None) is not None:
                         eng.set_step_counter(self._step)
-                    logs.update(self._epoch_logs(reduce_metrics(eng.read_metrics()), vsteps, "val_"))
+                train_sums, val_sums = eng.read_metrics_pair()
+                logs = self._epoch_logs(reduce_metrics(train_sums), nsteps, "")
+                if validation_data is not None:
+                    logs.update(self._epoch_logs(reduce_metrics(val_sums), vsteps, "val_"))
                 for k, v in logs.items():
                     hist.history.setdefault(k, []).append(float(v))
                 hist.epoch.append(epoch)

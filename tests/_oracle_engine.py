@@ -33,6 +33,7 @@ class OracleEngine:
         self.params = torch.from_numpy(params_to_flat(self.blocks, self.p, off, np.float64))
         self.grads = torch.zeros(off, dtype=torch.float64)
         self.metrics_acc = torch.zeros(self.F + 3, dtype=torch.float64)
+        self.metrics_acc_val = torch.zeros(self.F + 3, dtype=torch.float64)
         self.state = orc.adam_init(self.p)
         self.beta, self.lr = 1.0, 1e-3
         self._pred = None
@@ -126,12 +127,19 @@ class OracleEngine:
         self.state.v = flat_to_params(self.blocks, after[2], self.spec)
         self.state.t = t0 + 1 if (bump and optimizer[0] == "adam") else t0
 
-    def eval_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None):
+    def eval_step(self, x, y, row_idx, row0, batch, seed, step, loss_kind, inv_global_batch=None, metrics_acc=None):
         inv = 1.0 / batch if inv_global_batch is None else inv_global_batch
         rows, xb, c = self._fwd(x, row_idx, row0, batch, seed, step)
         yb = y.numpy()[rows]
         task, _ = orc.loss_and_grad(loss_kind, yb, c.pred)
-        self._account(c, task, yb, loss_kind, batch, inv)
+        if metrics_acc is None:
+            self._account(c, task, yb, loss_kind, batch, inv)
+        else:   # (the product's fit: validation sums go to an accumulator of their own)
+            keep, self.metrics_acc = self.metrics_acc, metrics_acc
+            try:
+                self._account(c, task, yb, loss_kind, batch, inv)
+            finally:
+                self.metrics_acc = keep
 
     def adam_step(self, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         g = flat_to_params(self.blocks, self.grads.numpy() * grad_scale, self.spec)
@@ -147,6 +155,13 @@ class OracleEngine:
         if reset:
             self.metrics_acc.zero_()
         return m
+
+    def read_metrics_pair(self, reset=True):
+        a, b = self.metrics_acc.numpy().copy(), self.metrics_acc_val.numpy().copy()
+        if reset:
+            self.metrics_acc.zero_()
+            self.metrics_acc_val.zero_()
+        return a, b
 
     def encode_feature(self, f, x_f):
         return torch.from_numpy(orc.encode_feature(self.spec, self.p, f, np.asarray(x_f, dtype=np.float64)))
