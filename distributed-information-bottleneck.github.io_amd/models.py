@@ -503,6 +503,9 @@ class DistributedIBNet:
                 # sums go to an accumulator of their own - and both are read back together (round 5 read the training sums
                 # first: the device idled through that round trip and the host work behind it, every epoch)
                 vsteps = 0
+                early = None
+                if getattr(self, "syncs_per_epoch", 1) == 2:   # A/B switch: round 5's order (training sums read before the validation pass)
+                    early = eng.read_metrics_pair()[0]
                 if validation_data is not None:
                     nv = xvd.shape[0]
                     if getattr(eng, "step_dev", None) is not None:
@@ -528,6 +531,8 @@ class DistributedIBNet:
                     if getattr(eng, "step_dev", None) is not None:
                         eng.set_step_counter(self._step)
                 train_sums, val_sums = eng.read_metrics_pair()
+                if early is not None:
+                    train_sums = early
                 logs = self._epoch_logs(reduce_metrics(train_sums), nsteps, "")
                 if validation_data is not None:
                     logs.update(self._epoch_logs(reduce_metrics(val_sums), vsteps, "val_"))
