@@ -81,12 +81,16 @@ struct dib_layout {
   int wg_groups() const { return n_enc * F + n_int + 1; }
   mutable std::map<int, std::vector<DibGemmGroup>> wg_tables;
   mutable std::mutex wg_mu;            // two threads may initialise workspaces of one layout (include/dib_hip.h "Threads")
+  // Most batch slabs any weight-gradient launch of this layout has written per (batch size, parameter block) - see
+  // retire_stale_slabs.  Conservative across the layout's workspaces (guarded by wg_mu).
+  mutable std::map<std::pair<int, long long>, int> slab_hwm;
 
   // ---- workspace map (float offsets), all per-row widths scale with the batch ----
   struct WsMap {
     int64_t P, enc_out, U, pred, g_pred, g_u, dout;
     std::vector<int64_t> enc_h, int_h, g_enc_h, g_int_h;
     int64_t step_out, kl_partial, loss_partial, wgrad_partial, dw1_partial, h2mask, h1mask, skinny_partial, sync, wg_table, total;
+    int64_t cl_sync; std::vector<int64_t> cl_x;   // cluster mode of the row-tile integration kernel (dib_small.h)
     int skinny_chunks, skinny_rows;
     int kl_blocks, loss_blocks, nsplit, rows_per_split;
   };
@@ -145,6 +149,11 @@ struct dib_layout {
     // descriptors of ALL weight gradients of a step with absolute workspace offsets for THIS batch size (written by
     // dib_workspace_init): one grouped launch instead of one per layer (merged_wgrad)
     m.wg_table = take((int64_t)wg_groups() * (int64_t)(sizeof(DibGemmGroup) / sizeof(float)));
+    // cluster mode of the row-tile integration kernel: arrival counters per row tile (zeroed by dib_workspace_init, self-cleaning)
+    // and the hidden activations' exchange buffers of launches that write no stashes
+    const bool cl_ok = sb_int && B <= kSmallMaxBatch;
+    m.cl_sync = take(cl_ok ? (int64_t)cdiv(B, DIB_SMALL_ROWS) * DIB_SMALL_CL_SYNC_WORDS : 0);
+    for (int l = 0; l < n_int; ++l) m.cl_x.push_back(take(cl_ok ? (int64_t)B * int_units[l] : 0));
     m.total = o;
     return m;
   }
@@ -223,6 +232,9 @@ struct Tuning {
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
+  int int_cluster = 4;       // row-tile integration kernel: workgroups per row tile (each a column slice of every layer, exchange
+                             // through L2: dib_small.h "cluster mode") while tiles x this <= int_cluster_wgs; <= 1: one per tile
+  int int_cluster_wgs = 128; // ...
   int wgrad_max_splits = 32; // most batch slabs of a layout's weight gradients (<= 32; read when a workspace is sized: set it first)
   int num_cus = 0;           // compute units the split rule prices rounds with; 0 = the current device's own count (device_cus)
 };
@@ -322,7 +334,8 @@ static void pick_wgrad_splits(long long tiles, int slots, int K, int max_splits,
 template <int MODE>
 int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* A, const float* B, float* C,
                 const float* bias, const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
-                long long split_stride, hipStream_t st, bool auto_split = false, int max_splits = 0) {
+                long long split_stride, hipStream_t st, bool auto_split = false, int max_splits = 0, int* ns_used = nullptr) {
+  if (ns_used) *ns_used = nsplit;
   if (c.count == 0) return DIB_OK;
   const int M = c.max_m < 0 ? batch : c.max_m;
   const int N = c.max_n < 0 ? batch : c.max_n;
@@ -347,6 +360,7 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
     const int per_cu = (!ni1 && !nj1) ? 2 : ((!ni1 && nj1) ? 4 : (ni1 && !nj1) ? 3 : 4);
     const long long tiles = (long long)cdiv(M, ni1 ? 64 : 128) * cdiv(N, nj1 ? 64 : 128) * c.count;
     pick_wgrad_splits(tiles, split_rule_cus() * per_cu, batch, std::max(nsplit, max_splits), &nsplit, &rows_per_split);
+    if (ns_used) *ns_used = nsplit;
   }
   ProfScope ps(MODE * 4 + (ni1 ? 0 : 2) + (nj1 ? 0 : 1), st);
   if constexpr (MODE == 2) {
@@ -364,14 +378,49 @@ int launch_gemm(const DibGemmGroup* dev_groups, const GemmCall& c, const float* 
 
 __global__ void dib_write_desc_kernel(DibGemmGroup* dst, DibGemmGroup g) { *dst = g; }
 
+// The reducers (dib_grads_finalize, the step tail) sum ALL the workspace's slabs of every parameter block, and a launch that
+// chose `ns` splits writes slabs [0, ns) of its blocks: the slabs above stay as they are - zero since dib_workspace_init unless a
+// DIFFERENT launch over the same block chose more splits earlier (the split rule prices whole launches: the row-tile regime's one
+// grouped launch of all weight gradients picked 3 slabs at B = 512 where the per-layer launches of dib_integration_bwd /
+// dib_encoder_bank_bwd - the custom-loss entry of a 1-unit output - picked 4, and a training step after a custom-loss step summed
+// that step's fourth slab into its gradients).  Per (batch, block) the layout remembers the most slabs any launch has written;
+// a launch that writes fewer zero-fills the difference behind itself.  Programs that stay on one path never pay; a program that
+// alternates pays a few small memsets per step.  A launch being CAPTURED into a hipGraph cannot know what will run between its
+// replays: it zero-fills every slab it does not write (slab_count = the slabs the workspace holds).
+static int retire_stale_slabs(const dib_layout* l, int batch, const DibGemmGroup* host_groups, int count, int ns, int slab_count,
+                              float* gt, long long split_stride, hipStream_t st) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+  std::lock_guard<std::mutex> lk(l->wg_mu);
+  for (int i = 0; i < count; ++i) {
+    const DibGemmGroup& g = host_groups[i];
+    int& mark = l->slab_hwm[std::make_pair(batch, g.c_off)];
+    mark = std::max(mark, ns);
+    const int hwm = capturing ? std::max(mark, slab_count) : mark;
+    if (ns >= hwm) continue;
+    const size_t wbytes = (size_t)g.M * (size_t)g.ldc * sizeof(float);   // the block's rows are contiguous (ldc == N)
+    for (int s = ns; s < hwm; ++s) {
+      hipError_t e = hipMemsetAsync(gt + (long long)s * split_stride + g.c_off, 0, wbytes, st);
+      if (e == hipSuccess && g.bias_off >= 0)
+        e = hipMemsetAsync(gt + (long long)s * split_stride + g.bias_off, 0, (size_t)g.N * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  return DIB_OK;
+}
+
 template <int MODE>
 int launch_gemm(const dib_layout* l, const GemmCall& c, const float* A, const float* B, float* C, const float* bias,
                 const float* aux, float* bias_out, int batch, int act, int nsplit, int rows_per_split,
                 long long split_stride, hipStream_t st, int slab_count = 0) {
   // the layout's weight gradients contract over the batch: their split count is chosen per launch (pick_wgrad_splits) among
   // 1 .. slab_count (the partial slabs the workspace holds)
-  return launch_gemm<MODE>(l->dev_groups, c, A, B, C, bias, aux, bias_out, batch, act, nsplit, rows_per_split, split_stride,
-                           st, /*auto_split=*/MODE == 2, slab_count);
+  int ns_used = nsplit;
+  int rc = launch_gemm<MODE>(l->dev_groups, c, A, B, C, bias, aux, bias_out, batch, act, nsplit, rows_per_split, split_stride,
+                             st, /*auto_split=*/MODE == 2, slab_count, &ns_used);
+  if (MODE == 2 && rc == DIB_OK && slab_count > 1)
+    rc = retire_stale_slabs(l, batch, l->table.data() + c.first, c.count, ns_used, slab_count, C, split_stride, st);
+  return rc;
 }
 
 inline int grid_for(int64_t n, int per_block = 256, int cap = 256 * 16) {
@@ -602,8 +651,12 @@ static int merged_wgrad(dib_layout* l, const dib_layout::WsMap& m, float* w, int
   c.first = 0; c.count = count;
   for (int i = first; i < first + count; ++i) { c.max_m = std::max(c.max_m, host[i].M); c.max_n = std::max(c.max_n, host[i].N); }
   const DibGemmGroup* dev = reinterpret_cast<const DibGemmGroup*>(w + m.wg_table) + first;
-  return launch_gemm<2>(dev, c, w, w, gt, nullptr, nullptr, gt, batch, 0, m.nsplit, m.rows_per_split, align_up(l->n_params, 4), st,
-                        /*auto_split=*/true, m.nsplit);
+  int ns_used = m.nsplit;
+  int rc = launch_gemm<2>(dev, c, w, w, gt, nullptr, nullptr, gt, batch, 0, m.nsplit, m.rows_per_split, align_up(l->n_params, 4), st,
+                          /*auto_split=*/true, m.nsplit, &ns_used);
+  if (rc == DIB_OK && m.nsplit > 1)
+    rc = retire_stale_slabs(l, batch, host.data() + first, count, ns_used, m.nsplit, gt, align_up(l->n_params, 4), st);
+  return rc;
 }
 // when one grouped launch for all weight gradients pays: the small-batch regime, where every launch is latency
 static bool use_merged_wgrad(const dib_layout* l, int batch) {
@@ -630,6 +683,18 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.pred = w + m.pred; a.g_pred = w + m.g_pred;
   a.loss_kind = loss_kind; a.Y = y; a.ldy = ldy; a.row_idx = (const int*)row_idx; a.row0 = row0; a.inv_bg = inv_bg;
   a.partial_w = w + m.skinny_partial; a.partial_l = w + m.loss_partial;
+  // cluster mode: few row tiles, each on `cl` workgroups (not for a launch that carries a companion network)
+  const int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
+  const size_t cl_lds = (size_t)l->sb_int_lds + (size_t)(DIB_SMALL_XCH_FLOATS_WIDE - DIB_SMALL_XCH_FLOATS) * sizeof(float);
+  if (!t_companion.armed && cl > 1 && small_tiles(batch) * cl <= knobs().int_cluster_wgs && cl_lds <= 160 * 1024) {
+    a.cl = cl; a.cl_sync = (unsigned*)(w + m.cl_sync);
+    for (int i = 0; i < l->n_int; ++i) a.xh[i] = w + m.cl_x[i];
+    static int cl_lds_have[64] = {};
+    if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_cluster_kernel, cl_lds, cl_lds_have)) return rc;
+    ProfScope ps(kProfOther, st);
+    DIB_LAUNCH(dib_small_integration_cluster_kernel, dim3(8 * cdiv(small_tiles(batch), 8) * cl), dim3(DIB_SMALL_THREADS), cl_lds, st, a);
+    return (int)hipGetLastError();
+  }
   if (t_companion.armed) {
     t_companion.armed = false;
     DibSmallIntPair p;
@@ -902,6 +967,11 @@ int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t st
   // the arrival counters of dib_step_tail (self-cleaning afterwards)
   hipError_t e0 = hipMemsetAsync((float*)ws + m.sync, 0, (size_t)DIB_TAIL_SYNC_WORDS * sizeof(unsigned), (hipStream_t)stream);
   if (e0 != hipSuccess) return (int)e0;
+  if (l->sb_int && batch <= kSmallMaxBatch) {   // ... and of the integration kernel's cluster mode
+    e0 = hipMemsetAsync((float*)ws + m.cl_sync, 0, (size_t)cdiv(batch, DIB_SMALL_ROWS) * DIB_SMALL_CL_SYNC_WORDS * sizeof(unsigned),
+                        (hipStream_t)stream);
+    if (e0 != hipSuccess) return (int)e0;
+  }
   {  // the merged weight-gradient table of this batch size (the host copy lives in the layout: the copy may be asynchronous)
     const auto& t = wg_table_host(l, m, batch);
     e0 = hipMemcpyAsync((float*)ws + m.wg_table, t.data(), t.size() * sizeof(DibGemmGroup), hipMemcpyHostToDevice, (hipStream_t)stream);
@@ -1483,6 +1553,8 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "wgrad_flat_tile")) return &t.wgrad_flat_tile;
   if (!std::strcmp(key, "wgrad_max_splits")) return &t.wgrad_max_splits;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
+  if (!std::strcmp(key, "int_cluster")) return &t.int_cluster;
+  if (!std::strcmp(key, "int_cluster_wgs")) return &t.int_cluster_wgs;
   return nullptr;
 }
 

@@ -20,12 +20,14 @@
 #include "dib_fused.h"   // dib_sigma, DIB_MFMA16, dib_f32x4
 
 #define DIB_SMALL_ROWS 16
+#define DIB_STD(i) do { if (dbg >= 0) DIB_ST(dbg + (i)); } while (0)   // marks inside a layer primitive (diagnostic build only)
 
 // (phase marks DIB_ST(i) of the diagnostic build -DDIB_SMALL_TIMING: dib_common.h)
 #define DIB_SMALL_THREADS 512   // 8 waves = 2 per SIMD: the contraction of every layer is split between wave w and w + 4, so
                                 // that one of the pair issues MFMAs while the other waits for its weights (each weight is read
                                 // once per workgroup, straight from L2: the kernels are latency-bound, not bandwidth-bound)
 #define DIB_SMALL_XCH_FLOATS (4 * 5 * 64 * 4)   // exchange buffer of the wave pairs: [4 column slots][<= 5 tiles][64 lanes] float4
+#define DIB_SMALL_XCH_FLOATS_WIDE (8 * 5 * 64 * 4)   // ... of the cluster-mode primitives: [8 waves][<= 5 tiles][64 lanes] float4
 
 __host__ __device__ inline int dib_small_pick_nt(int n) {   // column tiles of 16 per wave pass: balance the 4 column slots first
   if (n % 64 == 0 && (n / 64) % 4 == 0) return 4;
@@ -305,6 +307,236 @@ __device__ __forceinline__ void dib_small_bwd(const float* g, int pg, int N, con
   }
 }
 
+// =====================================================================================================================
+// cluster-mode layer primitives (a column SLICE of a layer on one workgroup, see "cluster mode" below)
+// =====================================================================================================================
+// A slice is narrow - 64 columns of a 256-wide layer on a cluster of 4 - and what bounds a layer on a row tile is the latency of
+// its weight stream (the weights are read once per XCD: every batch of loads is an L2 miss, ~ 2 us).  So: the slice's columns are
+// ONE group (two for 128 columns) and the waves the group rule would leave idle take shares of the CONTRACTION, sized so that a
+// share's loads are a single batch in flight - one memory round trip per layer; every share writes its partial tile to the exchange
+// buffer and the tiles are reduced in share order (fixed: 0 + 1 + ... ) by ONE WAVE PER TILE, which also applies bias / activation
+// (its bias values fetched at the start of the pass, under the weight stream) and stores - 8 partial reads per wave instead of 28
+// on the share-0 wave.
+template <int NT, int UB>
+__device__ __forceinline__ void dib_small_fwd_wide(const float* in, int pin, int K, const float* __restrict__ W, int ldw, int ncols,
+                                                   const float* __restrict__ bias, float slope, float* out, int pout,
+                                                   float* __restrict__ gdst, long long gld, int rows_valid, float* xch, int dbg) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  constexpr int CG = 16 * NT;
+  const int ngroups = ncols / CG;
+  const int kways = ngroups <= 1 ? 8 : (ngroups == 2 ? 4 : 2), nslots = 8 / kways;
+  const int wc = wave % nslots, kh = wave / nslots;   // column slot, contraction share
+  DIB_STD(0);
+  for (int g0 = 0; g0 < ngroups; g0 += nslots) {   // block-uniform trip count
+    const bool active = g0 + wc < ngroups;
+    const int n0 = (active ? g0 + wc : 0) * CG;
+    // this wave's reduction items of the pass: tile (slot, c) = item / NT, item % NT for items wave, wave + 8
+    float bv[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = wave + 8 * it, slot = item / NT, c = item - slot * NT;
+      bv[it] = (slot < nslots && g0 + slot < ngroups) ? bias[(g0 + slot) * CG + NT * j + c] : 0.f;
+    }
+    dib_f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = dib_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const float* ap = in + j * pin;
+      const float* wp = W + n0 + NT * j;
+      float acur[UB], bcur[UB][NT];
+      auto load = [&](int s0, float (&av)[UB], float (&bw)[UB][NT]) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int k = s0 + 4 * u + q;
+          const bool ok = k < K;
+          const int kc = ok ? k : 0;
+          av[u] = ok ? ap[kc] : 0.f;
+          dib_small_loadw<NT>(wp + (long long)kc * ldw, bw[u]);
+        }
+      };
+      load(4 * UB * kh, acur, bcur);
+      DIB_STD(1);
+      for (int s0 = 4 * UB * kh; s0 < K; s0 += 4 * UB * kways) {
+        float anxt[UB], bnxt[UB][NT];
+        if (s0 + 4 * UB * kways < K) load(s0 + 4 * UB * kways, anxt, bnxt);   // wave-uniform: usually a share IS one batch
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (s0 + 4 * u < K) {   // wave-uniform
+#pragma unroll
+            for (int c = 0; c < NT; ++c) acc[c] = DIB_MFMA16(acur[u], bcur[u][c], acc[c]);
+          }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          acur[u] = anxt[u];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bcur[u][c] = bnxt[u][c];
+        }
+      }
+    }
+    DIB_STD(2);
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+        *reinterpret_cast<float4*>(xch + (((kh * nslots + wc) * NT + c) * 64 + lane) * 4) =
+            make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    }
+    __syncthreads();
+    DIB_STD(3);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = wave + 8 * it, slot = item / NT, c = item - slot * NT;
+      if (slot < nslots && g0 + slot < ngroups) {   // wave-uniform
+        float4 sum = *reinterpret_cast<const float4*>(xch + ((slot * NT + c) * 64 + lane) * 4);
+        for (int p = 1; p < kways; ++p) {
+          const float4 o = *reinterpret_cast<const float4*>(xch + (((p * nslots + slot) * NT + c) * 64 + lane) * 4);
+          sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+        }
+        const int n = (g0 + slot) * CG + NT * j + c;
+        const float v4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * q + r;
+          const float v = dib_small_act(slope, v4[r] + bv[it]);
+          if (out != nullptr) out[row * pout + n] = v;
+          if (gdst != nullptr && row < rows_valid) gdst[(long long)row * gld + n] = v;
+        }
+      }
+    }
+    DIB_STD(4);
+    __syncthreads();   // the exchange buffer is free again, the output tile is visible
+    DIB_STD(5);
+  }
+}
+
+// columns [col0, col0 + ncols) of the layer only (W, bias, out, gdst: the FULL layer's pointers; ldn = its width)
+__device__ __forceinline__ void dib_small_fwd_cols(const float* in, int pin, int K, const float* __restrict__ W, int ldn, int col0,
+                                                   int ncols, const float* __restrict__ bias, float slope, float* out, int pout,
+                                                   float* __restrict__ gdst, int rows_valid, float* xch, int dbg = -1) {
+  W += col0; bias += col0; gdst += col0;
+  if (out != nullptr) out += col0;
+  // the widest column group the slice divides into; k-steps per batch = a share's whole part of the contraction where it fits
+  const int nt = ncols % 64 == 0 ? 4 : (ncols % 32 == 0 ? 2 : 1);
+  const int ngroups = ncols / (16 * nt);
+  const int kw = ngroups <= 1 ? 8 : (ngroups == 2 ? 4 : 2);
+  const int per_share = ((K + 3) / 4 + kw - 1) / kw;
+  const int ub = per_share <= 8 ? 8 : (per_share <= 10 ? 10 : 16);
+#define DIB_FW(NT_, UB_) dib_small_fwd_wide<NT_, UB_>(in, pin, K, W, ldn, ncols, bias, slope, out, pout, gdst, ldn, rows_valid, xch, dbg)
+  if (nt == 4) { if (ub == 8) DIB_FW(4, 8); else if (ub == 10) DIB_FW(4, 10); else DIB_FW(4, 16); }
+  else if (nt == 2) { if (ub == 8) DIB_FW(2, 8); else if (ub == 10) DIB_FW(2, 10); else DIB_FW(2, 16); }
+  else { if (ub == 8) DIB_FW(1, 8); else if (ub == 10) DIB_FW(1, 10); else DIB_FW(1, 16); }
+#undef DIB_FW
+}
+
+// gin[16][16 NT] = (g[16][N] @ W[16 NT][N]^T) (.) act'(h): ONE group of NT <= 5 input-unit tiles, the contraction on `kways`
+// shares of UB S-steps a batch; partial tiles reduced in share order by wave t for tile t (see dib_small_fwd_wide).
+template <int NT, int UB>
+__device__ __forceinline__ void dib_small_bwd_wide(const float* g, int pg, int N, const float* __restrict__ W, const float* h, int ph,
+                                                   float slope, float* gin, int pgi, float* __restrict__ gdst, long long gld,
+                                                   int rows_valid, float* xch, int kways, int dbg) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int kh = wave;   // one column slot: the wave index IS the contraction share
+  const bool active = kh < kways;
+  DIB_STD(0);
+  dib_f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = dib_f32x4{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float* ap = g + j * pg + 4 * q;
+    const float* wp = W + (long long)j * N + 4 * q;
+    float4 acur[UB], bcur[UB][NT];
+    auto load = [&](int S0, float4 (&av)[UB], float4 (&bw)[UB][NT]) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int S = S0 + 16 * u;
+        const bool ok = S < N;
+        const int Sc = ok ? S : 0;
+        av[u] = ok ? *reinterpret_cast<const float4*>(ap + Sc) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bw[u][t] = *reinterpret_cast<const float4*>(wp + (long long)(16 * t) * N + Sc);
+      }
+    };
+    load(16 * UB * kh, acur, bcur);
+    DIB_STD(1);
+    for (int S0 = 16 * UB * kh; S0 < N; S0 += 16 * UB * kways) {
+      float4 anxt[UB], bnxt[UB][NT];
+      if (S0 + 16 * UB * kways < N) load(S0 + 16 * UB * kways, anxt, bnxt);   // wave-uniform
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (S0 + 16 * u >= N) break;   // wave-uniform
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].x, bcur[u][t].x, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].y, bcur[u][t].y, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].z, bcur[u][t].z, acc[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].w, bcur[u][t].w, acc[t]);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        acur[u] = anxt[u];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bcur[u][t] = bnxt[u][t];
+      }
+    }
+    DIB_STD(2);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      *reinterpret_cast<float4*>(xch + ((kh * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  }
+  __syncthreads();
+  DIB_STD(3);
+  if (wave < NT) {   // tile t = wave
+    const int t = wave;
+    float4 sum = *reinterpret_cast<const float4*>(xch + (t * 64 + lane) * 4);
+    for (int p = 1; p < kways; ++p) {
+      const float4 o = *reinterpret_cast<const float4*>(xch + ((p * NT + t) * 64 + lane) * 4);
+      sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
+    }
+    const float v4[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r, k = 16 * t + j;
+      float v = v4[r];
+      if (h != nullptr) v *= dib_small_act_grad(slope, h[row * ph + k]);
+      if (gin != nullptr) gin[row * pgi + k] = v;
+      if (gdst != nullptr && row < rows_valid) gdst[(long long)row * gld + k] = v;
+    }
+  }
+  DIB_STD(4);
+  __syncthreads();
+  DIB_STD(5);
+}
+
+// input units [k0, k0 + kcols) of the layer only (W, h, gin, gdst: the FULL layer's pointers; ldk = its input width)
+__device__ __forceinline__ void dib_small_bwd_cols(const float* g, int pg, int N, const float* __restrict__ W, int ldk, int k0,
+                                                   int kcols, const float* h, int ph, float slope, float* gin, int pgi,
+                                                   float* __restrict__ gdst, int rows_valid, float* xch, int dbg = -1) {
+  W += (long long)k0 * N;
+  if (h != nullptr) h += k0;
+  if (gin != nullptr) gin += k0;
+  if (gdst != nullptr) gdst += k0;
+  const int tiles = kcols >> 4;
+  if (tiles > 5) { dib_small_bwd(g, pg, N, W, kcols, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch); return; }
+  // 2 S-steps a batch (N <= 256: a share's loads are one batch in flight), 4 for longer contractions
+  const int ub = N <= 256 ? 2 : 4;
+  const int nb = (N + 16 * ub - 1) / (16 * ub);
+  const int kw = nb >= 8 ? 8 : (nb >= 4 ? 4 : (nb >= 2 ? 2 : 1));
+#define DIB_BW(NT_) do { if (ub == 2) dib_small_bwd_wide<NT_, 2>(g, pg, N, W, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch, kw, dbg); \
+                         else dib_small_bwd_wide<NT_, 4>(g, pg, N, W, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch, kw, dbg); } while (0)
+  switch (tiles) {   // block-uniform
+    case 5: DIB_BW(5); break;
+    case 4: DIB_BW(4); break;
+    case 3: DIB_BW(3); break;
+    case 2: DIB_BW(2); break;
+    case 1: DIB_BW(1); break;
+    default: break;   // an empty slice
+  }
+#undef DIB_BW
+}
+
 // global [rows_valid][width] (leading dimension ld) -> LDS tile [16][pitch]; rows >= rows_valid are zero-filled
 __device__ __forceinline__ void dib_small_load_tile(const float* __restrict__ src, long long ld, int width, int rows_valid,
                                                     float* dst, int pitch) {
@@ -460,10 +692,71 @@ struct DibSmallIntArgs {
   // DIB_SMALL_INT_HEAD_REDUCE: d(W_out | b_out) -> head_gw [K], head_gb [1]; {loss sum, #correct, loss sum * loss_scale} -> sums3;
   // sync: one zero-initialised word (self-cleaning)
   float* head_gw; float* head_gb; float* sums3; float loss_scale; unsigned* sync;
+  // cluster mode (dib_small_integration_cluster_kernel): cl workgroups share a row tile, each owning a column slice of every
+  // layer; xh[l]: [B][width[l]] exchange buffers of the hidden activations for launches that write no stashes (INFER);
+  // cl_sync: DIB_SMALL_CL_SYNC_WORDS zero-initialised words per row tile (self-cleaning)
+  int cl; float* xh[3]; unsigned* cl_sync;
 };
 
-__device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs& a, const int tile) {
+// ---- cluster mode: the columns of a row tile's layers on `cl` co-resident workgroups (round 6) ----------------------------------
+// At the reference's default batch the integration network is 8 row tiles = 8 workgroups on 256 CUs, and a layer's time on a
+// row tile is the stream of the layer's WHOLE weight matrix through one CU plus its MFMA issue there (profiles/HISTORY.md
+// sections 13, 19: 8 - 12 us per layer).  In cluster mode workgroup c of a tile's cl computes output columns [slice c) of every
+// layer - 1 / cl of the weights and of the MFMAs - writes them to the layer's global buffer (the stash the weight gradients
+// read anyway, or xh when inferring) and the cl workgroups exchange slices through L2: one arrival counter per (tile, layer),
+// release / acquire at agent scope.  Every sum keeps its order (a column's contraction is computed by one workgroup exactly as the
+// single-workgroup kernel computes it): the results are the bits of dib_small_integration_kernel.
+// Progress: a workgroup waits only for the cl - 1 others of its own tile, whose ids are consecutive multiples of 8 apart inside one
+// block of 8 cl ids; the launch has <= 256 workgroups of one per CU, so every workgroup is resident once the kernels ahead of it on
+// other streams drain.  The wait is bounded all the same: after ~2 s of wall clock the kernel traps (the process sees a HIP error
+// at its next synchronisation) instead of hanging the device.
+#define DIB_SMALL_CL_SYNC_WORDS 32   // per tile: [0, 7) arrival counters (fwd layer l: l; output-layer dgrad: 3; dgrad into h_{l-1}: 3 + l), [7] departures
+#define DIB_SMALL_CL_MAX 8
+
+// publish this workgroup's slice, wait for the others'.  The layer primitives end with a workgroup barrier, but a barrier does not
+// wait for the waves' global stores (s_waitcnt lgkmcnt(0) only): every wave drains its own (vmcnt(0), the gfx9 encoding 0x0F70)
+// ahead of a second barrier, so that thread 0's release covers stores that HAVE reached L2.
+__device__ __forceinline__ void dib_small_cluster_exchange(unsigned* counter, int cl) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > 200000000ll) __builtin_trap();   // 2 s at 100 MHz: never a hang
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// the last of the tile's workgroups to leave zeroes the tile's counters for the next launch
+__device__ __forceinline__ void dib_small_cluster_leave(unsigned* words, int cl) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(words + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)cl - 1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) __hip_atomic_store(words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// slice c of cl of a width (in 16-column tiles): [c T / cl, (c + 1) T / cl) - empty when the layer has fewer tiles than workgroups
+__device__ __forceinline__ void dib_small_cluster_slice(int width, int c, int cl, int& col0, int& ncols) {
+  const int T = width >> 4;
+  const int t0 = c * T / cl, t1 = (c + 1) * T / cl;
+  col0 = 16 * t0; ncols = 16 * (t1 - t0);
+}
+
+// CLUSTER: workgroup `crank` of the a.cl that share `tile` (see above); else one workgroup per tile
+template <bool CLUSTER>
+__device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs& a, const int tile, const int crank = 0) {
   constexpr int ROWS = DIB_SMALL_ROWS;
+  const int cl = CLUSTER ? a.cl : 1;
+  const bool lead = !CLUSTER || crank == 0;   // writes what every workgroup of the tile computes alike (the head)
+  unsigned* const clw = CLUSTER ? a.cl_sync + (long long)tile * DIB_SMALL_CL_SYNC_WORDS : nullptr;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = tile * ROWS, rows_valid = min(ROWS, a.batch - r0);
@@ -480,7 +773,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
   for (int l = 0; l < 3; ++l) { gs[l] = cur; cur += ROWS * ph[l]; }
   const int po = dib_small_pitch(a.out_dim);
   float* ps = cur; cur += ROWS * po;
-  float* xch = cur; cur += DIB_SMALL_XCH_FLOATS;
+  float* xch = cur; cur += CLUSTER ? DIB_SMALL_XCH_FLOATS_WIDE : DIB_SMALL_XCH_FLOATS;
   float* scratch = cur;   // head: [8][K + 1] + 16
   const bool stash = !(a.mode & DIB_SMALL_INT_INFER);
   const float slope = dib_neg_slope(a.act);
@@ -541,8 +834,24 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
       if (l < n) {
         const float* in = l == 0 ? us : hs[l > 0 ? l - 1 : 0];
         const int K = l == 0 ? a.K0 : a.width[l > 0 ? l - 1 : 0], pin = l == 0 ? pu : ph[l > 0 ? l - 1 : 0];
-        dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], slope, hs[l], ph[l],
-                      stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid, xch);
+        if constexpr (CLUSTER) {
+          float* const gx = (stash ? a.h[l] : a.xh[l]) + (long long)r0 * a.width[l];
+          int col0, ncols;
+          dib_small_cluster_slice(a.width[l], crank, cl, col0, ncols);
+#ifdef DIB_SMALL_TIMING_REPEAT   // diagnostic: the layer twice - the second pass runs warm code on warm weights
+          dib_small_fwd_cols(in, pin, K, a.params + a.w_off[l], a.width[l], col0, ncols, a.params + a.b_off[l], slope, hs[l], ph[l],
+                             gx, rows_valid, xch, -1);
+#endif
+          dib_small_fwd_cols(in, pin, K, a.params + a.w_off[l], a.width[l], col0, ncols, a.params + a.b_off[l], slope, hs[l], ph[l],
+                             gx, rows_valid, xch, l == 0 ? 6 : 45);
+          DIB_ST(30 + l);
+          dib_small_cluster_exchange(clw + l, cl);
+          dib_small_load_tile(gx, a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
+          __syncthreads();
+        } else {
+          dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], slope, hs[l], ph[l],
+                        stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid, xch);
+        }
         DIB_ST(18 + l);
       }
     }
@@ -555,8 +864,15 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
   }
 
   if (a.mode & DIB_SMALL_INT_OUT) {   // general output layer (reference models.py:83)
-    dib_small_fwd(hl, pl, KL, KL, a.params + wo_off, a.out_dim, a.params + bo_off, dib_neg_slope(a.out_act), nullptr, 0,
-                  a.pred + (long long)r0 * a.out_dim, a.out_dim, rows_valid, xch);
+    if constexpr (CLUSTER) {   // its columns go straight to pred: nothing to exchange
+      int col0, ncols;
+      dib_small_cluster_slice(a.out_dim, crank, cl, col0, ncols);
+      dib_small_fwd_cols(hl, pl, KL, a.params + wo_off, a.out_dim, col0, ncols, a.params + bo_off, dib_neg_slope(a.out_act), nullptr, 0,
+                         a.pred + (long long)r0 * a.out_dim, rows_valid, xch);
+    } else {
+      dib_small_fwd(hl, pl, KL, KL, a.params + wo_off, a.out_dim, a.params + bo_off, dib_neg_slope(a.out_act), nullptr, 0,
+                    a.pred + (long long)r0 * a.out_dim, a.out_dim, rows_valid, xch);
+    }
   }
 
   if (a.mode & DIB_SMALL_INT_HEAD) {
@@ -593,8 +909,10 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
       }
       gg *= a.inv_bg;
       if (lane == 0) {
-        a.pred[b] = z;
-        if (grad) a.g_pred[b] = gg;
+        if (lead) {
+          a.pred[b] = z;
+          if (grad) a.g_pred[b] = gg;
+        }
         lsum += l;
         correct += ((z > 0.5f ? 1.f : 0.f) == yy) ? 1.f : 0.f;
         pb += gg;
@@ -607,7 +925,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
           const float hv = hl[row * pl + k];
           const float gv = gg * wv[k] * dib_small_act_grad(slope, hv);
           gl[row * pl + k] = gv;
-          g_last[(long long)b * KL + k] = gv;
+          if (lead) g_last[(long long)b * KL + k] = gv;
           pw[c] += hv * gg;
         }
       }
@@ -624,7 +942,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
     }
     if (lane == 0) { redw[wave * (KL + 1) + KL] = pb; redl[2 * wave] = lsum; redl[2 * wave + 1] = correct; }
     __syncthreads();
-    if (grad) {
+    if (grad && lead) {
       float* dst = a.partial_w + (long long)tile * (KL + 1);
       for (int i = tid; i <= KL; i += DIB_SMALL_THREADS) {
         float t = 0.f;
@@ -633,7 +951,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
         dst[i] = t;
       }
     }
-    if (tid < 2) {
+    if (tid < 2 && lead) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += redl[2 * w + tid];
@@ -645,7 +963,16 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
   if (a.mode & DIB_SMALL_INT_BWD_OUT) {   // dL/dh_{n-1} from a given dL/dpred (custom loss: InfoNCE, train.py:216-219)
     dib_small_load_tile(a.g_pred + (long long)r0 * a.out_dim, a.out_dim, a.out_dim, rows_valid, ps, po);
     __syncthreads();
-    dib_small_bwd(ps, po, a.out_dim, a.params + wo_off, KL, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, KL, rows_valid, xch);
+    if constexpr (CLUSTER) {
+      int k0, kc;
+      dib_small_cluster_slice(KL, crank, cl, k0, kc);
+      dib_small_bwd_cols(ps, po, a.out_dim, a.params + wo_off, KL, k0, kc, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, rows_valid, xch);
+      dib_small_cluster_exchange(clw + 3, cl);
+      dib_small_load_tile(g_last + (long long)r0 * KL, KL, KL, rows_valid, gl, pl);
+      __syncthreads();
+    } else {
+      dib_small_bwd(ps, po, a.out_dim, a.params + wo_off, KL, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, KL, rows_valid, xch);
+    }
   }
 
   if (a.mode & DIB_SMALL_INT_BWD) {
@@ -653,17 +980,38 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
 #pragma unroll
     for (int l = 2; l >= 1; --l) {   // dL/dh_{l-1} = (dL/dh_l @ W_l^T) (.) act'(h_{l-1})
       if (l < n) {
-        dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], slope, gs[l - 1],
-                      ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid, xch);
+        if constexpr (CLUSTER) {
+          float* const gx = a.g[l - 1] + (long long)r0 * a.width[l - 1];
+          int k0, kc;
+          dib_small_cluster_slice(a.width[l - 1], crank, cl, k0, kc);
+          dib_small_bwd_cols(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], k0, kc, hs[l - 1], ph[l - 1], slope,
+                             gs[l - 1], ph[l - 1], gx, rows_valid, xch, 34);
+          DIB_ST(32 + l);
+          dib_small_cluster_exchange(clw + 3 + l, cl);
+          dib_small_load_tile(gx, a.width[l - 1], a.width[l - 1], rows_valid, gs[l - 1], ph[l - 1]);
+          __syncthreads();
+        } else {
+          dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], slope, gs[l - 1],
+                        ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid, xch);
+        }
         DIB_ST(24 + l);
       }
     }
     // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output; a plain MLP's input needs no gradient)
-    if (!(a.mode & DIB_SMALL_INT_NO_GU))
-      dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
-                    a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
+    if (!(a.mode & DIB_SMALL_INT_NO_GU)) {
+      if constexpr (CLUSTER) {
+        int k0, kc;
+        dib_small_cluster_slice(a.K0, crank, cl, k0, kc);
+        dib_small_bwd_cols(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, k0, kc, nullptr, 0, 1.f, nullptr, 0,
+                           a.GU + (long long)r0 * a.K0, rows_valid, xch, 51);
+      } else {
+        dib_small_bwd(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, nullptr, 0, 1.f, nullptr, 0,
+                      a.GU + (long long)r0 * a.K0, a.K0, rows_valid, xch);
+      }
+    }
     DIB_ST(28);
   }
+  if constexpr (CLUSTER) dib_small_cluster_leave(clw, cl);
 
   if (a.mode & DIB_SMALL_INT_HEAD_REDUCE) {   // block-uniform
     // the per-tile partials of the output layer's gradient and of the loss sums, summed in tile order by the last workgroup
@@ -695,7 +1043,18 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
 }
 
 __global__ void __launch_bounds__(DIB_SMALL_THREADS)
-dib_small_integration_kernel(DibSmallIntArgs a) { dib_small_integration_body(a, blockIdx.x); }
+dib_small_integration_kernel(DibSmallIntArgs a) { dib_small_integration_body<false>(a, blockIdx.x); }
+
+// cluster mode: grid = 8 ceil(tiles / 8) x cl workgroups; id -> (tile, rank) keeps a tile's workgroups on ONE XCD under the
+// round-robin placement (XCD = id mod 8): tile = 8 (id / (8 cl)) + id mod 8, rank = (id / 8) mod cl - their exchange then stays
+// in that XCD's L2.  (Placement is a performance matter only: the exchange is agent-scope.)
+__global__ void __launch_bounds__(DIB_SMALL_THREADS)
+dib_small_integration_cluster_kernel(DibSmallIntArgs a) {
+  const int id = blockIdx.x, cl = a.cl;
+  const int tile = 8 * (id / (8 * cl)) + (id & 7), crank = (id >> 3) % cl;
+  if (tile * DIB_SMALL_ROWS >= a.batch) return;
+  dib_small_integration_body<true>(a, tile, crank);
+}
 
 // Two independent networks in ONE grid (blockIdx.y picks the argument set): the custom InfoNCE loop's X model and its output
 // encoder between the encoder bank and the loss (train.py:203-219) - each is 8 workgroups at the reference's batch of 128, and
@@ -705,7 +1064,7 @@ __global__ void __launch_bounds__(DIB_SMALL_THREADS)
 dib_small_integration_pair_kernel(DibSmallIntPair p) {
   const DibSmallIntArgs& a = p.s[blockIdx.y];
   if ((int)blockIdx.x * DIB_SMALL_ROWS >= a.batch) return;   // the two batches may differ
-  dib_small_integration_body(a, blockIdx.x);
+  dib_small_integration_body<false>(a, blockIdx.x);
 }
 
 // =====================================================================================================================

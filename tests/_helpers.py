@@ -105,7 +105,9 @@ FUSED_ELIGIBLE = ("boolean4_32x32", "pendulum_ragged", "tabular8_default", "fuse
 #                  otherwise the fused encoder-bank kernels where the architecture has an instantiation, otherwise grouped GEMMs
 #   "large_batch"  dib_set_tuning("small_batch", 0): the large-batch kernels at every batch size
 #   "grouped_gemm" ... and dib_set_tuning("fused_encoder", 0) for layouts created inside: the general grouped-GEMM path
-DISPATCH_PATHS = ("default", "large_batch", "grouped_gemm")
+#   "one_wg_tiles" dib_set_tuning("int_cluster", 0): the row-tile integration kernel with ONE workgroup per row tile at every batch
+#                  size ("default" puts each of <= 32 row tiles on a cluster of 4 workgroups, csrc/dib_small.h "cluster mode")
+DISPATCH_PATHS = ("default", "large_batch", "grouped_gemm", "one_wg_tiles")
 
 
 @contextlib.contextmanager
@@ -113,9 +115,11 @@ def dispatch_path(path):
     """Engines must be CREATED inside the context ("fused_encoder" is read by dib_layout_create)."""
     from dib_amd import _lib
     assert path in DISPATCH_PATHS, path
-    old = {k: _lib.get_tuning(k) for k in ("small_batch", "fused_encoder")}
+    old = {k: _lib.get_tuning(k) for k in ("small_batch", "fused_encoder", "int_cluster")}
     try:
-        if path != "default":
+        if path == "one_wg_tiles":
+            _lib.set_tuning("int_cluster", 0)
+        elif path != "default":
             _lib.set_tuning("small_batch", 0)
         if path == "grouped_gemm":
             _lib.set_tuning("fused_encoder", 0)

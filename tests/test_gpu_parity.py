@@ -173,6 +173,8 @@ def test_forward_backward_parity(name, B, path):
     run the persistent fused kernels over several 256-row tiles per workgroup on the default path too."""
     if B == 2100 and (name not in FUSED_ELIGIBLE or path == "large_batch"):
         pytest.skip("B = 2100 is the large-batch case of the fused-eligible entries (default == large_batch there)")
+    if path == "one_wg_tiles" and B not in (37, 300):
+        pytest.skip("one workgroup per row tile differs from the default only where the default clusters: 37 and 300 rows are in")
     with dispatch_path(path):
         _forward_backward_parity(name, B)
 
@@ -957,6 +959,8 @@ def _random_spec(rng, row_tiles=False):
 @pytest.mark.parametrize("path", DISPATCH_PATHS)
 @pytest.mark.parametrize("case", range(20))
 def test_random_architectures_forward_backward(case, path):
+    if path == "one_wg_tiles" and case < 12:
+        pytest.skip("cases 12+ are the ones inside the row-tile kernels' coverage")
     with dispatch_path(path):
         _random_architecture(case)
 
@@ -1281,6 +1285,115 @@ def test_small_batch_row_tile_kernels_equal_the_large_batch_path(arch, linear, B
                 bad[k] = ("norm", rel)
     assert not bad, bad
     assert torch.isfinite(s["grads"]).all()
+
+
+@pytest.mark.parametrize("B", [1, 37, 128, 300, 512])
+@pytest.mark.parametrize("cl", [2, 4, 8])
+@pytest.mark.parametrize("arch", sorted(_SMALL_ARCHS))
+def test_integration_cluster_equals_one_workgroup_per_tile(arch, cl, B):
+    """csrc/dib_small.h cluster mode (dib_set_tuning("int_cluster", cl): every row tile of the integration network on cl workgroups,
+    each a column slice of every layer, slices exchanged through L2 behind per-(tile, layer) arrival counters) against the
+    one-workgroup-per-tile kernel on the SAME engine: training step (forward + 1-unit head + dgrad chain, or the general output
+    layer), validation step (no stashes: the exchange buffers) and the custom-loss contract (the backward launched on its own from
+    the stashes).  A slice's columns are contracted by one workgroup but in its own batch order: fp32 summation-order tolerance for
+    the forward quantities; gradients in norm (a unit within rounding of a kink may take the other branch of act').  Slices of
+    widths with fewer 16-column tiles than workgroups are empty ("narrow": 48 and 32 wide on 4 and 8 workgroups).  Each mode twice
+    in a row: the same bits (the counters clean themselves, every sum has a fixed order)."""
+    from dib_amd import _lib
+    from dib_amd.engine import HipEngine
+    spec, kind = _SMALL_ARCHS[arch]
+    rng = np.random.default_rng(B + 7 * cl)
+    nin = sum(spec.feature_dimensionalities)
+    x = rng.standard_normal((B + 3, nin)).astype(np.float32)
+    y = rng.standard_normal((B + 3, spec.output_dimensionality)).astype(np.float32)
+    if kind == "bce_logits":
+        y = (y > 0).astype(np.float32)
+    eng = HipEngine(**spec_kwargs(spec), init_seed=13)
+    eng.set_beta(0.07)
+    xd, yd = eng.to_device(x), eng.to_device(y)
+    idx = eng.to_device(rng.permutation(B + 3)[:B].astype(np.int32), dtype=torch.int32)
+    old = {k: _lib.get_tuning(k) for k in ("int_cluster", "int_cluster_wgs")}
+
+    def run():
+        eng.metrics_acc.zero_()
+        eng.train_step(xd, yd, idx, 0, B, 5, 9, kind)
+        rec = dict(grads=eng.grads.clone(), step_out=eng.step_out(B).clone(), pred=eng.pred(B).clone(), g_u=eng.g_u(B).clone(),
+                   int_h0=eng.int_h(B, 0).clone())
+        eng.eval_step(xd, yd, None, 2, B, 5, 77, kind)
+        rec.update(val_step_out=eng.step_out(B).clone(), val_pred=eng.pred(B).clone())
+        eng.forward(xd, idx, 0, B, 5, 10)
+        gp = torch.sin(torch.arange(B * spec.output_dimensionality, device=eng.device, dtype=torch.float32)).view(B, -1) / B
+        eng.backward_from_pred_grad(gp, idx, 0, B, 5, 10)
+        rec.update(custom_pred=eng.pred(B).clone(), custom_grads=eng.grads.clone(), custom_g_u=eng.g_u(B).clone())
+        torch.cuda.synchronize()
+        return rec
+
+    try:
+        _lib.set_tuning("int_cluster_wgs", 256)
+        outs = []
+        for mode in (cl, 0):
+            _lib.set_tuning("int_cluster", mode)
+            a, b = run(), run()
+            for k in a:
+                assert torch.equal(a[k], b[k]), (mode, k)
+            outs.append(a)
+    finally:
+        for k, v in old.items():
+            _lib.set_tuning(k, v)
+    c, o = outs
+    bad = {}
+    for k in c:
+        a, ref = c[k].double(), o[k].double()
+        scale = 1e-6 + ref.abs().max().item()
+        if "grads" in k or "g_u" in k:
+            rel = ((a - ref).norm() / (ref.norm() + 1e-30)).item()
+            if rel > 5e-3:
+                bad[k] = ("norm", rel)
+        elif (a - ref).abs().max().item() > 3e-5 * scale + 1e-6:   # (+ 1e-6: a prediction that is itself a cancelling sum, B = 1)
+            bad[k] = ((a - ref).abs().max().item(), scale)
+    assert not bad, bad
+    assert torch.isfinite(c["grads"]).all()
+
+
+@pytest.mark.parametrize("B", [512, 1024, 2048])
+def test_alternating_entry_points_leave_no_stale_gradient_slabs(B):
+    """A workspace holds `nsplit` partial slabs per parameter block and the reducers sum all of them; a weight-gradient launch that
+    picks FEWER splits than an earlier launch over the same block (the split rule prices whole launches: at B = 512 the row-tile
+    regime's one grouped launch picks 3 slabs, the per-layer launches behind dib_backward's custom-loss entry of a 1-unit output
+    pick 4) must not leave that launch's upper slabs in the sum (csrc/dib_api.hip retire_stale_slabs; found in round 6: a training step
+    after a custom-loss step differed by 6e-3 in every GEMM-made gradient block).  Training step / custom-loss step / training
+    step / custom-loss step on one engine = the bits of each on a fresh engine."""
+    from dib_amd.engine import HipEngine
+    spec = orc.DIBSpec([1] * 10, [128, 128], [256, 256], 1, feature_embedding_dimension=32)
+    rng = np.random.default_rng(B)
+    x = rng.standard_normal((B, 10)).astype(np.float32)
+    y = (rng.random((B, 1)) > 0.5).astype(np.float32)
+
+    def make():
+        eng = HipEngine(**spec_kwargs(spec), init_seed=13)
+        eng.set_beta(0.07)
+        return eng
+
+    e = make()
+    xd, yd = e.to_device(x), e.to_device(y)
+
+    def train(eng):
+        eng.train_step(xd, yd, None, 0, B, 5, 9, "bce_logits")
+        torch.cuda.synchronize()
+        return eng.grads.clone()
+
+    def custom(eng):
+        eng.forward(xd, None, 0, B, 5, 10)
+        gp = torch.sin(torch.arange(B, device=eng.device, dtype=torch.float32)).view(B, 1) / B
+        eng.backward_from_pred_grad(gp, None, 0, B, 5, 10)
+        torch.cuda.synchronize()
+        return eng.grads.clone()
+
+    ref_t, ref_c = train(make()), custom(make())
+    for i in range(2):
+        assert torch.equal(train(e), ref_t), ("training step", i)
+        assert torch.equal(custom(e), ref_c), ("custom-loss step", i)
+    assert torch.equal(train(e), ref_t)
 
 
 @pytest.mark.parametrize("B", [128, 2048 + 77, 16384])

@@ -13,8 +13,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    from dib_amd import _lib
     from dib_amd.engine import HipEngine
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    nums = [a for a in sys.argv[1:] if a.isdigit()]
+    B = int(nums[0]) if nums else 128
+    for kv in [a for a in sys.argv[1:] if "=" in a]:   # dib_set_tuning keys, e.g. int_cluster=0
+        k, v = kv.split("=")
+        _lib.set_tuning(k, int(v))
     eng = HipEngine([1] * 10, [128, 128], [256, 256], 1, feature_embedding_dimension=32)
     rng = np.random.default_rng(0)
     x = eng.to_device(rng.standard_normal((B, 10)).astype(np.float32))
@@ -33,6 +38,13 @@ def main():
     print("training step, encoder forward (us):", {n: round(t[i + 1] - t[i], 2) for i, n in enumerate(names1) if i + 1 <= 5 and i != 1}, "total", round(t[5] - t[0], 2))
     print("training step, integration kernel (us): load u %.2f | fwd L1 %.2f | fwd L2 %.2f | head %.2f | dgrad L2 %.2f | dgrad -> g_u %.2f | total %.2f" % (
         t[17] - t[16], t[18] - t[17], t[19] - t[18], t[22] - t[19], t[25] - t[23], t[28] - t[25], t[28] - t[16]))
+    if t[30] > t[17]:   # cluster mode: [slice computed | exchange + reload] per layer
+        print("  cluster mode: fwd L1 %.2f + %.2f | fwd L2 %.2f + %.2f | dgrad L2 %.2f + %.2f" % (
+            t[30] - t[17], t[18] - t[30], t[31] - t[18], t[19] - t[31], t[33] - t[23], t[25] - t[33]))
+    if t[30] > t[17]:
+        for nm, b in (("fwd L1", 6), ("fwd L2", 45), ("dgrad L2", 34), ("dgrad g_u", 51)):
+            print("    inside %s (wave 0): issue %.2f | loads + MFMAs %.2f | partials + barrier %.2f | reduce + epilogue %.2f | barrier %.2f" % (
+                nm, t[b + 1] - t[b], t[b + 2] - t[b + 1], t[b + 3] - t[b + 2], t[b + 4] - t[b + 3], t[b + 5] - t[b + 4]))
     print("training step, encoder backward (us): loads + d(mu|logvar) %.2f | dgrad L3 %.2f | dgrad L2 %.2f | dW1 partial %.2f | total %.2f" % (
         t[41] - t[40], t[42] - t[41], t[43] - t[42], t[44] - t[43], t[44] - t[40]))
     print("gaps (us): enc fwd end -> integration start %.2f ; integration end -> enc bwd start %.2f" % (t[16] - t[5], t[40] - t[28]))
