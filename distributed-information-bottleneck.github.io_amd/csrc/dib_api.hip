@@ -233,8 +233,9 @@ struct Tuning {
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
   int int_cluster = 4;       // row-tile integration kernel: workgroups per row tile (each a column slice of every layer, exchange
-                             // through L2: dib_small.h "cluster mode") while tiles x this <= int_cluster_wgs; <= 1: one per tile
-  int int_cluster_wgs = 128; // ...
+                             // through L2: dib_small.h "cluster mode"; <= 1: one per tile) while row tiles x this <= ...
+  int int_cluster_wgs = 32;  // ... this (measured: pays up to 8 row tiles, profiles/r06s_int_cluster_sweep.txt) and the first layer
+  int int_cluster_min_weights = 65536;  // ... has at least this many weights (10 features x 32 -> 256: 81 920; 4 features: 32 768, no gain)
   int wgrad_max_splits = 32; // most batch slabs of a layout's weight gradients (<= 32; read when a workspace is sized: set it first)
   int num_cus = 0;           // compute units the split rule prices rounds with; 0 = the current device's own count (device_cus)
 };
@@ -686,7 +687,8 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
   // cluster mode: few row tiles, each on `cl` workgroups (not for a launch that carries a companion network)
   const int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
   const size_t cl_lds = (size_t)l->sb_int_lds + (size_t)(DIB_SMALL_XCH_FLOATS_WIDE - DIB_SMALL_XCH_FLOATS) * sizeof(float);
-  if (!t_companion.armed && cl > 1 && small_tiles(batch) * cl <= knobs().int_cluster_wgs && cl_lds <= 160 * 1024) {
+  if (!t_companion.armed && cl > 1 && small_tiles(batch) * cl <= knobs().int_cluster_wgs && cl_lds <= 160 * 1024 &&
+      (long long)a.K0 * a.width[0] >= knobs().int_cluster_min_weights) {
     a.cl = cl; a.cl_sync = (unsigned*)(w + m.cl_sync);
     for (int i = 0; i < l->n_int; ++i) a.xh[i] = w + m.cl_x[i];
     static int cl_lds_have[64] = {};
@@ -1555,6 +1557,7 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
   if (!std::strcmp(key, "int_cluster")) return &t.int_cluster;
   if (!std::strcmp(key, "int_cluster_wgs")) return &t.int_cluster_wgs;
+  if (!std::strcmp(key, "int_cluster_min_weights")) return &t.int_cluster_min_weights;
   return nullptr;
 }
 

@@ -355,23 +355,16 @@ __device__ __forceinline__ void dib_small_fwd_wide(const float* in, int pin, int
           dib_small_loadw<NT>(wp + (long long)kc * ldw, bw[u]);
         }
       };
-      load(4 * UB * kh, acur, bcur);
-      DIB_STD(1);
+      // (no register double buffer: a share is ONE batch wherever the caller could size it so - a second batch pays its round trip)
       for (int s0 = 4 * UB * kh; s0 < K; s0 += 4 * UB * kways) {
-        float anxt[UB], bnxt[UB][NT];
-        if (s0 + 4 * UB * kways < K) load(s0 + 4 * UB * kways, anxt, bnxt);   // wave-uniform: usually a share IS one batch
+        load(s0, acur, bcur);
+        DIB_STD(1);
 #pragma unroll
         for (int u = 0; u < UB; ++u)
           if (s0 + 4 * u < K) {   // wave-uniform
 #pragma unroll
             for (int c = 0; c < NT; ++c) acc[c] = DIB_MFMA16(acur[u], bcur[u][c], acc[c]);
           }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          acur[u] = anxt[u];
-#pragma unroll
-          for (int c = 0; c < NT; ++c) bcur[u][c] = bnxt[u][c];
-        }
       }
     }
     DIB_STD(2);
@@ -457,11 +450,9 @@ __device__ __forceinline__ void dib_small_bwd_wide(const float* g, int pg, int N
         for (int t = 0; t < NT; ++t) bw[u][t] = *reinterpret_cast<const float4*>(wp + (long long)(16 * t) * N + Sc);
       }
     };
-    load(16 * UB * kh, acur, bcur);
-    DIB_STD(1);
-    for (int S0 = 16 * UB * kh; S0 < N; S0 += 16 * UB * kways) {
-      float4 anxt[UB], bnxt[UB][NT];
-      if (S0 + 16 * UB * kways < N) load(S0 + 16 * UB * kways, anxt, bnxt);   // wave-uniform
+    for (int S0 = 16 * UB * kh; S0 < N; S0 += 16 * UB * kways) {   // (no double buffer: see dib_small_fwd_wide)
+      load(S0, acur, bcur);
+      DIB_STD(1);
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         if (S0 + 16 * u >= N) break;   // wave-uniform
@@ -473,12 +464,6 @@ __device__ __forceinline__ void dib_small_bwd_wide(const float* g, int pg, int N
         for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].z, bcur[u][t].z, acc[t]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = DIB_MFMA16(acur[u].w, bcur[u][t].w, acc[t]);
-      }
-#pragma unroll
-      for (int u = 0; u < UB; ++u) {
-        acur[u] = anxt[u];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bcur[u][t] = bnxt[u][t];
       }
     }
     DIB_STD(2);
@@ -720,16 +705,24 @@ __device__ __forceinline__ void dib_small_cluster_exchange(unsigned* counter, in
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (threadIdx.x == 0) {
+#ifndef DIB_CL_NOFENCE   // (diagnostic: what the agent-scope write-back / invalidate cost when the cluster shares an XCD's L2)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl) {
+#ifndef DIB_CL_NOSLEEP
       __builtin_amdgcn_s_sleep(1);
+#endif
       if (wall_clock64() - t0 > 200000000ll) __builtin_trap();   // 2 s at 100 MHz: never a hang
     }
   }
   __syncthreads();
+#ifndef DIB_CL_NOFENCE
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
 }
 
 // the last of the tile's workgroups to leave zeroes the tile's counters for the next launch

@@ -105,9 +105,10 @@ FUSED_ELIGIBLE = ("boolean4_32x32", "pendulum_ragged", "tabular8_default", "fuse
 #                  otherwise the fused encoder-bank kernels where the architecture has an instantiation, otherwise grouped GEMMs
 #   "large_batch"  dib_set_tuning("small_batch", 0): the large-batch kernels at every batch size
 #   "grouped_gemm" ... and dib_set_tuning("fused_encoder", 0) for layouts created inside: the general grouped-GEMM path
-#   "one_wg_tiles" dib_set_tuning("int_cluster", 0): the row-tile integration kernel with ONE workgroup per row tile at every batch
-#                  size ("default" puts each of <= 32 row tiles on a cluster of 4 workgroups, csrc/dib_small.h "cluster mode")
-DISPATCH_PATHS = ("default", "large_batch", "grouped_gemm", "one_wg_tiles")
+#   "cluster_tiles" the row-tile integration kernel with every row tile on a cluster of 4 workgroups (csrc/dib_small.h "cluster
+#                  mode") wherever the row-tile regime holds: dib_set_tuning("int_cluster_wgs", 256), ("int_cluster_min_weights", 0) -
+#                  "default" clusters only up to 8 row tiles of a network whose first layer has >= 65 536 weights
+DISPATCH_PATHS = ("default", "large_batch", "grouped_gemm", "cluster_tiles")
 
 
 @contextlib.contextmanager
@@ -115,10 +116,11 @@ def dispatch_path(path):
     """Engines must be CREATED inside the context ("fused_encoder" is read by dib_layout_create)."""
     from dib_amd import _lib
     assert path in DISPATCH_PATHS, path
-    old = {k: _lib.get_tuning(k) for k in ("small_batch", "fused_encoder", "int_cluster")}
+    old = {k: _lib.get_tuning(k) for k in ("small_batch", "fused_encoder", "int_cluster_wgs", "int_cluster_min_weights")}
     try:
-        if path == "one_wg_tiles":
-            _lib.set_tuning("int_cluster", 0)
+        if path == "cluster_tiles":
+            _lib.set_tuning("int_cluster_wgs", 256)
+            _lib.set_tuning("int_cluster_min_weights", 0)
         elif path != "default":
             _lib.set_tuning("small_batch", 0)
         if path == "grouped_gemm":

@@ -173,8 +173,8 @@ def test_forward_backward_parity(name, B, path):
     run the persistent fused kernels over several 256-row tiles per workgroup on the default path too."""
     if B == 2100 and (name not in FUSED_ELIGIBLE or path == "large_batch"):
         pytest.skip("B = 2100 is the large-batch case of the fused-eligible entries (default == large_batch there)")
-    if path == "one_wg_tiles" and B not in (37, 300):
-        pytest.skip("one workgroup per row tile differs from the default only where the default clusters: 37 and 300 rows are in")
+    if path == "cluster_tiles" and B not in (37, 300):
+        pytest.skip("the cluster mode of the row-tile integration kernel: 3 and 19 row tiles on 4 workgroups each")
     with dispatch_path(path):
         _forward_backward_parity(name, B)
 
@@ -959,7 +959,7 @@ def _random_spec(rng, row_tiles=False):
 @pytest.mark.parametrize("path", DISPATCH_PATHS)
 @pytest.mark.parametrize("case", range(20))
 def test_random_architectures_forward_backward(case, path):
-    if path == "one_wg_tiles" and case < 12:
+    if path == "cluster_tiles" and case < 12:
         pytest.skip("cases 12+ are the ones inside the row-tile kernels' coverage")
     with dispatch_path(path):
         _random_architecture(case)
@@ -1183,7 +1183,8 @@ def test_tuning_switchboard_is_the_only_hidden_input():
     from dib_amd.engine import HipEngine
     lib = _lib.load_library()
     for key in ("fwd_small_wgs", "fwd_narrow_wgs", "stream_rows", "split_policy", "split_overhead", "fused_encoder", "fused_head",
-                "small_batch", "small_wgs", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "wgrad_flat_tile", "wgrad_max_splits", "num_cus"):
+                "small_batch", "small_wgs", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "wgrad_flat_tile", "wgrad_max_splits", "num_cus",
+                "int_cluster", "int_cluster_wgs", "int_cluster_min_weights"):
         v = _lib.get_tuning(key)
         _lib.set_tuning(key, v + 1)
         assert _lib.get_tuning(key) == v + 1
@@ -1312,7 +1313,7 @@ def test_integration_cluster_equals_one_workgroup_per_tile(arch, cl, B):
     eng.set_beta(0.07)
     xd, yd = eng.to_device(x), eng.to_device(y)
     idx = eng.to_device(rng.permutation(B + 3)[:B].astype(np.int32), dtype=torch.int32)
-    old = {k: _lib.get_tuning(k) for k in ("int_cluster", "int_cluster_wgs")}
+    old = {k: _lib.get_tuning(k) for k in ("int_cluster", "int_cluster_wgs", "int_cluster_min_weights")}
 
     def run():
         eng.metrics_acc.zero_()
@@ -1330,6 +1331,7 @@ def test_integration_cluster_equals_one_workgroup_per_tile(arch, cl, B):
 
     try:
         _lib.set_tuning("int_cluster_wgs", 256)
+        _lib.set_tuning("int_cluster_min_weights", 0)
         outs = []
         for mode in (cl, 0):
             _lib.set_tuning("int_cluster", mode)

@@ -133,3 +133,7 @@ def test_round6_kernels_keep_their_budgets(kernels):
     assert flat["ScratchSize"] == 0 and flat["Occupancy"] >= 2 and flat["LDSByteSize"] <= 40 * 1024 and flat["mfma"] == 32
     single = _one(kernels, "dib_small_integration_kernel")
     assert single["ScratchSize"] == 0 and single["NumVgprs"] <= 256       # + the head-step reduce (dib_mlp_small_head_step)
+    # cluster mode: the slice primitives keep a share's whole batch of weight loads in registers (16 float4 a lane at most) - no
+    # scratch, two waves per SIMD
+    cluster = _one(kernels, "dib_small_integration_cluster_kernel")
+    assert cluster["ScratchSize"] == 0 and cluster["NumVgprs"] + cluster["NumAgprs"] <= 256
