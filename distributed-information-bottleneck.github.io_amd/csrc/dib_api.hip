@@ -152,7 +152,7 @@ struct dib_layout {
     // cluster mode of the row-tile integration kernel: arrival counters per row tile (zeroed by dib_workspace_init, self-cleaning)
     // and the hidden activations' exchange buffers of launches that write no stashes
     const bool cl_ok = sb_int && B <= kSmallMaxBatch;
-    m.cl_sync = take(cl_ok ? (int64_t)cdiv(B, DIB_SMALL_ROWS) * DIB_SMALL_CL_SYNC_WORDS : 0);
+    m.cl_sync = take(cl_ok ? 2ll * cdiv(B, DIB_SMALL_ROWS) * DIB_SMALL_CL_SYNC_WORDS : 0);   // x 2: a companion network's (paired grid)
     for (int l = 0; l < n_int; ++l) m.cl_x.push_back(take(cl_ok ? (int64_t)B * int_units[l] : 0));
     m.total = o;
     return m;
@@ -232,10 +232,11 @@ struct Tuning {
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
-  int int_cluster = 4;       // row-tile integration kernel: workgroups per row tile (each a column slice of every layer, exchange
+  int int_cluster = 8;       // row-tile integration kernel: workgroups per row tile (each a column slice of every layer, exchange
                              // through L2: dib_small.h "cluster mode"; <= 1: one per tile) while row tiles x this <= ...
-  int int_cluster_wgs = 32;  // ... this (measured: pays up to 8 row tiles, profiles/r06s_int_cluster_sweep.txt) and the first layer
-  int int_cluster_min_weights = 65536;  // ... has at least this many weights (10 features x 32 -> 256: 81 920; 4 features: 32 768, no gain)
+  int int_cluster_wgs = 256; // ... this (one workgroup per CU; measured up to 32 row tiles, profiles/r06q_int_cluster_sweep.txt) and
+  int int_cluster_min_weights = 65536;  // ... the network's hidden layers have at least this many weights (measured down to 4
+                             // features x 32 -> 256 -> 256: 98 304)
   int wgrad_max_splits = 32; // most batch slabs of a layout's weight gradients (<= 32; read when a workspace is sized: set it first)
   int num_cus = 0;           // compute units the split rule prices rounds with; 0 = the current device's own count (device_cus)
 };
@@ -669,6 +670,19 @@ static bool use_merged_wgrad(const dib_layout* l, int batch) {
 struct SmallCompanion { DibSmallIntArgs args; size_t lds = 0; bool armed = false; };
 static thread_local SmallCompanion t_companion;
 
+// workgroups per row tile of a row-tile network launch (dib_small.h "cluster mode"; 1 = the single-workgroup kernel): "int_cluster"
+// while the launch stays within "int_cluster_wgs" workgroups, the network's hidden layers hold at least "int_cluster_min_weights"
+// weights (below that a layer is a few microseconds on one CU and the exchanges cost more than they save) and the wider exchange
+// buffer fits the LDS
+static int small_cluster_size(const DibSmallIntArgs& a, size_t lds_bytes) {
+  const int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
+  if (cl <= 1 || small_tiles(a.batch) * cl > knobs().int_cluster_wgs || lds_bytes > 160 * 1024) return 1;
+  if (a.mode & (DIB_SMALL_INT_HEAD_REDUCE)) return 1;   // (its last-arriver reduce counts workgroups, not tiles)
+  long long weights = 0;
+  for (int i = 0, k = a.K0; i < a.n_hidden; k = a.width[i], ++i) weights += (long long)k * a.width[i];
+  return weights >= knobs().int_cluster_min_weights ? cl : 1;
+}
+
 // one launch of dib_small_integration_kernel; `mode` = DIB_SMALL_INT_* bits.  Head arguments may be null / 0 without a head.
 static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w, int batch, const float* params, int mode,
                              int loss_kind, const float* y, int64_t ldy, const int32_t* row_idx, int64_t row0, float inv_bg,
@@ -684,29 +698,45 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.pred = w + m.pred; a.g_pred = w + m.g_pred;
   a.loss_kind = loss_kind; a.Y = y; a.ldy = ldy; a.row_idx = (const int*)row_idx; a.row0 = row0; a.inv_bg = inv_bg;
   a.partial_w = w + m.skinny_partial; a.partial_l = w + m.loss_partial;
-  // cluster mode: few row tiles, each on `cl` workgroups (not for a launch that carries a companion network)
-  const int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
-  const size_t cl_lds = (size_t)l->sb_int_lds + (size_t)(DIB_SMALL_XCH_FLOATS_WIDE - DIB_SMALL_XCH_FLOATS) * sizeof(float);
-  if (!t_companion.armed && cl > 1 && small_tiles(batch) * cl <= knobs().int_cluster_wgs && cl_lds <= 160 * 1024 &&
-      (long long)a.K0 * a.width[0] >= knobs().int_cluster_min_weights) {
-    a.cl = cl; a.cl_sync = (unsigned*)(w + m.cl_sync);
-    for (int i = 0; i < l->n_int; ++i) a.xh[i] = w + m.cl_x[i];
-    static int cl_lds_have[64] = {};
-    if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_cluster_kernel, cl_lds, cl_lds_have)) return rc;
-    ProfScope ps(kProfOther, st);
-    DIB_LAUNCH(dib_small_integration_cluster_kernel, dim3(8 * cdiv(small_tiles(batch), 8) * cl), dim3(DIB_SMALL_THREADS), cl_lds, st, a);
-    return (int)hipGetLastError();
-  }
+  // cluster mode: few row tiles, each on `cl` workgroups (dib_small.h)
+  const size_t cl_extra = (size_t)(DIB_SMALL_XCH_FLOATS_WIDE - DIB_SMALL_XCH_FLOATS) * sizeof(float);
+  const int cl = small_cluster_size(a, (size_t)l->sb_int_lds + cl_extra);
   if (t_companion.armed) {
     t_companion.armed = false;
     DibSmallIntPair p;
     p.s[0] = a; p.s[1] = t_companion.args;
+    // the companion clusters by the same rule on its own size (training launches only: it has no exchange buffers for a launch
+    // without stashes); its arrival counters are the second half of this workspace's
+    DibSmallIntArgs& c = p.s[1];
+    int ccl = (c.mode & DIB_SMALL_INT_INFER) || small_tiles(c.batch) > small_tiles(batch) ? 1 : small_cluster_size(c, t_companion.lds + cl_extra);
+    if (cl > 1 || ccl > 1) {
+      p.s[0].cl = cl; p.s[0].cl_sync = (unsigned*)(w + m.cl_sync);
+      for (int i = 0; i < l->n_int; ++i) p.s[0].xh[i] = w + m.cl_x[i];
+      c.cl = ccl; c.cl_sync = (unsigned*)(w + m.cl_sync) + (size_t)small_tiles(batch) * DIB_SMALL_CL_SYNC_WORDS;
+      const size_t lds = std::max((size_t)l->sb_int_lds, t_companion.lds) + cl_extra;
+      static int pc_lds_have[64] = {};
+      if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_pair_cluster_kernel, lds, pc_lds_have)) return rc;
+      ProfScope ps(kProfOther, st);
+      const int gx = std::max(8 * cdiv(small_tiles(batch), 8) * cl, 8 * cdiv(small_tiles(c.batch), 8) * ccl);
+      DIB_LAUNCH(dib_small_integration_pair_cluster_kernel, dim3(gx, 2), dim3(DIB_SMALL_THREADS), lds, st, p);
+      return (int)hipGetLastError();
+    }
     const size_t lds = std::max((size_t)l->sb_int_lds, t_companion.lds);
     static int pair_lds_have[64] = {};
     if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_pair_kernel, lds, pair_lds_have)) return rc;
     ProfScope ps(kProfOther, st);
     DIB_LAUNCH(dib_small_integration_pair_kernel, dim3(std::max(small_tiles(batch), small_tiles(p.s[1].batch)), 2),
                dim3(DIB_SMALL_THREADS), lds, st, p);
+    return (int)hipGetLastError();
+  }
+  if (cl > 1) {
+    a.cl = cl; a.cl_sync = (unsigned*)(w + m.cl_sync);
+    for (int i = 0; i < l->n_int; ++i) a.xh[i] = w + m.cl_x[i];
+    const size_t cl_lds = (size_t)l->sb_int_lds + cl_extra;
+    static int cl_lds_have[64] = {};
+    if (int rc = ensure_dynamic_lds((const void*)dib_small_integration_cluster_kernel, cl_lds, cl_lds_have)) return rc;
+    ProfScope ps(kProfOther, st);
+    DIB_LAUNCH(dib_small_integration_cluster_kernel, dim3(8 * cdiv(small_tiles(batch), 8) * cl), dim3(DIB_SMALL_THREADS), cl_lds, st, a);
     return (int)hipGetLastError();
   }
   static int lds_have[64] = {};
@@ -970,7 +1000,7 @@ int dib_workspace_init(const dib_layout* l, int batch, void* ws, dib_stream_t st
   hipError_t e0 = hipMemsetAsync((float*)ws + m.sync, 0, (size_t)DIB_TAIL_SYNC_WORDS * sizeof(unsigned), (hipStream_t)stream);
   if (e0 != hipSuccess) return (int)e0;
   if (l->sb_int && batch <= kSmallMaxBatch) {   // ... and of the integration kernel's cluster mode
-    e0 = hipMemsetAsync((float*)ws + m.cl_sync, 0, (size_t)cdiv(batch, DIB_SMALL_ROWS) * DIB_SMALL_CL_SYNC_WORDS * sizeof(unsigned),
+    e0 = hipMemsetAsync((float*)ws + m.cl_sync, 0, 2 * (size_t)cdiv(batch, DIB_SMALL_ROWS) * DIB_SMALL_CL_SYNC_WORDS * sizeof(unsigned),
                         (hipStream_t)stream);
     if (e0 != hipSuccess) return (int)e0;
   }

@@ -689,40 +689,63 @@ struct DibSmallIntArgs {
 // sections 13, 19: 8 - 12 us per layer).  In cluster mode workgroup c of a tile's cl computes output columns [slice c) of every
 // layer - 1 / cl of the weights and of the MFMAs - writes them to the layer's global buffer (the stash the weight gradients
 // read anyway, or xh when inferring) and the cl workgroups exchange slices through L2: one arrival counter per (tile, layer),
-// release / acquire at agent scope.  Every sum keeps its order (a column's contraction is computed by one workgroup exactly as the
-// single-workgroup kernel computes it): the results are the bits of dib_small_integration_kernel.
+// release / acquire at agent scope (relaxed to the XCD's own L2 once the cluster is known to share one: dib_small_cluster_exchange).
+// Every sum has a fixed order - replays give the same bits - but not the single-workgroup kernel's order (a slice's contraction is
+// split over up to 8 waves): the two differ by fp32 rounding.
 // Progress: a workgroup waits only for the cl - 1 others of its own tile, whose ids are consecutive multiples of 8 apart inside one
 // block of 8 cl ids; the launch has <= 256 workgroups of one per CU, so every workgroup is resident once the kernels ahead of it on
 // other streams drain.  The wait is bounded all the same: after ~2 s of wall clock the kernel traps (the process sees a HIP error
 // at its next synchronisation) instead of hanging the device.
-#define DIB_SMALL_CL_SYNC_WORDS 32   // per tile: [0, 7) arrival counters (fwd layer l: l; output-layer dgrad: 3; dgrad into h_{l-1}: 3 + l), [7] departures
+#define DIB_SMALL_CL_SYNC_WORDS 32   // per tile: [0, 6) arrival counters (fwd layer l: l; output-layer dgrad: 3; dgrad into h_{l-1}: 3 + l), [6] XCC_ID bits, [7] departures, [8] hello
 #define DIB_SMALL_CL_MAX 8
 
 // publish this workgroup's slice, wait for the others'.  The layer primitives end with a workgroup barrier, but a barrier does not
 // wait for the waves' global stores (s_waitcnt lgkmcnt(0) only): every wave drains its own (vmcnt(0), the gfx9 encoding 0x0F70)
 // ahead of a second barrier, so that thread 0's release covers stores that HAVE reached L2.
-__device__ __forceinline__ void dib_small_cluster_exchange(unsigned* counter, int cl) {
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
+// `same` (block-uniform, -1 before the launch's first exchange): 1 when the cluster sits on ONE XCD (every workgroup's XCC_ID is
+// collected at kernel start: dib_small_cluster_hello).  The full agent-scope protocol is an L2 write-back before the arrival and
+// an L2 + L1 invalidate after the wait: 1.7 us of a 3.2 us exchange on 4 workgroups, 3.9 of 5.3 us on 8
+// (profiles/r06r_exchange_variants.txt) - and between CUs that share an L2 it buys nothing:
+// the vector L1 is write-through (a store is in L2 when vmcnt says so) and the readers only have to drop their own L1's lines
+// (buffer_inv sc0).  A cluster the dispatcher did NOT place on one XCD (the id -> XCD mapping is the hardware's round-robin, not a
+// contract) keeps the full protocol for every exchange.
+#define DIB_GETREG_XCC_ID ((3 << 11) | 20)   // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
+// first thing in the kernel (thread 0): this workgroup's XCC_ID into word 6, its arrival into word 8 - no data behind it, no fence;
+// by the first exchange (a layer later) the others' have long landed and that exchange already takes the short protocol
+__device__ __forceinline__ void dib_small_cluster_hello(unsigned* words) {
   if (threadIdx.x == 0) {
-#ifndef DIB_CL_NOFENCE   // (diagnostic: what the agent-scope write-back / invalidate cost when the cluster shares an XCD's L2)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cl) {
-#ifndef DIB_CL_NOSLEEP
-      __builtin_amdgcn_s_sleep(1);
-#endif
-      if (wall_clock64() - t0 > 200000000ll) __builtin_trap();   // 2 s at 100 MHz: never a hang
-    }
+    __hip_atomic_fetch_or(words + 6, 1u << (__builtin_amdgcn_s_getreg(DIB_GETREG_XCC_ID) & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // the or has been performed at L2 before the arrival is issued
+    __hip_atomic_fetch_add(words + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__device__ __forceinline__ void dib_small_cluster_wait(const unsigned* word, unsigned target) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > 200000000ll) __builtin_trap();   // 2 s at 100 MHz: never a hang
+  }
+}
+
+__device__ __forceinline__ void dib_small_cluster_exchange(unsigned* words, int idx, int cl, int& same) {
+  __shared__ int s_same;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  if (same < 0 && threadIdx.x == 0) {   // (block-uniform `same`)
+    dib_small_cluster_wait(words + 8, (unsigned)cl);
+    const unsigned xccs = __hip_atomic_load(words + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_same = (xccs & (xccs - 1u)) == 0u ? 1 : 0;
   }
   __syncthreads();
-#ifndef DIB_CL_NOFENCE
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
+  if (same < 0) same = s_same;
+  if (threadIdx.x == 0) {
+    if (same == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(words + idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dib_small_cluster_wait(words + idx, (unsigned)cl);
+  }
+  __syncthreads();
+  if (same == 1) asm volatile("buffer_inv sc0" ::: "memory");   // this CU's L1 only
+  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // the last of the tile's workgroups to leave zeroes the tile's counters for the next launch
@@ -731,7 +754,7 @@ __device__ __forceinline__ void dib_small_cluster_leave(unsigned* words, int cl)
   if (threadIdx.x == 0) {
     if (__hip_atomic_fetch_add(words + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)cl - 1) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) __hip_atomic_store(words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -748,8 +771,12 @@ template <bool CLUSTER>
 __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs& a, const int tile, const int crank = 0) {
   constexpr int ROWS = DIB_SMALL_ROWS;
   const int cl = CLUSTER ? a.cl : 1;
-  const bool lead = !CLUSTER || crank == 0;   // writes what every workgroup of the tile computes alike (the head)
-  unsigned* const clw = CLUSTER ? a.cl_sync + (long long)tile * DIB_SMALL_CL_SYNC_WORDS : nullptr;
+  // (a network of the paired grid may stay on one workgroup per tile - cl == 1: the single-workgroup primitives, its bits)
+  const bool clustered = CLUSTER && cl > 1;
+  const bool lead = crank == 0;   // writes what every workgroup of the tile computes alike (the head, the encoded input)
+  unsigned* const clw = clustered ? a.cl_sync + (long long)tile * DIB_SMALL_CL_SYNC_WORDS : nullptr;
+  int cl_same = -1;   // is the cluster on one XCD?  (read at its first exchange)
+  if (clustered) dib_small_cluster_hello(clw);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = tile * ROWS, rows_valid = min(ROWS, a.batch - r0);
@@ -805,7 +832,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
           x = a.X[grow * a.ldx + c];
         }
         float* dst = us + row * pu + c;
-        const bool keep = ok && a.a0 != nullptr;
+        const bool keep = ok && a.a0 != nullptr && lead;
         float* gd = a.a0 + (long long)(r0 + row) * a.K0 + c;
         dst[0] = x;
         if (keep) gd[0] = x;
@@ -827,7 +854,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
       if (l < n) {
         const float* in = l == 0 ? us : hs[l > 0 ? l - 1 : 0];
         const int K = l == 0 ? a.K0 : a.width[l > 0 ? l - 1 : 0], pin = l == 0 ? pu : ph[l > 0 ? l - 1 : 0];
-        if constexpr (CLUSTER) {
+        if (clustered) {
           float* const gx = (stash ? a.h[l] : a.xh[l]) + (long long)r0 * a.width[l];
           int col0, ncols;
           dib_small_cluster_slice(a.width[l], crank, cl, col0, ncols);
@@ -838,7 +865,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
           dib_small_fwd_cols(in, pin, K, a.params + a.w_off[l], a.width[l], col0, ncols, a.params + a.b_off[l], slope, hs[l], ph[l],
                              gx, rows_valid, xch, l == 0 ? 6 : 45);
           DIB_ST(30 + l);
-          dib_small_cluster_exchange(clw + l, cl);
+          dib_small_cluster_exchange(clw, l, cl, cl_same);
           dib_small_load_tile(gx, a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
           __syncthreads();
         } else {
@@ -857,7 +884,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
   }
 
   if (a.mode & DIB_SMALL_INT_OUT) {   // general output layer (reference models.py:83)
-    if constexpr (CLUSTER) {   // its columns go straight to pred: nothing to exchange
+    if (clustered) {   // its columns go straight to pred: nothing to exchange
       int col0, ncols;
       dib_small_cluster_slice(a.out_dim, crank, cl, col0, ncols);
       dib_small_fwd_cols(hl, pl, KL, a.params + wo_off, a.out_dim, col0, ncols, a.params + bo_off, dib_neg_slope(a.out_act), nullptr, 0,
@@ -880,17 +907,31 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
     float pw[16];                        // KL <= 1024: 16 lane-strided columns
 #pragma unroll
     for (int c = 0; c < 16; ++c) pw[c] = 0.f;
-    for (int row = wave; row < ROWS; row += 8) {   // rows w, w + 8
-      if (row >= rows_valid) continue;   // wave-uniform
-      const int b = r0 + row;
-      float dot = 0.f;
+    // rows w and w + 8 of the tile TOGETHER (the two rows' chains - LDS reads, the wave sum, exp / log1p, the stores - are each a
+    // string of latencies; side by side they overlap: head 4.9 -> see profiles/r06t_*).  Same operations in the same order per row.
+    float z2[2], gg2[2], yy2[2];
+    bool ok2[2];
+    {
+      float dot[2] = {0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const int k = lane + 64 * c;
-        if (k < KL) dot += hl[row * pl + k] * wv[k];
+        if (k < KL) {
+          const float w = wv[k];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) dot[r] += hl[(wave + 8 * r) * pl + k] * w;
+        }
       }
-      const float z = dib_wave_sum(dot) + b0;
-      const float yy = head_y[row];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        ok2[r] = wave + 8 * r < rows_valid;   // wave-uniform
+        z2[r] = dib_wave_sum(dot[r]) + b0;
+        yy2[r] = head_y[wave + 8 * r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float z = z2[r], yy = yy2[r];
       float l, gg;
       if (a.loss_kind == 0) {
         l = fmaxf(z, 0.f) - z * yy + log1pf(expf(-fabsf(z)));
@@ -901,7 +942,9 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
         gg = 2.f * dd;
       }
       gg *= a.inv_bg;
-      if (lane == 0) {
+      gg2[r] = gg;
+      if (lane == 0 && ok2[r]) {
+        const int b = r0 + wave + 8 * r;
         if (lead) {
           a.pred[b] = z;
           if (grad) a.g_pred[b] = gg;
@@ -910,16 +953,23 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
         correct += ((z > 0.5f ? 1.f : 0.f) == yy) ? 1.f : 0.f;
         pb += gg;
       }
-      if (!grad) continue;
+    }
+    if (grad) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const int k = lane + 64 * c;
         if (k < KL) {
-          const float hv = hl[row * pl + k];
-          const float gv = gg * wv[k] * dib_small_act_grad(slope, hv);
-          gl[row * pl + k] = gv;
-          if (lead) g_last[(long long)b * KL + k] = gv;
-          pw[c] += hv * gg;
+          const float w = wv[k];
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            if (ok2[r]) {
+              const int row = wave + 8 * r;
+              const float hv = hl[row * pl + k];
+              const float gv = gg2[r] * w * dib_small_act_grad(slope, hv);
+              gl[row * pl + k] = gv;
+              if (lead) g_last[(long long)(r0 + row) * KL + k] = gv;
+              pw[c] += hv * gg2[r];
+            }
         }
       }
     }
@@ -956,11 +1006,11 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
   if (a.mode & DIB_SMALL_INT_BWD_OUT) {   // dL/dh_{n-1} from a given dL/dpred (custom loss: InfoNCE, train.py:216-219)
     dib_small_load_tile(a.g_pred + (long long)r0 * a.out_dim, a.out_dim, a.out_dim, rows_valid, ps, po);
     __syncthreads();
-    if constexpr (CLUSTER) {
+    if (clustered) {
       int k0, kc;
       dib_small_cluster_slice(KL, crank, cl, k0, kc);
       dib_small_bwd_cols(ps, po, a.out_dim, a.params + wo_off, KL, k0, kc, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, rows_valid, xch);
-      dib_small_cluster_exchange(clw + 3, cl);
+      dib_small_cluster_exchange(clw, 3, cl, cl_same);
       dib_small_load_tile(g_last + (long long)r0 * KL, KL, KL, rows_valid, gl, pl);
       __syncthreads();
     } else {
@@ -973,14 +1023,14 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
 #pragma unroll
     for (int l = 2; l >= 1; --l) {   // dL/dh_{l-1} = (dL/dh_l @ W_l^T) (.) act'(h_{l-1})
       if (l < n) {
-        if constexpr (CLUSTER) {
+        if (clustered) {
           float* const gx = a.g[l - 1] + (long long)r0 * a.width[l - 1];
           int k0, kc;
           dib_small_cluster_slice(a.width[l - 1], crank, cl, k0, kc);
           dib_small_bwd_cols(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], k0, kc, hs[l - 1], ph[l - 1], slope,
                              gs[l - 1], ph[l - 1], gx, rows_valid, xch, 34);
           DIB_ST(32 + l);
-          dib_small_cluster_exchange(clw + 3 + l, cl);
+          dib_small_cluster_exchange(clw, 3 + l, cl, cl_same);
           dib_small_load_tile(gx, a.width[l - 1], a.width[l - 1], rows_valid, gs[l - 1], ph[l - 1]);
           __syncthreads();
         } else {
@@ -992,7 +1042,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
     }
     // dL/du = dL/dh_0 @ W_0^T   (u is not an activation output; a plain MLP's input needs no gradient)
     if (!(a.mode & DIB_SMALL_INT_NO_GU)) {
-      if constexpr (CLUSTER) {
+      if (clustered) {
         int k0, kc;
         dib_small_cluster_slice(a.K0, crank, cl, k0, kc);
         dib_small_bwd_cols(gs[0], ph[0], a.width[0], a.params + a.w_off[0], a.K0, k0, kc, nullptr, 0, 1.f, nullptr, 0,
@@ -1004,7 +1054,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
     }
     DIB_ST(28);
   }
-  if constexpr (CLUSTER) dib_small_cluster_leave(clw, cl);
+  if (clustered) dib_small_cluster_leave(clw, cl);
 
   if (a.mode & DIB_SMALL_INT_HEAD_REDUCE) {   // block-uniform
     // the per-tile partials of the output layer's gradient and of the loss sums, summed in tile order by the last workgroup
@@ -1058,6 +1108,17 @@ dib_small_integration_pair_kernel(DibSmallIntPair p) {
   const DibSmallIntArgs& a = p.s[blockIdx.y];
   if ((int)blockIdx.x * DIB_SMALL_ROWS >= a.batch) return;   // the two batches may differ
   dib_small_integration_body<false>(a, blockIdx.x);
+}
+
+// ... and the paired grid in cluster mode: each network with its own cluster size (s[i].cl; 1 = one workgroup per tile, the bits of
+// dib_small_integration_pair_kernel for that network); gridDim.x = 8 ceil(tiles / 8) x the larger of the two
+__global__ void __launch_bounds__(DIB_SMALL_THREADS)
+dib_small_integration_pair_cluster_kernel(DibSmallIntPair p) {
+  const DibSmallIntArgs& a = p.s[blockIdx.y];
+  const int id = blockIdx.x, cl = a.cl;
+  const int tile = 8 * (id / (8 * cl)) + (id & 7), crank = (id >> 3) % cl;
+  if (tile * DIB_SMALL_ROWS >= a.batch) return;
+  dib_small_integration_body<true>(a, tile, crank);
 }
 
 // =====================================================================================================================

@@ -256,11 +256,11 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *                           weight gradients: 32 / 24 / 16 / 8 -> 8.20 / 8.27 / 8.38 / 8.57 ms per config-3 step (profiles/r06j_*)
  *   "wgrad_flat_tile" (1)   weight gradients of a <= 32-row operand against >= 256 columns use the 32 x 256 tile (0: 64 x 128)
  *   "num_cus"        (0)    compute units the split rule prices rounds with; 0 = the calling thread's current device's own count
- *   "int_cluster"    (4)    the row-tile integration kernel puts each 16-row tile on this many co-resident workgroups, each a column
+ *   "int_cluster"    (8)    the row-tile integration kernel puts each 16-row tile on this many co-resident workgroups, each a column
  *                           slice of every layer, slices exchanged through L2 (csrc/dib_small.h "cluster mode"; 0 / 1: one workgroup
  *                           per tile) while
- *   "int_cluster_wgs" (32)  row tiles x "int_cluster" <= this (it pays up to 8 row tiles: profiles/r06s_int_cluster_sweep.txt) and
- *   "int_cluster_min_weights" (65536) the network's first layer has at least this many weights
+ *   "int_cluster_wgs" (256) row tiles x "int_cluster" <= this (one workgroup per CU; profiles/r06q_int_cluster_sweep.txt) and
+ *   "int_cluster_min_weights" (65536) the network's hidden layers hold at least this many weights
  * Returns DIB_E_ARG for an unknown key or a negative value. */
 int dib_set_tuning(const char* key, int value);
 int dib_get_tuning(const char* key, int* value);

@@ -106,8 +106,8 @@ FUSED_ELIGIBLE = ("boolean4_32x32", "pendulum_ragged", "tabular8_default", "fuse
 #   "large_batch"  dib_set_tuning("small_batch", 0): the large-batch kernels at every batch size
 #   "grouped_gemm" ... and dib_set_tuning("fused_encoder", 0) for layouts created inside: the general grouped-GEMM path
 #   "cluster_tiles" the row-tile integration kernel with every row tile on a cluster of 4 workgroups (csrc/dib_small.h "cluster
-#                  mode") wherever the row-tile regime holds: dib_set_tuning("int_cluster_wgs", 256), ("int_cluster_min_weights", 0) -
-#                  "default" clusters only up to 8 row tiles of a network whose first layer has >= 65 536 weights
+#                  mode") whatever the network's size: dib_set_tuning("int_cluster", 4), ("int_cluster_min_weights", 0) -
+#                  "default" clusters (8 workgroups) only networks whose first integration layer has >= 32 768 weights, i.e. few zoo entries
 DISPATCH_PATHS = ("default", "large_batch", "grouped_gemm", "cluster_tiles")
 
 
@@ -116,10 +116,10 @@ def dispatch_path(path):
     """Engines must be CREATED inside the context ("fused_encoder" is read by dib_layout_create)."""
     from dib_amd import _lib
     assert path in DISPATCH_PATHS, path
-    old = {k: _lib.get_tuning(k) for k in ("small_batch", "fused_encoder", "int_cluster_wgs", "int_cluster_min_weights")}
+    old = {k: _lib.get_tuning(k) for k in ("small_batch", "fused_encoder", "int_cluster", "int_cluster_min_weights")}
     try:
         if path == "cluster_tiles":
-            _lib.set_tuning("int_cluster_wgs", 256)
+            _lib.set_tuning("int_cluster", 4)
             _lib.set_tuning("int_cluster_min_weights", 0)
         elif path != "default":
             _lib.set_tuning("small_batch", 0)

@@ -764,6 +764,50 @@ def test_companion_grids_equal_the_separate_launches(arch, B):
     assert torch.isfinite(b["yg"]).all() and b["yg"].abs().max() > 0 and b["xg"].abs().max() > 0
 
 
+@pytest.mark.parametrize("B", [37, 128])
+def test_companion_grid_with_a_clustered_output_encoder(B):
+    """The paired grid in cluster mode (csrc/dib_small.h dib_small_integration_pair_cluster_kernel): each of the two networks picks
+    its own workgroups per row tile.  With a [256, 256] output encoder (>= "int_cluster_min_weights" weights) BOTH networks cluster
+    in the paired launches, while the output encoder launched on its own (dib_mlp_small_fwd / _bwd) stays on one workgroup per
+    tile: same values in another fp32 summation order - outputs elementwise, gradients in norm.  (test_companion_grids_equal_the_
+    separate_launches keeps the bit-identity for the [128, 128] encoder of the reference's loop, which does not cluster.)"""
+    from dib_amd.dense import DenseStack
+    from dib_amd.engine import HipEngine
+    spec = _SMALL_ARCHS["pendulum"][0]
+    eng = HipEngine(**spec_kwargs(spec), init_seed=3)
+    eng.set_beta(0.05)
+    D = spec.output_dimensionality
+    ds = DenseStack(eng, 6, [256, 256], D, "relu", True, 5, seed=9)
+    rng = np.random.default_rng(B)
+    nin = sum(spec.feature_dimensionalities)
+    xd = eng.to_device(rng.standard_normal((B + 5, nin)).astype(np.float32))
+    yd = eng.to_device(rng.standard_normal((B + 5, 6)).astype(np.float32))
+    idx = eng.to_device(rng.permutation(B + 5)[:B].astype(np.int32), dtype=torch.int32)
+    gp = eng.to_device(rng.standard_normal((B, D)).astype(np.float32) / B)
+    gy = eng.to_device(rng.standard_normal((B, D)).astype(np.float32) / B)
+    recs = []
+    for paired in (False, True, True):
+        eng.grads.zero_(); ds.grads.zero_()
+        comp = ds.companion_forward(yd, rows=idx) if paired else None
+        eng.forward(xd, idx, 0, B, 7, 3, companion=comp)
+        emb_y = (ds.companion_output() if paired else ds.forward(yd, rows=idx)).clone()
+        pred = eng.pred(B).clone()
+        compb = ds.companion_backward(gy) if paired else None
+        eng.backward_from_pred_grad(gp, idx, 0, B, 7, 3, inv_global_batch=1.0 / B, companion=compb)
+        ds.backward(gy, dgrad_done=paired)
+        torch.cuda.synchronize()
+        recs.append(dict(emb_y=emb_y, pred=pred, xg=eng.grads.clone(), yg=ds.grads.clone(), gu=eng.g_u(B).clone()))
+    a, b, c = recs
+    for k in a:
+        assert torch.equal(b[k], c[k]), ("replay", k)
+        ref, got = a[k].double(), b[k].double()
+        if k in ("emb_y", "pred"):
+            assert (got - ref).abs().max() <= 3e-5 * (1e-6 + ref.abs().max()) + 1e-6, k
+        else:
+            assert (got - ref).norm() <= 5e-3 * ref.norm(), (k, ((got - ref).norm() / ref.norm()).item())
+    assert torch.isfinite(b["yg"]).all() and b["yg"].abs().max() > 0
+
+
 def test_infonce_training_loop_on_pendulum(tmp_path):
     """BASELINE config 2 path: the custom InfoNCE loop (train.py:180-289) on simulated double-pendulum data -
     runs end to end, the InfoNCE loss drops below its untrained value ~ 2 ln B, series have the reference shapes."""

@@ -11,3 +11,6 @@ for rep in 1 2 3; do for c in 0 4; do
   DIB_SMALL_EPOCHS=1000 timeout 300 python tools/small_batch_bench.py int_cluster=$c 2>&1 | tail -n 1
 done; done > $O/default_pair_ab.txt
 cat $O/default_pair_ab.txt
+timeout 400 python tools/int_cluster_sweep.py 2>&1 | grep -v amdgpu.ids > $O/int_cluster_sweep.txt
+DIB_SWEEP_F=4 timeout 400 python tools/int_cluster_sweep.py 2>&1 | grep -v amdgpu.ids >> $O/int_cluster_sweep.txt
+cat $O/int_cluster_sweep.txt
