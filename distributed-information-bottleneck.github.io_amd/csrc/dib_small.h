@@ -771,12 +771,12 @@ template <bool CLUSTER>
 __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs& a, const int tile, const int crank = 0) {
   constexpr int ROWS = DIB_SMALL_ROWS;
   const int cl = CLUSTER ? a.cl : 1;
-  // (a network of the paired grid may stay on one workgroup per tile - cl == 1: the single-workgroup primitives, its bits)
-  const bool clustered = CLUSTER && cl > 1;
+  const bool clustered = CLUSTER;   // the slice primitives (a network of the paired grid may be a "cluster" of ONE workgroup per tile)
+  const bool multi = CLUSTER && cl > 1;   // ... with somebody to exchange with
   const bool lead = crank == 0;   // writes what every workgroup of the tile computes alike (the head, the encoded input)
-  unsigned* const clw = clustered ? a.cl_sync + (long long)tile * DIB_SMALL_CL_SYNC_WORDS : nullptr;
+  unsigned* const clw = multi ? a.cl_sync + (long long)tile * DIB_SMALL_CL_SYNC_WORDS : nullptr;
   int cl_same = -1;   // is the cluster on one XCD?  (read at its first exchange)
-  if (clustered) dib_small_cluster_hello(clw);
+  if (multi) dib_small_cluster_hello(clw);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = tile * ROWS, rows_valid = min(ROWS, a.batch - r0);
@@ -855,19 +855,18 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
         const float* in = l == 0 ? us : hs[l > 0 ? l - 1 : 0];
         const int K = l == 0 ? a.K0 : a.width[l > 0 ? l - 1 : 0], pin = l == 0 ? pu : ph[l > 0 ? l - 1 : 0];
         if (clustered) {
-          float* const gx = (stash ? a.h[l] : a.xh[l]) + (long long)r0 * a.width[l];
+          // (one workgroup per tile and no stash: nothing leaves the CU)
+          float* const gx = (stash || multi) ? (stash ? a.h[l] : a.xh[l]) + (long long)r0 * a.width[l] : nullptr;
           int col0, ncols;
           dib_small_cluster_slice(a.width[l], crank, cl, col0, ncols);
-#ifdef DIB_SMALL_TIMING_REPEAT   // diagnostic: the layer twice - the second pass runs warm code on warm weights
-          dib_small_fwd_cols(in, pin, K, a.params + a.w_off[l], a.width[l], col0, ncols, a.params + a.b_off[l], slope, hs[l], ph[l],
-                             gx, rows_valid, xch, -1);
-#endif
           dib_small_fwd_cols(in, pin, K, a.params + a.w_off[l], a.width[l], col0, ncols, a.params + a.b_off[l], slope, hs[l], ph[l],
                              gx, rows_valid, xch, l == 0 ? 6 : 45);
           DIB_ST(30 + l);
-          dib_small_cluster_exchange(clw, l, cl, cl_same);
-          dib_small_load_tile(gx, a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
-          __syncthreads();
+          if (multi) {
+            dib_small_cluster_exchange(clw, l, cl, cl_same);
+            dib_small_load_tile(gx, a.width[l], a.width[l], rows_valid, hs[l], ph[l]);
+            __syncthreads();
+          }
         } else {
           dib_small_fwd(in, pin, K, K, a.params + a.w_off[l], a.width[l], a.params + a.b_off[l], slope, hs[l], ph[l],
                         stash ? a.h[l] + (long long)r0 * a.width[l] : nullptr, a.width[l], rows_valid, xch);
@@ -1010,9 +1009,11 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
       int k0, kc;
       dib_small_cluster_slice(KL, crank, cl, k0, kc);
       dib_small_bwd_cols(ps, po, a.out_dim, a.params + wo_off, KL, k0, kc, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, rows_valid, xch);
-      dib_small_cluster_exchange(clw, 3, cl, cl_same);
-      dib_small_load_tile(g_last + (long long)r0 * KL, KL, KL, rows_valid, gl, pl);
-      __syncthreads();
+      if (multi) {
+        dib_small_cluster_exchange(clw, 3, cl, cl_same);
+        dib_small_load_tile(g_last + (long long)r0 * KL, KL, KL, rows_valid, gl, pl);
+        __syncthreads();
+      }
     } else {
       dib_small_bwd(ps, po, a.out_dim, a.params + wo_off, KL, hl, pl, slope, gl, pl, g_last + (long long)r0 * KL, KL, rows_valid, xch);
     }
@@ -1030,9 +1031,11 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
           dib_small_bwd_cols(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], k0, kc, hs[l - 1], ph[l - 1], slope,
                              gs[l - 1], ph[l - 1], gx, rows_valid, xch, 34);
           DIB_ST(32 + l);
-          dib_small_cluster_exchange(clw, 3 + l, cl, cl_same);
-          dib_small_load_tile(gx, a.width[l - 1], a.width[l - 1], rows_valid, gs[l - 1], ph[l - 1]);
-          __syncthreads();
+          if (multi) {
+            dib_small_cluster_exchange(clw, 3 + l, cl, cl_same);
+            dib_small_load_tile(gx, a.width[l - 1], a.width[l - 1], rows_valid, gs[l - 1], ph[l - 1]);
+            __syncthreads();
+          }
         } else {
           dib_small_bwd(gs[l], ph[l], a.width[l], a.params + a.w_off[l], a.width[l - 1], hs[l - 1], ph[l - 1], slope, gs[l - 1],
                         ph[l - 1], a.g[l - 1] + (long long)r0 * a.width[l - 1], a.width[l - 1], rows_valid, xch);
@@ -1054,7 +1057,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
     }
     DIB_ST(28);
   }
-  if (clustered) dib_small_cluster_leave(clw, cl);
+  if (multi) dib_small_cluster_leave(clw, cl);
 
   if (a.mode & DIB_SMALL_INT_HEAD_REDUCE) {   // block-uniform
     // the per-tile partials of the output layer's gradient and of the loss sums, summed in tile order by the last workgroup
@@ -1110,8 +1113,9 @@ dib_small_integration_pair_kernel(DibSmallIntPair p) {
   dib_small_integration_body<false>(a, blockIdx.x);
 }
 
-// ... and the paired grid in cluster mode: each network with its own cluster size (s[i].cl; 1 = one workgroup per tile, the bits of
-// dib_small_integration_pair_kernel for that network); gridDim.x = 8 ceil(tiles / 8) x the larger of the two
+// ... and the paired grid in cluster mode: each network with its own cluster size (s[i].cl; 1 = one workgroup per tile on the slice
+// primitives - no exchange, another fp32 summation order than dib_small_integration_pair_kernel); gridDim.x = 8 ceil(tiles / 8) x
+// the larger of the two
 __global__ void __launch_bounds__(DIB_SMALL_THREADS)
 dib_small_integration_pair_cluster_kernel(DibSmallIntPair p) {
   const DibSmallIntArgs& a = p.s[blockIdx.y];

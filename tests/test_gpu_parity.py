@@ -759,8 +759,22 @@ def test_companion_grids_equal_the_separate_launches(arch, B):
         torch.cuda.synchronize()
         recs.append(dict(emb_y=emb_y, pred=pred, xg=eng.grads.clone(), yg=ds.grads.clone(), gu=eng.g_u(B).clone()))
     a, b = recs
+    # the output encoder rides in a CLUSTER-mode grid whenever the X model's integration network clusters (round 6): it then runs on
+    # the slice primitives (one workgroup per tile, csrc/dib_small.h) - the separate launch's values in another fp32 summation order
+    from dib_amd import _lib
+    x_hidden = sum(i * o for i, o in zip([spec.number_features * spec.feature_embedding_dimension] + list(spec.integration_network_architecture),
+                                         spec.integration_network_architecture))
+    clustered = (arch != "no_row_tiles" and _lib.get_tuning("int_cluster") > 1 and x_hidden >= _lib.get_tuning("int_cluster_min_weights")
+                 and (B + 15) // 16 * _lib.get_tuning("int_cluster") <= _lib.get_tuning("int_cluster_wgs"))
     for k in a:
-        assert torch.equal(a[k], b[k]), k
+        if clustered and k in ("emb_y", "yg"):
+            ref, got = a[k].double(), b[k].double()
+            if k == "emb_y":
+                assert (got - ref).abs().max() <= 3e-5 * (1e-6 + ref.abs().max()) + 1e-6, k
+            else:
+                assert (got - ref).norm() <= 5e-3 * ref.norm(), k
+        else:
+            assert torch.equal(a[k], b[k]), k
     assert torch.isfinite(b["yg"]).all() and b["yg"].abs().max() > 0 and b["xg"].abs().max() > 0
 
 
