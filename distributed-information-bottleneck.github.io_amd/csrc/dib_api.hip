@@ -675,8 +675,9 @@ static thread_local SmallCompanion t_companion;
 // weights (below that a layer is a few microseconds on one CU and the exchanges cost more than they save) and the wider exchange
 // buffer fits the LDS
 static int small_cluster_size(const DibSmallIntArgs& a, size_t lds_bytes) {
-  const int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
-  if (cl <= 1 || small_tiles(a.batch) * cl > knobs().int_cluster_wgs || lds_bytes > 160 * 1024) return 1;
+  int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
+  while (cl > 1 && small_tiles(a.batch) * cl > knobs().int_cluster_wgs) cl >>= 1;   // more row tiles: smaller clusters (8 / 4 / 2)
+  if (cl <= 1 || lds_bytes > 160 * 1024) return 1;
   if (a.mode & (DIB_SMALL_INT_HEAD_REDUCE)) return 1;   // (its last-arriver reduce counts workgroups, not tiles)
   long long weights = 0;
   for (int i = 0, k = a.K0; i < a.n_hidden; k = a.width[i], ++i) weights += (long long)k * a.width[i];

@@ -1,6 +1,7 @@
 """Cluster mode of the row-tile integration kernel (csrc/dib_small.h; dib_set_tuning "int_cluster" / "int_cluster_wgs"): training-step
 and validation-step time of the reference's default layout (train.py:36-44: 10 features, encoders [128, 128], integration [256, 256],
-embedding 32) by batch size and workgroups per row tile, same process, interleaved repeats."""
+embedding 32) by batch size and REQUESTED workgroups per row tile (the library halves the request until row tiles x cluster <= 256),
+same process, interleaved repeats."""
 import os
 import sys
 import time
@@ -19,13 +20,13 @@ def main():
     _lib.set_tuning("int_cluster_wgs", 256)
     _lib.set_tuning("int_cluster_min_weights", 0)
     rng = np.random.default_rng(0)
-    for B in (32, 64, 128, 256, 512, 1024):
+    for B in (32, 64, 128, 256, 512, 1024, 2048):
         x = eng.to_device(rng.standard_normal((B, F)).astype(np.float32))
         y = eng.to_device((rng.random((B, 1)) > 0.5).astype(np.float32))
         res = {}
         for rep in range(3):
             for cl in (0, 2, 4, 8):
-                if (B + 15) // 16 * max(cl, 1) > 256:
+                if (B + 15) // 16 * F > 512:   # beyond the row-tile regime
                     continue
                 _lib.set_tuning("int_cluster", cl)
                 for kind in ("train", "val"):
