@@ -234,7 +234,7 @@ struct Tuning {
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
   int int_cluster = 8;       // row-tile integration kernel: workgroups per row tile (each a column slice of every layer, exchange
                              // through L2: dib_small.h "cluster mode"; <= 1: one per tile) while row tiles x this <= ...
-  int int_cluster_wgs = 256; // ... this (one workgroup per CU; measured up to 32 row tiles, profiles/r06q_int_cluster_sweep.txt) and
+  int int_cluster_wgs = 256; // ... this (one workgroup per CU; 8 per tile up to 32 row tiles, 4 up to 64: profiles/r06u_int_cluster_sweep.txt) and
   int int_cluster_min_weights = 65536;  // ... the network's hidden layers have at least this many weights (measured down to 4
                              // features x 32 -> 256 -> 256: 98 304)
   int wgrad_max_splits = 32; // most batch slabs of a layout's weight gradients (<= 32; read when a workspace is sized: set it first)
@@ -674,10 +674,13 @@ static thread_local SmallCompanion t_companion;
 // while the launch stays within "int_cluster_wgs" workgroups, the network's hidden layers hold at least "int_cluster_min_weights"
 // weights (below that a layer is a few microseconds on one CU and the exchanges cost more than they save) and the wider exchange
 // buffer fits the LDS
-static int small_cluster_size(const DibSmallIntArgs& a, size_t lds_bytes) {
+static int small_cluster_size(const DibSmallIntArgs& a, size_t lds_bytes, int other_wgs = 0) {
   int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
-  while (cl > 1 && small_tiles(a.batch) * cl > knobs().int_cluster_wgs) cl >>= 1;   // more row tiles: smaller clusters (8 / 4 / 2)
-  if (cl <= 1 || lds_bytes > 160 * 1024) return 1;
+  // more row tiles: 4 per tile instead of 8 while the launch (with the other network of a paired grid: other_wgs) stays within the
+  // budget - every workgroup must be resident for the networks to run side by side; 2 per tile measured no gain
+  // (profiles/r06u_int_cluster_sweep.txt)
+  while (cl > 4 && small_tiles(a.batch) * cl + other_wgs > knobs().int_cluster_wgs) cl >>= 1;
+  if (cl <= 1 || small_tiles(a.batch) * cl + other_wgs > knobs().int_cluster_wgs || lds_bytes > 160 * 1024) return 1;
   if (a.mode & (DIB_SMALL_INT_HEAD_REDUCE)) return 1;   // (its last-arriver reduce counts workgroups, not tiles)
   long long weights = 0;
   for (int i = 0, k = a.K0; i < a.n_hidden; k = a.width[i], ++i) weights += (long long)k * a.width[i];
@@ -701,7 +704,7 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.partial_w = w + m.skinny_partial; a.partial_l = w + m.loss_partial;
   // cluster mode: few row tiles, each on `cl` workgroups (dib_small.h)
   const size_t cl_extra = (size_t)(DIB_SMALL_XCH_FLOATS_WIDE - DIB_SMALL_XCH_FLOATS) * sizeof(float);
-  const int cl = small_cluster_size(a, (size_t)l->sb_int_lds + cl_extra);
+  int cl = small_cluster_size(a, (size_t)l->sb_int_lds + cl_extra);
   if (t_companion.armed) {
     t_companion.armed = false;
     DibSmallIntPair p;
@@ -710,6 +713,12 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
     // without stashes); its arrival counters are the second half of this workspace's
     DibSmallIntArgs& c = p.s[1];
     int ccl = (c.mode & DIB_SMALL_INT_INFER) || small_tiles(c.batch) > small_tiles(batch) ? 1 : small_cluster_size(c, t_companion.lds + cl_extra);
+    // the two networks run side by side only while all their workgroups are resident (one per CU): the companion first gives up
+    // its cluster, then this network sizes itself next to it
+    if (small_tiles(batch) * cl + small_tiles(c.batch) * ccl > knobs().int_cluster_wgs) {
+      ccl = 1;
+      cl = small_cluster_size(a, (size_t)l->sb_int_lds + cl_extra, small_tiles(c.batch));
+    }
     if (cl > 1 || ccl > 1) {
       p.s[0].cl = cl; p.s[0].cl_sync = (unsigned*)(w + m.cl_sync);
       for (int i = 0; i < l->n_int; ++i) p.s[0].xh[i] = w + m.cl_x[i];

@@ -259,7 +259,8 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "int_cluster"    (8)    the row-tile integration kernel puts each 16-row tile on this many co-resident workgroups, each a column
  *                           slice of every layer, slices exchanged through L2 (csrc/dib_small.h "cluster mode"; 0 / 1: one workgroup
  *                           per tile) while
- *   "int_cluster_wgs" (256) row tiles x "int_cluster" <= this (one workgroup per CU; profiles/r06q_int_cluster_sweep.txt) and
+ *   "int_cluster_wgs" (256) row tiles x cluster size <= this (one workgroup per CU; 8 per tile halves to 4 for more row tiles, the two
+ *                           networks of a paired grid are sized together; profiles/r06u_int_cluster_sweep.txt) and
  *   "int_cluster_min_weights" (65536) the network's hidden layers hold at least this many weights
  * Returns DIB_E_ARG for an unknown key or a negative value. */
 int dib_set_tuning(const char* key, int value);
