@@ -676,11 +676,12 @@ static thread_local SmallCompanion t_companion;
 // buffer fits the LDS
 static int small_cluster_size(const DibSmallIntArgs& a, size_t lds_bytes, int other_wgs = 0) {
   int cl = std::min(knobs().int_cluster, DIB_SMALL_CL_MAX);
+  const int budget = std::min(knobs().int_cluster_wgs, device_cus());   // one workgroup per CU (141 KB of LDS each)
   // more row tiles: 4 per tile instead of 8 while the launch (with the other network of a paired grid: other_wgs) stays within the
   // budget - every workgroup must be resident for the networks to run side by side; 2 per tile measured no gain
   // (profiles/r06u_int_cluster_sweep.txt)
-  while (cl > 4 && small_tiles(a.batch) * cl + other_wgs > knobs().int_cluster_wgs) cl >>= 1;
-  if (cl <= 1 || small_tiles(a.batch) * cl + other_wgs > knobs().int_cluster_wgs || lds_bytes > 160 * 1024) return 1;
+  while (cl > 4 && small_tiles(a.batch) * cl + other_wgs > budget) cl >>= 1;
+  if (cl <= 1 || small_tiles(a.batch) * cl + other_wgs > budget || lds_bytes > 160 * 1024) return 1;
   if (a.mode & (DIB_SMALL_INT_HEAD_REDUCE)) return 1;   // (its last-arriver reduce counts workgroups, not tiles)
   long long weights = 0;
   for (int i = 0, k = a.K0; i < a.n_hidden; k = a.width[i], ++i) weights += (long long)k * a.width[i];
@@ -715,7 +716,7 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
     int ccl = (c.mode & DIB_SMALL_INT_INFER) || small_tiles(c.batch) > small_tiles(batch) ? 1 : small_cluster_size(c, t_companion.lds + cl_extra);
     // the two networks run side by side only while all their workgroups are resident (one per CU): the companion first gives up
     // its cluster, then this network sizes itself next to it
-    if (small_tiles(batch) * cl + small_tiles(c.batch) * ccl > knobs().int_cluster_wgs) {
+    if (small_tiles(batch) * cl + small_tiles(c.batch) * ccl > std::min(knobs().int_cluster_wgs, device_cus())) {
       ccl = 1;
       cl = small_cluster_size(a, (size_t)l->sb_int_lds + cl_extra, small_tiles(c.batch));
     }
