@@ -595,7 +595,7 @@ static int small_encoder_fwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.enc_out = w + m.enc_out; a.U = w + m.U; a.kl_partial = w + m.kl_partial;
   a.seed = seed; a.step = step; a.deterministic = flags & DIB_FWD_DETERMINISTIC; a.step_dev = l->step_dev;
   const size_t lds = (size_t)DIB_SMALL_ROWS * (20 + dib_small_pitch(a.H1) + dib_small_pitch(a.H2) + dib_small_pitch(2 * a.E)) * sizeof(float) +
-                     (size_t)DIB_SMALL_XCH_FLOATS * sizeof(float);
+                     (size_t)DIB_SMALL_XCH_FLOATS_WIDE * sizeof(float);
   static int lds_have[64] = {};
   if (int rc = ensure_dynamic_lds((const void*)dib_small_encoder_fwd_kernel, lds, lds_have)) return rc;
   ProfScope ps(kProfOther, st);
@@ -612,7 +612,7 @@ static int small_encoder_bwd(dib_layout* l, const dib_layout::WsMap& m, float* w
   a.h1 = w + m.enc_h[0]; a.h2 = w + m.enc_h[1]; a.enc_out = w + m.enc_out; a.U = w + m.U; a.GU = w + m.g_u;
   a.dout = w + m.dout; a.dh2 = w + m.g_enc_h[1]; a.dw1_partial = w + m.dw1_partial; a.beta_dev = beta_dev; a.inv_bg = inv_bg;
   const size_t lds = (size_t)DIB_SMALL_ROWS * (20 + 2 * dib_small_pitch(a.H1) + 2 * dib_small_pitch(a.H2) + dib_small_pitch(2 * a.E)) * sizeof(float) +
-                     (size_t)DIB_SMALL_XCH_FLOATS * sizeof(float);
+                     (size_t)DIB_SMALL_XCH_FLOATS_WIDE * sizeof(float);
   static int lds_have[64] = {};
   if (int rc = ensure_dynamic_lds((const void*)dib_small_encoder_bwd_kernel, lds, lds_have)) return rc;
   ProfScope ps(kProfOther, st);

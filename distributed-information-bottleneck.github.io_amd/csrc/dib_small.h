@@ -97,7 +97,8 @@ __device__ __forceinline__ float dib_small_act_grad(float slope, float y) { retu
 template <int NT>
 __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
                                                  const float* __restrict__ bias, float slope, float* out, int pout,
-                                                 float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
+                                                 float* __restrict__ gdst, long long gld, int rows_valid, float* xch, int dbg = -1) {
+  DIB_STD(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   constexpr int CG = 16 * NT;
@@ -143,6 +144,7 @@ __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K
         }
       };
       load(4 * UB * kh, acur, bcur);
+      DIB_STD(1);
       for (int s0 = 4 * UB * kh; s0 < K; s0 += 4 * UB * kways) {
         float anxt[UA], bnxt[UB][NT];
         load(s0 + 4 * UB * kways, anxt, bnxt);   // past the end: masked (k >= kvalid), harmless re-read of row 0
@@ -163,6 +165,7 @@ __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K
         }
       }
     }
+    DIB_STD(2);
     // shares 1 .. kways - 1 hand their partial sums to share 0, which finishes the tile (fixed order: share 0 + 1 + 2 + ...);
     // exchange slot (kh - 1) * nslots + wc: at most 7 x NT <= 20 entries (kways == 8 only with NT <= 2)
     if (kh >= 1 && active) {
@@ -172,6 +175,7 @@ __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K
             make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
     }
     __syncthreads();
+    DIB_STD(3);
     if (kh == 0 && active) {
       for (int p = 1; p < kways; ++p) {
 #pragma unroll
@@ -190,18 +194,20 @@ __device__ __forceinline__ void dib_small_fwd_nt(const float* in, int pin, int K
         if (gdst != nullptr && row < rows_valid) dib_small_storev<NT>(gdst + (long long)row * gld + n0 + NT * j, v);
       }
     }
+    DIB_STD(4);
     __syncthreads();   // the exchange buffer is free again, the output tile is visible
+    DIB_STD(5);
   }
 }
 
 // (ends with a workgroup barrier: the output tile is visible to every wave on return)
 __device__ __forceinline__ void dib_small_fwd(const float* in, int pin, int K, int kvalid, const float* __restrict__ W, int N,
                                               const float* __restrict__ bias, float slope, float* out, int pout,
-                                              float* __restrict__ gdst, long long gld, int rows_valid, float* xch) {
+                                              float* __restrict__ gdst, long long gld, int rows_valid, float* xch, int dbg = -1) {
   switch (dib_small_pick_nt(N)) {   // block-uniform
-    case 4: dib_small_fwd_nt<4>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch); break;
-    case 2: dib_small_fwd_nt<2>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch); break;
-    default: dib_small_fwd_nt<1>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch); break;
+    case 4: dib_small_fwd_nt<4>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch, dbg); break;
+    case 2: dib_small_fwd_nt<2>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch, dbg); break;
+    default: dib_small_fwd_nt<1>(in, pin, K, kvalid, W, N, bias, slope, out, pout, gdst, gld, rows_valid, xch, dbg); break;
   }
 }
 
@@ -421,15 +427,15 @@ __device__ __forceinline__ void dib_small_fwd_cols(const float* in, int pin, int
 #undef DIB_FW
 }
 
-// gin[16][16 NT] = (g[16][N] @ W[16 NT][N]^T) (.) act'(h): ONE group of NT <= 5 input-unit tiles, the contraction on `kways`
-// shares of UB S-steps a batch; partial tiles reduced in share order by wave t for tile t (see dib_small_fwd_wide).
+// gin[16][16 NT G] = (g[16][N] @ W[16 NT G][N]^T) (.) act'(h): G = 1 or 2 groups of NT <= 5 input-unit tiles, the contraction on
+// `kways` <= 8 / G shares of UB S-steps a batch; partial tiles reduced in share order, one wave per tile (see dib_small_fwd_wide).
 template <int NT, int UB>
 __device__ __forceinline__ void dib_small_bwd_wide(const float* g, int pg, int N, const float* __restrict__ W, const float* h, int ph,
                                                    float slope, float* gin, int pgi, float* __restrict__ gdst, long long gld,
-                                                   int rows_valid, float* xch, int kways, int dbg) {
+                                                   int rows_valid, float* xch, int kways, int dbg, int G = 1) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
-  const int kh = wave;   // one column slot: the wave index IS the contraction share
+  const int wc = wave % G, kh = wave / G;   // tile group, contraction share
   const bool active = kh < kways;
   DIB_STD(0);
   dib_f32x4 acc[NT];
@@ -437,7 +443,7 @@ __device__ __forceinline__ void dib_small_bwd_wide(const float* g, int pg, int N
   for (int t = 0; t < NT; ++t) acc[t] = dib_f32x4{0.f, 0.f, 0.f, 0.f};
   if (active) {
     const float* ap = g + j * pg + 4 * q;
-    const float* wp = W + (long long)j * N + 4 * q;
+    const float* wp = W + (long long)(16 * NT * wc + j) * N + 4 * q;
     float4 acur[UB], bcur[UB][NT];
     auto load = [&](int S0, float4 (&av)[UB], float4 (&bw)[UB][NT]) {
 #pragma unroll
@@ -469,21 +475,21 @@ __device__ __forceinline__ void dib_small_bwd_wide(const float* g, int pg, int N
     DIB_STD(2);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
-      *reinterpret_cast<float4*>(xch + ((kh * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      *reinterpret_cast<float4*>(xch + (((kh * G + wc) * NT + t) * 64 + lane) * 4) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
   }
   __syncthreads();
   DIB_STD(3);
-  if (wave < NT) {   // tile t = wave
-    const int t = wave;
-    float4 sum = *reinterpret_cast<const float4*>(xch + (t * 64 + lane) * 4);
+  for (int item = wave; item < G * NT; item += 8) {   // tile (slot, t) = item / NT, item % NT (two groups of 5: ten tiles on 8 waves)
+    const int slot = item / NT, t = item - slot * NT;
+    float4 sum = *reinterpret_cast<const float4*>(xch + ((slot * NT + t) * 64 + lane) * 4);
     for (int p = 1; p < kways; ++p) {
-      const float4 o = *reinterpret_cast<const float4*>(xch + ((p * NT + t) * 64 + lane) * 4);
+      const float4 o = *reinterpret_cast<const float4*>(xch + (((p * G + slot) * NT + t) * 64 + lane) * 4);
       sum.x += o.x; sum.y += o.y; sum.z += o.z; sum.w += o.w;
     }
     const float v4[4] = {sum.x, sum.y, sum.z, sum.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 4 * q + r, k = 16 * t + j;
+      const int row = 4 * q + r, k = 16 * (NT * slot + t) + j;
       float v = v4[r];
       if (h != nullptr) v *= dib_small_act_grad(slope, h[row * ph + k]);
       if (gin != nullptr) gin[row * pgi + k] = v;
@@ -503,14 +509,19 @@ __device__ __forceinline__ void dib_small_bwd_cols(const float* g, int pg, int N
   if (h != nullptr) h += k0;
   if (gin != nullptr) gin += k0;
   if (gdst != nullptr) gdst += k0;
-  const int tiles = kcols >> 4;
-  if (tiles > 5) { dib_small_bwd(g, pg, N, W, kcols, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch); return; }
+  int tiles = kcols >> 4;
+  // up to 5 tiles: one group; 6 / 8 / 10: two groups of 3 / 4 / 5 on half the shares each; anything else: the general primitive
+  const int G = tiles <= 5 ? 1 : ((tiles <= 10 && (tiles & 1) == 0) ? 2 : 0);
+  if (G == 0) { dib_small_bwd(g, pg, N, W, kcols, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch); return; }
+  tiles /= G;
   // 2 S-steps a batch (N <= 256: a share's loads are one batch in flight), 4 for longer contractions
-  const int ub = N <= 256 ? 2 : 4;
+  const int kmax = 8 / G;
+  const int ub = N <= 16 * kmax ? 1 : (N <= 256 ? 2 : 4);   // (a short contraction: one S-step a share, every wave busy)
   const int nb = (N + 16 * ub - 1) / (16 * ub);
-  const int kw = nb >= 8 ? 8 : (nb >= 4 ? 4 : (nb >= 2 ? 2 : 1));
-#define DIB_BW(NT_) do { if (ub == 2) dib_small_bwd_wide<NT_, 2>(g, pg, N, W, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch, kw, dbg); \
-                         else dib_small_bwd_wide<NT_, 4>(g, pg, N, W, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch, kw, dbg); } while (0)
+  const int kw = nb >= 8 && kmax >= 8 ? 8 : (nb >= 4 && kmax >= 4 ? 4 : (nb >= 2 ? 2 : 1));
+#define DIB_BW(NT_) do { if (ub == 1) dib_small_bwd_wide<NT_, 1>(g, pg, N, W, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch, kw, dbg, G); \
+                         else if (ub == 2) dib_small_bwd_wide<NT_, 2>(g, pg, N, W, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch, kw, dbg, G); \
+                         else dib_small_bwd_wide<NT_, 4>(g, pg, N, W, h, ph, slope, gin, pgi, gdst, ldk, rows_valid, xch, kw, dbg, G); } while (0)
   switch (tiles) {   // block-uniform
     case 5: DIB_BW(5); break;
     case 4: DIB_BW(4); break;
@@ -610,11 +621,13 @@ dib_small_encoder_fwd_kernel(DibSmallEncFwdArgs a) {
   const long long frow = (long long)f * a.batch + r0;
   const float slope = dib_neg_slope(a.act);
   dib_small_fwd(Pl, 20, (in_dim + 3) & ~3, in_dim, W1, a.H1, b1, slope, h1s, p1, a.h1 ? a.h1 + frow * a.H1 : nullptr, a.H1,
-                rows_valid, xch);
+                rows_valid, xch, 6);
   DIB_ST(2);
-  dib_small_fwd(h1s, p1, a.H1, a.H1, W2, a.H2, b2, slope, h2s, p2, a.h2 ? a.h2 + frow * a.H2 : nullptr, a.H2, rows_valid, xch);
+  // layers 2 and 3 on the slice primitives of the cluster mode (the whole layer as one "slice": float4 weight loads, every wave a
+  // share of the contraction, one batch in flight): 4.3 + 4.3 -> see profiles/r06x_*; layer 1's ragged first dimension stays
+  dib_small_fwd_cols(h1s, p1, a.H1, W2, a.H2, 0, a.H2, b2, slope, h2s, p2, a.h2 ? a.h2 + frow * a.H2 : nullptr, rows_valid, xch, 45);
   DIB_ST(3);
-  dib_small_fwd(h2s, p2, a.H2, a.H2, W3, E2, b3, 1.f /* linear, models.py:78 */, os, p3, a.enc_out + frow * E2, E2, rows_valid, xch);
+  dib_small_fwd_cols(h2s, p2, a.H2, W3, E2, 0, E2, b3, 1.f /* linear, models.py:78 */, os, p3, a.enc_out + frow * E2, rows_valid, xch, 34);
   DIB_ST(4);
   // ---- reparameterise + KL: thread = (row, 4 consecutive embedding dims) = one Philox call ----
   const int E4 = E >> 2;
@@ -1197,9 +1210,9 @@ dib_small_encoder_bwd_kernel(DibSmallEncBwdArgs a) {
   const float* W3 = a.params + a.w_off[2 * F + f];
   // dh2 = (dout @ W3^T) (.) act'(h2) -> stash (operand of the layer-2 weight gradient) ; dh1 = (dh2 @ W2^T) (.) act'(h1)
   const float slope = dib_neg_slope(a.act);
-  dib_small_bwd(dos, p3, E2, W3, a.H2, h2s, p2, slope, dh2s, p2, a.dh2 + frow * a.H2, a.H2, rows_valid, xch);
+  dib_small_bwd_cols(dos, p3, E2, W3, a.H2, 0, a.H2, h2s, p2, slope, dh2s, p2, a.dh2 + frow * a.H2, rows_valid, xch);
   DIB_ST(42);
-  dib_small_bwd(dh2s, p2, a.H2, W2, a.H1, h1s, p1, slope, dh1s, p1, nullptr, 0, rows_valid, xch);
+  dib_small_bwd_cols(dh2s, p2, a.H2, W2, a.H1, 0, a.H1, h1s, p1, slope, dh1s, p1, nullptr, rows_valid, xch);
   DIB_ST(43);
   // d(W1|b1) partial of the tile = [P | 1]^T @ dh1: 16 x 16 output tiles (rows = encoder-input index, row in_dim = bias),
   // contraction over the 16 rows in 4 MFMA steps; lane (i, q): A[i][row 4 s + q] = Pl[row][i], B[row][n0 + j] = dh1[row][n0 + j]

@@ -41,6 +41,10 @@ def main():
     if t[30] > t[17]:   # cluster mode: [slice computed | exchange + reload] per layer
         print("  cluster mode: fwd L1 %.2f + %.2f | fwd L2 %.2f + %.2f | dgrad L2 %.2f + %.2f" % (
             t[30] - t[17], t[18] - t[30], t[31] - t[18], t[19] - t[31], t[33] - t[23], t[25] - t[33]))
+    if t[30] <= t[17]:   # (one workgroup per tile: the marks inside the layer primitive belong to the ENCODER forward's three layers)
+        for nm, b in (("enc fwd L1", 6), ("enc fwd L2", 45), ("enc fwd L3", 34)):
+            print("    inside %s (wave 0): issue %.2f | loads + MFMAs %.2f | partials + barrier %.2f | reduce + epilogue %.2f | barrier %.2f" % (
+                nm, t[b + 1] - t[b], t[b + 2] - t[b + 1], t[b + 3] - t[b + 2], t[b + 4] - t[b + 3], t[b + 5] - t[b + 4]))
     if t[30] > t[17]:
         for nm, b in (("fwd L1", 6), ("fwd L2", 45), ("dgrad L2", 34), ("dgrad g_u", 51)):
             print("    inside %s (wave 0): issue %.2f | loads + MFMAs %.2f | partials + barrier %.2f | reduce + epilogue %.2f | barrier %.2f" % (
