@@ -37,6 +37,12 @@
  *     point only reads.  Call it while no other entry point is running (start-up, or between steps of a single-threaded A/B);
  *     dib_get_tuning is always safe.  dib_profile_enable / dib_profile_summary are diagnostics with their own lock: spans
  *     from all threads land in one table.
+ *   - Co-resident workgroups (round 6).  The row-tile integration kernel's cluster mode ("int_cluster") makes the 8 (or 4) workgroups
+ *     of a row tile wait for each other inside the kernel.  They are consecutive in ONE XCD's dispatch order, so whatever share of the
+ *     CUs a launch gets, the clusters at the front of its queue are complete and drain; a stall needs every queue on an XCD to hold
+ *     only a PARTIAL cluster - five or more streams launching clustered steps onto the same 32 CUs at once.  The waits are bounded:
+ *     after 2 s of wall clock the kernel traps (the process sees a HIP error at its next synchronisation) instead of hanging the
+ *     device.  A program that steps many small models on more than four streams of one GPU sets "int_cluster" to 0.
  */
 #ifndef DIB_HIP_H
 #define DIB_HIP_H
