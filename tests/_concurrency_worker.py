@@ -10,6 +10,8 @@ work runs on one thread, one engine after the other.  Every buffer must hold the
   mode "same_arch":    both threads the same architecture and batch (two layouts): the same kernels and the same function-local
                        attribute flags from both threads
   mode "shared_layout": ONE dib_layout used by both threads with distinct workspaces and buffers
+  mode "four_small":   FOUR threads and streams of the reference-default step: its integration kernel runs in cluster mode (8 workgroups
+                       per row tile that wait for each other inside the kernel) - four such launches in flight at once
 """
 import sys
 import threading
@@ -47,12 +49,13 @@ def _run(eng, x, y, B, steps, seed):
 
 def main(mode, steps=6):
     from dib_amd.engine import HipEngine
-    kinds = {"two_layouts": ("large", "small"), "same_arch": ("small", "small"), "shared_layout": ("large", "large")}[mode]
+    kinds = {"two_layouts": ("large", "small"), "same_arch": ("small", "small"), "shared_layout": ("large", "large"),
+             "four_small": ("small",) * 4}[mode]   # four streams of clustered row-tile steps at once (the header's co-residency note)
     works = [_work(k) for k in kinds]
     data = [_data(spec, B, 5 + i) for i, (spec, B) in enumerate(works)]
-    out = [None, None]
+    out = [None] * len(kinds)
     err = []
-    barrier = threading.Barrier(2)
+    barrier = threading.Barrier(len(kinds))
     shared = {}
     restore = []
 
@@ -79,7 +82,7 @@ def main(mode, steps=6):
             err.append(repr(e))
             barrier.abort()
 
-    ts = [threading.Thread(target=thread, args=(i,)) for i in range(2)]
+    ts = [threading.Thread(target=thread, args=(i,)) for i in range(len(kinds))]
     for t in ts:
         t.start()
     for t in ts:
