@@ -232,6 +232,8 @@ struct Tuning {
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
+  int int_cluster_short_exchange = 1;  // clusters on one XCD exchange through that XCD's L2 (0: always the agent-scope protocol - the
+                             // path a cluster takes when it is NOT on one XCD; tests)
   int int_cluster = 8;       // row-tile integration kernel: workgroups per row tile (each a column slice of every layer, exchange
                              // through L2: dib_small.h "cluster mode"; <= 1: one per tile) while row tiles x this <= ...
   int int_cluster_wgs = 256; // ... this (one workgroup per CU; 8 per tile up to 32 row tiles, 4 up to 64: profiles/r06u_int_cluster_sweep.txt) and
@@ -722,6 +724,7 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
     }
     if (cl > 1 || ccl > 1) {
       p.s[0].cl = cl; p.s[0].cl_sync = (unsigned*)(w + m.cl_sync);
+      p.s[0].cl_agent_scope = c.cl_agent_scope = knobs().int_cluster_short_exchange ? 0 : 1;
       for (int i = 0; i < l->n_int; ++i) p.s[0].xh[i] = w + m.cl_x[i];
       c.cl = ccl; c.cl_sync = (unsigned*)(w + m.cl_sync) + (size_t)small_tiles(batch) * DIB_SMALL_CL_SYNC_WORDS;
       const size_t lds = std::max((size_t)l->sb_int_lds, t_companion.lds) + cl_extra;
@@ -741,7 +744,7 @@ static int small_integration(dib_layout* l, const dib_layout::WsMap& m, float* w
     return (int)hipGetLastError();
   }
   if (cl > 1) {
-    a.cl = cl; a.cl_sync = (unsigned*)(w + m.cl_sync);
+    a.cl = cl; a.cl_sync = (unsigned*)(w + m.cl_sync); a.cl_agent_scope = knobs().int_cluster_short_exchange ? 0 : 1;
     for (int i = 0; i < l->n_int; ++i) a.xh[i] = w + m.cl_x[i];
     const size_t cl_lds = (size_t)l->sb_int_lds + cl_extra;
     static int cl_lds_have[64] = {};
@@ -1596,6 +1599,7 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "wgrad_flat_tile")) return &t.wgrad_flat_tile;
   if (!std::strcmp(key, "wgrad_max_splits")) return &t.wgrad_max_splits;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
+  if (!std::strcmp(key, "int_cluster_short_exchange")) return &t.int_cluster_short_exchange;
   if (!std::strcmp(key, "int_cluster")) return &t.int_cluster;
   if (!std::strcmp(key, "int_cluster_wgs")) return &t.int_cluster_wgs;
   if (!std::strcmp(key, "int_cluster_min_weights")) return &t.int_cluster_min_weights;

@@ -694,6 +694,7 @@ struct DibSmallIntArgs {
   // layer; xh[l]: [B][width[l]] exchange buffers of the hidden activations for launches that write no stashes (INFER);
   // cl_sync: DIB_SMALL_CL_SYNC_WORDS zero-initialised words per row tile (self-cleaning)
   int cl; float* xh[3]; unsigned* cl_sync;
+  int cl_agent_scope;   // 1: every exchange takes the agent-scope protocol whatever the placement (dib_set_tuning "int_cluster_short_exchange" = 0)
 };
 
 // ---- cluster mode: the columns of a row tile's layers on `cl` co-resident workgroups (round 6) ----------------------------------
@@ -788,7 +789,7 @@ __device__ __forceinline__ void dib_small_integration_body(const DibSmallIntArgs
   const bool multi = CLUSTER && cl > 1;   // ... with somebody to exchange with
   const bool lead = crank == 0;   // writes what every workgroup of the tile computes alike (the head, the encoded input)
   unsigned* const clw = multi ? a.cl_sync + (long long)tile * DIB_SMALL_CL_SYNC_WORDS : nullptr;
-  int cl_same = -1;   // is the cluster on one XCD?  (read at its first exchange)
+  int cl_same = (CLUSTER && a.cl_agent_scope) ? 0 : -1;   // is the cluster on one XCD?  (-1: read at its first exchange; 0: forced)
   if (multi) dib_small_cluster_hello(clw);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

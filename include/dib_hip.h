@@ -267,6 +267,8 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *                           per tile) while
  *   "int_cluster_wgs" (256) row tiles x cluster size <= this (one workgroup per CU; 8 per tile halves to 4 for more row tiles, the two
  *                           networks of a paired grid are sized together; profiles/r06u_int_cluster_sweep.txt) and
+ *   "int_cluster_short_exchange" (1) a cluster whose workgroups all report one XCC_ID exchanges through that XCD's L2 (no L2 write-back /
+ *                           invalidate); 0: always the agent-scope protocol - what a cluster placed across XCDs takes (tests)
  *   "int_cluster_min_weights" (65536) the network's hidden layers hold at least this many weights
  * Returns DIB_E_ARG for an unknown key or a negative value. */
 int dib_set_tuning(const char* key, int value);

@@ -1242,7 +1242,7 @@ def test_tuning_switchboard_is_the_only_hidden_input():
     lib = _lib.load_library()
     for key in ("fwd_small_wgs", "fwd_narrow_wgs", "stream_rows", "split_policy", "split_overhead", "fused_encoder", "fused_head",
                 "small_batch", "small_wgs", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "wgrad_flat_tile", "wgrad_max_splits", "num_cus",
-                "int_cluster", "int_cluster_wgs", "int_cluster_min_weights"):
+                "int_cluster", "int_cluster_wgs", "int_cluster_min_weights", "int_cluster_short_exchange"):
         v = _lib.get_tuning(key)
         _lib.set_tuning(key, v + 1)
         assert _lib.get_tuning(key) == v + 1
@@ -1347,7 +1347,7 @@ def test_small_batch_row_tile_kernels_equal_the_large_batch_path(arch, linear, B
 
 
 @pytest.mark.parametrize("B", [1, 37, 128, 300, 512])
-@pytest.mark.parametrize("cl", [2, 4, 8])
+@pytest.mark.parametrize("cl", [2, 4, 8, -4])
 @pytest.mark.parametrize("arch", sorted(_SMALL_ARCHS))
 def test_integration_cluster_equals_one_workgroup_per_tile(arch, cl, B):
     """csrc/dib_small.h cluster mode (dib_set_tuning("int_cluster", cl): every row tile of the integration network on cl workgroups,
@@ -1361,7 +1361,7 @@ def test_integration_cluster_equals_one_workgroup_per_tile(arch, cl, B):
     from dib_amd import _lib
     from dib_amd.engine import HipEngine
     spec, kind = _SMALL_ARCHS[arch]
-    rng = np.random.default_rng(B + 7 * cl)
+    rng = np.random.default_rng(B + 7 * abs(cl))
     nin = sum(spec.feature_dimensionalities)
     x = rng.standard_normal((B + 3, nin)).astype(np.float32)
     y = rng.standard_normal((B + 3, spec.output_dimensionality)).astype(np.float32)
@@ -1371,7 +1371,10 @@ def test_integration_cluster_equals_one_workgroup_per_tile(arch, cl, B):
     eng.set_beta(0.07)
     xd, yd = eng.to_device(x), eng.to_device(y)
     idx = eng.to_device(rng.permutation(B + 3)[:B].astype(np.int32), dtype=torch.int32)
-    old = {k: _lib.get_tuning(k) for k in ("int_cluster", "int_cluster_wgs", "int_cluster_min_weights")}
+    old = {k: _lib.get_tuning(k) for k in ("int_cluster", "int_cluster_wgs", "int_cluster_min_weights", "int_cluster_short_exchange")}
+    if cl < 0:   # - 4: four workgroups per tile on the AGENT-SCOPE protocol for every exchange - what a cluster that the dispatcher
+        cl = -cl  # did not place on one XCD takes (csrc/dib_small.h dib_small_cluster_exchange); same values, same bits as the short one
+        _lib.set_tuning("int_cluster_short_exchange", 0)
 
     def run():
         eng.metrics_acc.zero_()
