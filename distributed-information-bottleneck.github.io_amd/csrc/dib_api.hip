@@ -232,6 +232,8 @@ struct Tuning {
   int infonce_one_launch = 1; // dib_infonce_fwd_bwd at B <= 128, D <= 64 (dot-product similarities): one launch instead of three
   int attn_small_bwd_waves = 8;  // dib_attention_bwd for <= 64 particles: 8 waves (two per SIMD) or the 4-wave kernel
   int wgrad_flat_tile = 1;   // weight gradients with <= 32 rows and >= 256 columns on the 32 x 256 tile (0: 64 x 128, A/B)
+  int attn_fwd_waves = 8;    // dib_attention_fwd for P >= 256: 8-wave workgroups of 256 queries sharing one staged K / V tile (4: the 4-wave
+                             // kernel, which shorter sets always take; bit-identical outputs)
   int int_cluster_short_exchange = 1;  // clusters on one XCD exchange through that XCD's L2 (0: always the agent-scope protocol - the
                              // path a cluster takes when it is NOT on one XCD; tests)
   int int_cluster = 8;       // row-tile integration kernel: workgroups per row tile (each a column slice of every layer, exchange
@@ -1599,6 +1601,7 @@ static int* tuning_slot(const char* key) {
   if (!std::strcmp(key, "wgrad_flat_tile")) return &t.wgrad_flat_tile;
   if (!std::strcmp(key, "wgrad_max_splits")) return &t.wgrad_max_splits;
   if (!std::strcmp(key, "num_cus")) return &t.num_cus;
+  if (!std::strcmp(key, "attn_fwd_waves")) return &t.attn_fwd_waves;
   if (!std::strcmp(key, "int_cluster_short_exchange")) return &t.int_cluster_short_exchange;
   if (!std::strcmp(key, "int_cluster")) return &t.int_cluster;
   if (!std::strcmp(key, "int_cluster_wgs")) return &t.int_cluster_wgs;
@@ -2305,7 +2308,8 @@ int dib_attention_fwd(const float* q, const float* k, const float* v, int B, int
     DIB_LAUNCH(dib_attn_small_fwd_kernel<false>, dim3(H, B), dim3(256), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
   }
-  DIB_LAUNCH(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
+  if (knobs().attn_fwd_waves == 8 && P >= 256) DIB_LAUNCH(dib_attn_fwd8_kernel, dim3(cdiv(P, 256), H, B), dim3(512), 0, (hipStream_t)stream, a);
+  else DIB_LAUNCH(dib_attn_fwd_kernel, dim3(cdiv(P, 128), H, B), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

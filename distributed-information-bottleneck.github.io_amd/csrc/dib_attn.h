@@ -30,6 +30,7 @@
 // Operand fetch follows dib_gemm.h: "KC" = a [rows][128+4] LDS image read along k with one ds_read_b128 per 4 MFMAs, "MC"
 // = the same image read along rows with ds_read_b32; MFMA step t of k-block q contracts k = 8q + 4*(lane>>5) + t.
 #pragma once
+#include <type_traits>
 #include "dib_common.h"
 #include "dib_gemm.h"
 
@@ -129,8 +130,24 @@ __device__ __forceinline__ void dib_attn_store_rows(float* __restrict__ base, lo
 // 2 waves / SIMD: measured (tools/attn_bench.py, 4 x 4096 x 12 heads, same box) 3.16-3.19 ms = 130 TFLOP/s = 0.83 of peak with
 // 206 registers and no spills; 3 waves / SIMD (168 registers, 36 spilled) 3.78-3.80 ms.  (Before the by-value tile staging the
 // order was the other way round, 4.98 vs 4.26 ms: the stack-object traffic of the prefetched tile hurt the 2-wave build more.)
-__global__ void __launch_bounds__(256, 2)   // workgroups per CU = waves per SIMD (2: <= 256 registers)
-dib_attn_fwd_kernel(DibAttnArgs a) {
+// 8-wave forward (round 6): 256 queries share ONE staged K / V tile - half the L2 -> LDS traffic and half the LDS
+// stores per query of two 4-wave workgroups; 512 threads stage a 32 x 128 tile as 2 float4 each
+struct DibAttnTile2 { float4 r0, r1; };
+__device__ __forceinline__ DibAttnTile2 dib_attn_gload2(const float* __restrict__ base, long long ld, int row0, int row_max, int tid) {
+  const unsigned ldu = (unsigned)ld, col = (unsigned)(tid & 31) * 4u;
+  const int r = row0 + (tid >> 5);   // 0 .. 15
+  DibAttnTile2 t;
+  t.r0 = *reinterpret_cast<const float4*>(base + ((unsigned)min(r, row_max) * ldu + col));
+  t.r1 = *reinterpret_cast<const float4*>(base + ((unsigned)min(r + 16, row_max) * ldu + col));
+  return t;
+}
+__device__ __forceinline__ void dib_attn_lstore2(float* __restrict__ T, const DibAttnTile2 t, int tid) {
+  float* dst = T + (tid >> 5) * kAttnPitch + (tid & 31) * 4;
+  *reinterpret_cast<float4*>(dst) = t.r0;
+  *reinterpret_cast<float4*>(dst + 16 * kAttnPitch) = t.r1;
+}
+template <int WAVES>   // 4: 128 queries per workgroup, two workgroups per CU; 8: 256 queries, one workgroup per CU (the same 2 waves per SIMD)
+__device__ __forceinline__ void dib_attn_fwd_body(const DibAttnArgs& a) {
   __shared__ __attribute__((aligned(16))) float Ks[kAttnTile * kAttnPitch];
   __shared__ __attribute__((aligned(16))) float Vs[kAttnTile * kAttnPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -139,9 +156,9 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
   const float* Qb = a.q + tok0 * a.ld + head * kAttnD;
   const float* Kb = a.k + tok0 * a.ld + head * kAttnD;
   const float* Vb = a.v + tok0 * a.ld + head * kAttnD;
-  const int qrow = blockIdx.x * 128 + wave * 32 + l31;          // this lane's query
+  const int qrow = blockIdx.x * (32 * WAVES) + wave * 32 + l31;          // this lane's query
   const bool q_ok = qrow < P;
-  const bool wave_ok = blockIdx.x * 128 + wave * 32 < P;        // wave has at least one real query
+  const bool wave_ok = blockIdx.x * (32 * WAVES) + wave * 32 < P;        // wave has at least one real query
 
   float4 qf[16];
   dib_attn_rowfrag(qf, Qb, a.ld, min(qrow, P - 1), h, a.scale);
@@ -153,15 +170,20 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   const int n_tiles = (P + kAttnTile - 1) / kAttnTile;
-  DibAttnTile rk = dib_attn_gload(Kb, a.ld, 0, P - 1, tid);
-  DibAttnTile rv = dib_attn_gload(Vb, a.ld, 0, P - 1, tid);
+  using Tile = typename std::conditional<WAVES == 8, DibAttnTile2, DibAttnTile>::type;
+  auto gload = [&](const float* base, int row0) -> Tile {
+    if constexpr (WAVES == 8) return dib_attn_gload2(base, a.ld, row0, P - 1, tid);
+    else return dib_attn_gload(base, a.ld, row0, P - 1, tid);
+  };
+  Tile rk = gload(Kb, 0);
+  Tile rv = gload(Vb, 0);
   for (int kt = 0; kt < n_tiles; ++kt) {
-    dib_attn_lstore(Ks, rk, tid);
-    dib_attn_lstore(Vs, rv, tid);
+    if constexpr (WAVES == 8) { dib_attn_lstore2(Ks, rk, tid); dib_attn_lstore2(Vs, rv, tid); }
+    else { dib_attn_lstore(Ks, rk, tid); dib_attn_lstore(Vs, rv, tid); }
     __syncthreads();
     if (kt + 1 < n_tiles) {   // (issuing the V tile's loads after the S product instead - the GEMM's prefetch-piece trick - measured
-      rk = dib_attn_gload(Kb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);   // no different here: profiles/r03s_*)
-      rv = dib_attn_gload(Vb, a.ld, (kt + 1) * kAttnTile, P - 1, tid);
+      rk = gload(Kb, (kt + 1) * kAttnTile);   // no different here: profiles/r03s_*)
+      rv = gload(Vb, (kt + 1) * kAttnTile);
     }
     if (wave_ok) {
       // S^T[key][query] = sum_d K[key][d] (scale Q[query][d]); the K fragment of step q + 1 is fetched before the MFMAs of
@@ -184,7 +206,7 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
         // store per register group (plain: the two 16-byte halves of a 32-byte sector come from two lanes and merge in L2;
         // non-temporal stores measured 1.7 % slower, profiles/r03g_attention_stash_cache_policy_ab.txt); values of keys /
         // queries beyond P are finite and multiplied by 0 there
-        float* sp = a.s_stash + dib_attn_stash_tile(b, a.H, head, n_tiles, kt, blockIdx.x * 4 + wave) + l31 * kAttnTile + 4 * h;
+        float* sp = a.s_stash + dib_attn_stash_tile(b, a.H, head, n_tiles, kt, blockIdx.x * WAVES + wave) + l31 * kAttnTile + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *reinterpret_cast<dib_nt4a*>(sp + 8 * g) = dib_nt4a{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
@@ -252,6 +274,14 @@ dib_attn_fwd_kernel(DibAttnArgs a) {
   dib_attn_store_rows(a.o + tok0 * a.ld + head * kAttnD, a.ld, qrow, q_ok && wave_ok, h, acc, inv);
   if (q_ok && wave_ok && h == 0) a.lse[((long long)b * a.H + head) * P + qrow] = m_run + __logf(l_tot);
 }
+
+
+__global__ void __launch_bounds__(256, 2)   // workgroups per CU = waves per SIMD (2: <= 256 registers)
+dib_attn_fwd_kernel(DibAttnArgs a) { dib_attn_fwd_body<4>(a); }
+// P >= 256 (dib_set_tuning "attn_fwd_waves" = 8, the default): bit-identical outputs, 3.34 -> 3.20 - 3.28 ms at 4 x 4096 x 12 heads,
+// BASELINE config 5's step 69.9 -> 69.5 ms (profiles/r06ab_attention_forward_8_waves_ab.txt)
+__global__ void __launch_bounds__(512, 1)
+dib_attn_fwd8_kernel(DibAttnArgs a) { dib_attn_fwd_body<8>(a); }
 
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d] : grid (ceil(T*H / 4)), one wave per (token, head)
 __global__ void __launch_bounds__(256)

@@ -257,6 +257,8 @@ int dib_step_tail(dib_layout* l, int batch, int part, int flags, float* params, 
  *   "infonce_one_launch" (1) dib_infonce_fwd_bwd at batch <= 128, dim <= 64 with l2sq / l2 / cosine: one launch instead of three
  *   "attn_small_bwd_waves" (8) dib_attention_bwd for neighbourhoods of <= 64 particles: 8 waves per workgroup (two per SIMD), or 4
  *                           (the round-4 kernel; bit-identical results)
+ *   "attn_fwd_waves" (8)    dib_attention_fwd for >= 256 particles: 8-wave workgroups of 256 queries sharing one staged K / V tile (4: the
+ *                           4-wave kernel of 128 queries, which shorter sets always take); bit-identical outputs
  *   "wgrad_max_splits" (32) most batch slabs of a layout's weight gradients (1 .. 32; read when a workspace is SIZED: set it before the
  *                           first dib_workspace_bytes of a layout).  Fewer slabs shrink the tail's reduce but starve the small
  *                           weight gradients: 32 / 24 / 16 / 8 -> 8.20 / 8.27 / 8.38 / 8.57 ms per config-3 step (profiles/r06j_*)

@@ -1242,7 +1242,7 @@ def test_tuning_switchboard_is_the_only_hidden_input():
     lib = _lib.load_library()
     for key in ("fwd_small_wgs", "fwd_narrow_wgs", "stream_rows", "split_policy", "split_overhead", "fused_encoder", "fused_head",
                 "small_batch", "small_wgs", "mlp_row_tiles", "infonce_one_launch", "attn_small_bwd_waves", "wgrad_flat_tile", "wgrad_max_splits", "num_cus",
-                "int_cluster", "int_cluster_wgs", "int_cluster_min_weights", "int_cluster_short_exchange"):
+                "int_cluster", "int_cluster_wgs", "int_cluster_min_weights", "int_cluster_short_exchange", "attn_fwd_waves"):
         v = _lib.get_tuning(key)
         _lib.set_tuning(key, v + 1)
         assert _lib.get_tuning(key) == v + 1

@@ -253,6 +253,40 @@ def test_attention_backward_score_stash_equals_recompute(B, P, H):
         assert (a.double().cpu() - b).abs().max() <= 2e-5 * b.abs().max() + 1e-6, name
 
 
+@pytest.mark.parametrize("B,P,H", [(2, 300, 3), (1, 256, 2), (1, 1100, 1), (1, 2049, 1)])
+def test_attention_forward_8_waves_equals_4_waves(B, P, H):
+    """csrc/dib_attn.h: from 256 particles up the flash forward runs on 8-wave workgroups of 256 queries that share one staged K / V
+    tile (dib_set_tuning("attn_fwd_waves", 8), the default) - the same wave code on the same tiles as the 4-wave kernel
+    ("attn_fwd_waves" = 4): outputs, log-sum-exps and the stashed score tiles BIT-identical; partial last query blocks included."""
+    import ctypes
+    from dib_amd import _lib
+    from dib_amd._lib import check, load_library
+    lib = load_library()
+    D, dev = 128, torch.device("cuda:0")
+    T, ld = B * P, H * D
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + P)
+    mk = lambda: (torch.randn((T, ld), generator=g) * 0.5).to(dev)
+    q, k, v = mk(), mk(), mk()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib.get_tuning("attn_fwd_waves") == 8
+    res = {}
+    try:
+        for waves in (8, 4):
+            _lib.set_tuning("attn_fwd_waves", waves)
+            o = torch.zeros_like(q)
+            lse = torch.zeros(B * H * P, device=dev)
+            stash = torch.zeros(int(lib.dib_attention_stash_bytes(B, P, H)) // 4, device=dev)
+            n0 = lib.dib_launch_count()
+            check(lib.dib_attention_fwd(p(q), p(k), p(v), B, P, H, D, ld, 1.0 / D ** 0.5, p(o), p(lse), p(stash), st), "fwd")
+            torch.cuda.synchronize()
+            res[waves] = (o, lse, stash)
+    finally:
+        _lib.set_tuning("attn_fwd_waves", 8)
+    for name, a, b in zip(("o", "lse", "stash"), res[8], res[4]):
+        assert torch.isfinite(a).all() and torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("B,P,H", [(2, 50, 3), (1, 64, 2), (3, 1, 1), (2, 33, 12)])
 def test_attention_backward_8_waves_equals_4_waves(B, P, H):
     """csrc/dib_attn_small.h: the 8-wave backward (two waves per SIMD, the five products split between the wave groups) runs

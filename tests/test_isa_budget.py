@@ -135,5 +135,7 @@ def test_round6_kernels_keep_their_budgets(kernels):
     assert single["ScratchSize"] == 0 and single["NumVgprs"] <= 256       # + the head-step reduce (dib_mlp_small_head_step)
     # cluster mode: the slice primitives keep a share's whole batch of weight loads in registers (16 float4 a lane at most) - no
     # scratch, two waves per SIMD
+    fwd8 = _one(kernels, "dib_attn_fwd8_kernel")   # the 8-wave flash forward: the 4-wave kernel's wave code, two waves per SIMD
+    assert fwd8["ScratchSize"] == 0 and fwd8["NumVgprs"] + fwd8["NumAgprs"] <= 256 and fwd8["mfma"] == 128
     cluster = _one(kernels, "dib_small_integration_cluster_kernel")
     assert cluster["ScratchSize"] == 0 and cluster["NumVgprs"] + cluster["NumAgprs"] <= 256
